@@ -1,0 +1,209 @@
+/*
+ * tloam_hip.h -- C ABI of the MI355X-native T-LOAM pose-optimisation path.
+ *
+ * This library replaces ONE path of the reference: LocalRegistration::scanMatching and
+ * what it calls (reference: src/models/registration/registration.cpp:879-1133), i.e. the
+ * four KDTreeFlann::SearchHybrid correspondence builders (:427-505, :517-559, :571-635,
+ * :714-778), the three Ceres cost functors (:19-117), the SE(3) local parameterisation
+ * (:162-179), ceres::Solve as configured at :1036-1047, the GNC-TLS weight update
+ * (:858-876) and getFitnessScore (:257-296).  It sits behind the reference's plugin
+ * boundary tloam::RegistrationInterface
+ * (include/tloam/models/registration/registration_interface.hpp:40-48); the C++ adapter
+ * that marshals a reference `Frame` into these calls is adapters/hip_registration.hpp and
+ * the binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch / Eigen / Open3D types; pointers + sizes only.
+ *   - every function returns TLOAM_OK (0) or a negative tloam_status; nothing throws or
+ *     aborts (the reference asserts / SOPHUS_ENSUREs instead, registration.cpp:928-929,
+ *     sophus/se3.hpp:497-504).
+ *   - point clouds are borrowed for the duration of the call as contiguous AoS double[3]
+ *     (== open3d::geometry::PointCloud2::points_.data(), PointCloud2.hpp:396) and copied
+ *     to HBM as SoA.  4x4 poses are column-major doubles (== Eigen::Isometry3d::matrix()).
+ *   - one context = one device + one HIP stream; not thread-safe (the reference has a
+ *     single caller thread, lidar_odometry_nodelet.cpp:57-63).
+ *   - se(3) vectors are (upsilon[3], omega[3]) -- translation part first, as
+ *     registration.hpp:327-329.
+ *   - there is NO CPU fallback: every entry point that computes needs a gfx950 device and
+ *     returns TLOAM_E_HIP if none is usable.
+ */
+#ifndef TLOAM_HIP_H
+#define TLOAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLOAM_ABI_VERSION 1
+
+/* feature kinds; order = the builder order of registration.cpp:981-992 */
+#define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
+#define TLOAM_KIND_GROUND 1 /* addGroundCostFactor  -> point-to-plane  */
+#define TLOAM_KIND_EDGE 2   /* addEdgeCostFactor    -> point-to-line   */
+#define TLOAM_KIND_SPHERE 3 /* addSphereCostFactor  -> point-to-point  */
+#define TLOAM_NUM_KINDS 4
+
+/* residual types of pre-built correspondence sets (tloam_set_correspondences) */
+#define TLOAM_RES_PLANE 0 /* PointToPlaneErr registration.cpp:96-117  */
+#define TLOAM_RES_LINE 1  /* PointToLineErr  registration.cpp:55-88   */
+#define TLOAM_RES_POINT 2 /* PointToPointErr registration.cpp:19-47   */
+#define TLOAM_NUM_RES 3
+
+typedef enum tloam_status {
+  TLOAM_OK = 0,
+  TLOAM_E_INVALID = -1,        /* null pointer / bad enum / bad size                        */
+  TLOAM_E_TOO_FEW_POINTS = -2, /* < 10 points in one of the 8 clouds (registration.cpp:928) */
+  TLOAM_E_BAD_POSE = -3,       /* predict pose is not a rigid transform (sophus se3.hpp:497) */
+  TLOAM_E_HIP = -4,            /* HIP runtime error / no device                             */
+  TLOAM_E_RCCL = -5,           /* RCCL error / librccl not loadable                         */
+  TLOAM_E_NOT_READY = -6,      /* call sequence violated (e.g. outer step before begin)     */
+  TLOAM_E_WEIGHT_RANGE = -7    /* GNC weight left [0,1] (the reference's assert, :871)      */
+} tloam_status;
+
+/* The 16 keys of the `TLS:` block, config/mapping/lidar_odometry.yaml:23-39, read by
+ * LocalRegistration::initConfig (registration.cpp:212-230). */
+typedef struct tloam_tls_config {
+  int32_t k_corr;     /* unused on the live path (only the dead PlaneToPlane builders) */
+  int32_t factor_num; /* 2: planar+ground, 3: +edge, 4: +sphere (registration.hpp:144-148) */
+  double edge_dist_thres;
+  double edge_dir_thres;
+  int32_t edge_maxnum;
+  int32_t sphere_maxnum;
+  double sphere_dist_thres;
+  double planar_dist_thres;
+  int32_t planar_maxnum;
+  int32_t ground_maxnum;
+  double ground_dist_thres;
+  int32_t max_iterations;
+  int32_t reserved0;
+  double cost_threshold;
+  double gnc_factor;
+  double noise_bound;
+  double fitness_thres;
+} tloam_tls_config;
+
+/* Fills *cfg with the shipped values of lidar_odometry.yaml:23-39. */
+void tloam_default_config(tloam_tls_config* cfg);
+
+/* What one scan_match (or one outer GNC iteration) did. */
+typedef struct tloam_stats {
+  int32_t outer_iterations;       /* GNC iterations executed (<= max_iterations)              */
+  int32_t gn_evaluations;         /* residual+Jacobian sweeps (K3 launches that did work)     */
+  int32_t gn_iterations;          /* trust-region iterations attempted (<= 4 per outer)       */
+  int32_t accepted_steps;         /* ... of which accepted                                    */
+  int32_t n_corr[TLOAM_NUM_KINDS];/* factors added in the LAST outer iteration, per kind      */
+  int32_t converged_early;        /* 1 if the planar-cost plateau test broke the loop (:1108) */
+  int32_t reserved0;
+  double kind_cost[TLOAM_NUM_KINDS]; /* side-channel cost sums of the last iteration (:1091-1094) */
+  double mu;                      /* GNC mu after the last update (:1089)                      */
+  double solver_cost;             /* Ceres-style cost 0.5*sum(rho) at the final iterate        */
+  double se3[6];                  /* final tangent vector `parameters` (registration.hpp:328)  */
+} tloam_stats;
+
+typedef struct tloam_ctx tloam_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* LocalRegistration::LocalRegistration(config["TLS"]) (registration.cpp:182-206). */
+int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out);
+void tloam_destroy(tloam_ctx* ctx);
+int tloam_abi_version(void);
+const char* tloam_status_string(int status);
+/* text of the last HIP/RCCL error seen by this context ("" if none) */
+const char* tloam_last_error(const tloam_ctx* ctx);
+
+/* ---- inputs: RegistrationInterface::setInputSource / setInputTarget -------------------
+ * (registration.cpp:232-248).  The reference keeps shared_ptrs; here the cloud is copied
+ * to HBM (AoS -> SoA on device).  In a sharded context (tloam_comm_*) every rank passes
+ * the FULL cloud and the context keeps its contiguous index block. */
+int tloam_set_source(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
+int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
+
+/* ---- RegistrationInterface::scanMatching (registration.cpp:879-1133) -------------------
+ * predict/result: 4x4 column-major.  omega_perturb3: the unit vector the reference draws
+ * with Eigen::Vector3d::Random() when |omega| < 1e-2 (:884-886); NULL = (0,0,1).
+ * scan_xyz_aos/n_scan: optional cloud transformed IN PLACE by the result pose
+ * (out_result_.scan_cloud, :1126-1128); NULL/0 to skip.  stats may be NULL. */
+int tloam_scan_match(tloam_ctx* ctx, const double predict_colmajor[16],
+                     const double* omega_perturb3_or_null, double result_colmajor[16],
+                     double* scan_xyz_aos_or_null, size_t n_scan, tloam_stats* stats);
+
+/* The same, one outer GNC iteration at a time (tests inspect the state in between).
+ * begin -> outer x N (until *done) -> end. */
+int tloam_sm_begin(tloam_ctx* ctx, const double predict_colmajor[16],
+                   const double* omega_perturb3_or_null);
+int tloam_sm_outer(tloam_ctx* ctx, int* done, tloam_stats* stats);
+int tloam_sm_end(tloam_ctx* ctx, double result_colmajor[16], tloam_stats* stats);
+
+/* ---- RegistrationInterface::getFitnessScore (registration.cpp:257-296) ----------------- */
+int tloam_fitness(tloam_ctx* ctx, double* fitness, double* rmse);
+
+/* ---- introspection (parity tests) ------------------------------------------------------
+ * Correspondences built by the last outer iteration for `kind`, in source-index order.
+ * src_index[n]; a[3n] = plane normal | line point a | target point; b[3n] = line point b
+ * (edge only; else untouched); d[n] = plane offset (planar/ground only); w[n] = weight
+ * captured at build time; cost[n] = side-channel cost after the last sweep.  Any output
+ * pointer may be NULL.  capacity = elements available; returns count via *n. */
+int tloam_get_correspondences(tloam_ctx* ctx, int kind, size_t capacity, size_t* n,
+                              int32_t* src_index, double* a_aos, double* b_aos, double* d,
+                              double* w, double* cost);
+/* current per-source-point GNC weights of `kind` (this rank's block if sharded) */
+int tloam_get_weights(tloam_ctx* ctx, int kind, size_t capacity, size_t* n, double* w);
+/* exact hybrid search on the device structure of `kind` (KDTreeFlann::SearchHybrid, B.2):
+ * for each of nq queries (AoS) the k nearest targets with squared distance < radius^2,
+ * ascending; out_idx[nq*k] (-1 padded), out_d2[nq*k], out_cnt[nq]. */
+int tloam_knn(tloam_ctx* ctx, int kind, const double* queries_aos, size_t nq, double radius,
+              int k, int32_t* out_idx, double* out_d2, int32_t* out_cnt);
+
+/* ---- pre-built correspondence sets (roofline / parity of K3 and the solver) ------------
+ * res_type TLOAM_RES_*: p = source point (scan frame); a = normal | line a | target;
+ * b = line b (LINE only, else NULL); d = plane offset (PLANE only, else NULL); w = weights.
+ * Replaces whatever the builders produced.  Sharded contexts keep their index block. */
+int tloam_set_correspondences(tloam_ctx* ctx, int res_type, size_t n, const double* p_aos,
+                              const double* a_aos, const double* b_aos, const double* d,
+                              const double* w);
+/* One residual+Jacobian sweep at se3 (K3): H = sum rho' J^T J (row-major 6x6),
+ * g = sum rho' J^T r, cost = sum 0.5*log(1+|r|^2)  (Ceres evaluator + CauchyLoss(1.0)
+ * corrector, registration.cpp:970).  Also refreshes the side-channel costs.  In a sharded
+ * context the outputs are the all-reduced totals. */
+int tloam_accumulate(tloam_ctx* ctx, const double se3[6], double H_rowmajor[36], double g[6],
+                     double* cost);
+/* side-channel costs of the current set, per residual type (after tloam_accumulate/solve) */
+int tloam_get_costs(tloam_ctx* ctx, int res_type, size_t capacity, size_t* n, double* cost);
+/* One ceres::Solve as configured at registration.cpp:1036-1047 on the current set:
+ * se3_inout is `parameters`.  stats->gn_* filled. */
+int tloam_solve(tloam_ctx* ctx, double se3_inout[6], tloam_stats* stats);
+/* Timing helper for the bench: `launches` back-to-back K3 sweeps at se3 on the context's
+ * stream bracketed by HIP events; returns the mean kernel-pair time in microseconds. */
+int tloam_time_accumulate(tloam_ctx* ctx, const double se3[6], int launches, double* mean_us);
+/* accumulated HIP-event time (us) and launch count of the K3 kernel since the last reset */
+int tloam_k3_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* launches,
+                   double* algorithmic_bytes);
+
+/* ---- multi-GPU: correspondence set sharded over ranks, one all-reduce per sweep --------
+ * (nothing in the reference).  Call before set_source / set_correspondences.
+ * (a) native RCCL over xGMI: unique_id = the 128 bytes of an ncclUniqueId made on rank 0
+ *     by tloam_rccl_unique_id and broadcast by the launcher. */
+int tloam_rccl_unique_id(void* out128);
+int tloam_comm_init_rccl(tloam_ctx* ctx, int rank, int nranks, const void* unique_id128);
+/* (b) caller-provided sum all-reduce on a DEVICE buffer of `count` doubles, enqueued on (or
+ *     synchronised with) `hip_stream`; returns 0 on success.  Used by the gloo-backed tests
+ *     and by hosts that already own a communicator. */
+typedef int (*tloam_allreduce_fn)(void* user, double* device_buf, int count, void* hip_stream);
+int tloam_comm_init_callback(tloam_ctx* ctx, int rank, int nranks, tloam_allreduce_fn fn,
+                             void* user);
+/* contiguous index block [*lo,*hi) of n items owned by `rank` of `nranks` (pure function) */
+void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi);
+
+/* ---- SE(3) helpers (host; the ~150 lines of vendored Sophus the path uses) -------------
+ * se3.hpp:761-785 (exp), :223-256 (log), :497-504 (from matrix), registration.cpp:162-173 */
+int tloam_se3_exp(const double se3[6], double T_colmajor[16]);
+int tloam_se3_log(const double T_colmajor[16], double se3[6]);
+int tloam_se3_plus(const double x[6], const double delta[6], double x_plus_delta[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLOAM_HIP_H */

@@ -1,0 +1,268 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT -- ctypes binding of oracle/_build/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+class TlsConfig(C.Structure):
+    """== tloam_tls_config (include/tloam_hip.h)."""
+    _fields_ = [
+        ("k_corr", C.c_int32), ("factor_num", C.c_int32),
+        ("edge_dist_thres", C.c_double), ("edge_dir_thres", C.c_double),
+        ("edge_maxnum", C.c_int32), ("sphere_maxnum", C.c_int32),
+        ("sphere_dist_thres", C.c_double), ("planar_dist_thres", C.c_double),
+        ("planar_maxnum", C.c_int32), ("ground_maxnum", C.c_int32),
+        ("ground_dist_thres", C.c_double),
+        ("max_iterations", C.c_int32), ("reserved0", C.c_int32),
+        ("cost_threshold", C.c_double), ("gnc_factor", C.c_double),
+        ("noise_bound", C.c_double), ("fitness_thres", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    """== tloam_stats (include/tloam_hip.h)."""
+    _fields_ = [
+        ("outer_iterations", C.c_int32), ("gn_evaluations", C.c_int32),
+        ("gn_iterations", C.c_int32), ("accepted_steps", C.c_int32),
+        ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
+        ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
+        ("se3", C.c_double * 6),
+    ]
+
+    def as_dict(self):
+        return dict(outer_iterations=self.outer_iterations, gn_evaluations=self.gn_evaluations,
+                    gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
+                    n_corr=list(self.n_corr), converged_early=self.converged_early,
+                    kind_cost=list(self.kind_cost), mu=self.mu, solver_cost=self.solver_cost,
+                    se3=np.array(self.se3))
+
+
+DEFAULTS = dict(k_corr=10, factor_num=4, edge_dist_thres=1.0, edge_dir_thres=0.85, edge_maxnum=1200,
+                sphere_dist_thres=0.5, sphere_maxnum=200, planar_dist_thres=0.5, planar_maxnum=2500,
+                ground_dist_thres=0.5, ground_maxnum=2000, max_iterations=4, cost_threshold=5e-9,
+                gnc_factor=11.8, noise_bound=0.01, fitness_thres=0.02)
+
+
+def make_config(**over) -> TlsConfig:
+    cfg = TlsConfig()
+    vals = dict(DEFAULTS)
+    vals.update(over)
+    for k, v in vals.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "tloam_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_create.argtypes = [C.POINTER(TlsConfig), C.POINTER(C.c_void_p)]
+        _lib.orc_destroy.argtypes = [C.c_void_p]
+        _lib.orc_destroy.restype = None
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _aos(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 3))
+
+
+class Oracle:
+    """Same call surface as tloam_amd.HipRegistration, backed by the C restatement."""
+
+    def __init__(self, cfg: TlsConfig | None = None, builder_threads=1, eval_threads=1):
+        self.L = lib()
+        self.cfg = cfg or make_config()
+        self.h = C.c_void_p()
+        rc = self.L.orc_create(C.byref(self.cfg), C.byref(self.h))
+        assert rc == 0
+        self.L.orc_set_threads(self.h, int(builder_threads), int(eval_threads))
+        self._n = {}
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_source(self, kind, xyz):
+        a = _aos(xyz)
+        self._n[("s", kind)] = len(a)
+        return self.L.orc_set_source(self.h, int(kind), _dp(a), C.c_size_t(len(a)))
+
+    def set_target(self, kind, xyz):
+        a = _aos(xyz)
+        self._n[("t", kind)] = len(a)
+        return self.L.orc_set_target(self.h, int(kind), _dp(a), C.c_size_t(len(a)))
+
+    def set_frames(self, source, target):
+        for k in range(4):
+            self.set_source(k, source.cloud(k))
+            self.set_target(k, target.cloud(k))
+
+    def scan_match(self, predict, omega=None, scan=None):
+        P = np.asfortranarray(np.asarray(predict, float))
+        pred = np.ascontiguousarray(P.T.reshape(-1))  # column-major flatten
+        res = np.zeros(16)
+        st = Stats()
+        om = None if omega is None else np.ascontiguousarray(omega, float)
+        sc = None if scan is None else scan
+        rc = self.L.orc_scan_match(self.h, _dp(pred), _dp(om), _dp(res), _dp(sc),
+                                   C.c_size_t(0 if sc is None else len(sc)), C.byref(st))
+        return rc, res.reshape(4, 4).T.copy(), st.as_dict()
+
+    def sm_begin(self, predict, omega=None):
+        pred = np.ascontiguousarray(np.asarray(predict, float).T.reshape(-1))
+        om = None if omega is None else np.ascontiguousarray(omega, float)
+        return self.L.orc_sm_begin(self.h, _dp(pred), _dp(om))
+
+    def sm_outer(self):
+        done = C.c_int(0)
+        st = Stats()
+        rc = self.L.orc_sm_outer(self.h, C.byref(done), C.byref(st))
+        return rc, bool(done.value), st.as_dict()
+
+    def sm_end(self):
+        res = np.zeros(16)
+        st = Stats()
+        rc = self.L.orc_sm_end(self.h, _dp(res), C.byref(st))
+        return rc, res.reshape(4, 4).T.copy(), st.as_dict()
+
+    def fitness(self):
+        f, r = C.c_double(0), C.c_double(0)
+        rc = self.L.orc_fitness(self.h, C.byref(f), C.byref(r))
+        return rc, f.value, r.value
+
+    def get_correspondences(self, kind, capacity=None):
+        cap = capacity or max(self._n.get(("s", kind), 0), 1)
+        n = C.c_size_t(0)
+        idx = np.zeros(cap, np.int32); a = np.zeros((cap, 3)); b = np.zeros((cap, 3))
+        d = np.zeros(cap); w = np.zeros(cap); cost = np.zeros(cap)
+        rc = self.L.orc_get_correspondences(self.h, int(kind), C.c_size_t(cap), C.byref(n), _ip(idx),
+                                            _dp(a), _dp(b), _dp(d), _dp(w), _dp(cost))
+        assert rc == 0, rc
+        m = n.value
+        return dict(idx=idx[:m], a=a[:m], b=b[:m], d=d[:m], w=w[:m], cost=cost[:m])
+
+    def get_weights(self, kind):
+        cap = max(self._n.get(("s", kind), 0), 1)
+        n = C.c_size_t(0)
+        w = np.zeros(cap)
+        rc = self.L.orc_get_weights(self.h, int(kind), C.c_size_t(cap), C.byref(n), _dp(w))
+        assert rc == 0, rc
+        return w[:n.value]
+
+    def knn(self, kind, queries, radius, k):
+        q = _aos(queries)
+        idx = np.zeros((len(q), k), np.int32); d2 = np.zeros((len(q), k)); cnt = np.zeros(len(q), np.int32)
+        rc = self.L.orc_knn(self.h, int(kind), _dp(q), C.c_size_t(len(q)), C.c_double(radius), int(k),
+                            _ip(idx), _dp(d2), _ip(cnt))
+        assert rc == 0, rc
+        return idx, d2, cnt
+
+    def set_correspondences(self, res_type, p, a, b=None, d=None, w=None):
+        p = _aos(p); a = _aos(a)
+        b = None if b is None else _aos(b)
+        d = None if d is None else np.ascontiguousarray(d, float)
+        w = np.ones(len(p)) if w is None else np.ascontiguousarray(w, float)
+        self._n[("c", res_type)] = len(p)
+        return self.L.orc_set_correspondences(self.h, int(res_type), C.c_size_t(len(p)), _dp(p), _dp(a),
+                                              _dp(b), _dp(d), _dp(w))
+
+    def accumulate(self, se3):
+        x = np.ascontiguousarray(se3, float)
+        H = np.zeros(36); g = np.zeros(6); cost = C.c_double(0)
+        rc = self.L.orc_accumulate(self.h, _dp(x), _dp(H), _dp(g), C.byref(cost))
+        assert rc == 0, rc
+        return H.reshape(6, 6), g, cost.value
+
+    def get_costs(self, res_type):
+        cap = max(self._n.get(("c", res_type), 0), 1)
+        n = C.c_size_t(0)
+        c = np.zeros(cap)
+        rc = self.L.orc_get_costs(self.h, int(res_type), C.c_size_t(cap), C.byref(n), _dp(c))
+        assert rc == 0, rc
+        return c[:n.value]
+
+    def solve(self, se3):
+        x = np.array(se3, float)
+        st = Stats()
+        rc = self.L.orc_solve(self.h, _dp(x), C.byref(st))
+        assert rc == 0, rc
+        return x, st.as_dict()
+
+
+# thin wrappers for the free functions
+def se3_exp(a):
+    q = np.zeros(4); t = np.zeros(3)
+    x = np.ascontiguousarray(a, float)
+    lib().orc_se3_exp(_dp(x), _dp(q), _dp(t))
+    M = np.zeros(16)
+    lib().orc_se3_to_matrix(_dp(q), _dp(t), _dp(M))
+    return M.reshape(4, 4).T.copy()
+
+
+def se3_log(T):
+    M = np.ascontiguousarray(np.asarray(T, float).T.reshape(-1))
+    q = np.zeros(4); t = np.zeros(3); a = np.zeros(6)
+    rc = lib().orc_se3_from_matrix(_dp(M), _dp(q), _dp(t))
+    if rc != 0:
+        raise ValueError(f"not a rigid transform (status {rc})")
+    lib().orc_se3_log(_dp(q), _dp(t), _dp(a))
+    return a
+
+
+def plus(x, delta):
+    o = np.zeros(6)
+    lib().orc_plus(_dp(np.ascontiguousarray(x, float)), _dp(np.ascontiguousarray(delta, float)), _dp(o))
+    return o
+
+
+def fit_plane(pts):
+    p = _aos(pts)
+    out = np.zeros(4)
+    lib().orc_fit_plane(_dp(p), int(len(p)), _dp(out))
+    return out
+
+
+def eig3(cov):
+    c = np.ascontiguousarray(cov, float).reshape(9)
+    ev = np.zeros(3); V = np.zeros(9)
+    lib().orc_eig3_sym(_dp(c), _dp(ev), _dp(V))
+    return ev, V.reshape(3, 3)
+
+
+def knn_brute(targets, q, radius, k):
+    t = _aos(targets)
+    qq = np.ascontiguousarray(q, float)
+    idx = np.zeros(k, np.int32); d2 = np.zeros(k)
+    lib().orc_knn_hybrid_brute.restype = C.c_int
+    cnt = lib().orc_knn_hybrid_brute(_dp(t), int(len(t)), _dp(qq), C.c_double(radius), int(k), _ip(idx), _dp(d2))
+    cnt = max(cnt, 0)
+    return idx[:cnt], d2[:cnt]

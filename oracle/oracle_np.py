@@ -1,0 +1,537 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT -- independent numpy/scipy restatement of the reference's
+pose-optimisation path (LocalRegistration::scanMatching, registration.cpp:879-1133).
+
+Purpose: a SECOND, independently written statement of the same algorithm, used to
+(1) cross-check oracle/tloam_oracle.c and (2) generate the committed golden vectors under
+tests/golden/ (tests/golden/make_golden.py).  It deliberately uses different building blocks
+from the C oracle:
+
+  =====================  ==============================  ===============================
+  step                   C oracle                        this file
+  =====================  ==============================  ===============================
+  SE(3) exp / log        quaternion + Sophus branches    rotation matrices, Rodrigues
+  hybrid k-NN            uniform grid, own top-k         scipy.spatial.cKDTree
+  3x3 eigen (edge fit)   cyclic Jacobi                   numpy.linalg.eigh (LAPACK)
+  Gauss-Newton step      Cholesky of 6x6 normal eqs      QR/lstsq of the stacked Nx6
+                                                         Jacobian [J S; sqrt(mu) D] -- the
+                                                         literal Ceres DENSE_QR form
+  evaluation             per block, scalar               vectorised over all blocks
+  =====================  ==============================  ===============================
+
+PARITY UNPINNED: like the C oracle this restates Ceres 2.0 / Open3D 0.12 behaviour from their
+published algorithms; the reference has no tests or vectors to pin it.
+Reference line numbers below are relative to /root/reference/src/models/registration/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+KIND_PLANAR, KIND_GROUND, KIND_EDGE, KIND_SPHERE = 0, 1, 2, 3
+KIND_NAMES = ("planar", "ground", "edge", "sphere")
+
+DEFAULT_CFG = dict(  # config/mapping/lidar_odometry.yaml:23-39
+    k_corr=10, factor_num=4,
+    edge_dist_thres=1.0, edge_dir_thres=0.85, edge_maxnum=1200,
+    sphere_dist_thres=0.5, sphere_maxnum=200,
+    planar_dist_thres=0.5, planar_maxnum=2500,
+    ground_dist_thres=0.5, ground_maxnum=2000,
+    max_iterations=4, cost_threshold=5e-9, gnc_factor=11.8, noise_bound=0.01,
+    fitness_thres=0.02,
+)
+
+
+# --------------------------------------------------------------------------- SE(3)
+def hat(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def se3_exp(a):
+    """(upsilon, omega) -> 4x4.  sophus/se3.hpp:761-785 in matrix form."""
+    ups, om = np.asarray(a[:3], float), np.asarray(a[3:], float)
+    th = np.linalg.norm(om)
+    Om = hat(om)
+    if th < 1e-10:
+        R = np.eye(3) + Om + 0.5 * Om @ Om
+        V = R
+    else:
+        R = np.eye(3) + math.sin(th) / th * Om + (1.0 - math.cos(th)) / th**2 * (Om @ Om)
+        V = np.eye(3) + (1.0 - math.cos(th)) / th**2 * Om + (th - math.sin(th)) / th**3 * (Om @ Om)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ ups
+    return T
+
+
+def so3_log(R):
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) * 0.5  # sin(th) * axis
+    s = np.linalg.norm(w)
+    c = (np.trace(R) - 1.0) * 0.5
+    th = math.atan2(s, c)
+    if s < 1e-12:
+        return w  # th/sin(th) -> 1  (angles near pi are never used on this path)
+    return w * (th / s)
+
+
+def se3_log(T):
+    """4x4 -> (upsilon, omega).  sophus/se3.hpp:223-256."""
+    om = so3_log(T[:3, :3])
+    th = np.linalg.norm(om)
+    Om = hat(om)
+    if th < 1e-10:
+        Vinv = np.eye(3) - 0.5 * Om + (1.0 / 12.0) * (Om @ Om)
+    else:
+        Vinv = np.eye(3) - 0.5 * Om + (1.0 - th * math.cos(th / 2) / (2.0 * math.sin(th / 2))) / th**2 * (Om @ Om)
+    return np.concatenate([Vinv @ T[:3, 3], om])
+
+
+def plus(x, delta):
+    """registration.cpp:162-173: log(exp(delta) * exp(x))."""
+    return se3_log(se3_exp(delta) @ se3_exp(x))
+
+
+# --------------------------------------------------------------------------- geometry
+def fit_best_plane(pts):
+    """registration.cpp:303-368."""
+    pts = np.asarray(pts, float)
+    n = len(pts)
+    c = pts.sum(axis=0) / n
+    q = pts - c
+    xx, xy, xz = (q[:, 0] * q[:, 0]).sum() / n, (q[:, 0] * q[:, 1]).sum() / n, (q[:, 0] * q[:, 2]).sum() / n
+    yy, yz, zz = (q[:, 1] * q[:, 1]).sum() / n, (q[:, 1] * q[:, 2]).sum() / n, (q[:, 2] * q[:, 2]).sum() / n
+    wd = np.zeros(3)
+    det_x = yy * zz - yz * yz
+    det_y = xx * zz - xz * xz
+    det_z = xx * yy - xy * xy
+    for det, ax in ((det_x, np.array([det_x, xz * yz - xy * zz, xy * yz - xz * yy])),
+                    (det_y, np.array([xz * yz - xy * zz, det_y, xy * xz - yz * xx])),
+                    (det_z, np.array([xy * yz - xz * yy, xy * xz - yz * xx, det_z]))):
+        w = det * det
+        if wd @ ax < 0.0:
+            w = -w
+        wd = wd + ax * w
+    nrm = np.linalg.norm(wd)
+    if nrm == 0:
+        return np.zeros(4)
+    wd = wd / nrm
+    return np.array([wd[0], wd[1], wd[2], -(wd @ c)])
+
+
+def hybrid_search(tree, q, radius, k):
+    """KDTreeFlann::SearchHybrid (Open3D 0.12): indices, SQUARED distances."""
+    d, i = tree.query(q, k=k)
+    d = np.atleast_1d(d)
+    i = np.atleast_1d(i)
+    keep = np.isfinite(d) & (d * d < radius * radius)
+    return i[keep], (d * d)[keep]
+
+
+# --------------------------------------------------------------------------- evaluation
+@dataclass
+class CorrSet:
+    kind: int
+    idx: np.ndarray   # source indices
+    p: np.ndarray     # (n,3) source points (scan frame)
+    a: np.ndarray     # (n,3) plane normal | line a | target
+    b: np.ndarray     # (n,3) line b
+    d: np.ndarray     # (n,) plane offset
+    w: np.ndarray     # (n,) weights captured at build time
+    cost: np.ndarray = field(default=None)
+
+    @property
+    def n(self):
+        return len(self.idx)
+
+
+def _hat_rows(pw):
+    """hat(pw) for many points: (n,3,3)."""
+    n = len(pw)
+    H = np.zeros((n, 3, 3))
+    H[:, 0, 1] = -pw[:, 2]; H[:, 0, 2] = pw[:, 1]
+    H[:, 1, 0] = pw[:, 2];  H[:, 1, 2] = -pw[:, 0]
+    H[:, 2, 0] = -pw[:, 1]; H[:, 2, 1] = pw[:, 0]
+    return H
+
+
+def residual_blocks(cs: CorrSet, T):
+    """Raw (un-robustified) residuals r (n,nres) and Jacobians J (n,nres,6) + side-channel cost.
+    registration.cpp:19-47 (point), :55-88 (line), :96-117 (plane)."""
+    n = cs.n
+    if n == 0:
+        nres = 1 if cs.kind in (KIND_PLANAR, KIND_GROUND) else 3
+        return np.zeros((0, nres)), np.zeros((0, nres, 6)), np.zeros(0)
+    pw = cs.p @ T[:3, :3].T + T[:3, 3]
+    Hp = _hat_rows(pw)
+    w = cs.w[:, None]
+    I3 = np.broadcast_to(np.eye(3), (n, 3, 3))
+    if cs.kind == KIND_SPHERE:
+        r = (cs.a - pw) * w                                   # :26-30
+        side = r.sum(axis=1) ** 2                             # :32
+        J = np.concatenate([-I3 * w[:, :, None], Hp * w[:, :, None]], axis=2)   # :39-40
+    elif cs.kind == KIND_EDGE:
+        nu = np.cross(pw - cs.a, pw - cs.b)                   # :62
+        den = np.linalg.norm(cs.a - cs.b, axis=1)[:, None]    # :63
+        r = nu / den * w                                      # :65-67
+        side = r.sum(axis=1) ** 2                             # :69
+        A = np.concatenate([I3 * w[:, :, None], -Hp * w[:, :, None]], axis=2)   # :77-78
+        S = _hat_rows(cs.b - cs.a)                            # :80-81
+        J = np.einsum("nij,njk->nik", S, A) / den[:, :, None]  # :83
+    else:
+        r = (np.einsum("ni,ni->n", cs.a, pw) + cs.d)[:, None]  # :100 unweighted
+        side = r[:, 0] ** 2                                    # :101
+        A = np.concatenate([I3 * w[:, :, None], -Hp * w[:, :, None]], axis=2)   # :109-110
+        J = np.einsum("ni,nij->nj", cs.a, A)[:, None, :]       # :112
+    return r, J, side
+
+
+# --------------------------------------------------------------------------- the registration
+class NpRegistration:
+    """numpy mirror of tloam::LocalRegistration (registration.hpp / registration.cpp)."""
+
+    def __init__(self, cfg=None):
+        self.cfg = dict(DEFAULT_CFG)
+        if cfg:
+            self.cfg.update(cfg)
+        self.src = [None] * 4
+        self.tgt = [None] * 4
+        self.trees = [None] * 4
+        self.tree_pts = [None] * 4
+        self.sets = [None] * 4
+        self.prebuilt = False
+
+    # registration.cpp:232-248
+    def set_source(self, kind, xyz):
+        self.src[kind] = np.ascontiguousarray(xyz, float).reshape(-1, 3)
+
+    def set_target(self, kind, xyz):
+        self.tgt[kind] = np.ascontiguousarray(xyz, float).reshape(-1, 3)
+
+    def _radius(self, kind):
+        return (self.cfg["planar_dist_thres"], self.cfg["ground_dist_thres"],
+                self.cfg["edge_dist_thres"], self.cfg["sphere_dist_thres"])[kind]
+
+    def _maxnum(self, kind):
+        return (self.cfg["planar_maxnum"], self.cfg["ground_maxnum"],
+                self.cfg["edge_maxnum"], self.cfg["sphere_maxnum"])[kind]
+
+    def _active(self, kind):
+        f = self.cfg["factor_num"]
+        return {4: True, 3: kind != KIND_SPHERE, 2: kind in (KIND_PLANAR, KIND_GROUND)}.get(f, False)
+
+    # ---- builders :427-505, :517-559, :571-635, :714-778
+    def _build(self, kind, x):
+        T = se3_exp(x)
+        src = self.src[kind]
+        tp = self.tree_pts[kind]
+        tree = self.trees[kind]
+        radius, maxnum = self._radius(kind), self._maxnum(kind)
+        pw_all = src @ T[:3, :3].T + T[:3, 3]
+        idx, P, A, B, D, W = [], [], [], [], [], []
+        num = 0
+        k = 1 if kind == KIND_SPHERE else 5
+        dd, ii = tree.query(pw_all, k=k)
+        dd = dd.reshape(len(src), k)
+        ii = ii.reshape(len(src), k)
+        for i in range(len(src)):
+            keep = np.isfinite(dd[i]) & (dd[i] * dd[i] < radius * radius)
+            nn = ii[i][keep]
+            d2 = (dd[i] * dd[i])[keep]
+            if kind == KIND_SPHERE:
+                if len(nn) > 0:
+                    if d2[0] > 0.2:            # :536
+                        continue
+                    if num >= maxnum:          # :538
+                        break
+                    idx.append(i); P.append(src[i]); A.append(tp[nn[0]]); B.append(np.zeros(3)); D.append(0.0)
+                    W.append(self.weights[kind][i])
+                num += 1                       # :551
+                continue
+            if len(nn) == 0:
+                continue
+            if kind == KIND_EDGE:
+                if len(nn) <= 3:               # :445
+                    continue
+                if num >= maxnum:              # :448
+                    break
+                pts = tp[nn]
+                m = len(nn)
+                mean = pts.sum(axis=0) / m
+                second = (pts[:, :, None] * pts[:, None, :]).sum(axis=0) / m
+                cov = second - np.outer(mean, mean)          # :466-474
+                ev, evec = np.linalg.eigh(cov)               # ascending
+                direction = evec[:, 2]
+                if ev[2] > 3 * ev[1] and abs(direction[2]) > self.cfg["edge_dir_thres"]:   # :481
+                    idx.append(i); P.append(src[i])
+                    A.append(0.1 * direction + mean); B.append(-0.1 * direction + mean); D.append(0.0)
+                    W.append(self.weights[kind][i])
+                    num += 1
+            else:
+                if len(nn) <= 4:               # :589 / :732
+                    continue
+                if num >= maxnum:              # :592 / :735
+                    break
+                near = tp[nn]
+                plane = fit_best_plane(near)
+                if np.all(near @ plane[:3] + plane[3] <= 0.2):   # :605-613 (signed)
+                    idx.append(i); P.append(src[i]); A.append(plane[:3]); B.append(np.zeros(3)); D.append(plane[3])
+                    W.append(self.weights[kind][i])
+                    num += 1
+        n = len(idx)
+        return CorrSet(kind, np.array(idx, np.int64), np.array(P, float).reshape(n, 3),
+                       np.array(A, float).reshape(n, 3), np.array(B, float).reshape(n, 3),
+                       np.array(D, float), np.array(W, float), np.zeros(n))
+
+    # ---- Ceres evaluator with CauchyLoss(1.0) + clamped Corrector (SURVEY B.1 EVAL)
+    def _evaluate(self, x, want_jac=True):
+        T = se3_exp(x)
+        cost = 0.0
+        rs, Js = [], []
+        for cs in self.sets:
+            if cs is None or cs.n == 0:
+                continue
+            r, J, side = residual_blocks(cs, T)
+            cs.cost = side
+            if not self.prebuilt:
+                self.resid[cs.kind][cs.idx] = side
+            s = (r * r).sum(axis=1)
+            cost += 0.5 * np.log(1.0 + s).sum()
+            if want_jac:
+                sr = np.sqrt(np.maximum(1.0 / (1.0 + s), np.finfo(float).tiny))
+                rs.append((r * sr[:, None]).reshape(-1))
+                Js.append((J * sr[:, None, None]).reshape(-1, 6))
+        if not want_jac:
+            return cost, None, None
+        if rs:
+            return cost, np.concatenate(rs), np.concatenate(Js)
+        return cost, np.zeros(0), np.zeros((0, 6))
+
+    def accumulate(self, x):
+        cost, r, J = self._evaluate(np.asarray(x, float), True)
+        return J.T @ J, J.T @ r, cost
+
+    # ---- ceres::Solve as configured at :1036-1047, literal DENSE_QR form
+    def _ceres_solve(self, x, stats):
+        x = np.array(x, float)
+        radius, mu, reuse = 1e4, 1e-8, False
+        x_cost, r, J = self._evaluate(x, True)
+        stats["gn_evaluations"] += 1
+        S = 1.0 / (1.0 + np.sqrt((J * J).sum(axis=0)))
+        x_norm = np.linalg.norm(x)
+        g = J.T @ r
+        gmax = np.abs(x - plus(x, -g)).max()
+        successful = True
+        iteration = 0
+        invalid = 0
+        st = {}
+        while True:
+            if iteration >= 4:
+                break
+            if successful and gmax <= 1e-10:
+                break
+            if radius <= 1e-32:
+                break
+            iteration += 1
+            stats["gn_iterations"] += 1
+            Js = J * S
+            if not reuse:
+                reuse = True
+                D = np.sqrt(np.clip((Js * Js).sum(axis=0), 1e-6, 1e32))
+                grad = (Js.T @ r) / D
+                ok = False
+                while mu < 1.0:
+                    Astack = np.vstack([Js, np.diag(np.sqrt(mu) * D)])
+                    bstack = np.concatenate([r, np.zeros(6)])
+                    y, *_ = np.linalg.lstsq(Astack, bstack, rcond=None)
+                    if np.all(np.isfinite(y)):
+                        ok = True
+                        break
+                    mu *= 10.0
+                if ok:
+                    gn = -D * y
+                    st = dict(D=D, grad=grad, gn=gn)
+            else:
+                ok = True
+            valid = False
+            if ok:
+                D, grad, gn = st["D"], st["grad"], st["gn"]
+                gnn = np.linalg.norm(gn)
+                if gnn <= radius:
+                    step = gn / D
+                    step_norm = gnn
+                else:
+                    step, step_norm = self._subspace_dogleg(Js, D, grad, gn, radius), radius
+                m = Js @ step
+                model_cost_change = -m @ (r + m / 2.0)
+                valid = model_cost_change > 0.0
+            if not valid:
+                invalid += 1
+                if invalid >= 5:
+                    break
+                mu *= 10.0
+                reuse = False
+                successful = False
+                continue
+            invalid = 0
+            delta = step * S
+            x_cand = plus(x, delta)
+            cand_cost, _, _ = self._evaluate(x_cand, False)
+            stats["gn_evaluations"] += 1
+            if np.linalg.norm(x - x_cand) <= 1e-8 * (x_norm + 1e-8):
+                break
+            if abs(x_cost - cand_cost) <= 1e-6 * x_cost:
+                break
+            rel = (x_cost - cand_cost) / model_cost_change
+            if rel > 1e-3:
+                x = x_cand
+                x_norm = np.linalg.norm(x)
+                x_cost, r, J = self._evaluate(x, True)
+                g = J.T @ r
+                gmax = np.abs(x - plus(x, -g)).max()
+                successful = True
+                stats["accepted_steps"] += 1
+                if rel < 0.25:
+                    radius *= 0.5
+                if rel > 0.75:
+                    radius = max(radius, 3.0 * step_norm)
+                mu = max(1e-8, 2.0 * mu / 10.0)
+                reuse = False
+            else:
+                successful = False
+                radius *= 0.5
+                reuse = True
+        stats["solver_cost"] = x_cost
+        return x
+
+    @staticmethod
+    def _subspace_dogleg(Js, D, grad, gn, radius):
+        """dogleg_strategy.cc ComputeSubspaceModel + ComputeSubspaceDoglegStep (GN outside)."""
+        M = np.stack([grad, gn], axis=1)
+        Q, Rm = np.linalg.qr(M)
+        if abs(Rm[1, 1]) <= 1e-14 * max(abs(Rm[0, 0]), 1e-300):
+            return -(radius / np.linalg.norm(grad)) * grad / D
+        sg = Q.T @ grad
+        JB = Js @ (Q / D[:, None])
+        B = JB.T @ JB
+        th = np.linspace(0.0, 2 * np.pi, 200001)
+        xs = radius * np.stack([np.cos(th), np.sin(th)])
+        f = 0.5 * np.einsum("in,ij,jn->n", xs, B, xs) + sg @ xs
+        t0 = th[np.argmin(f)]
+        lo, hi = t0 - 1e-4, t0 + 1e-4
+        for _ in range(200):   # golden-section free: bisect on derivative
+            mid = 0.5 * (lo + hi)
+            xm = radius * np.array([math.cos(mid), math.sin(mid)])
+            dxm = radius * np.array([-math.sin(mid), math.cos(mid)])
+            if (B @ xm + sg) @ dxm > 0:
+                hi = mid
+            else:
+                lo = mid
+        m2 = radius * np.array([math.cos(0.5 * (lo + hi)), math.sin(0.5 * (lo + hi))])
+        return (Q @ m2) / D
+
+    # ---- scanMatching :879-1133
+    def scan_match(self, predict, omega=None, trace=None):
+        cfg = self.cfg
+        for k in range(4):
+            if self.src[k] is None or self.tgt[k] is None or len(self.src[k]) < 10 or len(self.tgt[k]) < 10:
+                raise ValueError("TLOAM_E_TOO_FEW_POINTS")          # :928-929
+        x = se3_log(np.asarray(predict, float))                      # :881
+        if np.linalg.norm(x[3:]) < 1e-2:                             # :884-886
+            u = np.array([0.0, 0.0, 1.0]) if omega is None else np.asarray(omega, float) / np.linalg.norm(omega)
+            x[3:] = u * 1e-4
+        for k in range(4):                                           # :889-915
+            self.tree_pts[k] = self.tgt[k].copy()
+            self.trees[k] = cKDTree(self.tree_pts[k])
+        self.prebuilt = False
+        self.weights = [np.ones(len(self.src[k])) for k in range(4)]   # :931-949
+        self.resid = [np.zeros(len(self.src[k])) for k in range(4)]
+        prev = [math.inf] * 4
+        mu = 1.0
+        nb2 = cfg["noise_bound"] ** 2
+        if nb2 < 1e-16:
+            nb2 = 1e-2
+        stats = dict(outer_iterations=0, gn_evaluations=0, gn_iterations=0, accepted_steps=0,
+                     converged_early=0, solver_cost=0.0, bad_weights=0)
+        for it in range(cfg["max_iterations"]):                      # :966
+            self.sets = [self._build(k, x) if self._active(k) else None for k in range(4)]
+            if it == 0:                                              # :1027-1033
+                mr = max(self.resid[KIND_PLANAR].max(), self.resid[KIND_EDGE].max(), self.resid[KIND_SPHERE].max())
+                mu = 1.0 / (2.0 * mr / nb2 - 1.0)
+                if mu <= 0:
+                    mu = 1e-10
+            x = self._ceres_solve(x, stats)                          # :1036-1047
+            th1 = (mu + 1) / mu * nb2                                # :1049
+            th2 = mu / (mu + 1) * nb2                                # :1050
+            for k in range(4):                                       # :858-876
+                if not self._active(k):
+                    continue
+                r, w = self.resid[k], self.weights[k]
+                nz = r != 0
+                hi_m = nz & (r >= th1)
+                lo_m = nz & ~hi_m & (r <= th2)
+                mid = nz & ~hi_m & ~lo_m
+                w[hi_m] = 0.0
+                w[lo_m] = 1.0
+                w[mid] = np.sqrt(nb2 * mu * (mu + 1) / r[mid]) - mu
+                stats["bad_weights"] += int(((w[mid] < 0) | (w[mid] > 1)).sum())
+            mu_used = mu
+            mu = mu * math.exp((it + 1) * cfg["gnc_factor"])          # :1089
+            cur = [float(self.resid[k].sum()) for k in range(4)]     # :1091-1094
+            stats["outer_iterations"] = it + 1
+            if trace is not None:
+                trace.append(dict(
+                    iter=it, x=x.copy(), mu_used=mu_used, mu_next=mu, kind_cost=list(cur),
+                    n_corr=[0 if s is None else s.n for s in self.sets],
+                    idx=[np.zeros(0, np.int64) if s is None else s.idx.copy() for s in self.sets],
+                    a=[np.zeros((0, 3)) if s is None else s.a.copy() for s in self.sets],
+                    d=[np.zeros(0) if s is None else s.d.copy() for s in self.sets],
+                    weights=[w.copy() for w in self.weights],
+                    gn_evaluations=stats["gn_evaluations"], gn_iterations=stats["gn_iterations"],
+                    accepted_steps=stats["accepted_steps"]))
+            if abs(cur[KIND_PLANAR] - prev[KIND_PLANAR]) < cfg["cost_threshold"]:   # :1108
+                stats["converged_early"] = 1
+                break
+            prev = cur                                               # :1113-1121
+            for k in range(4):
+                self.resid[k][:] = 0.0
+        stats["kind_cost"] = cur
+        stats["mu"] = mu
+        stats["se3"] = x.copy()
+        stats["n_corr"] = [0 if s is None else s.n for s in self.sets]
+        return se3_exp(x), stats                                     # :1124
+
+    # ---- pre-built sets (K3 / solver parity)
+    def set_correspondences(self, res_type, p, a, b=None, d=None, w=None):
+        kind = {0: KIND_PLANAR, 1: KIND_EDGE, 2: KIND_SPHERE}[res_type]
+        if not self.prebuilt:
+            self.sets = [None] * 4
+            self.prebuilt = True
+        p = np.asarray(p, float).reshape(-1, 3)
+        n = len(p)
+        self.sets[kind] = CorrSet(kind, np.arange(n), p, np.asarray(a, float).reshape(n, 3),
+                                  np.zeros((n, 3)) if b is None else np.asarray(b, float).reshape(n, 3),
+                                  np.zeros(n) if d is None else np.asarray(d, float),
+                                  np.ones(n) if w is None else np.asarray(w, float), np.zeros(n))
+
+    def solve(self, x):
+        stats = dict(gn_evaluations=0, gn_iterations=0, accepted_steps=0, solver_cost=0.0)
+        x = self._ceres_solve(np.asarray(x, float), stats)
+        return x, stats
+
+    # ---- getFitnessScore :257-296
+    def fitness(self):
+        thr = self.cfg["fitness_thres"]
+        if thr <= 0:
+            return 0.0, 0.0
+        fit = rmse = 0.0
+        for k in (KIND_EDGE, KIND_SPHERE, KIND_PLANAR, KIND_GROUND):
+            if self.trees[k] is None:
+                continue
+            d, _ = self.trees[k].query(self.src[k], k=1)
+            hit = d * d < thr * thr
+            if hit.sum() > 0:
+                fit += hit.sum() / len(self.src[k])
+                rmse += math.sqrt((d[hit] ** 2).sum() / hit.sum())
+        return fit, rmse
