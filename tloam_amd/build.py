@@ -1,0 +1,72 @@
+"""Builds tloam_amd/libtloam_hip.so (hand-written HIP kernels + the C ABI) for gfx950 with hipcc.
+
+In-tree on purpose: the .so travels with the repo snapshot to the GPU box.  No CPU fallback is
+built -- if hipcc is missing this raises.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtloam_hip.so")
+OBJ = os.path.join(CSRC, "_obj")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+UNITS = [
+    # K1/K2: un-fused fp64 so the discontinuous gates see the oracle's operation order
+    ("tl_nn.hip", ["-ffp-contract=off"]),
+    ("tl_gn.hip", []),
+    ("tl_api.hip", []),
+]
+HEADERS = ["tl_common.hpp", "tl_se3.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    srcs = [os.path.join(CSRC, u) for u, _ in UNITS] + [os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    procs = []
+    for src, extra in UNITS:
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cmd = [hipcc, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

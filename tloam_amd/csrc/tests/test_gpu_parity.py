@@ -1,0 +1,133 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances: bit-exact for index work (k-NN indices, correspondence index lists, counts);
+|dt| < 1e-6 m and |dR| < 1e-6 rad for poses (BASELINE.json north_star); 1e-9 relative for the
+fp64 normal equations (different summation order / FMA contraction only).
+"""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+from oracle import binding as ob
+from tloam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_T = 1e-6
+POSE_TOL_R = 1e-6
+
+
+def _cfg_pair(reg, **over):
+    return reg.default_config(**over), ob.make_config(**over)
+
+
+def _make_pair(reg, scene, **over):
+    hc, oc = _cfg_pair(reg, **over)
+    H = reg.HipRegistration(hc)
+    O = ob.Oracle(oc)
+    H.set_frames(scene.source, scene.target)
+    O.set_frames(scene.source, scene.target)
+    return H, O
+
+
+@pytest.mark.parametrize("kind,radius,k", [(0, 0.5, 5), (1, 0.5, 5), (2, 1.0, 5), (3, 0.5, 1), (1, 0.02, 1), (2, 2.5, 8)])
+def test_knn_matches_oracle(hip_module, kind, radius, k):
+    sc = synth.make_scene(seed=3)
+    H, O = _make_pair(hip_module, sc)
+    rng = np.random.default_rng(0)
+    tgt = sc.target.cloud(kind)
+    q = np.concatenate([tgt[rng.integers(0, len(tgt), 400)] + rng.normal(0, 0.15, (400, 3)),
+                        rng.uniform(-80, 80, (50, 3)), tgt[:20]])
+    hi, hd, hc = H.knn(kind, q, radius, k)
+    oi, od, oc = O.knn(kind, q, radius, k)
+    assert np.array_equal(hc, oc)
+    assert np.array_equal(hi, oi)
+    assert np.array_equal(hd, od)          # same un-fused fp64 arithmetic -> bit-exact distances
+
+
+def test_knn_brute_force_spot_check(hip_module):
+    sc = synth.make_scene(seed=4)
+    H, _ = _make_pair(hip_module, sc)
+    tgt = sc.target.cloud(2)
+    q = tgt[::37][:64] + 0.05
+    hi, hd, hc = H.knn(2, q, 1.0, 5)
+    for j in range(len(q)):
+        bi, bd = ob.knn_brute(tgt, q[j], 1.0, 5)
+        assert hc[j] == len(bi)
+        assert np.array_equal(hi[j, :hc[j]], bi)
+        assert np.array_equal(hd[j, :hc[j]], bd)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_scan_match_stepwise_parity(hip_module, seed):
+    """Every outer GNC iteration: same correspondences (index lists bit-exact), same minimiser
+    bookkeeping, same weights, pose within 1e-6."""
+    sc = synth.make_scene(seed=seed)
+    H, O = _make_pair(hip_module, sc)
+    assert H.sm_begin(sc.T_pred) == 0
+    assert O.sm_begin(sc.T_pred) == 0
+    for it in range(4):
+        rc_h, done_h, st_h = H.sm_outer()
+        rc_o, done_o, st_o = O.sm_outer()
+        assert rc_h == 0 and rc_o == 0
+        assert st_h["n_corr"] == st_o["n_corr"], (it, st_h["n_corr"], st_o["n_corr"])
+        for kind in range(4):
+            ch, co = H.get_correspondences(kind), O.get_correspondences(kind)
+            assert np.array_equal(ch["idx"], co["idx"]), (it, kind)
+            np.testing.assert_allclose(ch["a"], co["a"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(ch["d"], co["d"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(ch["w"], co["w"], rtol=1e-9, atol=1e-15)
+            np.testing.assert_allclose(ch["cost"], co["cost"], rtol=1e-7, atol=1e-14)
+            np.testing.assert_allclose(H.get_weights(kind), O.get_weights(kind), rtol=1e-7, atol=1e-12)
+        assert (st_h["gn_iterations"], st_h["accepted_steps"], st_h["gn_evaluations"]) == \
+               (st_o["gn_iterations"], st_o["accepted_steps"], st_o["gn_evaluations"]), (it, st_h, st_o)
+        np.testing.assert_allclose(st_h["se3"], st_o["se3"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(st_h["kind_cost"], st_o["kind_cost"], rtol=1e-7, atol=1e-14)
+        assert done_h == done_o
+        if done_h:
+            break
+    _, T_h, st_h = H.sm_end()
+    _, T_o, st_o = O.sm_end()
+    dt, dr = pose_delta(T_h, T_o)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R, (dt, dr)
+    assert st_h["outer_iterations"] == st_o["outer_iterations"]
+
+
+def test_scan_match_one_call_and_scan_cloud(hip_module):
+    sc = synth.make_scene(seed=5)
+    H, O = _make_pair(hip_module, sc)
+    scan_h = np.ascontiguousarray(sc.source.planar.copy())
+    scan_o = scan_h.copy()
+    rc, T_h, st_h = H.scan_match(sc.T_pred, scan=scan_h)
+    assert rc == 0
+    rc, T_o, st_o = O.scan_match(sc.T_pred, scan=scan_o)
+    assert rc == 0
+    dt, dr = pose_delta(T_h, T_o)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R
+    np.testing.assert_allclose(scan_h, scan_o, rtol=0, atol=1e-6)
+    # and the solve actually moved the prediction towards the truth
+    assert pose_delta(T_h, sc.T_true)[0] < pose_delta(sc.T_pred, sc.T_true)[0]
+
+
+def test_prebuilt_accumulate_and_solve(hip_module):
+    sets, x_true, x_eval = synth.make_prebuilt(seed=1, n_plane=7600, n_line=2000, n_point=400)
+    H = hip_module.HipRegistration()
+    O = ob.Oracle()
+    for rt in range(3):
+        p, a, b, d, w = sets[rt]
+        H.set_correspondences(rt, p, a, b, d, w)
+        O.set_correspondences(rt, p, a, b, d, w)
+    Hh, gh, ch = H.accumulate(x_eval)
+    Ho, go, co = O.accumulate(x_eval)
+    np.testing.assert_allclose(Hh, Ho, rtol=1e-10, atol=1e-10 * np.abs(Ho).max())
+    np.testing.assert_allclose(gh, go, rtol=1e-10, atol=1e-10 * np.abs(go).max())
+    assert abs(ch - co) <= 1e-11 * abs(co)
+    for rt in range(3):
+        np.testing.assert_allclose(H.get_costs(rt), O.get_costs(rt), rtol=1e-9, atol=1e-18)
+    xh, sh = H.solve(x_eval)
+    xo, so = O.solve(x_eval)
+    np.testing.assert_allclose(xh, xo, rtol=0, atol=1e-9)
+    assert (sh["gn_iterations"], sh["accepted_steps"], sh["gn_evaluations"]) == \
+           (so["gn_iterations"], so["accepted_steps"], so["gn_evaluations"])
+    # known answer: the solve lands on the generating pose (noise 2-5 cm over ~10 k blocks)
+    assert np.linalg.norm(xh[:3] - x_true[:3]) < 5e-3 and np.linalg.norm(xh[3:] - x_true[3:]) < 2e-4

@@ -1,0 +1,1086 @@
+// tl_api.hip -- the C ABI of include/tloam_hip.h: context, HBM residency, the host driver of
+// LocalRegistration::scanMatching (registration.cpp:879-1133) and the multi-GPU exchange.
+//
+// Host side mirrors the reference's control flow (outer GNC loop, mu schedule, plateau test);
+// every per-point / per-correspondence computation is a HIP kernel (tl_nn.hip, tl_gn.hip).
+// There is no CPU fallback: without a usable device every computing entry point returns
+// TLOAM_E_HIP.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tl_common.hpp"
+
+using namespace tl;
+
+struct Uid128 { char bytes[128]; };  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+//  grow-only device buffer
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    size_t want = std::max(n, cap + cap / 2);
+    want = (want + 63) & ~size_t(63);
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, want * sizeof(T) + 256);
+    if (e != hipSuccess) return e;
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct KindData {
+  // source (this rank's block)
+  size_t n_src_full = 0, src_lo = 0, n_src = 0;
+  DBuf<double> src_aos;
+  bool src_set = false;
+  // target as given by set_target
+  size_t n_tgt = 0;
+  DBuf<double> tgt_aos, tx, ty, tz;
+  bool tgt_set = false;
+  // grid built at sm_begin (the deep copy KDTreeFlann::SetGeometry makes, :898-913)
+  DBuf<double> gx, gy, gz;
+  DBuf<int> gidx, cell_start, cell_of_pt, cell_fill;
+  DBuf<unsigned long long> cell_cnt, cell_scan;
+  GridView gv{};
+  bool grid_valid = false;
+  // compact correspondence segment
+  DBuf<int> c_idx;
+  DBuf<double> c_px, c_py, c_pz, c_ax, c_ay, c_az, c_bx, c_by, c_bz, c_d, c_w, c_cost;
+  size_t c_cap = 0;
+  size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
+};
+
+enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2 };
+
+// ---- RCCL, loaded at run time so the library also loads where librccl is absent ----------------
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Uid128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+bool load_rccl(std::string* err) {
+  if (g_rccl.handle) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // prefer the copy already in the process
+    if (h) break;
+  }
+  if (!h)
+    for (const char* nm : names) {
+      h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+  if (!h) { if (err) *err = std::string("dlopen librccl: ") + dlerror(); return false; }
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Uid128, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    if (err) *err = "librccl: missing symbols";
+    return false;
+  }
+  g_rccl.handle = h;
+  return true;
+}
+constexpr int kNcclFloat64 = 8;  // ncclDataType_t ncclFloat64 (rccl.h)
+constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
+}  // namespace
+
+struct tloam_ctx {
+  tloam_tls_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  KindData kd[kKinds];
+  // concatenated per-source-slot arrays of the current scan_match
+  DBuf<double> sx, sy, sz, w_src, rax, ray, raz, rbx, rby, rbz, rd;
+  DBuf<unsigned long long> flags, scan, scan_tmp;
+  SlotView sv{};
+  CorrView cv{};
+  DBuf<int> seg_n;
+  DBuf<double> partials, red48, sums16, wpart, rank_counts, se3_dev, bbox_dev, misc;
+  DBuf<GnState> state;
+  GnState* h_state = nullptr;  // pinned mirror
+  double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
+  int k3_grid = 1;
+  bool prebuilt = false;
+  // comm
+  int rank = 0, nranks = 1;
+  CommMode comm = COMM_NONE;
+  tloam_allreduce_fn cb = nullptr;
+  void* cb_user = nullptr;
+  void* nccl_comm = nullptr;
+  // scanMatching host state
+  bool active = false;
+  int iter = 0;
+  double mu = 1.0, noise_bound_sq = 1e-4;
+  double prev_cost[kKinds], cur_cost[kKinds];
+  tloam_stats stats;
+  // K3 timing (bench roofline)
+  bool k3_timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double k3_total_us = 0.0;
+  int64_t k3_launches = 0;
+  double k3_alg_bytes = 0.0;  // algorithmic bytes of ONE sweep over the current set
+  std::string last_error;
+};
+
+namespace {
+
+#define HIPC(ctx, expr)                                                                 \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);            \
+      return TLOAM_E_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+double kind_radius(const tloam_tls_config& c, int k) {
+  switch (k) {
+    case TLOAM_KIND_PLANAR: return c.planar_dist_thres;
+    case TLOAM_KIND_GROUND: return c.ground_dist_thres;
+    case TLOAM_KIND_EDGE: return c.edge_dist_thres;
+    default: return c.sphere_dist_thres;
+  }
+}
+int kind_maxnum(const tloam_tls_config& c, int k) {
+  switch (k) {
+    case TLOAM_KIND_PLANAR: return c.planar_maxnum;
+    case TLOAM_KIND_GROUND: return c.ground_maxnum;
+    case TLOAM_KIND_EDGE: return c.edge_maxnum;
+    default: return c.sphere_maxnum;
+  }
+}
+// registration.cpp:979-1016: factor_num 4 -> all four builders, 3 -> planar+ground+edge, 2 -> planar+ground
+int kind_active(const tloam_tls_config& c, int k) {
+  if (c.factor_num == 4) return 1;
+  if (c.factor_num == 3) return k != TLOAM_KIND_SPHERE;
+  if (c.factor_num == 2) return k == TLOAM_KIND_PLANAR || k == TLOAM_KIND_GROUND;
+  return 0;
+}
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+int sync_stream(tloam_ctx* c) {
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
+// sum all-reduce of a small device buffer of doubles across the ranks of this context
+int allreduce(tloam_ctx* c, double* dev, int count) {
+  if (c->nranks <= 1 || c->comm == COMM_NONE) return TLOAM_OK;
+  if (c->comm == COMM_CALLBACK) {
+    const int rc = c->cb(c->cb_user, dev, count, (void*)c->stream);
+    if (rc != 0) { c->last_error = "allreduce callback failed"; return TLOAM_E_RCCL; }
+    return TLOAM_OK;
+  }
+  const int rc = g_rccl.AllReduce(dev, dev, (size_t)count, kNcclFloat64, kNcclSum, c->nccl_comm, c->stream);
+  if (rc != 0) {
+    c->last_error = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return TLOAM_E_RCCL;
+  }
+  return TLOAM_OK;
+}
+
+int reserve_seg(tloam_ctx* c, int k, size_t n) {
+  KindData& K = c->kd[k];
+  const size_t cap = round_up(std::max<size_t>(n, 1), kChunk) + kChunk;  // + one chunk: double2 tail reads
+  HIPC(c, K.c_idx.reserve(cap));
+  HIPC(c, K.c_px.reserve(cap)); HIPC(c, K.c_py.reserve(cap)); HIPC(c, K.c_pz.reserve(cap));
+  HIPC(c, K.c_ax.reserve(cap)); HIPC(c, K.c_ay.reserve(cap)); HIPC(c, K.c_az.reserve(cap));
+  if (k == TLOAM_KIND_EDGE) { HIPC(c, K.c_bx.reserve(cap)); HIPC(c, K.c_by.reserve(cap)); HIPC(c, K.c_bz.reserve(cap)); }
+  if (k <= TLOAM_KIND_GROUND) HIPC(c, K.c_d.reserve(cap));
+  HIPC(c, K.c_w.reserve(cap));
+  HIPC(c, K.c_cost.reserve(cap));
+  K.c_cap = cap - kChunk;
+  CorrSeg& s = c->cv.k[k];
+  s.idx = K.c_idx.p;
+  s.px = K.c_px.p; s.py = K.c_py.p; s.pz = K.c_pz.p;
+  s.ax = K.c_ax.p; s.ay = K.c_ay.p; s.az = K.c_az.p;
+  s.bx = K.c_bx.p; s.by = K.c_by.p; s.bz = K.c_bz.p;
+  s.d = K.c_d.p;
+  s.w = K.c_w.p;
+  s.cost = K.c_cost.p;
+  s.cap = (int)K.c_cap;
+  s.pad = 0;
+  return TLOAM_OK;
+}
+
+// (re)build the search grid of one kind from the target currently set
+struct GridPlan {
+  double lo[3], hi[3];
+};
+int plan_and_build_grid(tloam_ctx* c, int k, const GridPlan& gp, double radius) {
+  KindData& K = c->kd[k];
+  const int n = (int)K.n_tgt;
+  double cell = radius * (1.0 + 1e-6);
+  double dims[3];
+  for (;;) {
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) {
+      dims[a] = floor((gp.hi[a] - gp.lo[a]) / cell) + 1.0;
+      cells *= dims[a];
+    }
+    if (cells <= 4.0e6) break;  // dense cell table bound (u64 histogram + scan per frame)
+    cell *= 1.25;
+  }
+  GridView& g = K.gv;
+  g.cell = cell;
+  g.inv_cell = 1.0 / cell;
+  size_t ncell = 1;
+  for (int a = 0; a < 3; ++a) {
+    g.org[a] = gp.lo[a];
+    g.dim[a] = (int)dims[a];
+    ncell *= (size_t)g.dim[a];
+  }
+  g.n = n;
+  HIPC(c, K.gx.reserve(n)); HIPC(c, K.gy.reserve(n)); HIPC(c, K.gz.reserve(n));
+  HIPC(c, K.gidx.reserve(n)); HIPC(c, K.cell_of_pt.reserve(n));
+  HIPC(c, K.cell_start.reserve(ncell + 1)); HIPC(c, K.cell_fill.reserve(ncell));
+  HIPC(c, K.cell_cnt.reserve(ncell)); HIPC(c, K.cell_scan.reserve(ncell));
+  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ncell)));
+  g.gx = K.gx.p; g.gy = K.gy.p; g.gz = K.gz.p; g.gidx = K.gidx.p; g.cell_start = K.cell_start.p;
+  HIPC(c, hipMemsetAsync(K.cell_cnt.p, 0, ncell * sizeof(unsigned long long), c->stream));
+  HIPC(c, hipMemsetAsync(K.cell_fill.p, 0, ncell * sizeof(int), c->stream));
+  launch_grid_count(K.tx.p, K.ty.p, K.tz.p, n, g, K.cell_cnt.p, K.cell_of_pt.p, c->stream);
+  launch_exclusive_scan_u64(K.cell_cnt.p, K.cell_scan.p, ncell, c->scan_tmp.p, c->stream);
+  launch_grid_finalize(K.cell_scan.p, ncell, n, K.cell_start.p, c->stream);
+  launch_grid_scatter(K.tx.p, K.ty.p, K.tz.p, n, K.cell_of_pt.p, K.cell_scan.p, K.cell_fill.p, K.gx.p, K.gy.p,
+                      K.gz.p, K.gidx.p, c->stream);
+  K.grid_valid = true;
+  return TLOAM_OK;
+}
+
+// bounding boxes of up to 4 target clouds with ONE host synchronisation
+int target_bboxes(tloam_ctx* c, const int* kinds, int nk, GridPlan* plans) {
+  HIPC(c, c->bbox_dev.reserve((size_t)kKinds * 64 * 6));
+  for (int i = 0; i < nk; ++i) {
+    KindData& K = c->kd[kinds[i]];
+    launch_bbox(K.tx.p, K.ty.p, K.tz.p, (int)K.n_tgt, c->bbox_dev.p + (size_t)i * 64 * 6, c->stream);
+  }
+  HIPC(c, hipMemcpyAsync(c->h_small, c->bbox_dev.p, sizeof(double) * (size_t)nk * 64 * 6, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nk; ++i) {
+    GridPlan& p = plans[i];
+    for (int a = 0; a < 3; ++a) { p.lo[a] = 1e300; p.hi[a] = -1e300; }
+    for (int b = 0; b < 64; ++b) {
+      const double* row = c->h_small + ((size_t)i * 64 + b) * 6;
+      for (int a = 0; a < 3; ++a) {
+        p.lo[a] = std::min(p.lo[a], row[a]);
+        p.hi[a] = std::max(p.hi[a], row[3 + a]);
+      }
+    }
+  }
+  return TLOAM_OK;
+}
+
+// record a pair of events around one K3 launch when the bench asks for kernel timing
+int launch_k3_timed(tloam_ctx* c, bool force) {
+  if (c->k3_timing) {
+    if (c->ev_used + 2 > c->ev_pool.size()) {
+      const size_t old = c->ev_pool.size();
+      c->ev_pool.resize(old + 256);
+      for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
+    }
+    HIPC(c, hipEventRecord(c->ev_pool[c->ev_used], c->stream));
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, force, c->stream);
+    HIPC(c, hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream));
+    c->ev_used += 2;
+  } else {
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, force, c->stream);
+  }
+  return TLOAM_OK;
+}
+// fold the recorded event pairs into the accumulated timer (stream must be idle)
+int harvest_k3_events(tloam_ctx* c, int counted_launches) {
+  if (!c->k3_timing) { c->ev_used = 0; return TLOAM_OK; }
+  // only the first `counted_launches` pairs did work (later ones were no-ops after `done`)
+  const size_t pairs = c->ev_used / 2;
+  for (size_t i = 0; i < pairs; ++i) {
+    float ms = 0.f;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
+    if ((int)i < counted_launches) {
+      c->k3_total_us += (double)ms * 1e3;
+      c->k3_launches += 1;
+    }
+  }
+  c->ev_used = 0;
+  return TLOAM_OK;
+}
+
+// one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
+// sweeps after a tolerance exit are no-op launches (GnState.done).
+int enqueue_solve(tloam_ctx* c) {
+  launch_solve_init(c->state.p, c->stream);
+  for (int sweep = 0; sweep < 5; ++sweep) {
+    int rc = launch_k3_timed(c, false);
+    if (rc != TLOAM_OK) return rc;
+    if (c->nranks > 1) {
+      launch_reduce(c->partials.p, c->k3_grid, c->state.p, c->red48.p, c->stream);
+      rc = allreduce(c, c->red48.p, kReduceBuf);  // the 42 normal-equation scalars + cost
+      if (rc != TLOAM_OK) return rc;
+      launch_gn_step(c->state.p, c->red48.p, c->stream);
+    } else {
+      launch_reduce_and_step(c->partials.p, c->k3_grid, c->state.p, c->stream);
+    }
+  }
+  return TLOAM_OK;
+}
+
+int ensure_common(tloam_ctx* c) {
+  HIPC(c, c->state.reserve(1));
+  HIPC(c, c->seg_n.reserve(8));
+  HIPC(c, c->red48.reserve(kReduceBuf));
+  HIPC(c, c->sums16.reserve(16));
+  HIPC(c, c->wpart.reserve(256 * 8));
+  HIPC(c, c->rank_counts.reserve(64 * kKinds));
+  HIPC(c, c->se3_dev.reserve(8));
+  c->cv.seg_n = c->seg_n.p;
+  return TLOAM_OK;
+}
+
+double alg_bytes_of(const int n[kKinds]) {
+  // plane 72 B, line 88 B, point 64 B per correspondence (fp64 SoA, cost write included)
+  return 72.0 * ((double)n[TLOAM_KIND_PLANAR] + (double)n[TLOAM_KIND_GROUND]) + 88.0 * (double)n[TLOAM_KIND_EDGE] +
+         64.0 * (double)n[TLOAM_KIND_SPHERE];
+}
+
+}  // namespace
+
+// ================================================================================================
+//  C ABI
+// ================================================================================================
+extern "C" {
+
+int tloam_abi_version(void) { return TLOAM_ABI_VERSION; }
+
+const char* tloam_status_string(int s) {
+  switch (s) {
+    case TLOAM_OK: return "ok";
+    case TLOAM_E_INVALID: return "invalid argument";
+    case TLOAM_E_TOO_FEW_POINTS: return "fewer than 10 points in a feature cloud";
+    case TLOAM_E_BAD_POSE: return "predicted pose is not a rigid transform";
+    case TLOAM_E_HIP: return "HIP error / no gfx950 device";
+    case TLOAM_E_RCCL: return "RCCL error";
+    case TLOAM_E_NOT_READY: return "call sequence violated";
+    case TLOAM_E_WEIGHT_RANGE: return "GNC weight outside [0,1]";
+    default: return "unknown status";
+  }
+}
+
+void tloam_default_config(tloam_tls_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));  // config/mapping/lidar_odometry.yaml:23-39
+  c->k_corr = 10;
+  c->factor_num = 4;
+  c->edge_dist_thres = 1.0;
+  c->edge_dir_thres = 0.85;
+  c->edge_maxnum = 1200;
+  c->sphere_dist_thres = 0.5;
+  c->sphere_maxnum = 200;
+  c->planar_dist_thres = 0.5;
+  c->planar_maxnum = 2500;
+  c->ground_dist_thres = 0.5;
+  c->ground_maxnum = 2000;
+  c->max_iterations = 4;
+  c->cost_threshold = 5e-9;
+  c->gnc_factor = 11.8;
+  c->noise_bound = 0.01;
+  c->fitness_thres = 0.02;
+}
+
+int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
+  if (!cfg || !out) return TLOAM_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return TLOAM_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return TLOAM_E_HIP;
+  tloam_ctx* c = new (std::nothrow) tloam_ctx();
+  if (!c) return TLOAM_E_INVALID;
+  c->cfg = *cfg;
+  c->device = device_id;
+  memset(&c->stats, 0, sizeof(c->stats));
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_small, sizeof(double) * 4096, hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return TLOAM_E_HIP;
+  }
+  if (ensure_common(c) != TLOAM_OK) { tloam_destroy(c); return TLOAM_E_HIP; }
+  (void)hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream);
+  (void)hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  *out = c;
+  return TLOAM_OK;
+}
+
+void tloam_destroy(tloam_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl_comm);
+  for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+  for (int k = 0; k < kKinds; ++k) {
+    KindData& K = c->kd[k];
+    K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
+    K.gx.release(); K.gy.release(); K.gz.release(); K.gidx.release(); K.cell_start.release();
+    K.cell_of_pt.release(); K.cell_fill.release(); K.cell_cnt.release(); K.cell_scan.release();
+    K.c_idx.release(); K.c_px.release(); K.c_py.release(); K.c_pz.release(); K.c_ax.release();
+    K.c_ay.release(); K.c_az.release(); K.c_bx.release(); K.c_by.release(); K.c_bz.release();
+    K.c_d.release(); K.c_w.release(); K.c_cost.release();
+  }
+  c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
+  c->rax.release(); c->ray.release(); c->raz.release(); c->rbx.release(); c->rby.release(); c->rbz.release();
+  c->rd.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
+  c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
+  c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release();
+  if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* tloam_last_error(const tloam_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi) {
+  if (nranks < 1) nranks = 1;
+  if (rank < 0) rank = 0;
+  if (rank >= nranks) rank = nranks - 1;
+  // contiguous index blocks keep the reference's "first N valid in index order" cap semantics
+  const size_t a = (size_t)(((unsigned __int128)n * (unsigned)rank) / (unsigned)nranks);
+  const size_t b = (size_t)(((unsigned __int128)n * (unsigned)(rank + 1)) / (unsigned)nranks);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+
+// ---- setInputSource / setInputTarget (registration.cpp:232-248) --------------------------------
+int tloam_set_source(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (!c || kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  KindData& K = c->kd[kind];
+  size_t lo = 0, hi = n;
+  tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
+  K.n_src_full = n;
+  K.src_lo = lo;
+  K.n_src = hi - lo;
+  HIPC(c, K.src_aos.reserve(3 * std::max<size_t>(K.n_src, 1)));
+  if (K.n_src > 0)
+    HIPC(c, hipMemcpyAsync(K.src_aos.p, xyz + 3 * lo, sizeof(double) * 3 * K.n_src, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
+  K.src_set = true;
+  return TLOAM_OK;
+}
+
+int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (!c || kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  KindData& K = c->kd[kind];
+  K.n_tgt = n;
+  const size_t m = std::max<size_t>(n, 1);
+  HIPC(c, K.tgt_aos.reserve(3 * m));
+  HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
+  if (n > 0) {
+    HIPC(c, hipMemcpyAsync(K.tgt_aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(K.tgt_aos.p, n, K.tx.p, K.ty.p, K.tz.p, c->stream);  // AoS -> SoA on the device
+  }
+  HIPC(c, hipStreamSynchronize(c->stream));
+  K.tgt_set = true;
+  return TLOAM_OK;
+}
+
+// ---- scanMatching, stepwise ---------------------------------------------------------------------
+int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3) {
+  if (!c || !predict) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  for (int k = 0; k < kKinds; ++k)  // the reference asserts (registration.cpp:928-929)
+    if (c->kd[k].n_src_full < 10 || c->kd[k].n_tgt < 10) return TLOAM_E_TOO_FEW_POINTS;
+  Pose P;
+  if (!pose_from_matrix(predict, &P)) return TLOAM_E_BAD_POSE;  // SOPHUS_ENSURE in the reference
+  double x[6];
+  se3_log(P, x);  // :881
+  if (sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]) < 1e-2) {  // :884-886
+    double u[3] = {0.0, 0.0, 1.0};
+    if (omega3) {
+      const double nn = sqrt(omega3[0] * omega3[0] + omega3[1] * omega3[1] + omega3[2] * omega3[2]);
+      if (nn > 0.0) { u[0] = omega3[0] / nn; u[1] = omega3[1] / nn; u[2] = omega3[2] / nn; }
+    }
+    x[3] = u[0] * 1e-4; x[4] = u[1] * 1e-4; x[5] = u[2] * 1e-4;
+  }
+  int rc = ensure_common(c);
+  if (rc != TLOAM_OK) return rc;
+  // ---- :889-915 four search structures over the submap clouds, one host sync for the 4 boxes
+  {
+    int kinds[kKinds] = {0, 1, 2, 3};
+    GridPlan plans[kKinds];
+    rc = target_bboxes(c, kinds, kKinds, plans);
+    if (rc != TLOAM_OK) return rc;
+    for (int k = 0; k < kKinds; ++k) {
+      rc = plan_and_build_grid(c, k, plans[k], kind_radius(c->cfg, k));
+      if (rc != TLOAM_OK) return rc;
+    }
+  }
+  // ---- per-source-slot arrays (:931-949 weights = 1, residual slots = 0)
+  size_t off = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    c->sv.slot_off[k] = (int)off;
+    c->sv.src_lo[k] = (int)c->kd[k].src_lo;
+    off += c->kd[k].n_src;
+  }
+  c->sv.slot_off[kKinds] = (int)off;
+  const size_t ns = std::max<size_t>(off, 1);
+  HIPC(c, c->sx.reserve(ns)); HIPC(c, c->sy.reserve(ns)); HIPC(c, c->sz.reserve(ns)); HIPC(c, c->w_src.reserve(ns));
+  HIPC(c, c->rax.reserve(ns)); HIPC(c, c->ray.reserve(ns)); HIPC(c, c->raz.reserve(ns));
+  HIPC(c, c->rbx.reserve(ns)); HIPC(c, c->rby.reserve(ns)); HIPC(c, c->rbz.reserve(ns)); HIPC(c, c->rd.reserve(ns));
+  HIPC(c, c->flags.reserve(ns + 1)); HIPC(c, c->scan.reserve(ns + 1));
+  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ns + 1)));
+  c->sv.sx = c->sx.p; c->sv.sy = c->sy.p; c->sv.sz = c->sz.p; c->sv.w_src = c->w_src.p;
+  c->sv.rax = c->rax.p; c->sv.ray = c->ray.p; c->sv.raz = c->raz.p;
+  c->sv.rbx = c->rbx.p; c->sv.rby = c->rby.p; c->sv.rbz = c->rbz.p; c->sv.rd = c->rd.p;
+  c->sv.flags = c->flags.p; c->sv.scan = c->scan.p;
+  for (int k = 0; k < kKinds; ++k) {
+    const KindData& K = c->kd[k];
+    launch_aos_to_soa(K.src_aos.p, K.n_src, c->sx.p + c->sv.slot_off[k], c->sy.p + c->sv.slot_off[k],
+                      c->sz.p + c->sv.slot_off[k], c->stream);
+  }
+  launch_fill_f64(c->w_src.p, off, 1.0, c->stream);
+  HIPC(c, hipMemsetAsync(c->flags.p + off, 0, sizeof(unsigned long long), c->stream));
+  // ---- compact segments: at most min(n_src, maxnum) factors per kind
+  size_t total_cap = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    const size_t cap = std::min<size_t>(c->kd[k].n_src, (size_t)std::max(kind_maxnum(c->cfg, k), 0));
+    rc = reserve_seg(c, k, cap);
+    if (rc != TLOAM_OK) return rc;
+    total_cap += round_up(std::max<size_t>(cap, 1), kChunk);
+  }
+  c->prebuilt = false;
+  c->k3_grid = k3_grid_for((int)total_cap);
+  HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
+  // ---- minimiser state: zero counters, upload `parameters`
+  HIPC(c, hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream));
+  HIPC(c, hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream));
+  memcpy(c->h_small, x, sizeof(double) * 6);
+  HIPC(c, hipMemcpyAsync(c->state.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));  // GnState.x is first
+  launch_solve_init(c->state.p, c->stream);  // T_cur = exp(x) for the first builder pass
+  HIPC(c, hipStreamSynchronize(c->stream));  // h_small is reused below
+  c->mu = 1.0;  // :961
+  c->noise_bound_sq = c->cfg.noise_bound * c->cfg.noise_bound;
+  if (c->noise_bound_sq < 1e-16) c->noise_bound_sq = 1e-2;  // :963-964
+  for (int k = 0; k < kKinds; ++k) { c->prev_cost[k] = INFINITY; c->cur_cost[k] = INFINITY; }  // :952-959
+  c->iter = 0;
+  c->active = true;
+  memset(&c->stats, 0, sizeof(c->stats));
+  memcpy(c->stats.se3, x, sizeof(x));
+  c->ev_used = 0;
+  return TLOAM_OK;
+}
+
+int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
+  if (!c || !c->active) return TLOAM_E_NOT_READY;
+  HIPC(c, hipSetDevice(c->device));
+  const int iter = c->iter;
+  if (iter >= c->cfg.max_iterations) {  // loop condition :966
+    if (done) *done = 1;
+    if (stats) *stats = c->stats;
+    return TLOAM_OK;
+  }
+  int rc;
+  // ---- :976-1020 the four builders (K1 + K2), then the index-order caps
+  BuildParams bp;
+  for (int k = 0; k < kKinds; ++k) {
+    bp.radius[k] = kind_radius(c->cfg, k);
+    bp.maxnum[k] = kind_maxnum(c->cfg, k);
+    bp.active[k] = kind_active(c->cfg, k);
+  }
+  bp.edge_dir_thres = c->cfg.edge_dir_thres;
+  GridView grids[kKinds];
+  for (int k = 0; k < kKinds; ++k) grids[k] = c->kd[k].gv;
+  const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
+  launch_build(c->sv, grids, bp, c->state.p, c->stream);
+  launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream);
+  const double* rank_counts = nullptr;
+  if (c->nranks > 1) {
+    launch_rank_counts(c->sv, c->rank_counts.p, c->rank, c->nranks, c->stream);
+    rc = allreduce(c, c->rank_counts.p, c->nranks * kKinds);
+    if (rc != TLOAM_OK) return rc;
+    rank_counts = c->rank_counts.p;
+  }
+  HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
+  launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->stream);
+  if (iter == 0) {
+    // :1027-1033.  At this point no Evaluate() has run in iteration 0, so every residual slot the
+    // reference takes maxCoeff() over is still the 0 it was initialised with (:931-949); the
+    // literal formula then gives mu = 1/(0 - 1) = -1 -> 1e-10.
+    const double max_residual = 0.0;
+    c->mu = 1 / (2 * max_residual / c->noise_bound_sq - 1.0);
+    if (c->mu <= 0) c->mu = 1e-10;
+  }
+  // ---- :1036-1047 ceres::Solve, device resident
+  rc = enqueue_solve(c);
+  if (rc != TLOAM_OK) return rc;
+  // ---- :1049-1086 thresholds + weight update, :1091-1094 cost sums
+  const double mu = c->mu;
+  WeightParams wp;
+  wp.th1 = (mu + 1) / mu * c->noise_bound_sq;
+  wp.th2 = mu / (mu + 1) * c->noise_bound_sq;
+  wp.mu = mu;
+  wp.noise_bound_sq = c->noise_bound_sq;
+  for (int k = 0; k < kKinds; ++k) wp.active[k] = bp.active[k];
+  const int wblocks = 64;
+  launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->stream);
+  launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->sums16.p, c->stream);
+  rc = allreduce(c, c->sums16.p, 16);
+  if (rc != TLOAM_OK) return rc;
+  launch_outer_publish(c->sums16.p, c->state.p, c->stream);
+  const int evals_before = c->stats.gn_evaluations;
+  HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const GnState& S = *c->h_state;
+  rc = harvest_k3_events(c, S.gn_evaluations - evals_before);
+  if (rc != TLOAM_OK) return rc;
+  c->mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
+  tloam_stats& st = c->stats;
+  st.outer_iterations = iter + 1;
+  st.gn_evaluations = S.gn_evaluations;
+  st.gn_iterations = S.gn_iterations;
+  st.accepted_steps = S.accepted_steps;
+  st.reserved0 = S.bad_weights;
+  st.mu = c->mu;
+  st.solver_cost = S.x_cost;
+  memcpy(st.se3, S.x, sizeof(double) * 6);
+  for (int k = 0; k < kKinds; ++k) {
+    c->cur_cost[k] = S.kind_cost[k];
+    st.kind_cost[k] = S.kind_cost[k];
+    st.n_corr[k] = S.n_corr[k];
+  }
+  {
+    int nn[kKinds];
+    for (int k = 0; k < kKinds; ++k) nn[k] = S.n_corr[k];
+    c->k3_alg_bytes = alg_bytes_of(nn);
+  }
+  int fin = 0;
+  if (fabs(c->cur_cost[TLOAM_KIND_PLANAR] - c->prev_cost[TLOAM_KIND_PLANAR]) < c->cfg.cost_threshold) {  // :1108
+    st.converged_early = 1;
+    fin = 1;
+  } else {
+    for (int k = 0; k < kKinds; ++k) c->prev_cost[k] = c->cur_cost[k];  // :1113-1116 (slots re-zeroed by the next compaction)
+    c->iter = iter + 1;
+    if (c->iter >= c->cfg.max_iterations) fin = 1;
+  }
+  if (fin) c->iter = c->cfg.max_iterations;
+  if (done) *done = fin;
+  if (stats) *stats = st;
+  return TLOAM_OK;
+}
+
+int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
+  if (!c || !c->active || !result) return TLOAM_E_NOT_READY;
+  const Pose T = se3_exp(c->stats.se3);  // :1124 exp(se3_pose_).matrix()
+  pose_to_matrix(T, result);
+  if (stats) *stats = c->stats;
+  c->active = false;
+  return TLOAM_OK;
+}
+
+int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega3, double result[16],
+                     double* scan_xyz, size_t n_scan, tloam_stats* stats) {
+  int rc = tloam_sm_begin(c, predict, omega3);
+  if (rc != TLOAM_OK) return rc;
+  int done = 0;
+  while (!done) {
+    rc = tloam_sm_outer(c, &done, nullptr);
+    if (rc != TLOAM_OK) return rc;
+  }
+  rc = tloam_sm_end(c, result, stats);
+  if (rc != TLOAM_OK) return rc;
+  if (scan_xyz && n_scan > 0) {  // :1126-1128 out_result_.scan_cloud->Transform(curr_frame_pose)
+    HIPC(c, c->misc.reserve(3 * n_scan));
+    HIPC(c, hipMemcpyAsync(c->misc.p, scan_xyz, sizeof(double) * 3 * n_scan, hipMemcpyHostToDevice, c->stream));
+    launch_transform_cloud(c->misc.p, n_scan, result, c->stream);
+    HIPC(c, hipMemcpyAsync(scan_xyz, c->misc.p, sizeof(double) * 3 * n_scan, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
+  return TLOAM_OK;
+}
+
+// ---- getFitnessScore (registration.cpp:257-296) -------------------------------------------------
+int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
+  if (!c || !fitness || !rmse) return TLOAM_E_INVALID;
+  *fitness = 0.0;
+  *rmse = 0.0;
+  if (c->cfg.fitness_thres <= 0.0) return TLOAM_OK;  // :258-261
+  HIPC(c, hipSetDevice(c->device));
+  const int blocks = 64;
+  HIPC(c, c->misc.reserve(4096));
+  const int order[kKinds] = {TLOAM_KIND_EDGE, TLOAM_KIND_SPHERE, TLOAM_KIND_PLANAR, TLOAM_KIND_GROUND};  // :287-290
+  double fit_local[kKinds] = {0, 0, 0, 0}, err_local[kKinds] = {0, 0, 0, 0};
+  for (int o = 0; o < kKinds; ++o) {
+    const int k = order[o];
+    KindData& K = c->kd[k];
+    // the kd-trees are the ones built by the last scanMatching (:889-915); none yet -> no hits
+    if (!K.grid_valid || K.n_src == 0) continue;
+    if (c->cfg.fitness_thres > K.gv.cell) { c->last_error = "fitness_thres larger than the search cell"; return TLOAM_E_INVALID; }
+    // raw scan-frame source points (:271): convert this kind's AoS block to SoA scratch
+    HIPC(c, c->sx.reserve(K.n_src)); HIPC(c, c->sy.reserve(K.n_src)); HIPC(c, c->sz.reserve(K.n_src));
+    launch_aos_to_soa(K.src_aos.p, K.n_src, c->sx.p, c->sy.p, c->sz.p, c->stream);
+    launch_fitness(K.gv, c->sx.p, c->sy.p, c->sz.p, (int)K.n_src, c->cfg.fitness_thres, c->misc.p, blocks, c->stream);
+    HIPC(c, hipMemcpyAsync(c->h_small, c->misc.p, sizeof(double) * blocks * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < blocks; ++b) { err_local[k] += c->h_small[2 * b]; fit_local[k] += c->h_small[2 * b + 1]; }
+  }
+  if (c->nranks > 1) {  // sharded sources: hits and squared errors add up across ranks
+    HIPC(c, c->misc.reserve(16));
+    for (int k = 0; k < kKinds; ++k) { c->h_small[k] = fit_local[k]; c->h_small[4 + k] = err_local[k]; }
+    HIPC(c, hipMemcpyAsync(c->misc.p, c->h_small, sizeof(double) * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = allreduce(c, c->misc.p, 8);
+    if (rc != TLOAM_OK) return rc;
+    HIPC(c, hipMemcpyAsync(c->h_small, c->misc.p, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < kKinds; ++k) { fit_local[k] = c->h_small[k]; err_local[k] = c->h_small[4 + k]; }
+  }
+  for (int o = 0; o < kKinds; ++o) {
+    const int k = order[o];
+    if (fit_local[k] > 0.0) {  // :278-284
+      *fitness += fit_local[k] / (double)c->kd[k].n_src_full;
+      *rmse += sqrt(err_local[k] / fit_local[k]);
+    }
+  }
+  return TLOAM_OK;
+}
+
+// ---- introspection --------------------------------------------------------------------------------
+static int download_soa3(tloam_ctx* c, const double* x, const double* y, const double* z, size_t n, double* aos) {
+  std::vector<double> tmp(3 * n);
+  HIPC(c, hipMemcpy(tmp.data(), x, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIPC(c, hipMemcpy(tmp.data() + n, y, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIPC(c, hipMemcpy(tmp.data() + 2 * n, z, sizeof(double) * n, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) { aos[3 * i] = tmp[i]; aos[3 * i + 1] = tmp[n + i]; aos[3 * i + 2] = tmp[2 * n + i]; }
+  return TLOAM_OK;
+}
+
+int tloam_get_correspondences(tloam_ctx* c, int kind, size_t capacity, size_t* n, int32_t* src_index, double* a,
+                              double* b, double* d, double* w, double* cost) {
+  if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  int segn[kKinds];
+  HIPC(c, hipMemcpy(segn, c->seg_n.p, sizeof(segn), hipMemcpyDeviceToHost));
+  const size_t m = (size_t)segn[kind];
+  *n = m;
+  if (m > capacity) return TLOAM_E_INVALID;
+  if (m == 0) return TLOAM_OK;
+  const CorrSeg& s = c->cv.k[kind];
+  int rc;
+  if (src_index) HIPC(c, hipMemcpy(src_index, s.idx, sizeof(int) * m, hipMemcpyDeviceToHost));
+  if (a && (rc = download_soa3(c, s.ax, s.ay, s.az, m, a)) != TLOAM_OK) return rc;
+  if (b && kind == TLOAM_KIND_EDGE && (rc = download_soa3(c, s.bx, s.by, s.bz, m, b)) != TLOAM_OK) return rc;
+  if (d && kind <= TLOAM_KIND_GROUND) HIPC(c, hipMemcpy(d, s.d, sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (w) HIPC(c, hipMemcpy(w, s.w, sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (cost) HIPC(c, hipMemcpy(cost, s.cost, sizeof(double) * m, hipMemcpyDeviceToHost));
+  return TLOAM_OK;
+}
+
+int tloam_get_weights(tloam_ctx* c, int kind, size_t capacity, size_t* n, double* w) {
+  if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  const size_t m = c->kd[kind].n_src;
+  *n = m;
+  if (m > capacity || !c->w_src.p) return TLOAM_E_INVALID;
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (w && m > 0) HIPC(c, hipMemcpy(w, c->w_src.p + c->sv.slot_off[kind], sizeof(double) * m, hipMemcpyDeviceToHost));
+  return TLOAM_OK;
+}
+
+int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius, int k, int32_t* out_idx,
+              double* out_d2, int32_t* out_cnt) {
+  if (!c || kind < 0 || kind >= kKinds || !q || k < 1 || k > kMaxK || !(radius > 0.0) || !out_idx || !out_d2 || !out_cnt)
+    return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  KindData& K = c->kd[kind];
+  if (!K.tgt_set || K.n_tgt == 0) {
+    for (size_t i = 0; i < nq; ++i) out_cnt[i] = 0;
+    for (size_t i = 0; i < nq * (size_t)k; ++i) { out_idx[i] = -1; out_d2[i] = 0.0; }
+    return TLOAM_OK;
+  }
+  int rc;
+  {  // a grid over the target currently set, sized for this radius
+    int kinds[1] = {kind};
+    GridPlan plan;
+    rc = target_bboxes(c, kinds, 1, &plan);
+    if (rc != TLOAM_OK) return rc;
+    rc = plan_and_build_grid(c, kind, plan, radius);
+    if (rc != TLOAM_OK) return rc;
+  }
+  DBuf<double> qa, qx, qy, qz, d2;
+  DBuf<int> idx, cnt;
+  auto cleanup = [&]() { qa.release(); qx.release(); qy.release(); qz.release(); d2.release(); idx.release(); cnt.release(); };
+  hipError_t e = hipSuccess;
+  if ((e = qa.reserve(3 * nq + 3)) != hipSuccess || (e = qx.reserve(nq + 1)) != hipSuccess ||
+      (e = qy.reserve(nq + 1)) != hipSuccess || (e = qz.reserve(nq + 1)) != hipSuccess ||
+      (e = d2.reserve(nq * k + 1)) != hipSuccess || (e = idx.reserve(nq * k + 1)) != hipSuccess ||
+      (e = cnt.reserve(nq + 1)) != hipSuccess) {
+    cleanup();
+    c->last_error = hipGetErrorString(e);
+    return TLOAM_E_HIP;
+  }
+  if (nq > 0) {
+    (void)hipMemcpyAsync(qa.p, q, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, c->stream);
+    launch_aos_to_soa(qa.p, nq, qx.p, qy.p, qz.p, c->stream);
+    launch_knn(K.gv, qx.p, qy.p, qz.p, (int)nq, radius, k, idx.p, d2.p, cnt.p, c->stream);
+    (void)hipMemcpyAsync(out_idx, idx.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, c->stream);
+    (void)hipMemcpyAsync(out_d2, d2.p, sizeof(double) * nq * k, hipMemcpyDeviceToHost, c->stream);
+    (void)hipMemcpyAsync(out_cnt, cnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost, c->stream);
+  }
+  e = hipStreamSynchronize(c->stream);
+  cleanup();
+  if (e != hipSuccess) { c->last_error = hipGetErrorString(e); return TLOAM_E_HIP; }
+  return TLOAM_OK;
+}
+
+// ---- pre-built correspondence sets ------------------------------------------------------------------
+int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double* p, const double* a, const double* b,
+                              const double* d, const double* w) {
+  if (!c || res_type < 0 || res_type >= TLOAM_NUM_RES) return TLOAM_E_INVALID;
+  if (n > 0 && (!p || !a || !w || (res_type == TLOAM_RES_LINE && !b) || (res_type == TLOAM_RES_PLANE && !d)))
+    return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  int rc = ensure_common(c);
+  if (rc != TLOAM_OK) return rc;
+  const int kind = res_type == TLOAM_RES_PLANE ? TLOAM_KIND_PLANAR : (res_type == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE);
+  if (!c->prebuilt) {
+    HIPC(c, hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream));
+    for (int k = 0; k < kKinds; ++k) {
+      rc = reserve_seg(c, k, 1);
+      if (rc != TLOAM_OK) return rc;
+      c->kd[k].pre_n_full = 0;
+    }
+    c->prebuilt = true;
+    c->active = false;
+  }
+  size_t lo = 0, hi = n;
+  tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
+  const size_t m = hi - lo;
+  KindData& K = c->kd[kind];
+  K.pre_lo = lo;
+  K.pre_n_full = n;
+  rc = reserve_seg(c, kind, m);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, c->misc.reserve(3 * std::max<size_t>(m, 1)));
+  const CorrSeg& s = c->cv.k[kind];
+  if (m > 0) {
+    HIPC(c, hipMemcpyAsync(c->misc.p, p + 3 * lo, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(c->misc.p, m, s.px, s.py, s.pz, c->stream);
+    HIPC(c, hipMemcpyAsync(c->misc.p, a + 3 * lo, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(c->misc.p, m, s.ax, s.ay, s.az, c->stream);
+    if (res_type == TLOAM_RES_LINE) {
+      HIPC(c, hipMemcpyAsync(c->misc.p, b + 3 * lo, sizeof(double) * 3 * m, hipMemcpyHostToDevice, c->stream));
+      launch_aos_to_soa(c->misc.p, m, s.bx, s.by, s.bz, c->stream);
+    }
+    if (res_type == TLOAM_RES_PLANE) HIPC(c, hipMemcpyAsync(s.d, d + lo, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(s.w, w + lo, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemsetAsync(s.cost, 0, sizeof(double) * m, c->stream));
+    std::vector<int> ids(m);
+    for (size_t i = 0; i < m; ++i) ids[i] = (int)(lo + i);
+    HIPC(c, hipMemcpyAsync(s.idx, ids.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
+  const int mi = (int)m;
+  HIPC(c, hipMemcpyAsync(c->seg_n.p + kind, &mi, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  size_t total_cap = 0;
+  int nn[kKinds];
+  for (int k = 0; k < kKinds; ++k) {
+    total_cap += c->kd[k].c_cap;
+    nn[k] = (k == kind) ? mi : 0;
+  }
+  {  // algorithmic bytes of one sweep over the whole (job-wide) pre-built set
+    int full[kKinds] = {(int)c->kd[0].pre_n_full, 0, (int)c->kd[2].pre_n_full, (int)c->kd[3].pre_n_full};
+    c->k3_alg_bytes = alg_bytes_of(full);
+    (void)nn;
+  }
+  c->k3_grid = k3_grid_for((int)total_cap);
+  HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
+  return TLOAM_OK;
+}
+
+int tloam_accumulate(tloam_ctx* c, const double se3[6], double H[36], double g[6], double* cost) {
+  if (!c || !se3) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!c->partials.p) return TLOAM_E_NOT_READY;
+  memcpy(c->h_small, se3, sizeof(double) * 6);
+  HIPC(c, hipMemcpyAsync(c->se3_dev.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+  launch_set_eval(c->state.p, c->se3_dev.p, c->stream);
+  int rc = launch_k3_timed(c, true);
+  if (rc != TLOAM_OK) return rc;
+  launch_reduce(c->partials.p, c->k3_grid, c->state.p, c->red48.p, c->stream);
+  rc = allreduce(c, c->red48.p, kReduceBuf);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, hipMemcpyAsync(c->h_small + 8, c->red48.p, sizeof(double) * kReduceBuf, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  rc = harvest_k3_events(c, 1);
+  if (rc != TLOAM_OK) return rc;
+  const double* t = c->h_small + 8;
+  if (H) {
+    int u = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) { H[i * 6 + j] = t[u]; H[j * 6 + i] = t[u]; ++u; }
+  }
+  if (g) for (int i = 0; i < 6; ++i) g[i] = t[21 + i];
+  if (cost) *cost = t[27];
+  return TLOAM_OK;
+}
+
+int tloam_get_costs(tloam_ctx* c, int res_type, size_t capacity, size_t* n, double* cost) {
+  if (!c || res_type < 0 || res_type >= TLOAM_NUM_RES || !n) return TLOAM_E_INVALID;
+  const int kind = res_type == TLOAM_RES_PLANE ? TLOAM_KIND_PLANAR : (res_type == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE);
+  return tloam_get_correspondences(c, kind, capacity, n, nullptr, nullptr, nullptr, nullptr, nullptr, cost);
+}
+
+int tloam_solve(tloam_ctx* c, double se3[6], tloam_stats* stats) {
+  if (!c || !se3) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!c->partials.p) return TLOAM_E_NOT_READY;
+  HIPC(c, hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream));
+  memcpy(c->h_small, se3, sizeof(double) * 6);
+  HIPC(c, hipMemcpyAsync(c->state.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+  int rc = enqueue_solve(c);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const GnState& S = *c->h_state;
+  rc = harvest_k3_events(c, S.gn_evaluations);
+  if (rc != TLOAM_OK) return rc;
+  memcpy(se3, S.x, sizeof(double) * 6);
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->gn_evaluations = S.gn_evaluations;
+    stats->gn_iterations = S.gn_iterations;
+    stats->accepted_steps = S.accepted_steps;
+    stats->solver_cost = S.x_cost;
+    memcpy(stats->se3, S.x, sizeof(double) * 6);
+  }
+  return TLOAM_OK;
+}
+
+int tloam_time_accumulate(tloam_ctx* c, const double se3[6], int launches, double* mean_us) {
+  if (!c || !se3 || launches < 1 || !mean_us) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!c->partials.p) return TLOAM_E_NOT_READY;
+  memcpy(c->h_small, se3, sizeof(double) * 6);
+  HIPC(c, hipMemcpyAsync(c->se3_dev.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+  launch_set_eval(c->state.p, c->se3_dev.p, c->stream);
+  hipEvent_t e0, e1;
+  HIPC(c, hipEventCreate(&e0));
+  HIPC(c, hipEventCreate(&e1));
+  HIPC(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; ++i) launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, true, c->stream);
+  HIPC(c, hipEventRecord(e1, c->stream));
+  HIPC(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_us = (double)ms * 1e3 / launches;
+  return TLOAM_OK;
+}
+
+int tloam_k3_timer(tloam_ctx* c, int reset, double* total_us, int64_t* launches, double* algorithmic_bytes) {
+  if (!c) return TLOAM_E_INVALID;
+  if (total_us) *total_us = c->k3_total_us;
+  if (launches) *launches = c->k3_launches;
+  if (algorithmic_bytes) *algorithmic_bytes = c->k3_alg_bytes;
+  if (reset) {
+    c->k3_total_us = 0.0;
+    c->k3_launches = 0;
+  }
+  c->k3_timing = true;  // first call arms the per-launch event pairs
+  return TLOAM_OK;
+}
+
+// ---- multi-GPU -------------------------------------------------------------------------------------
+int tloam_rccl_unique_id(void* out128) {
+  if (!out128) return TLOAM_E_INVALID;
+  std::string err;
+  if (!load_rccl(&err)) return TLOAM_E_RCCL;
+  Uid128 id;
+  memset(&id, 0, sizeof(id));
+  if (g_rccl.GetUniqueId(&id) != 0) return TLOAM_E_RCCL;
+  memcpy(out128, &id, sizeof(id));
+  return TLOAM_OK;
+}
+
+int tloam_comm_init_rccl(tloam_ctx* c, int rank, int nranks, const void* unique_id128) {
+  if (!c || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!load_rccl(&c->last_error)) return TLOAM_E_RCCL;
+  Uid128 id;
+  memcpy(&id, unique_id128, sizeof(id));
+  void* comm = nullptr;
+  const int rc = g_rccl.CommInitRank(&comm, nranks, id, rank);
+  if (rc != 0) {
+    c->last_error = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return TLOAM_E_RCCL;
+  }
+  c->nccl_comm = comm;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->comm = COMM_RCCL;
+  return TLOAM_OK;
+}
+
+int tloam_comm_init_callback(tloam_ctx* c, int rank, int nranks, tloam_allreduce_fn fn, void* user) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return TLOAM_E_INVALID;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->cb = fn;
+  c->cb_user = user;
+  c->comm = COMM_CALLBACK;
+  return TLOAM_OK;
+}
+
+// ---- SE(3) helpers (host) ------------------------------------------------------------------------------
+int tloam_se3_exp(const double se3[6], double T[16]) {
+  if (!se3 || !T) return TLOAM_E_INVALID;
+  pose_to_matrix(se3_exp(se3), T);
+  return TLOAM_OK;
+}
+int tloam_se3_log(const double T[16], double se3[6]) {
+  if (!se3 || !T) return TLOAM_E_INVALID;
+  Pose P;
+  if (!pose_from_matrix(T, &P)) return TLOAM_E_BAD_POSE;
+  se3_log(P, se3);
+  return TLOAM_OK;
+}
+int tloam_se3_plus(const double x[6], const double delta[6], double out[6]) {
+  if (!x || !delta || !out) return TLOAM_E_INVALID;
+  se3_plus(x, delta, out);
+  return TLOAM_OK;
+}
+
+}  // extern "C"

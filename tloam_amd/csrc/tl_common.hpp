@@ -1,0 +1,166 @@
+// tl_common.hpp -- shared device-side data structures of the MI355X T-LOAM pose-optimisation path.
+//
+// HBM layout (all fp64 SoA, one array per component, 256-B aligned, sized for 288 GB parts):
+//   source clouds   sx/sy/sz[k][n_src_local], GNC weights w_src[k][n]      (one slot per source point)
+//   target clouds   tx/ty/tz[k][n_tgt] (as given) + cell-sorted copy gx/gy/gz/gidx + cell table
+//   raw records     per source slot: a(3) b(3) d + flags        (written by the builder, K1+K2)
+//   compact set     one SoA segment per kind: idx, px py pz, ax ay az, [bx by bz], [d], w, cost
+//                   (streamed by K3; cost written back)
+//   partials        [gridDim][32] per-block sums of H(21) g(6) cost(1)
+//   GnState         the Ceres-minimiser / dogleg state machine + pose, device resident
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tloam_hip.h"
+#include "tl_se3.hpp"
+
+namespace tl {
+
+constexpr int kKinds = 4;
+constexpr int kAccN = 28;        // 21 upper-triangular H + 6 g + 1 cost
+constexpr int kAccStride = 32;   // padded row of the partials buffer
+constexpr int kReduceBuf = 48;   // the all-reduced buffer: 28 used + per-kind tail
+constexpr int kChunk = 128;      // correspondences per wave-chunk in K3 (64 lanes x 2)
+constexpr int kMaxK = 8;         // max neighbours of tloam_knn
+
+// residual type of a kind (registration.cpp:981-992 builder -> cost functor)
+__host__ __device__ inline int res_type_of_kind(int kind) {
+  return kind == TLOAM_KIND_EDGE ? TLOAM_RES_LINE : (kind == TLOAM_KIND_SPHERE ? TLOAM_RES_POINT : TLOAM_RES_PLANE);
+}
+
+// ---- uniform grid over a target cloud (the device stand-in for KDTreeFlann) -----------------
+struct GridView {
+  const double* gx;   // cell-sorted target coordinates
+  const double* gy;
+  const double* gz;
+  const int* gidx;    // original target index of each sorted entry
+  const int* cell_start;  // ncell + 1
+  double org[3];
+  double inv_cell;    // 1 / cell
+  double cell;
+  int dim[3];
+  int n;
+};
+
+// ---- compact correspondence set: one SoA segment per kind ------------------------------------
+struct CorrSeg {
+  int* idx;                 // global source index of each correspondence
+  double *px, *py, *pz;     // source point (sensor frame)
+  double *ax, *ay, *az;     // plane normal | line point a | target point
+  double *bx, *by, *bz;     // line point b (edge only, else null)
+  double* d;                // plane offset (planar/ground only, else null)
+  double* w;                // TLS weight captured at build time
+  double* cost;             // side channel (`mutable double* cost`, registration.hpp:51,76,96)
+  int cap;                  // capacity (multiple of kChunk)
+  int pad;
+};
+struct CorrView {
+  CorrSeg k[kKinds];
+  const int* seg_n;         // DEVICE: number of valid entries per kind [4]
+};
+
+// ---- per-source-slot arrays of one scan_match (concatenated over kinds) ----------------------
+struct SlotView {
+  const double *sx, *sy, *sz;  // source points (sensor frame)
+  double* w_src;               // GNC weights
+  // raw builder output
+  double *rax, *ray, *raz, *rbx, *rby, *rbz, *rd;
+  unsigned long long* flags;   // low 32: counted, high 32: valid (then scanned in place -> exclusive prefix)
+  unsigned long long* scan;    // exclusive scan of flags
+  int slot_off[kKinds + 1];    // concatenated slot ranges per kind
+  int src_lo[kKinds];          // global index of local slot 0 (sharded contexts)
+};
+
+// ---- Ceres TrustRegionMinimizer + DoglegStrategy state -----------------
+enum GnPhase : int { PH_ITER0 = 0, PH_CAND = 1 };
+
+struct GnState {
+  // poses
+  double x[6];        // accepted iterate == `parameters` (registration.hpp:328)
+  double x_cand[6];   // candidate evaluated by the sweep in flight
+  Pose T_eval;        // exp(point being swept)
+  Pose T_cur;         // exp(x), used by the builders
+  // minimiser
+  double x_cost, x_norm, gmax, model_cost_change;
+  double g[6], H[36]; // robustified normal equations at x
+  double S[6];        // Jacobi scaling (fixed at iteration 0 of each Solve)
+  // dogleg
+  double radius, mu, alpha, step_norm;
+  double D[6], grad[6], gn[6], U[12], sg[2], sB[4];
+  int reuse, subspace_1d;
+  int phase, iteration, invalid, step_successful, done;
+  // counters (whole scan_match)
+  int gn_evaluations, gn_iterations, accepted_steps;
+  // outer-loop bookkeeping written by the finish kernel
+  int n_corr[kKinds];
+  int bad_weights;
+  int pad0;
+  double kind_cost[kKinds];
+  double total[kReduceBuf];  // last reduced sweep (H upper 0..20, g 21..26, cost 27)
+};
+
+// ---- host-callable launchers (defined in tl_nn.hip / tl_gn.hip) ------------------------------
+struct ScanTemp;  // opaque
+
+// AoS double[3] -> SoA, for a sub-range
+void launch_aos_to_soa(const double* aos, size_t n, double* x, double* y, double* z, hipStream_t s);
+void launch_fill_f64(double* p, size_t n, double v, hipStream_t s);
+void launch_fill_i32(int* p, size_t n, int v, hipStream_t s);
+
+// exclusive scan of u64 values; tmp must hold scan_tmp_elems(n) u64
+size_t scan_tmp_elems(size_t n);
+void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n,
+                               unsigned long long* tmp, hipStream_t s);
+
+// grid build: bbox (host side from a small device reduction), histogram, scan, scatter
+void launch_bbox(const double* x, const double* y, const double* z, int n, double* out6, hipStream_t s);
+void launch_grid_count(const double* x, const double* y, const double* z, int n, GridView g,
+                       unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
+void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
+                         const unsigned long long* cell_scan, int* cell_fill, double* gx, double* gy,
+                         double* gz, int* gidx, hipStream_t s);
+void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start,
+                          hipStream_t s);
+
+struct BuildParams {
+  double radius[kKinds];
+  int maxnum[kKinds];
+  int active[kKinds];
+  double edge_dir_thres;
+};
+// K1+K2: per source slot kNN + fit + gates -> raw records + flags
+void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp,
+                  const GnState* st, hipStream_t s);
+// cap + compaction (after the flag scan)
+void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
+                    const double* rank_counts, int rank, int nranks, hipStream_t s);
+void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s);
+// generic hybrid search (tloam_knn / fitness)
+void launch_knn(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
+                double radius, int k, int* out_idx, double* out_d2, int* out_cnt, hipStream_t s);
+void launch_fitness(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
+                    double radius, double* partial /*[blocks*2]*/, int blocks, hipStream_t s);
+
+// K3 and the minimiser
+int k3_grid_for(int total_cap);
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s);
+void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
+void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x
+void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);
+void launch_gn_step(GnState* st, const double* in48, hipStream_t s);  // consume a reduced sweep
+void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s);
+// K4
+struct WeightParams {
+  double th1, th2, mu, noise_bound_sq;
+  int active[kKinds];
+};
+void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
+                    int blocks, hipStream_t s);
+void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st, double* sums8,
+                         hipStream_t s);
+void launch_outer_publish(const double* sums8, GnState* st, hipStream_t s);
+void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
+
+}  // namespace tl

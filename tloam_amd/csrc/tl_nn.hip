@@ -1,0 +1,681 @@
+// tl_nn.hip -- K1 (exact hybrid nearest-neighbour search) + K2 (correspondence builders) for gfx950.
+//
+// Replaces, on the device:
+//   KDTreeFlann::SetGeometry x4            registration.cpp:889-915  -> uniform-grid build
+//   KDTreeFlann::SearchHybrid call sites   registration.cpp:444 (edge r=1.0 k=5), :535 (sphere r=0.5
+//                                          k=1), :588 (planar r=0.5 k=5), :731 (ground), :272 (fitness)
+//   addEdgeCostFactor :427-505, addSphereCostFactor :517-559, addSurfCostFactor :571-635,
+//   addGroundCostFactor :714-778, fitBestPlane :303-368
+//
+// Search structure: a dense uniform grid with cell >= radius*(1+1e-6), built per frame by
+// histogram -> exclusive scan -> scatter.  Every target with squared distance < radius^2 lies in the
+// 27-cell neighbourhood of the query's cell, so "k nearest, then cut at radius^2" (Open3D 0.12
+// SearchHybrid) over that neighbourhood is EXACT.  Ties in distance are broken
+// towards the lower original target index, which makes the result independent of the (atomic)
+// scatter order inside a cell.
+//
+// This translation unit is compiled with -ffp-contract=off: the discontinuous gates (radius cut,
+// eig[2] > 3 eig[1], |dir.z| > 0.85, plane validity > 0.2, knn_dist > 0.2) are evaluated with
+// the same un-fused fp64 operation order as the CPU oracle, so a correspondence flips in/out on
+// the device only where it flips on the host.
+#include "tl_common.hpp"
+
+namespace tl {
+
+// ================================================================================================
+//  small utility kernels
+// ================================================================================================
+__global__ void k_aos_to_soa(const double* __restrict__ aos, size_t n, double* __restrict__ x,
+                             double* __restrict__ y, double* __restrict__ z) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    x[i] = aos[3 * i];
+    y[i] = aos[3 * i + 1];
+    z[i] = aos[3 * i + 2];
+  }
+}
+void launch_aos_to_soa(const double* aos, size_t n, double* x, double* y, double* z, hipStream_t s) {
+  if (n == 0) return;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks), dim3(256), 0, s, aos, n, x, y, z);
+}
+
+__global__ void k_fill_f64(double* p, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill_f64(double* p, size_t n, double v, hipStream_t s) {
+  if (n == 0) return;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill_f64, dim3(blocks), dim3(256), 0, s, p, n, v);
+}
+__global__ void k_fill_i32(int* p, size_t n, int v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill_i32(int* p, size_t n, int v, hipStream_t s) {
+  if (n == 0) return;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill_i32, dim3(blocks), dim3(256), 0, s, p, n, v);
+}
+
+// ================================================================================================
+//  exclusive scan of u64 (block-local scan + recursive scan of block totals + add)
+// ================================================================================================
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile(const unsigned long long* __restrict__ in,
+                                                            unsigned long long* __restrict__ out, size_t n,
+                                                            unsigned long long* __restrict__ tile_total) {
+  __shared__ unsigned long long wave_tot[kScanThreads / 64];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  unsigned long long v[kScanItems];
+  unsigned long long sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0ull;
+    sum += v[i];
+  }
+  // inclusive scan of `sum` across the wave (64 lanes)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned long long t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  unsigned long long wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  unsigned long long run = wave_off + inc - sum;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+  if (threadIdx.x == kScanThreads - 1) tile_total[blockIdx.x] = wave_off + inc;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(unsigned long long* __restrict__ out, size_t n,
+                                                           const unsigned long long* __restrict__ tile_off) {
+  const unsigned long long add = tile_off[blockIdx.x];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) out[base + i] += add;
+}
+size_t scan_tmp_elems(size_t n) {
+  size_t total = 0;
+  while (n > 1) {
+    const size_t tiles = (n + kScanTile - 1) / kScanTile;
+    total += 2 * tiles;
+    if (tiles == 1) break;
+    n = tiles;
+  }
+  return total + 16;
+}
+void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n,
+                               unsigned long long* tmp, hipStream_t s) {
+  if (n == 0) return;
+  const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  unsigned long long* totals = tmp;
+  unsigned long long* totals_scan = tmp + tiles;
+  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals);
+  if (tiles > 1) {
+    launch_exclusive_scan_u64(totals, totals_scan, tiles, tmp + 2 * tiles, s);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals_scan);
+  }
+}
+
+// ================================================================================================
+//  grid build
+// ================================================================================================
+// per-block min/max of a cloud; host finishes over <= 256 rows of 6
+__global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ x, const double* __restrict__ y,
+                                              const double* __restrict__ z, int n, double* __restrict__ out6) {
+  __shared__ double red[4][6];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double a = x[i], b = y[i], c = z[i];
+    lo[0] = fmin(lo[0], a); hi[0] = fmax(hi[0], a);
+    lo[1] = fmin(lo[1], b); hi[1] = fmax(hi[1], b);
+    lo[2] = fmin(lo[2], c); hi[2] = fmax(hi[2], c);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmax(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+    out6[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+void launch_bbox(const double* x, const double* y, const double* z, int n, double* out6, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox, dim3(64), dim3(256), 0, s, x, y, z, n, out6);
+}
+
+__device__ __forceinline__ int cell_coord(double v, double org, double cell, int dim) {
+  double f = floor((v - org) / cell);
+  f = fmax(f, -2.0);
+  f = fmin(f, (double)dim + 1.0);
+  return (int)f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ void k_grid_count(const double* __restrict__ x, const double* __restrict__ y,
+                             const double* __restrict__ z, int n, GridView g,
+                             unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int cx = clampi(cell_coord(x[i], g.org[0], g.cell, g.dim[0]), 0, g.dim[0] - 1);
+    const int cy = clampi(cell_coord(y[i], g.org[1], g.cell, g.dim[1]), 0, g.dim[1] - 1);
+    const int cz = clampi(cell_coord(z[i], g.org[2], g.cell, g.dim[2]), 0, g.dim[2] - 1);
+    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    cell_of_pt[i] = c;
+    atomicAdd(&cell_cnt[c], 1ull);
+  }
+}
+void launch_grid_count(const double* x, const double* y, const double* z, int n, GridView g,
+                       unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s) {
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_grid_count, dim3(blocks), dim3(256), 0, s, x, y, z, n, g, cell_cnt, cell_of_pt);
+}
+__global__ void k_grid_scatter(const double* __restrict__ x, const double* __restrict__ y,
+                               const double* __restrict__ z, int n, const int* __restrict__ cell_of_pt,
+                               const unsigned long long* __restrict__ cell_scan, int* __restrict__ cell_fill,
+                               double* __restrict__ gx, double* __restrict__ gy, double* __restrict__ gz,
+                               int* __restrict__ gidx) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = cell_of_pt[i];
+    const int pos = (int)cell_scan[c] + atomicAdd(&cell_fill[c], 1);
+    gx[pos] = x[i];
+    gy[pos] = y[i];
+    gz[pos] = z[i];
+    gidx[pos] = i;
+  }
+}
+void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
+                         const unsigned long long* cell_scan, int* cell_fill, double* gx, double* gy,
+                         double* gz, int* gidx, hipStream_t s) {
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, s, x, y, z, n, cell_of_pt, cell_scan,
+                     cell_fill, gx, gy, gz, gidx);
+}
+__global__ void k_grid_finalize(const unsigned long long* __restrict__ cell_scan, size_t ncell, int n,
+                                int* __restrict__ cell_start) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i <= ncell; i += stride) cell_start[i] = (i < ncell) ? (int)cell_scan[i] : n;
+}
+void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start,
+                          hipStream_t s) {
+  int blocks = (int)((ncell + 256) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, cell_scan, ncell, n, cell_start);
+}
+
+// ================================================================================================
+//  K1: exact k-NN over the 27-cell neighbourhood, top-K kept sorted in registers
+// ================================================================================================
+template <int K>
+struct TopK {
+  double d[K];
+  int j[K];  // position in the cell-sorted arrays
+};
+
+// nanoflann L2_Simple_Adaptor: sum of squared differences accumulated in dimension order
+__device__ __forceinline__ double sqdist(double qx, double qy, double qz, double x, double y, double z) {
+  const double d0 = qx - x, d1 = qy - y, d2 = qz - z;
+  double r = d0 * d0;
+  r += d1 * d1;
+  r += d2 * d2;
+  return r;
+}
+
+template <int K>
+__device__ __forceinline__ void topk_insert(TopK<K>& tk, const int* __restrict__ gidx, double d, int j) {
+  // strict total order (d, original index): ties broken towards the lower target index
+  auto less = [&](double da, int ja, double db, int jb) -> bool {
+    if (da < db) return true;
+    if (da > db) return false;
+    if (jb < 0) return true;  // empty slot (both +inf cannot happen: da is finite)
+    return gidx[ja] < gidx[jb];
+  };
+  if (!less(d, j, tk.d[K - 1], tk.j[K - 1])) return;
+  bool placed = false;
+#pragma unroll
+  for (int m = K - 1; m >= 0; --m) {
+    if (!placed) {
+      const bool before_prev = (m > 0) && less(d, j, tk.d[m > 0 ? m - 1 : 0], tk.j[m > 0 ? m - 1 : 0]);
+      if (before_prev) {
+        tk.d[m] = tk.d[m - 1 >= 0 ? m - 1 : 0];
+        tk.j[m] = tk.j[m - 1 >= 0 ? m - 1 : 0];
+      } else {
+        tk.d[m] = d;
+        tk.j[m] = j;
+        placed = true;
+      }
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    tk.d[m] = __builtin_inf();
+    tk.j[m] = -1;
+  }
+  if (g.n <= 0) return;
+  const int cx = cell_coord(qx, g.org[0], g.cell, g.dim[0]);
+  const int cy = cell_coord(qy, g.org[1], g.cell, g.dim[1]);
+  const int cz = cell_coord(qz, g.org[2], g.cell, g.dim[2]);
+  int x0 = cx - 1, x1 = cx + 1;
+  if (x0 < 0) x0 = 0;
+  if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
+  if (x0 > x1) return;
+  for (int z = cz - 1; z <= cz + 1; ++z) {
+    if (z < 0 || z >= g.dim[2]) continue;
+    for (int y = cy - 1; y <= cy + 1; ++y) {
+      if (y < 0 || y >= g.dim[1]) continue;
+      const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
+      const int s = g.cell_start[base + x0];
+      const int e = g.cell_start[base + x1 + 1];
+      for (int j = s; j < e; ++j) {
+        const double d = sqdist(qx, qy, qz, g.gx[j], g.gy[j], g.gz[j]);
+        topk_insert<K>(tk, g.gidx, d, j);
+      }
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ int radius_cut(const TopK<K>& tk, double radius) {
+  const double r2 = radius * radius;
+  int cnt = 0;
+#pragma unroll
+  for (int m = 0; m < K; ++m) cnt += (tk.d[m] < r2) ? 1 : 0;  // sorted ascending => prefix
+  return cnt;
+}
+
+// ================================================================================================
+//  K2 helpers: fitBestPlane (registration.cpp:303-368) and the 3x3 symmetric eigen solve that stands
+//  in for Eigen::SelfAdjointEigenSolver (registration.cpp:476-479) -- cyclic Jacobi, all indices
+//  compile-time so the 3x3 work stays in VGPRs.
+// ================================================================================================
+__device__ __forceinline__ void fit_best_plane5(const double px[5], const double py[5], const double pz[5],
+                                                double plane[4]) {
+  const double total = 5.0;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { c0 += px[i]; c1 += py[i]; c2 += pz[i]; }
+  c0 /= total; c1 /= total; c2 /= total;
+  double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double a = px[i] - c0, b = py[i] - c1, g = pz[i] - c2;
+    xx += a * a; xy += a * b; xz += a * g; yy += b * b; yz += b * g; zz += g * g;
+  }
+  xx /= total; xy /= total; xz /= total; yy /= total; yz /= total; zz /= total;
+  double w0 = 0, w1 = 0, w2 = 0;
+  {
+    const double det_x = yy * zz - yz * yz;
+    const double a0 = det_x, a1 = xz * yz - xy * zz, a2 = xy * yz - xz * yy;
+    double w = det_x * det_x;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  {
+    const double det_y = xx * zz - xz * xz;
+    const double a0 = xz * yz - xy * zz, a1 = det_y, a2 = xy * xz - yz * xx;
+    double w = det_y * det_y;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  {
+    const double det_z = xx * yy - xy * xy;
+    const double a0 = xy * yz - xz * yy, a1 = xy * xz - yz * xx, a2 = det_z;
+    double w = det_z * det_z;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  const double norm = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+  if (norm == 0.0) { plane[0] = plane[1] = plane[2] = plane[3] = 0.0; return; }
+  w0 /= norm; w1 /= norm; w2 /= norm;
+  plane[0] = w0; plane[1] = w1; plane[2] = w2;
+  plane[3] = -(w0 * c0 + w1 * c1 + w2 * c2);
+}
+
+struct Sym3 {
+  double a[3][3];
+  double v[3][3];
+};
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(Sym3& m) {
+  const double apq = m.a[P][Q];
+  if (apq == 0.0) return;
+  const double app = m.a[P][P], aqq = m.a[Q][Q];
+  const double tau = (aqq - app) / (2.0 * apq);
+  const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
+  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = m.a[k][P], akq = m.a[k][Q];
+    m.a[k][P] = cs * akp - sn * akq;
+    m.a[k][Q] = sn * akp + cs * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = m.a[P][k], aqk = m.a[Q][k];
+    m.a[P][k] = cs * apk - sn * aqk;
+    m.a[Q][k] = sn * apk + cs * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double vkp = m.v[k][P], vkq = m.v[k][Q];
+    m.v[k][P] = cs * vkp - sn * vkq;
+    m.v[k][Q] = sn * vkp + cs * vkq;
+  }
+}
+template <int J>
+__device__ __forceinline__ void sort_swap(double ev[3], Sym3& m) {
+  if (ev[J] > ev[J + 1]) {
+    const double t = ev[J]; ev[J] = ev[J + 1]; ev[J + 1] = t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double tv = m.v[k][J]; m.v[k][J] = m.v[k][J + 1]; m.v[k][J + 1] = tv; }
+  }
+}
+// eigenvalues ascending in ev, unit eigenvectors in the columns of m.v
+__device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m.v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = m.a[0][1] * m.a[0][1] + m.a[0][2] * m.a[0][2] + m.a[1][2] * m.a[1][2];
+    if (off == 0.0) break;
+    jacobi_rotate<0, 1>(m);
+    jacobi_rotate<0, 2>(m);
+    jacobi_rotate<1, 2>(m);
+  }
+  ev[0] = m.a[0][0]; ev[1] = m.a[1][1]; ev[2] = m.a[2][2];
+  sort_swap<0>(ev, m);
+  sort_swap<1>(ev, m);
+  sort_swap<0>(ev, m);
+}
+
+// ================================================================================================
+//  K1+K2 fused: one thread per source slot -> raw record + (counted, valid) flags
+// ================================================================================================
+struct BuildArgs {
+  SlotView sv;
+  GridView grid[kKinds];
+  BuildParams bp;
+};
+
+__global__ __launch_bounds__(256) void k_build(BuildArgs A, const GnState* __restrict__ st) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const int n_slots = A.sv.slot_off[kKinds];
+  if (slot >= n_slots) return;
+  int kind = 0;
+#pragma unroll
+  for (int k = 1; k < kKinds; ++k) kind += (slot >= A.sv.slot_off[k]) ? 1 : 0;
+  unsigned long long flag = 0ull;
+  if (!A.bp.active[kind]) { A.sv.flags[slot] = 0ull; return; }
+  const Pose T = st->T_cur;  // exp(se3_pose_)  registration.cpp:434/:524/:578/:721
+  const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
+  const double radius = A.bp.radius[kind];
+  double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
+  if (kind == TLOAM_KIND_SPHERE) {
+    const GridView& g = A.grid[TLOAM_KIND_SPHERE];
+    TopK<1> tk;
+    knn_grid<1>(g, pw.x, pw.y, pw.z, tk);
+    const int cnt = radius_cut<1>(tk, radius);
+    const bool found = cnt > 0;
+    const bool skip = found && (tk.d[0] > 0.2);   // :536 squared distance vs 0.2 -> `continue`
+    const bool valid = found && !skip;
+    const bool counted = !skip;                     // :551 sphere_sum++ for every non-`continue`d point
+    if (valid) { ra[0] = g.gx[tk.j[0]]; ra[1] = g.gy[tk.j[0]]; ra[2] = g.gz[tk.j[0]]; }
+    flag = ((unsigned long long)(valid ? 1 : 0) << 32) | (unsigned long long)(counted ? 1 : 0);
+  } else {
+    const GridView& g = A.grid[kind];
+    TopK<5> tk;
+    knn_grid<5>(g, pw.x, pw.y, pw.z, tk);
+    const int cnt = radius_cut<5>(tk, radius);
+    bool valid = false;
+    if (kind == TLOAM_KIND_EDGE) {
+      if (cnt > 3) {  // :445
+        double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          if (m < cnt) {  // :453-464, neighbours in ascending distance
+            const double x = g.gx[tk.j[m]], y = g.gy[tk.j[m]], z = g.gz[tk.j[m]];
+            cum[0] += x; cum[1] += y; cum[2] += z;
+            cum[3] += x * x; cum[4] += x * y; cum[5] += x * z;
+            cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;
+          }
+        }
+        const double inv_n = (double)cnt;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) cum[m] /= inv_n;  // :465
+        Sym3 M;
+        M.a[0][0] = cum[3] - cum[0] * cum[0];
+        M.a[1][1] = cum[6] - cum[1] * cum[1];
+        M.a[2][2] = cum[8] - cum[2] * cum[2];
+        M.a[0][1] = M.a[1][0] = cum[4] - cum[0] * cum[1];
+        M.a[0][2] = M.a[2][0] = cum[5] - cum[0] * cum[2];
+        M.a[1][2] = M.a[2][1] = cum[7] - cum[1] * cum[2];
+        double ev[3];
+        eig3_sym(M, ev);
+        const double dx = M.v[0][2], dy = M.v[1][2], dz = M.v[2][2];  // eigenvectors().col(2) :479
+        if (ev[2] > 3 * ev[1] && fabs(dz) > A.bp.edge_dir_thres) {   // :481
+          ra[0] = 0.1 * dx + cum[0];  ra[1] = 0.1 * dy + cum[1];  ra[2] = 0.1 * dz + cum[2];   // :483
+          rb[0] = -0.1 * dx + cum[0]; rb[1] = -0.1 * dy + cum[1]; rb[2] = -0.1 * dz + cum[2];  // :484
+          valid = true;
+        }
+      }
+    } else {
+      if (cnt > 4) {  // :589 / :732  (all five neighbours inside the radius)
+        double nx[5], ny[5], nz[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { nx[m] = g.gx[tk.j[m]]; ny[m] = g.gy[tk.j[m]]; nz[m] = g.gz[tk.j[m]]; }
+        double plane[4];
+        fit_best_plane5(nx, ny, nz, plane);
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {  // :605-613 signed, no fabs
+          const double dis = plane[0] * nx[m] + plane[1] * ny[m] + plane[2] * nz[m] + plane[3];
+          if (dis > 0.2) ok = false;
+        }
+        if (ok) { ra[0] = plane[0]; ra[1] = plane[1]; ra[2] = plane[2]; rd = plane[3]; valid = true; }
+      }
+    }
+    // the cap tests (:448 / :592 / :735) run on every point that reached them, i.e. that had
+    // >3 (>4) neighbours; but a `return` there only matters once num >= maxnum, and num counts
+    // ADDED factors, so "added iff valid && #valid before < maxnum" (see launch_compact).
+    flag = valid ? ((1ull << 32) | 1ull) : 0ull;
+  }
+  A.sv.flags[slot] = flag;
+  A.sv.rax[slot] = ra[0]; A.sv.ray[slot] = ra[1]; A.sv.raz[slot] = ra[2];
+  A.sv.rbx[slot] = rb[0]; A.sv.rby[slot] = rb[1]; A.sv.rbz[slot] = rb[2];
+  A.sv.rd[slot] = rd;
+}
+
+void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
+                  hipStream_t s) {
+  const int n = sv.slot_off[kKinds];
+  if (n <= 0) return;
+  BuildArgs A;
+  A.sv = sv;
+  for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
+  A.bp = bp;
+  hipLaunchKernelGGL(k_build, dim3((n + 255) / 256), dim3(256), 0, s, A, st);
+}
+
+// ================================================================================================
+//  cap + compaction.  With C = exclusive prefix of `counted` within the kind (+ the counts of the
+//  lower ranks when sharded) and V = exclusive prefix of `valid`:
+//     added(i)  <=>  valid(i) && C(i) < maxnum           (registration.cpp:448/:538/:592/:735)
+//  and because C is non-decreasing every valid j < i of an added i was added too, so the compact
+//  position of i is simply V(i).
+// ================================================================================================
+struct CompactArgs {
+  SlotView sv;
+  CorrView cv;
+  int maxnum[kKinds];
+  int* seg_n;
+  const double* rank_counts;  // [nranks*4] counted totals per rank (all-reduced), or null
+  int rank, nranks;
+};
+__global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  const int n_slots = A.sv.slot_off[kKinds];
+  if (slot >= n_slots) return;
+  int kind = 0;
+#pragma unroll
+  for (int k = 1; k < kKinds; ++k) kind += (slot >= A.sv.slot_off[k]) ? 1 : 0;
+  const unsigned long long f = A.sv.flags[slot];
+  if ((f >> 32) == 0ull) return;  // not valid
+  const unsigned long long sc = A.sv.scan[slot];
+  const unsigned long long sb = A.sv.scan[A.sv.slot_off[kind]];
+  long long C = (long long)((sc & 0xffffffffull) - (sb & 0xffffffffull));
+  const int V = (int)((sc >> 32) - (sb >> 32));
+  if (A.rank_counts) {
+    double off = 0.0;
+    for (int r = 0; r < A.rank; ++r) off += A.rank_counts[r * kKinds + kind];
+    C += (long long)off;
+  }
+  if (C >= (long long)A.maxnum[kind]) return;
+  const CorrSeg& seg = A.cv.k[kind];
+  if (V >= seg.cap) return;  // cannot happen (cap >= min(n, maxnum)); defensive
+  const int pos = V;
+  const int local = slot - A.sv.slot_off[kind];
+  seg.idx[pos] = local + A.sv.src_lo[kind];
+  seg.px[pos] = A.sv.sx[slot]; seg.py[pos] = A.sv.sy[slot]; seg.pz[pos] = A.sv.sz[slot];
+  seg.ax[pos] = A.sv.rax[slot]; seg.ay[pos] = A.sv.ray[slot]; seg.az[pos] = A.sv.raz[slot];
+  if (kind == TLOAM_KIND_EDGE) { seg.bx[pos] = A.sv.rbx[slot]; seg.by[pos] = A.sv.rby[slot]; seg.bz[pos] = A.sv.rbz[slot]; }
+  if (kind <= TLOAM_KIND_GROUND) seg.d[pos] = A.sv.rd[slot];
+  seg.w[pos] = A.sv.w_src[slot];  // weight captured by value at construction (registration.hpp:51,76,96)
+  seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
+  atomicMax(&A.seg_n[kind], V + 1);
+}
+void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
+                    const double* rank_counts, int rank, int nranks, hipStream_t s) {
+  const int n = sv.slot_off[kKinds];
+  if (n <= 0) return;
+  CompactArgs A;
+  A.sv = sv;
+  A.cv = cv;
+  for (int k = 0; k < kKinds; ++k) A.maxnum[k] = bp.maxnum[k];
+  A.seg_n = seg_n;
+  A.rank_counts = rank_counts;
+  A.rank = rank;
+  A.nranks = nranks;
+  hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, A);
+}
+// per-rank `counted` totals -> row `rank` of a zeroed [nranks*4] buffer (summed by the all-reduce)
+__global__ void k_rank_counts(SlotView sv, double* rank_counts, int rank, int nranks) {
+  const int t = threadIdx.x;
+  if (t < nranks * kKinds) rank_counts[t] = 0.0;
+  __syncthreads();
+  if (t < kKinds) {
+    const unsigned long long a = sv.scan[sv.slot_off[t]];
+    const unsigned long long b = sv.scan[sv.slot_off[t + 1]];
+    rank_counts[rank * kKinds + t] = (double)((b & 0xffffffffull) - (a & 0xffffffffull));
+  }
+}
+void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s) {
+  hipLaunchKernelGGL(k_rank_counts, dim3(1), dim3(64), 0, s, sv, rank_counts, rank, nranks);
+}
+
+// ================================================================================================
+//  generic hybrid search (tloam_knn) and getFitnessScore (registration.cpp:257-296)
+// ================================================================================================
+template <int K>
+__global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restrict__ qx,
+                                             const double* __restrict__ qy, const double* __restrict__ qz,
+                                             int nq, double radius, int k, int* __restrict__ out_idx,
+                                             double* __restrict__ out_d2, int* __restrict__ out_cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  TopK<K> tk;
+  knn_grid<K>(g, qx[i], qy[i], qz[i], tk);
+  const double r2 = radius * radius;
+  int cnt = 0;
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const bool in = (m < k) && (tk.d[m] < r2);
+    cnt += in ? 1 : 0;
+    if (m < k) {
+      out_idx[(size_t)i * k + m] = in ? g.gidx[tk.j[m]] : -1;
+      out_d2[(size_t)i * k + m] = in ? tk.d[m] : 0.0;
+    }
+  }
+  out_cnt[i] = cnt;
+}
+void launch_knn(const GridView& g, const double* qx, const double* qy, const double* qz, int nq, double radius,
+                int k, int* out_idx, double* out_d2, int* out_cnt, hipStream_t s) {
+  if (nq <= 0) return;
+  const dim3 grid((nq + 255) / 256), block(256);
+  // top-k of exactly k: instantiate the sizes the path uses plus the test sizes
+  if (k == 1) hipLaunchKernelGGL(k_knn<1>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k <= 5 && k == 5) hipLaunchKernelGGL(k_knn<5>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k == 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k == 3) hipLaunchKernelGGL(k_knn<3>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k == 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k == 6) hipLaunchKernelGGL(k_knn<6>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else if (k == 7) hipLaunchKernelGGL(k_knn<7>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+  else hipLaunchKernelGGL(k_knn<8>, grid, block, 0, s, g, qx, qy, qz, nq, radius, k, out_idx, out_d2, out_cnt);
+}
+
+// fitness: per block (sum of squared distances of hits, number of hits); fixed grid, fixed tree
+__global__ __launch_bounds__(256) void k_fitness(GridView g, const double* __restrict__ qx,
+                                                 const double* __restrict__ qy, const double* __restrict__ qz,
+                                                 int nq, double radius, double* __restrict__ partial) {
+  __shared__ double red[4][2];
+  double err = 0.0, hits = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+    TopK<1> tk;
+    knn_grid<1>(g, qx[i], qy[i], qz[i], tk);  // :271-272 raw scan-frame point, k = 1
+    if (tk.d[0] < radius * radius) { err += tk.d[0]; hits += 1.0; }  // :273 adds the SQUARED distance
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    err += __shfl_down(err, off, 64);
+    hits += __shfl_down(hits, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = err; red[wave][1] = hits; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v += red[w][threadIdx.x];
+    partial[blockIdx.x * 2 + threadIdx.x] = v;
+  }
+}
+void launch_fitness(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
+                    double radius, double* partial, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_fitness, dim3(blocks), dim3(256), 0, s, g, qx, qy, qz, nq, radius, partial);
+}
+
+}  // namespace tl
