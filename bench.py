@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- T-LOAM pose-optimisation hot path on MI355X: Gauss-Newton iterations/s + ms/frame.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is ONE full `scan_match` (LocalRegistration::scanMatching, registration.cpp:879-1133 -- the
+bracket the reference times at front_end.cpp:320-322: grid build, 4 outer GNC iterations of
+[correspondence search + Ceres-configured solve + weight update]) over one synthetic frame pair
+whose eight feature clouds are already resident in HBM.  Workload (BASELINE.json configs[2]/[3]):
+the synthetic 1 M-correspondence frame -- 1 M source points / 1 M target points, all three residual
+types -- STRONG-scaled over N GPUs: the source points are sharded in contiguous index blocks, the
+targets are replicated, and every GN sweep ends in one RCCL all-reduce of the 6x6/6x1 normal
+equations (48 doubles) over xGMI.  `value` = GN iterations (residual+Jacobian sweep + all-reduce +
+6x6 dogleg step + pose update) per second of wall time, whole job; `ms_per_step` = ms/frame.
+The KITTI-density frame (configs[1], ~10 k source / ~85 k target points, reference caps) is timed on
+rank 0 at N=1 and reported under "kitti_density" in the same line.
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (the residual/Jacobian kernel K3, HIP events
+around every K3 launch of the timed region, algorithmic bytes 72/88/64 B per plane/line/point
+correspondence) and "cpu_baseline" (the C oracle -- a port, NOT Ceres -- on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="m1", choices=["m1", "kitti"], help="m1 = 1 M-correspondence frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kitti", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    multi = world > 1
+
+    import torch  # plumbing only: process group, barrier, device sync (imported first so that one HIP runtime is shared)
+    from tloam_amd import registration as reg
+    from tloam_amd import synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if multi:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- workload ----------------
+    if args.workload == "m1":
+        n_src, n_tgt = synth.M1_SRC, synth.M1_TGT
+        big = 1 << 30
+        cfg = reg.default_config(planar_maxnum=big, ground_maxnum=big, edge_maxnum=big, sphere_maxnum=big)
+        wl_name = "synthetic 1M-correspondence frame (1.0M src / 1.0M tgt pts, plane:line:point = 760k:200k:40k, caps lifted)"
+    else:
+        n_src, n_tgt = synth.KITTI_SRC, synth.KITTI_TGT
+        cfg = reg.default_config()
+        wl_name = "synthetic KITTI-density frame (9.4k src / 83.5k tgt pts, reference caps 2500/2000/1200/200)"
+    scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
+
+    H = reg.HipRegistration(cfg, device=local_rank)
+    if multi:
+        uid = [reg.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        H.comm_init_rccl(rank, world, uid[0])
+    H.set_frames(scene.source, scene.target)   # inputs resident in HBM before the timed region
+    H.k3_timer(reset=True)                      # arm per-launch HIP events around K3
+
+    def step():
+        rc, T, st = H.scan_match(scene.T_pred)
+        if rc != 0:
+            raise SystemExit(f"scan_match failed: {reg.STATUS.get(rc, rc)}")
+        return T, st
+
+    for _ in range(args.warmup):
+        T, st = step()
+    H.k3_timer(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    gn_iters = 0
+    for _ in range(args.steps):
+        T, st = step()
+        gn_iters += st["gn_evaluations"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    k3_us, k3_n, k3_bytes_job = H.k3_timer()
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = gn_iters / elapsed
+        # pose sanity (not timed): the solve must land near the generating pose
+        D = np.linalg.inv(T) @ scene.T_true
+        pose_err_m = float(np.linalg.norm(D[:3, 3]))
+        # ---- roofline of the dominant streaming kernel K3 (per launch, this rank's shard)
+        n_corr = st["n_corr"]  # job-wide counts (all-reduced)
+        alg_job = 72.0 * (n_corr[0] + n_corr[1]) + 88.0 * n_corr[2] + 64.0 * n_corr[3]
+        alg_launch = alg_job / world      # contiguous shards: this rank streams 1/N of the set
+        k3_avg_us = k3_us / max(k3_n, 1)
+        achieved = alg_launch / (k3_avg_us * 1e-6) / 1e9 if k3_n else 0.0
+        roofline = {"kernel": "k3_accumulate", "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(k3_avg_us, 3), "launches": int(k3_n),
+                    "algorithmic_bytes_per_launch": alg_launch}
+        out = {
+            "metric": "gauss_newton_iters_per_sec", "value": round(value, 2), "unit": "GN iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl_name, "step": "one scan_match (ms_per_step = ms/frame)",
+                       "gn_iters_per_frame": gn_iters / args.steps, "n_corr": n_corr,
+                       "outer_iterations": st["outer_iterations"],
+                       "parallelism": f"source points sharded x{world}, targets replicated, 1 RCCL all-reduce(48 f64) per GN sweep" if multi else "1 GPU",
+                       "pose_err_vs_truth_m": pose_err_m},
+            "roofline": roofline,
+        }
+    H.close()
+
+    # ---------------- KITTI-density frame + CPU baseline: rank 0, N = 1 only ----------------
+    if rank == 0 and not multi:
+        if not args.no_kitti and args.workload == "m1":
+            sk = synth.make_scene(seed=args.seed, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
+            Hk = reg.HipRegistration(reg.default_config(), device=local_rank)
+            Hk.set_frames(sk.source, sk.target)
+            for _ in range(5):
+                Hk.scan_match(sk.T_pred)
+            torch.cuda.synchronize()
+            nk, it = 100, 0
+            t0 = time.perf_counter()
+            for _ in range(nk):
+                rc, Tk, stk = Hk.scan_match(sk.T_pred)
+                it += stk["gn_evaluations"]
+            dtk = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for _ in range(20):
+                Hk.set_frames(sk.source, sk.target)
+            dt_up = (time.perf_counter() - t0) / 20
+            out["kitti_density"] = {"ms_per_frame": round(dtk / nk * 1e3, 4), "gn_iters_per_sec": round(it / dtk, 1),
+                                    "n_corr": stk["n_corr"], "frames": nk,
+                                    "ms_per_frame_incl_pcie_upload": round((dtk / nk + dt_up) * 1e3, 4)}
+            Hk.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cfg, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, cfg, args):
+    """The oracle (a dependency-free port of the reference's Ceres-configured solve, NOT Ceres) on the
+    host cores, threaded in the reference's shape: 4 builder threads (registration.cpp:976-1020),
+    evaluation on hardware_concurrency()/2 threads (:184, :1044).  Bounded sample: ONE scan_match of
+    the same frame."""
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    eval_threads = max(1, cores // 2)
+    oc = ob.make_config(**{f: getattr(cfg, f) for f, _ in cfg._fields_ if f != "reserved0"})
+    O = ob.Oracle(oc, builder_threads=4, eval_threads=eval_threads)
+    O.set_frames(scene.source, scene.target)
+    t0 = time.perf_counter()
+    rc, T, st = O.scan_match(scene.T_pred)
+    dt = time.perf_counter() - t0
+    return {"value": round(st["gn_evaluations"] / dt, 3), "unit": "GN iter/s", "cores": max(4, eval_threads),
+            "host_cores": cores, "kind": "port", "ms_per_frame": round(dt * 1e3, 2),
+            "sample": "1 scan_match of the same frame (C oracle, -O3, OpenMP: 4 builder threads, eval on cores/2)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -339,7 +340,9 @@ int harvest_k3_events(tloam_ctx* c, int counted_launches) {
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 int enqueue_solve(tloam_ctx* c) {
   launch_solve_init(c->state.p, c->stream);
-  for (int sweep = 0; sweep < 5; ++sweep) {
+  int max_sweeps = 5;
+  if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) max_sweeps = atoi(e);  // debugging aid only
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     int rc = launch_k3_timed(c, false);
     if (rc != TLOAM_OK) return rc;
     if (c->nranks > 1) {
@@ -1021,6 +1024,16 @@ int tloam_k3_timer(tloam_ctx* c, int reset, double* total_us, int64_t* launches,
   }
   c->k3_timing = true;  // first call arms the per-launch event pairs
   return TLOAM_OK;
+}
+
+// debugging aid: raw copy of the device-resident minimiser state (layout: tl_common.hpp GnState)
+int tloam_debug_state(tloam_ctx* c, double* out, int n_doubles) {
+  if (!c || !out) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  const size_t bytes = std::min(sizeof(GnState), sizeof(double) * (size_t)n_doubles);
+  HIPC(c, hipMemcpy(out, c->state.p, bytes, hipMemcpyDeviceToHost));
+  return (int)(sizeof(GnState) / sizeof(double));
 }
 
 // ---- multi-GPU -------------------------------------------------------------------------------------

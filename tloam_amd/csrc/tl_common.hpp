@@ -98,7 +98,6 @@ struct GnState {
   int bad_weights;
   int pad0;
   double kind_cost[kKinds];
-  double total[kReduceBuf];  // last reduced sweep (H upper 0..20, g 21..26, cost 27)
 };
 
 // ---- host-callable launchers (defined in tl_nn.hip / tl_gn.hip) ------------------------------

@@ -23,21 +23,46 @@ namespace tl {
 // ================================================================================================
 //  K3
 // ================================================================================================
+// 28 running sums per lane: v[0..20] upper-triangular H, v[21..26] g.  The cost 0.5*sum log(1+s) is
+// carried as a running PRODUCT of (1+s) in (mantissa, exponent) form -- two VALU ops per
+// correspondence instead of a ~50-instruction fp64 log -- and turned into a log once per lane.
 struct Acc {
-  double v[kAccN];
+  double v[27];
+  double pm;  // product mantissa in [0.5, 1)
+  int pe;     // product exponent
 };
 
 // upper-triangular index of (i,j), i<=j, row-major: 0..20
 __host__ __device__ constexpr int ut(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
-// one residual row: r (already loss-corrected is NOT assumed): adds rho*J^T J and rho*J^T r
+__device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + one Newton step (<= 1 ulp)
+  double r = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {  // v_rsq_f64 + one Newton step
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x * y;
+  return __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
+}
+
+// CauchyLoss(1.0): rho' = 1/(1+s) (rho'' < 0 -> Ceres' Corrector takes its clamped branch: r and J
+// are only scaled by sqrt(rho')), block cost 0.5*log(1+s).  Returns rho'.
+__device__ __forceinline__ double cauchy(Acc& a, double s) {
+  const double sum = 1.0 + s;
+  a.pm *= sum;
+  a.pe += __builtin_amdgcn_frexp_exp(a.pm);
+  a.pm = __builtin_amdgcn_frexp_mant(a.pm);
+  return fast_rcp(sum);
+}
+
+// one residual row: adds rho*J^T J (upper triangle) and rho*J^T r
 __device__ __forceinline__ void acc_row(Acc& a, const double J[6], double r, double rho) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double ji = rho * J[i];
-    a.v[21 + i] += ji * r;
+    a.v[21 + i] = __builtin_fma(ji, r, a.v[21 + i]);
 #pragma unroll
-    for (int j = i; j < 6; ++j) a.v[ut(i, j)] += ji * J[j];
+    for (int j = i; j < 6; ++j) a.v[ut(i, j)] = __builtin_fma(ji, J[j], a.v[ut(i, j)]);
   }
 }
 
@@ -47,66 +72,68 @@ __device__ __forceinline__ double eval_plane(const Pose& T, Vec3 p, Vec3 n, doub
   const double r = dot(n, pw) + d;           // :100 (unweighted)
   const Vec3 c = cross(pw, n);               // n^T (-hat(pw)) = (pw x n)^T   :110,:112
   const double J[6] = {n.x * w, n.y * w, n.z * w, c.x * w, c.y * w, c.z * w};
-  const double s = r * r;                    // squared norm of the block
-  const double sum = 1.0 + s;
-  const double rho1 = 1.0 / sum;             // CauchyLoss(1): rho' ; rho'' < 0 -> clamped corrector
-  a.v[27] += 0.5 * log(sum);
-  acc_row(a, J, r, rho1);
-  return s;                                  // side channel *cost = r^2  :101
+  const double s = r * r;                    // squared norm of the block; also *cost = r^2  :101
+  acc_row(a, J, r, cauchy(a, s));
+  return s;
 }
 
 // PointToLineErr::Evaluate (registration.cpp:55-88)
 __device__ __forceinline__ double eval_line(const Pose& T, Vec3 p, Vec3 la, Vec3 lb, double w, Acc& a) {
   const Vec3 pw = act(T, p);
   const Vec3 nu = cross(pw - la, pw - lb);   // :62
-  const Vec3 de = la - lb;                   // :63
-  const double den = sqrt(dot(de, de));
-  const double r0 = nu.x / den * w, r1 = nu.y / den * w, r2 = nu.z / den * w;  // :65-67
-  const double side = (r0 + r1 + r2) * (r0 + r1 + r2);                          // :69
-  // J = hat(lb - la) * [I w, -hat(pw) w] / |de|   :77-83.  With e = lb - la:
-  //   rows of hat(e) = (0,-ez,ey), (ez,0,-ex), (-ey,ex,0);  hat(e) * (-hat(pw)) = -hat(e) hat(pw)
-  const Vec3 e = lb - la;
-  const double k = w / den;
-  // -hat(e) hat(pw) = -(pw e^T - (e.pw) I)  ->  (e.pw) I - pw e^T  ... row i, col j: (e.pw) d_ij - e_j... see below
-  // hat(a) hat(b) = b a^T - (a.b) I  =>  -hat(e) hat(pw) = (e.pw) I - pw e^T
+  const Vec3 e = lb - la;                    // :80  (|la - lb| = |e|, :63)
+  const double k = w * fast_rsqrt(dot(e, e));
+  const double r0 = nu.x * k, r1 = nu.y * k, r2 = nu.z * k;    // :65-67  nu / |de| * w
+  const double rs = r0 + r1 + r2;
+  // J = hat(e) [I w, -hat(pw) w] / |de|  :77-83 ; hat(a) hat(b) = b a^T - (a.b) I  =>
+  // -hat(e) hat(pw) = (e.pw) I - pw e^T
   const double ep = dot(e, pw);
-  const double J0[6] = {0.0, -e.z * k, e.y * k, (ep - pw.x * e.x) * k, (-pw.x * e.y) * k, (-pw.x * e.z) * k};
-  const double J1[6] = {e.z * k, 0.0, -e.x * k, (-pw.y * e.x) * k, (ep - pw.y * e.y) * k, (-pw.y * e.z) * k};
-  const double J2[6] = {-e.y * k, e.x * k, 0.0, (-pw.z * e.x) * k, (-pw.z * e.y) * k, (ep - pw.z * e.z) * k};
-  const double s = r0 * r0 + r1 * r1 + r2 * r2;
-  const double sum = 1.0 + s;
-  const double rho1 = 1.0 / sum;
-  a.v[27] += 0.5 * log(sum);
+  const double ex = e.x * k, ey = e.y * k, ez = e.z * k, epk = ep * k;
+  const double J0[6] = {0.0, -ez, ey, epk - pw.x * ex, -pw.x * ey, -pw.x * ez};
+  const double J1[6] = {ez, 0.0, -ex, -pw.y * ex, epk - pw.y * ey, -pw.y * ez};
+  const double J2[6] = {-ey, ex, 0.0, -pw.z * ex, -pw.z * ey, epk - pw.z * ez};
+  const double rho1 = cauchy(a, r0 * r0 + r1 * r1 + r2 * r2);
   acc_row(a, J0, r0, rho1);
   acc_row(a, J1, r1, rho1);
   acc_row(a, J2, r2, rho1);
-  return side;
+  return rs * rs;                            // :69 side channel (r0+r1+r2)^2
 }
 
 // PointToPointErr::Evaluate (registration.cpp:19-47)
 __device__ __forceinline__ double eval_point(const Pose& T, Vec3 p, Vec3 q, double w, Acc& a) {
   const Vec3 pw = act(T, p);
   const double r0 = (q.x - pw.x) * w, r1 = (q.y - pw.y) * w, r2 = (q.z - pw.z) * w;  // :26-30
-  const double side = (r0 + r1 + r2) * (r0 + r1 + r2);                                // :32
-  // J = [-I w, hat(pw) w]  :39-40
-  const double J0[6] = {-w, 0.0, 0.0, 0.0, -pw.z * w, pw.y * w};
-  const double J1[6] = {0.0, -w, 0.0, pw.z * w, 0.0, -pw.x * w};
-  const double J2[6] = {0.0, 0.0, -w, -pw.y * w, pw.x * w, 0.0};
-  const double s = r0 * r0 + r1 * r1 + r2 * r2;
-  const double sum = 1.0 + s;
-  const double rho1 = 1.0 / sum;
-  a.v[27] += 0.5 * log(sum);
+  const double rs = r0 + r1 + r2;
+  const double wx = pw.x * w, wy = pw.y * w, wz = pw.z * w;
+  const double J0[6] = {-w, 0.0, 0.0, 0.0, -wz, wy};   // [-I w, hat(pw) w]  :39-40
+  const double J1[6] = {0.0, -w, 0.0, wz, 0.0, -wx};
+  const double J2[6] = {0.0, 0.0, -w, -wy, wx, 0.0};
+  const double rho1 = cauchy(a, r0 * r0 + r1 * r1 + r2 * r2);
   acc_row(a, J0, r0, rho1);
   acc_row(a, J1, r1, rho1);
   acc_row(a, J2, r2, rho1);
-  return side;
+  return rs * rs;                            // :32
 }
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
-__global__ __launch_bounds__(256) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
-                                                     double* __restrict__ partials, int force) {
-  __shared__ double red[4][kAccN];
+// wave-level reduce-scatter of 32 per-lane values: after the five exchange steps (xor 32,16,8,4,2)
+// every lane holds ONE component (index lane>>1) summed over its 32-lane class, the last xor-1 step
+// completes the 64-lane sum.  32 cross-lane exchanges instead of 28 x 6.
+template <int N, int D>
+__device__ __forceinline__ void rs_step(double (&v)[32], int lane) {
+  const bool hi = (lane & D) != 0;
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const double keep = hi ? v[i + N / 2] : v[i];
+    const double send = hi ? v[i] : v[i + N / 2];
+    v[i] = keep + __shfl_xor(send, D, 64);
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
+                                                        double* __restrict__ partials, int force) {
+  __shared__ double red[4][32];
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Pose T = st->T_eval;       // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   int n[kKinds], chunk_end[kKinds];
@@ -119,7 +146,9 @@ __global__ __launch_bounds__(256) void k3_accumulate(CorrView cv, GnState* __res
   }
   Acc a;
 #pragma unroll
-  for (int i = 0; i < kAccN; ++i) a.v[i] = 0.0;
+  for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
+  a.pm = 0.5;
+  a.pe = 1;  // 0.5 * 2^1 = 1
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + wave, W = gridDim.x * 4;
   for (int c = gw; c < total_chunks; c += W) {
@@ -127,45 +156,58 @@ __global__ __launch_bounds__(256) void k3_accumulate(CorrView cv, GnState* __res
 #pragma unroll
     for (int k = 0; k < kKinds - 1; ++k) kind += (c >= chunk_end[k]) ? 1 : 0;
     const int first = (kind == 0) ? 0 : chunk_end[kind - 1];
-    const int local = (c - first) * kChunk + lane * 2;
-    const int rem = n[kind] - local;  // >=2: both elements, 1: first only
-    if (rem <= 0) continue;
+    const int base = (c - first) * kChunk;
     const CorrSeg& seg = cv.k[kind];
-    const int j = local;
-    const double2 px = ld2(seg.px + j), py = ld2(seg.py + j), pz = ld2(seg.pz + j);
-    const double2 ax = ld2(seg.ax + j), ay = ld2(seg.ay + j), az = ld2(seg.az + j);
-    const double2 w = ld2(seg.w + j);
-    double c0, c1 = 0.0;
     if (kind <= TLOAM_KIND_GROUND) {
-      const double2 d = ld2(seg.d + j);
-      c0 = eval_plane(T, Vec3{px.x, py.x, pz.x}, Vec3{ax.x, ay.x, az.x}, d.x, w.x, a);
-      if (rem > 1) c1 = eval_plane(T, Vec3{px.y, py.y, pz.y}, Vec3{ax.y, ay.y, az.y}, d.y, w.y, a);
-    } else if (kind == TLOAM_KIND_EDGE) {
-      const double2 bx = ld2(seg.bx + j), by = ld2(seg.by + j), bz = ld2(seg.bz + j);
-      c0 = eval_line(T, Vec3{px.x, py.x, pz.x}, Vec3{ax.x, ay.x, az.x}, Vec3{bx.x, by.x, bz.x}, w.x, a);
-      if (rem > 1) c1 = eval_line(T, Vec3{px.y, py.y, pz.y}, Vec3{ax.y, ay.y, az.y}, Vec3{bx.y, by.y, bz.y}, w.y, a);
+      // planes (76 % of the set): two consecutive correspondences per lane, 16-byte loads
+      const int j = base + lane * 2;
+      const int rem = n[kind] - j;  // >=2: both elements, 1: first only
+      if (rem > 0) {
+        const double2 px = ld2(seg.px + j), py = ld2(seg.py + j), pz = ld2(seg.pz + j);
+        const double2 ax = ld2(seg.ax + j), ay = ld2(seg.ay + j), az = ld2(seg.az + j);
+        const double2 d = ld2(seg.d + j), w = ld2(seg.w + j);
+        const double c0 = eval_plane(T, Vec3{px.x, py.x, pz.x}, Vec3{ax.x, ay.x, az.x}, d.x, w.x, a);
+        // the `mutable double* cost` side channel (registration.hpp:96): written on EVERY sweep
+        if (rem > 1) {
+          const double c1 = eval_plane(T, Vec3{px.y, py.y, pz.y}, Vec3{ax.y, ay.y, az.y}, d.y, w.y, a);
+          *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
+        } else {
+          seg.cost[j] = c0;
+        }
+      }
     } else {
-      c0 = eval_point(T, Vec3{px.x, py.x, pz.x}, Vec3{ax.x, ay.x, az.x}, w.x, a);
-      if (rem > 1) c1 = eval_point(T, Vec3{px.y, py.y, pz.y}, Vec3{ax.y, ay.y, az.y}, w.y, a);
+      // lines / points: one correspondence per lane, two 64-wide passes per chunk
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        const int j = base + h * 64 + lane;
+        if (j < n[kind]) {
+          const Vec3 p{seg.px[j], seg.py[j], seg.pz[j]};
+          const Vec3 q{seg.ax[j], seg.ay[j], seg.az[j]};
+          const double w = seg.w[j];
+          double c0;
+          if (kind == TLOAM_KIND_EDGE) c0 = eval_line(T, p, q, Vec3{seg.bx[j], seg.by[j], seg.bz[j]}, w, a);
+          else c0 = eval_point(T, p, q, w, a);
+          seg.cost[j] = c0;  // registration.hpp:51,76
+        }
+      }
     }
-    // the `mutable double* cost` side channel (registration.hpp:51,76,96): written on EVERY sweep
-    if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
-    else seg.cost[j] = c0;
   }
-  // wave reduction (fixed xor-free down tree), then 4 waves through LDS in wave order
+  double v[32];
 #pragma unroll
-  for (int i = 0; i < kAccN; ++i) {
-    double v = a.v[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) red[wave][i] = v;
-  }
+  for (int i = 0; i < 27; ++i) v[i] = a.v[i];
+  v[27] = 0.5 * (log(a.pm) + (double)a.pe * 0.6931471805599453094);  // 0.5 * sum log(1+s)
+  v[28] = v[29] = v[30] = v[31] = 0.0;
+  rs_step<32, 32>(v, lane);
+  rs_step<16, 16>(v, lane);
+  rs_step<8, 8>(v, lane);
+  rs_step<4, 4>(v, lane);
+  rs_step<2, 2>(v, lane);
+  const double tot = v[0] + __shfl_xor(v[0], 1, 64);
+  if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
-  if (threadIdx.x < kAccStride) {
-    double v = 0.0;
-    if (threadIdx.x < kAccN) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] = v;
-  }
+  if (threadIdx.x < kAccStride)
+    partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 int k3_grid_for(int total_cap) {
@@ -186,287 +228,358 @@ void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool
 }
 
 // ================================================================================================
-//  fixed-order reduction of the per-block rows  (1 block x 1024 threads)
+//  fixed-order reduction of the per-block rows (one block of 256 threads: 8 row groups x 32 columns)
 // ================================================================================================
-__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[32][33]*/,
+constexpr int kRedThreads = 256;
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[8][33]*/,
                                             double* out32 /* LDS [32] */) {
-  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 32 groups of 32 components
-  double v = 0.0;
-  for (int b = grp; b < rows; b += 32) v += partials[(size_t)b * kAccStride + comp];
-  lds[grp * 33 + comp] = v;
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four independent chains keep loads in flight
+  int b = grp;
+  for (; b + 24 < rows; b += 32) {
+    v0 += partials[(size_t)b * kAccStride + comp];
+    v1 += partials[(size_t)(b + 8) * kAccStride + comp];
+    v2 += partials[(size_t)(b + 16) * kAccStride + comp];
+    v3 += partials[(size_t)(b + 24) * kAccStride + comp];
+  }
+  for (; b < rows; b += 8) v0 += partials[(size_t)b * kAccStride + comp];
+  lds[grp * 33 + comp] = (v0 + v1) + (v2 + v3);
   __syncthreads();
   if (threadIdx.x < 32) {
     double t = 0.0;
-    for (int g = 0; g < 32; ++g) t += lds[g * 33 + threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += lds[g * 33 + threadIdx.x];
     out32[threadIdx.x] = t;
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ partials, int rows,
-                                                 const GnState* __restrict__ st, double* __restrict__ out48) {
-  __shared__ double lds[32 * 33];
+__global__ __launch_bounds__(kRedThreads) void k_reduce(const double* __restrict__ partials, int rows,
+                                                        const GnState* __restrict__ st, double* __restrict__ out48) {
+  __shared__ double lds[8 * 33];
   __shared__ double tot[32];
   (void)st;
   reduce_rows(partials, rows, lds, tot);
   if (threadIdx.x < kReduceBuf) out48[threadIdx.x] = (threadIdx.x < kAccN) ? tot[threadIdx.x] : 0.0;
 }
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, partials, grid, st, out48);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st, out48);
 }
 
 // ================================================================================================
-//  K5: Ceres TrustRegionMinimizer + DoglegStrategy on the 6x6 system (one lane)
+//  K5: Ceres TrustRegionMinimizer + DoglegStrategy on the 6x6 system -- ONE WAVE AS A 6x6 MATRIX.
+//  Lane l < 36 owns matrix element (l/6, l%6); lane k < 6 owns element k of every 6-vector; scalars
+//  are wave-uniform.  Hs = S H S, the Cholesky factorisation, the two triangular solves, quadratic
+//  forms and norms are a handful of cross-lane shuffles each, so the whole trust-region step is a
+//  few hundred wave instructions with no scratch and no serial 36-element loops.  The two SE(3)
+//  "Plus" evaluations a step needs (candidate point on lane 0, Ceres' projected-gradient point on
+//  lane 1) run in lockstep and cost one.
 // ================================================================================================
-__device__ bool chol6_solve(const double A[36], const double b[6], double y[6]) {
-  double L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  for (int j = 0; j < 6; ++j) {
-    double s = A[j * 6 + j];
-    for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
-    if (!(s > 0.0) || !isfinite(s)) return false;
-    const double ljj = sqrt(s);
-    L[j * 6 + j] = ljj;
-    for (int i = j + 1; i < 6; ++i) {
-      double v = A[i * 6 + j];
-      for (int k = 0; k < j; ++k) v -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = v / ljj;
-    }
-  }
-  double z[6];
-  for (int i = 0; i < 6; ++i) {
-    double v = b[i];
-    for (int k = 0; k < i; ++k) v -= L[i * 6 + k] * z[k];
-    z[i] = v / L[i * 6 + i];
-  }
-  for (int i = 5; i >= 0; --i) {
-    double v = z[i];
-    for (int k = i + 1; k < 6; ++k) v -= L[k * 6 + i] * y[k];
-    y[i] = v / L[i * 6 + i];
-  }
-  for (int i = 0; i < 6; ++i)
-    if (!isfinite(y[i])) return false;
-  return true;
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
-__device__ double norm_n(const double* v, int n) {
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) s += v[i] * v[i];
-  return sqrt(s);
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
 }
+__device__ __forceinline__ double lget(double v, int src) { return __shfl(v, src, 64); }
+
+struct Vec2 { double x, y; };
 // minimum of 0.5 x^T B x + g^T x on |x| = r (dogleg_strategy.cc FindMinimumOnTrustRegionBoundary;
 // Ceres roots a quartic -- the global minimiser is unique, here bracketed by sampling the angle
 // and polished by bisection on the tangential derivative).  Rare branch: only when the
 // Gauss-Newton step leaves the trust region.
-__device__ void min_on_circle(const double B[4], const double g[2], double r, double x[2]) {
+__device__ __noinline__ Vec2 min_on_circle(double B0, double B1, double B2, double B3, double g0, double g1, double r) {
   const int NS = 720;
   double best = 1e300, bth = 0.0;
-  const double b01 = 0.5 * (B[1] + B[2]);
+  const double b01 = 0.5 * (B1 + B2);
   for (int i = 0; i < NS; ++i) {
     const double th = 2.0 * kPi * i / NS;
     const double cx = r * cos(th), sx = r * sin(th);
-    const double f = 0.5 * (B[0] * cx * cx + 2.0 * b01 * cx * sx + B[3] * sx * sx) + g[0] * cx + g[1] * sx;
+    const double f = 0.5 * (B0 * cx * cx + 2.0 * b01 * cx * sx + B3 * sx * sx) + g0 * cx + g1 * sx;
     if (f < best) { best = f; bth = th; }
   }
   double lo = bth - 2.0 * kPi / NS, hi = bth + 2.0 * kPi / NS;
   for (int it = 0; it < 200; ++it) {
     const double th = 0.5 * (lo + hi);
     const double cx = r * cos(th), sx = r * sin(th);
-    const double gx = B[0] * cx + b01 * sx + g[0];
-    const double gy = b01 * cx + B[3] * sx + g[1];
+    const double gx = B0 * cx + b01 * sx + g0;
+    const double gy = b01 * cx + B3 * sx + g1;
     const double df = gx * (-sx) + gy * cx;
     if (df > 0.0) hi = th; else lo = th;
     if (hi - lo < 1e-16 * (1.0 + fabs(th))) break;
   }
   const double th = 0.5 * (lo + hi);
-  x[0] = r * cos(th);
-  x[1] = r * sin(th);
+  return Vec2{r * cos(th), r * sin(th)};
 }
 
-// DoglegStrategy::ComputeStep (SUBSPACE_DOGLEG) on the Jacobi-scaled system; true = solver success
-__device__ bool dogleg_compute_step(GnState& s, const double Hs[36], const double gs[6], double step[6]) {
-  if (!s.reuse) {
-    s.reuse = 1;
-    for (int i = 0; i < 6; ++i) {
-      double v = Hs[i * 6 + i];
-      v = fmax(v, 1e-6);   // min_diagonal_
-      v = fmin(v, 1e32);   // max_diagonal_
-      s.D[i] = sqrt(v);
-    }
-    for (int i = 0; i < 6; ++i) s.grad[i] = gs[i] / s.D[i];
-    {
-      double v[6], Hv = 0.0, gg = 0.0;
-      for (int i = 0; i < 6; ++i) v[i] = s.grad[i] / s.D[i];
-      for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) Hv += v[i] * Hs[i * 6 + j] * v[j];
-      for (int i = 0; i < 6; ++i) gg += s.grad[i] * s.grad[i];
-      s.alpha = gg / Hv;
-    }
-    bool ok = false;
-    double y[6];
-    while (s.mu < 1.0) {  // max_mu_
-      double A[36];
-      for (int i = 0; i < 36; ++i) A[i] = Hs[i];
-      for (int i = 0; i < 6; ++i) A[i * 6 + i] += s.mu * s.D[i] * s.D[i];
-      if (chol6_solve(A, gs, y)) { ok = true; break; }
-      s.mu *= 10.0;  // mu_increase_factor_
-    }
-    if (!ok) return false;
-    for (int i = 0; i < 6; ++i) s.gn[i] = -s.D[i] * y[i];
-    // ComputeSubspaceModel
-    const double n0 = norm_n(s.grad, 6), n1 = norm_n(s.gn, 6);
-    if (n0 == 0.0 && n1 == 0.0) return false;
-    const bool gfirst = n0 >= n1;  // column pivoting: larger column first
-    const double* first = gfirst ? s.grad : s.gn;
-    const double* second = gfirst ? s.gn : s.grad;
-    const double nf = gfirst ? n0 : n1, ns = gfirst ? n1 : n0;
-    double u0[6], u1[6], proj = 0.0;
-    for (int i = 0; i < 6; ++i) u0[i] = first[i] / nf;
-    for (int i = 0; i < 6; ++i) proj += u0[i] * second[i];
-    for (int i = 0; i < 6; ++i) u1[i] = second[i] - proj * u0[i];
-    const double nr = norm_n(u1, 6);
-    if (ns == 0.0 || nr <= 1e-14 * nf) {
-      s.subspace_1d = 1;
-    } else {
-      s.subspace_1d = 0;
-      for (int i = 0; i < 6; ++i) { u1[i] /= nr; s.U[i] = u0[i]; s.U[6 + i] = u1[i]; }
-      s.sg[0] = s.sg[1] = 0.0;
-      for (int i = 0; i < 6; ++i) { s.sg[0] += u0[i] * s.grad[i]; s.sg[1] += u1[i] * s.grad[i]; }
-      double v0[6], v1[6], b00 = 0, b01 = 0, b11 = 0;
-      for (int i = 0; i < 6; ++i) { v0[i] = u0[i] / s.D[i]; v1[i] = u1[i] / s.D[i]; }
-      for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-          b00 += v0[i] * Hs[i * 6 + j] * v0[j];
-          b01 += v0[i] * Hs[i * 6 + j] * v1[j];
-          b11 += v1[i] * Hs[i * 6 + j] * v1[j];
-        }
-      s.sB[0] = b00; s.sB[1] = b01; s.sB[2] = b01; s.sB[3] = b11;
-    }
+// lane-distributed helpers.  M: element (mi,mj) on lane mi*6+mj (lanes >= 36 hold 0);
+// v: element k on lane k (lanes >= 6 hold 0).
+struct LaneIx {
+  int lane, mi, mj;   // mi/mj clamped to 0 for lanes >= 36 (their values are masked anyway)
+  bool ism, isv;
+};
+__device__ __forceinline__ double quad_form(const LaneIx& L, double a, double M, double b) {  // a^T M b
+  const double ai = lget(a, L.mi), bj = lget(b, L.mj);  // all lanes active for the shuffles
+  return wsum(L.ism ? ai * M * bj : 0.0);
+}
+__device__ __forceinline__ double vdot(double a, double b) { return wsum(a * b); }  // lanes >= 6 hold 0
+
+// Solve (A) y = b with A symmetric positive definite, lane-distributed right-looking Cholesky.
+// Returns false where a pivot is not positive / the result not finite (Ceres: LINEAR_SOLVER_FAILURE).
+__device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, double b, double* y_out) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double pivot = lget(a, k * 7);
+    if (!(pivot > 0.0) || !isfinite(pivot)) ok = false;
+    const double lkk = sqrt(pivot);
+    if (L.ism && L.mj == k && L.mi >= k) a = (L.mi == k) ? lkk : a / lkk;
+    const double lik = lget(a, L.mi * 6 + k);
+    const double ljk = lget(a, L.mj * 6 + k);
+    if (L.ism && L.mi > k && L.mj > k) a -= lik * ljk;
   }
-  // ComputeSubspaceDoglegStep
-  const double gnn = norm_n(s.gn, 6);
-  if (gnn <= s.radius) {
-    for (int i = 0; i < 6; ++i) step[i] = s.gn[i] / s.D[i];
-    s.step_norm = gnn;
-    return true;
+  // forward: L z = b
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double zk = lget(b, k) / lget(a, k * 7);
+    const double lik = lget(a, (L.isv ? L.lane : 0) * 6 + k);
+    if (L.lane == k) b = zk;
+    if (L.isv && L.lane > k) b -= lik * zk;
   }
-  if (s.subspace_1d) {
-    const double gnorm = norm_n(s.grad, 6);
-    for (int i = 0; i < 6; ++i) step[i] = -(s.radius / gnorm) * s.grad[i] / s.D[i];
-    s.step_norm = s.radius;
-    return true;
+  // backward: L^T y = z
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+    const double yk = lget(b, k) / lget(a, k * 7);
+    const double lki = lget(a, k * 6 + (L.isv ? L.lane : 0));
+    if (L.lane == k) b = yk;
+    if (L.isv && L.lane < k) b -= lki * yk;
   }
-  double m2[2];
-  min_on_circle(s.sB, s.sg, s.radius, m2);
-  for (int i = 0; i < 6; ++i) step[i] = (s.U[i] * m2[0] + s.U[6 + i] * m2[1]) / s.D[i];
-  s.step_norm = s.radius;
-  return true;
+  if (__any((L.isv && !isfinite(b)) ? 1 : 0)) ok = false;
+  *y_out = L.isv ? b : 0.0;
+  return ok;
 }
 
-// || x - Plus(x, -g) ||_inf   (TrustRegionMinimizer::EvaluateGradientAndJacobian)
-__device__ double grad_max_norm(const double x[6], const double g[6]) {
-  double ng[6], xp[6], m = 0.0;
-  for (int i = 0; i < 6; ++i) ng[i] = -g[i];
-  se3_plus(x, ng, xp);
-  for (int i = 0; i < 6; ++i) m = fmax(m, fabs(x[i] - xp[i]));
-  return m;
-}
-
-__device__ void unpack_total(const double* tot, double* cost, double g[6], double H[36]) {
-  for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 6; ++j) {
-      const double v = tot[ut(i, j)];
-      H[i * 6 + j] = v;
-      H[j * 6 + i] = v;
-    }
-  for (int i = 0; i < 6; ++i) g[i] = tot[21 + i];
-  *cost = tot[27];
-}
-
-// Consume one reduced sweep and run the minimiser until the next sweep is needed (or it is done).
-// Mirrors trust_region_minimizer.cc Minimize(): IterationZero, then per iteration
-// ComputeTrustRegionStep -> candidate -> tolerances -> IsStepSuccessful -> Handle(Un)SuccessfulStep.
+// Consume one reduced sweep (tot: H upper triangle 0..20, g 21..26, cost 27 -- in LDS) and run the
+// minimiser until the next sweep is needed or it is done.  Mirrors trust_region_minimizer.cc
+// Minimize(): IterationZero, then per iteration ComputeTrustRegionStep -> candidate -> tolerances
+// -> IsStepSuccessful -> Handle(Un)SuccessfulStep, with DoglegStrategy (SUBSPACE_DOGLEG) inlined.
 // The candidate sweep is fused (cost + Jacobian in one pass): Ceres evaluates the candidate
-// cost-only and re-evaluates an accepted point with Jacobians; same numbers, half the traffic.
-__device__ void gn_consume(GnState& s, const double* tot) {
-  if (s.done) return;
+// cost-only and re-evaluates an accepted point with Jacobians -- same numbers, half the traffic.
+// The gradient-tolerance test of a freshly accepted point is evaluated together with the next
+// candidate and, if it fires, the speculative iteration is rolled back.
+__device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const double* tot, int lane) {
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   const int max_num_iterations = 4, max_consecutive_invalid = 5;
-  double cost, g[6], H[36];
-  unpack_total(tot, &cost, g, H);
-  s.gn_evaluations++;
-  if (s.phase == PH_ITER0) {
-    s.x_cost = cost;
-    for (int i = 0; i < 6; ++i) s.g[i] = g[i];
-    for (int i = 0; i < 36; ++i) s.H[i] = H[i];
-    for (int i = 0; i < 6; ++i) s.S[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));  // jacobi_scaling, iteration 0 only
-    s.x_norm = norm_n(s.x, 6);
-    s.step_successful = 1;
-    s.gmax = grad_max_norm(s.x, g);
+  LaneIx L;
+  L.lane = lane;
+  L.ism = lane < 36;
+  L.isv = lane < 6;
+  L.mi = L.ism ? lane / 6 : 0;
+  L.mj = L.ism ? lane - L.mi * 6 : 0;
+  // ---- wave-uniform state
+  int phase = st->phase, iteration = st->iteration, invalid = st->invalid, step_successful = st->step_successful;
+  int reuse = st->reuse, subspace_1d = st->subspace_1d, done = 0;
+  int evals = st->gn_evaluations + 1, iters = st->gn_iterations, accepted = st->accepted_steps;
+  double x_cost = st->x_cost, x_norm = st->x_norm, gmax = st->gmax, mcc = st->model_cost_change;
+  double radius = st->radius, mu = st->mu, alpha = st->alpha, step_norm = st->step_norm;
+  double sg0 = st->sg[0], sg1 = st->sg[1], sB0 = st->sB[0], sB1 = st->sB[1], sB3 = st->sB[3];
+  Pose T_cur = st->T_cur, T_eval = st->T_eval;
+  // ---- lane-distributed state
+  const int vk = L.isv ? lane : 0;
+  double x = L.isv ? st->x[vk] : 0.0, xc = L.isv ? st->x_cand[vk] : 0.0;
+  double S = L.isv ? st->S[vk] : 0.0, D = L.isv ? st->D[vk] : 1.0;
+  double grad = L.isv ? st->grad[vk] : 0.0, gnv = L.isv ? st->gn[vk] : 0.0;
+  double U0 = L.isv ? st->U[vk] : 0.0, U1 = L.isv ? st->U[6 + vk] : 0.0;
+  double Hc = L.ism ? st->H[lane] : 0.0, gc = L.isv ? st->g[vk] : 0.0;
+  // ---- the new sweep
+  const double cost = tot[27];
+  const int ui = L.mi < L.mj ? L.mi : L.mj, uj = L.mi < L.mj ? L.mj : L.mi;
+  const double Hn = L.ism ? tot[ui * 6 - (ui * (ui - 1)) / 2 + (uj - ui)] : 0.0;
+  const double gn_new = L.isv ? tot[21 + vk] : 0.0;
+  bool need_gmax = false;
+  if (phase == PH_ITER0) {
+    x_cost = cost;
+    Hc = Hn;
+    gc = gn_new;
+    const double hkk = lget(Hn, vk * 7);
+    S = L.isv ? 1.0 / (1.0 + sqrt(hkk)) : 0.0;  // jacobi_scaling, fixed at iteration 0 of the Solve
+    x_norm = sqrt(vdot(x, x));
+    step_successful = 1;
+    need_gmax = true;
   } else {
     const double candidate_cost = cost;
-    double dx[6];
-    for (int i = 0; i < 6; ++i) dx[i] = s.x[i] - s.x_cand[i];
-    if (norm_n(dx, 6) <= parameter_tolerance * (s.x_norm + parameter_tolerance)) { s.done = 1; return; }
-    if (fabs(s.x_cost - candidate_cost) <= function_tolerance * s.x_cost) { s.done = 1; return; }
-    const double rel = (s.x_cost - candidate_cost) / s.model_cost_change;
-    if (rel > min_relative_decrease) {
-      for (int i = 0; i < 6; ++i) s.x[i] = s.x_cand[i];
-      s.T_cur = s.T_eval;
-      s.x_norm = norm_n(s.x, 6);
-      s.x_cost = candidate_cost;
-      for (int i = 0; i < 6; ++i) s.g[i] = g[i];
-      for (int i = 0; i < 36; ++i) s.H[i] = H[i];
-      s.gmax = grad_max_norm(s.x, g);
-      s.step_successful = 1;
-      s.accepted_steps++;
-      if (rel < 0.25) s.radius *= 0.5;                               // DoglegStrategy::StepAccepted
-      if (rel > 0.75) s.radius = fmax(s.radius, 3.0 * s.step_norm);
-      s.mu = fmax(1e-8, 2.0 * s.mu / 10.0);
-      s.reuse = 0;
-    } else {
-      s.step_successful = 0;                                         // StepRejected
-      s.radius *= 0.5;
-      s.reuse = 1;
+    const double dx = x - xc;
+    if (sqrt(vdot(dx, dx)) <= parameter_tolerance * (x_norm + parameter_tolerance)) done = 1;   // ParameterToleranceReached
+    else if (fabs(x_cost - candidate_cost) <= function_tolerance * x_cost) done = 1;             // FunctionToleranceReached
+    else {
+      const double rel = (x_cost - candidate_cost) / mcc;   // TrustRegionStepEvaluator::StepQuality
+      if (rel > min_relative_decrease) {                    // HandleSuccessfulStep
+        x = xc;
+        T_cur = T_eval;
+        x_norm = sqrt(vdot(x, x));
+        x_cost = candidate_cost;
+        Hc = Hn;
+        gc = gn_new;
+        step_successful = 1;
+        accepted++;
+        need_gmax = true;
+        if (rel < 0.25) radius *= 0.5;                      // DoglegStrategy::StepAccepted
+        if (rel > 0.75) radius = fmax(radius, 3.0 * step_norm);
+        mu = fmax(1e-8, 2.0 * mu / 10.0);
+        reuse = 0;
+      } else {                                              // HandleUnsuccessfulStep / StepRejected
+        step_successful = 0;
+        radius *= 0.5;
+        reuse = 1;
+      }
     }
   }
-  for (;;) {
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (s.iteration >= max_num_iterations) { s.done = 1; return; }
-    if (s.step_successful && s.gmax <= gradient_tolerance) { s.done = 1; return; }
-    if (s.radius <= min_trust_region_radius) { s.done = 1; return; }
-    s.iteration++;
-    s.gn_iterations++;
-    double Hs[36], gs[6], step[6];
-    for (int i = 0; i < 6; ++i) {
-      gs[i] = s.S[i] * s.g[i];
-      for (int j = 0; j < 6; ++j) Hs[i * 6 + j] = s.S[i] * s.H[i * 6 + j] * s.S[j];
-    }
-    const bool lin_ok = dogleg_compute_step(s, Hs, gs, step);
-    bool valid = false;
-    if (lin_ok) {
-      double sg = 0.0, sHs = 0.0;
-      for (int i = 0; i < 6; ++i) {
-        sg += step[i] * gs[i];
-        for (int j = 0; j < 6; ++j) sHs += step[i] * Hs[i * 6 + j] * step[j];
+  while (!done) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient test deferred while need_gmax)
+    if (iteration >= max_num_iterations) { done = 1; break; }
+    if (!need_gmax && step_successful && gmax <= gradient_tolerance) { done = 1; break; }
+    if (radius <= min_trust_region_radius) { done = 1; break; }
+    iteration++;
+    iters++;
+    // ---- Jacobi-scaled system
+    const double s_i = lget(S, L.mi), s_j = lget(S, L.mj);
+    const double Hs = L.ism ? s_i * Hc * s_j : 0.0;
+    const double gs = S * gc;
+    bool lin_ok = true;
+    if (!reuse) {  // DoglegStrategy::ComputeStep, fresh
+      reuse = 1;
+      const double hkk = lget(Hs, vk * 7);
+      D = L.isv ? sqrt(fmin(fmax(hkk, 1e-6), 1e32)) : 1.0;  // min_diagonal_ / max_diagonal_
+      grad = gs / D;                                         // ComputeGradient
+      {                                                      // ComputeCauchyPoint
+        const double v = grad / D;
+        alpha = vdot(grad, grad) / quad_form(L, v, Hs, v);
       }
-      s.model_cost_change = -sg - 0.5 * sHs;
-      valid = s.model_cost_change > 0.0;
+      // ComputeGaussNewtonStep: (Hs + mu D^2) y = gs ; on failure mu *= 10 while mu < max_mu (1.0)
+      bool ok = false;
+      double y = 0.0;
+      while (mu < 1.0) {
+        const double dd = lget(D, L.mi);
+        const double A = Hs + ((L.ism && L.mi == L.mj) ? mu * dd * dd : 0.0);
+        if (chol_solve_wave(L, A, gs, &y)) { ok = true; break; }
+        mu *= 10.0;
+      }
+      if (!ok) lin_ok = false;
+      else {
+        gnv = -D * y;
+        // ComputeSubspaceModel: orthonormal basis of span{grad, gn}, larger column first
+        const double n0 = sqrt(vdot(grad, grad)), n1 = sqrt(vdot(gnv, gnv));
+        if (n0 == 0.0 && n1 == 0.0) lin_ok = false;
+        else {
+          const bool gfirst = n0 >= n1;
+          const double nf = gfirst ? n0 : n1, ns = gfirst ? n1 : n0;
+          const double first = gfirst ? grad : gnv, second = gfirst ? gnv : grad;
+          const double u0 = first / nf;
+          const double proj = vdot(u0, second);
+          double u1 = second - proj * u0;
+          const double nr = sqrt(vdot(u1, u1));
+          if (ns == 0.0 || nr <= 1e-14 * nf) {
+            subspace_1d = 1;
+          } else {
+            subspace_1d = 0;
+            u1 /= nr;
+            U0 = u0;
+            U1 = u1;
+            sg0 = vdot(u0, grad);
+            sg1 = vdot(u1, grad);
+            const double v0 = u0 / D, v1 = u1 / D;
+            sB0 = quad_form(L, v0, Hs, v0);
+            sB1 = quad_form(L, v0, Hs, v1);
+            sB3 = quad_form(L, v1, Hs, v1);
+          }
+        }
+      }
     }
-    if (!valid) {  // HandleInvalidStep
-      if (++s.invalid >= max_consecutive_invalid) { s.done = 1; return; }
-      s.mu *= 10.0;
-      s.reuse = 0;
-      s.step_successful = 0;
+    double step = 0.0;
+    bool valid = false;
+    if (lin_ok) {  // ComputeSubspaceDoglegStep
+      const double gnn = sqrt(vdot(gnv, gnv));
+      if (gnn <= radius) {
+        step = gnv / D;
+        step_norm = gnn;
+      } else if (subspace_1d) {
+        const double gnorm = sqrt(vdot(grad, grad));
+        step = -(radius / gnorm) * grad / D;
+        step_norm = radius;
+      } else {
+        const Vec2 m2 = min_on_circle(sB0, sB1, sB1, sB3, sg0, sg1, radius);
+        step = (U0 * m2.x + U1 * m2.y) / D;
+        step_norm = radius;
+      }
+      if (!L.isv) step = 0.0;
+      mcc = -vdot(step, gs) - 0.5 * quad_form(L, step, Hs, step);  // model_cost_change_
+      valid = mcc > 0.0;
+    }
+    // ---- candidate Plus(x, delta) on lane 0 and projected-gradient point Plus(x, -g) on lane 1
+    const double delta = valid ? step * S : 0.0;
+    if (valid || need_gmax) {
+      double in[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        // shuffles must run with all lanes active: hoisted out of the per-lane select
+        const double gi = lget(gc, i), di = lget(delta, i);
+        in[i] = (lane == 1) ? -gi : di;
+      }
+      const Pose C = compose(se3_exp(in), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
+      double out[6];
+      se3_log(C, out);
+      double xc_new = 0.0, diff = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double c0 = lget(out[i], 0), c1 = lget(out[i], 1);
+        if (lane == i) { xc_new = c0; diff = fabs(x - c1); }
+      }
+      if (need_gmax) {
+        need_gmax = false;
+        gmax = wmax(L.isv ? diff : 0.0);  // || x - Plus(x, -g) ||_inf
+        if (gmax <= gradient_tolerance) {  // the accepted point was already converged: roll back
+          iteration--;
+          iters--;
+          done = 1;
+          break;
+        }
+      }
+      if (valid) {
+        xc = xc_new;
+        T_eval.qw = lget(C.qw, 0); T_eval.qx = lget(C.qx, 0); T_eval.qy = lget(C.qy, 0); T_eval.qz = lget(C.qz, 0);
+        T_eval.tx = lget(C.tx, 0); T_eval.ty = lget(C.ty, 0); T_eval.tz = lget(C.tz, 0);
+      }
+    }
+    if (!valid) {  // HandleInvalidStep -> DoglegStrategy::StepIsInvalid
+      if (++invalid >= max_consecutive_invalid) { done = 1; break; }
+      mu *= 10.0;
+      reuse = 0;
+      step_successful = 0;
       continue;
     }
-    s.invalid = 0;
-    double delta[6];
-    for (int i = 0; i < 6; ++i) delta[i] = step[i] * s.S[i];
-    se3_plus(s.x, delta, s.x_cand);      // PoseSE3Parameterization::Plus  registration.cpp:162-173
-    s.T_eval = se3_exp(s.x_cand);        // what every Evaluate() then computes (:22,:58,:98)
-    s.phase = PH_CAND;
-    return;
+    invalid = 0;
+    phase = PH_CAND;
+    break;  // the next K3 sweep evaluates x_cand
+  }
+  // ---- write back
+  if (L.isv) {
+    st->x[vk] = x; st->x_cand[vk] = xc; st->S[vk] = S; st->D[vk] = D; st->grad[vk] = grad; st->gn[vk] = gnv;
+    st->U[vk] = U0; st->U[6 + vk] = U1; st->g[vk] = gc;
+  }
+  if (L.ism) st->H[lane] = Hc;
+  if (lane == 0) {
+    st->phase = phase; st->iteration = iteration; st->invalid = invalid; st->step_successful = step_successful;
+    st->reuse = reuse; st->subspace_1d = subspace_1d; st->done = done;
+    st->gn_evaluations = evals; st->gn_iterations = iters; st->accepted_steps = accepted;
+    st->x_cost = x_cost; st->x_norm = x_norm; st->gmax = gmax; st->model_cost_change = mcc;
+    st->radius = radius; st->mu = mu; st->alpha = alpha; st->step_norm = step_norm;
+    st->sg[0] = sg0; st->sg[1] = sg1; st->sB[0] = sB0; st->sB[1] = sB1; st->sB[2] = sB1; st->sB[3] = sB3;
+    st->T_cur = T_cur; st->T_eval = T_eval;
   }
 }
 
@@ -482,6 +595,7 @@ __global__ void k_solve_init(GnState* st) {
   s.invalid = 0;
   s.step_successful = 1;
   s.done = 0;
+  s.gmax = 1e300;
   s.T_eval = se3_exp(s.x);
   s.T_cur = s.T_eval;
 }
@@ -497,29 +611,28 @@ void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_set_eval, dim3(1), dim3(64), 0, s, st, se3_dev);
 }
 
-__global__ void k_gn_step(GnState* st, const double* __restrict__ in48) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int i = 0; i < kReduceBuf; ++i) st->total[i] = in48[i];
-  gn_consume(*st, st->total);
+__global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __restrict__ in48) {
+  __shared__ double tot[kReduceBuf];
+  if (threadIdx.x < kReduceBuf) tot[threadIdx.x] = in48[threadIdx.x];
+  __syncthreads();
+  if (st->done) return;
+  gn_consume_wave(st, tot, threadIdx.x);
 }
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
 }
 
 // single-GPU fast path: reduce the block rows and advance the minimiser in ONE launch
-__global__ __launch_bounds__(1024) void k_reduce_and_step(const double* __restrict__ partials, int rows,
-                                                          GnState* __restrict__ st) {
-  __shared__ double lds[32 * 33];
+__global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* __restrict__ partials, int rows,
+                                                                 GnState* __restrict__ st) {
+  __shared__ double lds[8 * 33];
   __shared__ double tot[32];
   if (st->done) return;
   reduce_rows(partials, rows, lds, tot);
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < kAccN; ++i) st->total[i] = tot[i];
-    gn_consume(*st, st->total);
-  }
+  if (threadIdx.x < 64) gn_consume_wave(st, tot, threadIdx.x);
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(1024), 0, s, partials, grid, st);
+  hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
 }
 
 // ================================================================================================
@@ -579,20 +692,25 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
   hipLaunchKernelGGL(k_weights, dim3(blocks), dim3(256), 0, s, A, partial);
 }
 
-// sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded
-__global__ void k_outer_finish(const double* __restrict__ partial, int blocks, const int* __restrict__ seg_n,
-                               double* __restrict__ sums16) {
+// sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded.
+// One lane per partial row (blocks == 64), fixed shuffle tree.
+__global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
+                                                     const int* __restrict__ seg_n, double* __restrict__ sums16) {
   const int t = threadIdx.x;
-  if (t < 16) {
-    double v = 0.0;
-    if (t < 4 || t == 8) {
-      const int col = (t == 8) ? 4 : t;
-      for (int b = 0; b < blocks; ++b) v += partial[b * 8 + col];
-    } else if (t < 8) {
-      v = (double)seg_n[t - 4];
-    }
-    sums16[t] = v;
+  double v[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) v[c] = (t < blocks) ? partial[t * 8 + c] : 0.0;
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+  if (t == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sums16[c] = v[c];
+    sums16[8] = v[4];
   }
+  if (t >= 4 && t < 8) sums16[t] = (double)seg_n[t - 4];
+  if (t > 8 && t < 16) sums16[t] = 0.0;
 }
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st, double* sums16,
                          hipStream_t s) {

@@ -555,17 +555,26 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
 #pragma unroll
   for (int k = 1; k < kKinds; ++k) kind += (slot >= A.sv.slot_off[k]) ? 1 : 0;
   const unsigned long long f = A.sv.flags[slot];
-  if ((f >> 32) == 0ull) return;  // not valid
   const unsigned long long sc = A.sv.scan[slot];
+  const unsigned long long sn = A.sv.scan[slot + 1];  // the scan has n_slots + 1 entries
   const unsigned long long sb = A.sv.scan[A.sv.slot_off[kind]];
   long long C = (long long)((sc & 0xffffffffull) - (sb & 0xffffffffull));
+  long long Cn = (long long)((sn & 0xffffffffull) - (sb & 0xffffffffull));
   const int V = (int)((sc >> 32) - (sb >> 32));
+  const int Vn = (int)((sn >> 32) - (sb >> 32));
   if (A.rank_counts) {
     double off = 0.0;
     for (int r = 0; r < A.rank; ++r) off += A.rank_counts[r * kKinds + kind];
     C += (long long)off;
+    Cn += (long long)off;
   }
-  if (C >= (long long)A.maxnum[kind]) return;
+  const long long maxnum = (long long)A.maxnum[kind];
+  // number of factors of this kind = V just past the LAST slot whose C is still below the cap;
+  // exactly one slot per kind satisfies this (no atomics)
+  const bool last_slot = (slot + 1 == A.sv.slot_off[kind + 1]);
+  if (C < maxnum && (last_slot || Cn >= maxnum)) A.seg_n[kind] = Vn;
+  if ((f >> 32) == 0ull) return;  // not valid
+  if (C >= maxnum) return;
   const CorrSeg& seg = A.cv.k[kind];
   if (V >= seg.cap) return;  // cannot happen (cap >= min(n, maxnum)); defensive
   const int pos = V;
@@ -577,7 +586,6 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
   if (kind <= TLOAM_KIND_GROUND) seg.d[pos] = A.sv.rd[slot];
   seg.w[pos] = A.sv.w_src[slot];  // weight captured by value at construction (registration.hpp:51,76,96)
   seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
-  atomicMax(&A.seg_n[kind], V + 1);
 }
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
                     const double* rank_counts, int rank, int nranks, hipStream_t s) {
