@@ -81,6 +81,7 @@ struct GnState {
   double x[6];        // accepted iterate == `parameters` (registration.hpp:328)
   double x_cand[6];   // candidate evaluated by the sweep in flight
   Pose T_eval;        // exp(point being swept)
+  Rt Rt_eval;         // the same as rotation matrix + translation (what K3 streams against)
   Pose T_cur;         // exp(x), used by the builders
   // minimiser
   double x_cost, x_norm, gmax, model_cost_change;

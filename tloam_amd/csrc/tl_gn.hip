@@ -16,6 +16,8 @@
 // 128-correspondence chunks, 28 fp64 accumulators per lane (21 upper-triangular H, 6 g, cost),
 // wave reduction by cross-lane shuffles, 4-wave LDS combine, one 32-double partial row per block,
 // then a fixed-order tree over the rows: bit-reproducible run to run (no atomics).
+#include <stdlib.h>
+
 #include "tl_common.hpp"
 
 namespace tl {
@@ -45,6 +47,14 @@ __device__ __forceinline__ double fast_rsqrt(double x) {  // v_rsq_f64 + one New
   return __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
 }
 
+// T * p with T as a row-major rotation matrix + translation (what SE3::operator* computes through the
+// quaternion sandwich, sophus so3.hpp:358-367; same value to rounding, 9 FMAs instead of ~21 ops)
+__device__ __forceinline__ Vec3 act_rt(const Rt& T, Vec3 p) {
+  return {__builtin_fma(T.r[0], p.x, __builtin_fma(T.r[1], p.y, __builtin_fma(T.r[2], p.z, T.t[0]))),
+          __builtin_fma(T.r[3], p.x, __builtin_fma(T.r[4], p.y, __builtin_fma(T.r[5], p.z, T.t[1]))),
+          __builtin_fma(T.r[6], p.x, __builtin_fma(T.r[7], p.y, __builtin_fma(T.r[8], p.z, T.t[2])))};
+}
+
 // CauchyLoss(1.0): rho' = 1/(1+s) (rho'' < 0 -> Ceres' Corrector takes its clamped branch: r and J
 // are only scaled by sqrt(rho')), block cost 0.5*log(1+s).  Returns rho'.
 __device__ __forceinline__ double cauchy(Acc& a, double s) {
@@ -67,8 +77,8 @@ __device__ __forceinline__ void acc_row(Acc& a, const double J[6], double r, dou
 }
 
 // PointToPlaneErr::Evaluate (registration.cpp:96-117) through ResidualBlock::Evaluate + CauchyLoss(1)
-__device__ __forceinline__ double eval_plane(const Pose& T, Vec3 p, Vec3 n, double d, double w, Acc& a) {
-  const Vec3 pw = act(T, p);
+__device__ __forceinline__ double eval_plane(const Rt& T, Vec3 p, Vec3 n, double d, double w, Acc& a) {
+  const Vec3 pw = act_rt(T, p);
   const double r = dot(n, pw) + d;           // :100 (unweighted)
   const Vec3 c = cross(pw, n);               // n^T (-hat(pw)) = (pw x n)^T   :110,:112
   const double J[6] = {n.x * w, n.y * w, n.z * w, c.x * w, c.y * w, c.z * w};
@@ -78,8 +88,8 @@ __device__ __forceinline__ double eval_plane(const Pose& T, Vec3 p, Vec3 n, doub
 }
 
 // PointToLineErr::Evaluate (registration.cpp:55-88)
-__device__ __forceinline__ double eval_line(const Pose& T, Vec3 p, Vec3 la, Vec3 lb, double w, Acc& a) {
-  const Vec3 pw = act(T, p);
+__device__ __forceinline__ double eval_line(const Rt& T, Vec3 p, Vec3 la, Vec3 lb, double w, Acc& a) {
+  const Vec3 pw = act_rt(T, p);
   const Vec3 nu = cross(pw - la, pw - lb);   // :62
   const Vec3 e = lb - la;                    // :80  (|la - lb| = |e|, :63)
   const double k = w * fast_rsqrt(dot(e, e));
@@ -100,8 +110,8 @@ __device__ __forceinline__ double eval_line(const Pose& T, Vec3 p, Vec3 la, Vec3
 }
 
 // PointToPointErr::Evaluate (registration.cpp:19-47)
-__device__ __forceinline__ double eval_point(const Pose& T, Vec3 p, Vec3 q, double w, Acc& a) {
-  const Vec3 pw = act(T, p);
+__device__ __forceinline__ double eval_point(const Rt& T, Vec3 p, Vec3 q, double w, Acc& a) {
+  const Vec3 pw = act_rt(T, p);
   const double r0 = (q.x - pw.x) * w, r1 = (q.y - pw.y) * w, r2 = (q.z - pw.z) * w;  // :26-30
   const double rs = r0 + r1 + r2;
   const double wx = pw.x * w, wy = pw.y * w, wz = pw.z * w;
@@ -131,66 +141,127 @@ __device__ __forceinline__ void rs_step(double (&v)[32], int lane) {
   }
 }
 
-__global__ __launch_bounds__(256, 4) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
+// One wave-chunk in flight: RES-dependent number of 16-byte streams per lane (plane 8, line 10,
+// point 7).  fetch() is branch-free -- every lane always issues every load (the segments are padded
+// by one chunk, so a tail lane reads valid memory and is masked in consume()) -- which lets the
+// compiler count outstanding loads exactly and wait with vmcnt(N) for the OLDER chunk only.
+template <int RES>
+struct ChunkBuf {
+  double2 px, py, pz, ax, ay, az, bx, by, bz, d, w;
+};
+// uniform base pointer (SGPR pair) + 32-bit per-lane byte offset: lets the compiler use the
+// `global_load_dwordx4 v, v_off, s[base]` addressing form (one offset VGPR for all streams)
+template <bool NT>
+__device__ __forceinline__ double2 ld2o_t(const double* base, unsigned byte_off) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d* p = reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(base) + byte_off);
+  const v2d v = NT ? __builtin_nontemporal_load(p) : *p;
+  return double2{v.x, v.y};
+}
+#ifndef TLOAM_K3_NT
+#define TLOAM_K3_NT false
+#endif
+__device__ __forceinline__ double2 ld2o(const double* base, unsigned byte_off) { return ld2o_t<TLOAM_K3_NT>(base, byte_off); }
+template <int RES>
+__device__ __forceinline__ void fetch(const CorrSeg& seg, int j, ChunkBuf<RES>& b) {
+  const unsigned o = (unsigned)j * 8u;
+  b.px = ld2o(seg.px, o); b.py = ld2o(seg.py, o); b.pz = ld2o(seg.pz, o);
+  b.ax = ld2o(seg.ax, o); b.ay = ld2o(seg.ay, o); b.az = ld2o(seg.az, o);
+  b.w = ld2o(seg.w, o);
+  if (RES == TLOAM_RES_PLANE) b.d = ld2o(seg.d, o);
+  if (RES == TLOAM_RES_LINE) { b.bx = ld2o(seg.bx, o); b.by = ld2o(seg.by, o); b.bz = ld2o(seg.bz, o); }
+}
+template <int RES>
+__device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a) {
+  const int rem = n - j;  // >= 2: both correspondences of this lane, 1: the first only, <= 0: none
+  if (rem <= 0) return;
+  double c0, c1 = 0.0;
+  if (RES == TLOAM_RES_PLANE) {
+    c0 = eval_plane(T, Vec3{b.px.x, b.py.x, b.pz.x}, Vec3{b.ax.x, b.ay.x, b.az.x}, b.d.x, b.w.x, a);
+    if (rem > 1) c1 = eval_plane(T, Vec3{b.px.y, b.py.y, b.pz.y}, Vec3{b.ax.y, b.ay.y, b.az.y}, b.d.y, b.w.y, a);
+  } else if (RES == TLOAM_RES_LINE) {
+    c0 = eval_line(T, Vec3{b.px.x, b.py.x, b.pz.x}, Vec3{b.ax.x, b.ay.x, b.az.x}, Vec3{b.bx.x, b.by.x, b.bz.x}, b.w.x, a);
+    if (rem > 1)
+      c1 = eval_line(T, Vec3{b.px.y, b.py.y, b.pz.y}, Vec3{b.ax.y, b.ay.y, b.az.y}, Vec3{b.bx.y, b.by.y, b.bz.y}, b.w.y, a);
+  } else {
+    c0 = eval_point(T, Vec3{b.px.x, b.py.x, b.pz.x}, Vec3{b.ax.x, b.ay.x, b.az.x}, b.w.x, a);
+    if (rem > 1) c1 = eval_point(T, Vec3{b.px.y, b.py.y, b.pz.y}, Vec3{b.ax.y, b.ay.y, b.az.y}, b.w.y, a);
+  }
+  // the `mutable double* cost` side channel (registration.hpp:51,76,96): written on EVERY sweep
+  if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
+  else seg.cost[j] = c0;
+}
+
+// All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment, software-pipelined: the loads of the
+// next DEPTH-1 chunks are in flight while the current one is evaluated.  Control flow is wave-uniform.
+#ifndef TLOAM_K3_DEPTH
+#define TLOAM_K3_DEPTH 2
+#endif
+template <int RES>
+__device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, int n, int nchunks, int i0, int W,
+                                              int lane, Acc& a) {
+  if (i0 >= nchunks) return;
+  const int m = (nchunks - i0 + W - 1) / W;  // chunks owned by this wave
+  const int l2 = lane * 2;
+#define TL_J(t) ((i0 + (t) * W) * kChunk + l2)
+#if TLOAM_K3_DEPTH == 2
+  ChunkBuf<RES> b0, b1;
+  fetch<RES>(seg, TL_J(0), b0);
+  for (int t = 1;; t += 2) {
+    if (t >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b0, a); break; }
+    fetch<RES>(seg, TL_J(t), b1);
+    consume<RES>(T, seg, TL_J(t - 1), n, b0, a);
+    if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t), n, b1, a); break; }
+    fetch<RES>(seg, TL_J(t + 1), b0);
+    consume<RES>(T, seg, TL_J(t), n, b1, a);
+  }
+#else
+  ChunkBuf<RES> b0, b1, b2;
+  fetch<RES>(seg, TL_J(0), b0);
+  if (m == 1) { consume<RES>(T, seg, TL_J(0), n, b0, a); return; }
+  fetch<RES>(seg, TL_J(1), b1);
+  for (int t = 2;; t += 3) {
+    if (t >= m) { consume<RES>(T, seg, TL_J(t - 2), n, b0, a); consume<RES>(T, seg, TL_J(t - 1), n, b1, a); break; }
+    fetch<RES>(seg, TL_J(t), b2);
+    consume<RES>(T, seg, TL_J(t - 2), n, b0, a);
+    if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b1, a); consume<RES>(T, seg, TL_J(t), n, b2, a); break; }
+    fetch<RES>(seg, TL_J(t + 1), b0);
+    consume<RES>(T, seg, TL_J(t - 1), n, b1, a);
+    if (t + 2 >= m) { consume<RES>(T, seg, TL_J(t), n, b2, a); consume<RES>(T, seg, TL_J(t + 1), n, b0, a); break; }
+    fetch<RES>(seg, TL_J(t + 2), b1);
+    consume<RES>(T, seg, TL_J(t), n, b2, a);
+  }
+#endif
+#undef TL_J
+}
+
+__global__ __launch_bounds__(256, 2) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
                                                         double* __restrict__ partials, int force) {
   __shared__ double red[4][32];
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
-  const Pose T = st->T_eval;       // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
-  int n[kKinds], chunk_end[kKinds];
-  int total_chunks = 0;
-#pragma unroll
-  for (int k = 0; k < kKinds; ++k) {
-    n[k] = cv.seg_n[k];
-    total_chunks += (n[k] + kChunk - 1) / kChunk;
-    chunk_end[k] = total_chunks;
-  }
+  const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
   a.pe = 1;  // 0.5 * 2^1 = 1
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
+  // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave, W = gridDim.x * 4;
-  for (int c = gw; c < total_chunks; c += W) {
-    int kind = 0;
+  // chunk g of the concatenated (planar | ground | edge | sphere) chunk list belongs to wave g % W:
+  // within segment k the wave starts at i0 = (gw - first_k) mod W -- balanced across segments
+  int first = 0;
 #pragma unroll
-    for (int k = 0; k < kKinds - 1; ++k) kind += (c >= chunk_end[k]) ? 1 : 0;
-    const int first = (kind == 0) ? 0 : chunk_end[kind - 1];
-    const int base = (c - first) * kChunk;
-    const CorrSeg& seg = cv.k[kind];
-    if (kind <= TLOAM_KIND_GROUND) {
-      // planes (76 % of the set): two consecutive correspondences per lane, 16-byte loads
-      const int j = base + lane * 2;
-      const int rem = n[kind] - j;  // >=2: both elements, 1: first only
-      if (rem > 0) {
-        const double2 px = ld2(seg.px + j), py = ld2(seg.py + j), pz = ld2(seg.pz + j);
-        const double2 ax = ld2(seg.ax + j), ay = ld2(seg.ay + j), az = ld2(seg.az + j);
-        const double2 d = ld2(seg.d + j), w = ld2(seg.w + j);
-        const double c0 = eval_plane(T, Vec3{px.x, py.x, pz.x}, Vec3{ax.x, ay.x, az.x}, d.x, w.x, a);
-        // the `mutable double* cost` side channel (registration.hpp:96): written on EVERY sweep
-        if (rem > 1) {
-          const double c1 = eval_plane(T, Vec3{px.y, py.y, pz.y}, Vec3{ax.y, ay.y, az.y}, d.y, w.y, a);
-          *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
-        } else {
-          seg.cost[j] = c0;
-        }
-      }
-    } else {
-      // lines / points: one correspondence per lane, two 64-wide passes per chunk
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        const int j = base + h * 64 + lane;
-        if (j < n[kind]) {
-          const Vec3 p{seg.px[j], seg.py[j], seg.pz[j]};
-          const Vec3 q{seg.ax[j], seg.ay[j], seg.az[j]};
-          const double w = seg.w[j];
-          double c0;
-          if (kind == TLOAM_KIND_EDGE) c0 = eval_line(T, p, q, Vec3{seg.bx[j], seg.by[j], seg.bz[j]}, w, a);
-          else c0 = eval_point(T, p, q, w, a);
-          seg.cost[j] = c0;  // registration.hpp:51,76
-        }
-      }
-    }
+  for (int k = 0; k < kKinds; ++k) {
+    const int n = cv.seg_n[k];
+    const int nchunks = (n + kChunk - 1) / kChunk;
+    int i0 = (gw - first) % W;
+    if (i0 < 0) i0 += W;
+    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    else sweep_segment<TLOAM_RES_POINT>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    first = (first + nchunks) % W;
   }
   double v[32];
 #pragma unroll
@@ -211,13 +282,17 @@ __global__ __launch_bounds__(256, 4) void k3_accumulate(CorrView cv, GnState* __
 }
 
 int k3_grid_for(int total_cap) {
-  // one wave per 128-correspondence chunk up to a full-chip resident grid (256 CUs x 4 blocks)
+  if (const char* e = getenv("TLOAM_K3_BLOCKS")) {  // tuning aid
+    const int b = atoi(e);
+    if (b > 0) return b;
+  }
+  // one wave per 128-correspondence chunk up to a full-chip resident grid (256 CUs x 2 blocks)
   int waves = (total_cap + kChunk - 1) / kChunk;
   int blocks = (waves + 3) / 4;
   if (blocks < 1) blocks = 1;
-  if (blocks > 1024) {
-    // balance: every wave gets the same number of chunks
-    const int per_wave = (waves + 4096 - 1) / 4096;
+  if (blocks > 512) {
+    // two resident blocks per CU (8 waves); balance: every wave gets the same number of chunks
+    const int per_wave = (waves + 2048 - 1) / 2048;
     const int need_waves = (waves + per_wave - 1) / per_wave;
     blocks = (need_waves + 3) / 4;
   }
@@ -580,6 +655,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     st->radius = radius; st->mu = mu; st->alpha = alpha; st->step_norm = step_norm;
     st->sg[0] = sg0; st->sg[1] = sg1; st->sB[0] = sB0; st->sB[1] = sB1; st->sB[2] = sB1; st->sB[3] = sB3;
     st->T_cur = T_cur; st->T_eval = T_eval;
+    st->Rt_eval = to_rt(T_eval);
   }
 }
 
@@ -598,6 +674,7 @@ __global__ void k_solve_init(GnState* st) {
   s.gmax = 1e300;
   s.T_eval = se3_exp(s.x);
   s.T_cur = s.T_eval;
+  s.Rt_eval = to_rt(s.T_eval);
 }
 void launch_solve_init(GnState* st, hipStream_t s) { hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(64), 0, s, st); }
 
@@ -606,6 +683,7 @@ __global__ void k_set_eval(GnState* st, const double* se3) {
   double a[6];
   for (int i = 0; i < 6; ++i) a[i] = se3[i];
   st->T_eval = se3_exp(a);
+  st->Rt_eval = to_rt(st->T_eval);
 }
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_set_eval, dim3(1), dim3(64), 0, s, st, se3_dev);

@@ -63,6 +63,18 @@ TL_HD void rotation_matrix(const Pose& T, double R[9]) {
   R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
+// rotation matrix (row-major) + translation form of a Pose
+struct Rt {
+  double r[9];
+  double t[3];
+};
+TL_HD Rt to_rt(const Pose& T) {
+  Rt o;
+  rotation_matrix(T, o.r);
+  o.t[0] = T.tx; o.t[1] = T.ty; o.t[2] = T.tz;
+  return o;
+}
+
 // so3.hpp:583-619 expAndTheta + se3.hpp:761-785
 TL_HD Pose se3_exp(const double a[6]) {
   const double ox = a[3], oy = a[4], oz = a[5];

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtloam_hip.so")
+LIB_PATH = os.environ.get("TLOAM_HIP_LIB") or os.path.join(_HERE, "libtloam_hip.so")  # env override: tuning builds only
 
 KIND_PLANAR, KIND_GROUND, KIND_EDGE, KIND_SPHERE = 0, 1, 2, 3
 RES_PLANE, RES_LINE, RES_POINT = 0, 1, 2
