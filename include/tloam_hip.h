@@ -178,9 +178,16 @@ int tloam_solve(tloam_ctx* ctx, double se3_inout[6], tloam_stats* stats);
 /* Timing helper for the bench: `launches` back-to-back K3 sweeps at se3 on the context's
  * stream bracketed by HIP events; returns the mean kernel-pair time in microseconds. */
 int tloam_time_accumulate(tloam_ctx* ctx, const double se3[6], int launches, double* mean_us);
-/* accumulated HIP-event time (us) and launch count of the K3 kernel since the last reset */
+/* accumulated HIP-event time (us) and launch count of the K3 sweeps since the last reset; the first
+ * call arms the timer: each K3 dispatch then carries a HIP start/stop event pair bound to the
+ * dispatch packet (hipExtLaunchKernelGGL), i.e. the elapsed time is the kernel duration itself */
 int tloam_k3_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* launches,
                    double* algorithmic_bytes);
+/* the same over EVERY K3 launch, including the no-op launches enqueued after a solver tolerance exit
+ * (the population a kernel trace averages over) */
+int tloam_k3_timer_all(tloam_ctx* ctx, double* total_us, int64_t* launches);
+/* debugging aid: raw copy of the device-resident minimiser state; returns its size in doubles */
+int tloam_debug_state(tloam_ctx* ctx, double* out, int n_doubles);
 
 /* ---- multi-GPU: correspondence set sharded over ranks, one all-reduce per sweep --------
  * (nothing in the reference).  Call before set_source / set_correspondences.

@@ -145,7 +145,8 @@ void launch_fitness(const GridView& g, const double* qx, const double* qy, const
 
 // K3 and the minimiser
 int k3_grid_for(int total_cap);
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s);
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s,
+               hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
 void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);

@@ -18,6 +18,8 @@
 // then a fixed-order tree over the rows: bit-reproducible run to run (no atomics).
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "tl_common.hpp"
 
 namespace tl {
@@ -298,8 +300,16 @@ int k3_grid_for(int total_cap) {
   }
   return blocks;
 }
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s) {
-  hipLaunchKernelGGL(k3_accumulate, dim3(grid), dim3(256), 0, s, cv, st, partials, force ? 1 : 0);
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s,
+               hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (ev_start && ev_stop) {
+    // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
+    // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
+    hipExtLaunchKernelGGL(k3_accumulate, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, cv, st, partials,
+                          force ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(k3_accumulate, dim3(grid), dim3(256), 0, s, cv, st, partials, force ? 1 : 0);
+  }
 }
 
 // ================================================================================================
