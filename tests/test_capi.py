@@ -1,0 +1,113 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/tloam_hip.h declares, agrees on
+struct layout, and its host-only entry points (SE(3) helpers, shard ranges) behave.  No GPU compute is
+attempted here; on a machine without a gfx950 device tloam_create must FAIL loudly (TLOAM_E_HIP) --
+there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tloam_amd import registration as reg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tloam_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tloam_[a-z0-9_]+)\s*\(", txt)) - {"tloam_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = reg.load_library()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/tloam_hip.h but not exported"
+    assert set(reg.EXPORTED_SYMBOLS) == set(names)
+    assert L.tloam_abi_version() == 1
+
+
+def test_struct_layout_matches_the_c_header():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "tloam_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(tloam_tls_config), offsetof(tloam_tls_config, sphere_dist_thres),
+         offsetof(tloam_tls_config, cost_threshold), sizeof(tloam_stats), offsetof(tloam_stats, kind_cost),
+         offsetof(tloam_stats, se3));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c"); exe = os.path.join(d, "t")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        vals = list(map(int, subprocess.check_output([exe]).split()))
+    for S in (reg.TlsConfig, ob.TlsConfig):
+        assert vals[0] == C.sizeof(S) and vals[1] == S.sphere_dist_thres.offset and vals[2] == S.cost_threshold.offset
+    for S in (reg.Stats, ob.Stats):
+        assert vals[3] == C.sizeof(S) and vals[4] == S.kind_cost.offset and vals[5] == S.se3.offset
+
+
+def test_default_config_is_the_shipped_yaml():
+    cfg = reg.default_config()
+    expect = dict(k_corr=10, factor_num=4, edge_dist_thres=1.0, edge_dir_thres=0.85, edge_maxnum=1200,
+                  sphere_dist_thres=0.5, sphere_maxnum=200, planar_dist_thres=0.5, planar_maxnum=2500,
+                  ground_dist_thres=0.5, ground_maxnum=2000, max_iterations=4, cost_threshold=5e-9,
+                  gnc_factor=11.8, noise_bound=0.01, fitness_thres=0.02)   # lidar_odometry.yaml:23-39
+    for k, v in expect.items():
+        assert getattr(cfg, k) == v, k
+        assert getattr(ob.make_config(), k) == v, k
+
+
+def test_status_strings_and_factory():
+    L = reg.load_library()
+    assert L.tloam_status_string(0) == b"ok"
+    assert b"rigid" in L.tloam_status_string(-3)
+    with pytest.raises(ValueError, match="Other methods are not yet supported"):   # front_end.cpp:163
+        reg.make_registration("NDT")
+
+
+def test_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the -m gpu tests")
+    h = C.c_void_p()
+    cfg = reg.default_config()
+    assert reg.load_library().tloam_create(C.byref(cfg), 0, C.byref(h)) == -4       # TLOAM_E_HIP
+    with pytest.raises(reg.TloamHipError, match="no CPU fallback"):
+        reg.HipRegistration()
+
+
+def test_host_se3_helpers_match_the_oracle():
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        x = np.concatenate([rng.normal(0, 2, 3), rng.normal(0, 0.8, 3)])
+        d = np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)])
+        np.testing.assert_allclose(reg.se3_exp(x), ob.se3_exp(x), atol=1e-14)
+        np.testing.assert_allclose(reg.se3_log(reg.se3_exp(x)), x, atol=1e-12)
+        np.testing.assert_allclose(reg.se3_plus(x, d), ob.plus(x, d), atol=1e-13)
+    bad = reg.se3_exp(x); bad[:3, :3] *= 1.01
+    with pytest.raises(reg.TloamHipError, match="BAD_POSE"):
+        reg.se3_log(bad)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 1_000_003])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_shard_ranges_tile_the_index_space(n, nranks):
+    prev = 0
+    sizes = []
+    for r in range(nranks):
+        lo, hi = reg.shard_range(n, r, nranks)
+        assert lo == prev and hi >= lo
+        prev = hi
+        sizes.append(hi - lo)
+    assert prev == n
+    assert max(sizes) - min(sizes) <= 1                 # contiguous, balanced blocks

@@ -1,0 +1,116 @@
+"""-m gpu: the sharded (multi-rank) path on ONE GPU.  Two processes each own a context on cuda:0 with a
+contiguous block of the source points; the sum all-reduce of the 48-double normal-equation buffer (and of
+the cap / cost-sum side buffers) is supplied through tloam_comm_init_callback and carried by gloo.  The
+pose, the per-iteration bookkeeping and the correspondence counts must equal the single-rank solve.
+(RCCL refuses two ranks on one device, so the native ncclAllReduce path is exercised with nranks = 1.)"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import pose_delta
+from tloam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_allreduce():
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def allreduce(dev_ptr, count, stream):
+        assert hip.hipStreamSynchronize(stream) == 0
+        host = np.zeros(count)
+        assert hip.hipMemcpy(host.ctypes.data, dev_ptr, 8 * count, 2) == 0    # D2H
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert hip.hipMemcpy(dev_ptr, host.ctypes.data, 8 * count, 1) == 0    # H2D
+        return 0
+    return allreduce
+
+
+def _worker(rank, world, port, q, caps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tloam_amd import registration as reg
+        sc = synth.make_scene(seed=31)
+        H = reg.HipRegistration(reg.default_config(**caps))
+        H.comm_init_callback(rank, world, _make_allreduce())
+        H.set_frames(sc.source, sc.target)
+        rc, T, st = H.scan_match(sc.T_pred)
+        assert rc == 0
+        idx = [H.get_correspondences(k)["idx"].tolist() for k in range(4)]
+        # pre-built sets, sharded
+        sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=3001, n_line=777, n_point=130)
+        P = reg.HipRegistration(); P.comm_init_callback(rank, world, _make_allreduce())
+        for rt in range(3):
+            P.set_correspondences(rt, *sets[rt])
+        Hm, g, cost = P.accumulate(x_eval)
+        x, pst = P.solve(x_eval)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, idx)
+        if rank == 0:
+            q.put(dict(T=T, st={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in st.items()},
+                       idx=gathered, H=Hm, g=g, cost=cost, x=x))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("caps", [{}, dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)],
+                         ids=["default_caps", "caps_bind_across_ranks"])
+def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, caps)) for r in range(world)]
+    for p in procs: p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120); assert p.exitcode == 0
+    sc = synth.make_scene(seed=31)
+    S = hip_module.HipRegistration(hip_module.default_config(**caps)); S.set_frames(sc.source, sc.target)
+    rc, T1, st1 = S.scan_match(sc.T_pred)
+    dt, dr = pose_delta(res["T"], T1)
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    assert res["st"]["n_corr"] == st1["n_corr"]
+    for key in ("gn_evaluations", "gn_iterations", "accepted_steps", "outer_iterations"):
+        assert res["st"][key] == st1[key], key
+    for k in range(4):
+        merged = sum((res["idx"][r][k] for r in range(world)), [])
+        assert merged == S.get_correspondences(k)["idx"].tolist(), k
+    sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=3001, n_line=777, n_point=130)
+    P = hip_module.HipRegistration()
+    for rt in range(3):
+        P.set_correspondences(rt, *sets[rt])
+    Hm, g, cost = P.accumulate(x_eval)
+    np.testing.assert_allclose(res["H"], Hm, rtol=1e-12, atol=1e-12 * np.abs(Hm).max())
+    np.testing.assert_allclose(res["g"], g, rtol=1e-12, atol=1e-12 * np.abs(g).max())
+    x, _ = P.solve(x_eval)
+    np.testing.assert_allclose(res["x"], x, atol=1e-10)
+
+
+def test_native_rccl_single_rank(hip_module):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce through the dlopen'ed librccl with nranks = 1:
+    proves the library resolves and the call signatures (128-byte id by value, ncclFloat64, ncclSum) hold."""
+    uid = hip_module.rccl_unique_id()
+    assert len(uid) == 128
+    sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=3001, n_line=777, n_point=130)
+    A = hip_module.HipRegistration(); B = hip_module.HipRegistration()
+    A.comm_init_rccl(0, 1, uid)
+    for R in (A, B):
+        for rt in range(3):
+            R.set_correspondences(rt, *sets[rt])
+    xa, _ = A.solve(x_eval); xb, _ = B.solve(x_eval)
+    assert np.array_equal(xa, xb)

@@ -1,0 +1,99 @@
+"""-m gpu: BASELINE.json's full sizes (1 M correspondences / 1 M-point frames) through size-independent
+properties -- the oracle needs seconds per frame at this size, so it checks a bounded sample only."""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+from oracle import binding as ob
+from tloam_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIG = 1 << 30
+
+
+@pytest.fixture(scope="module")
+def prebuilt_1m():
+    return synth.make_prebuilt(seed=1)
+
+
+def test_k3_additivity_over_splits_1m(hip_module, prebuilt_1m):
+    """H, g and cost are sums over correspondences: sweeping two halves separately must add up to the
+    sweep over the whole 1 M set (the property the multi-GPU sharding relies on)."""
+    sets, x_true, x_eval = prebuilt_1m
+    H = hip_module.HipRegistration()
+    for rt in range(3):
+        H.set_correspondences(rt, *sets[rt])
+    Hf, gf, cf = H.accumulate(x_eval)
+    tot = [np.zeros((6, 6)), np.zeros(6), 0.0]
+    for half in (0, 1):
+        Hh = hip_module.HipRegistration()
+        for rt in range(3):
+            p, a, b, d, w = sets[rt]
+            m = len(p) // 2
+            sl = slice(0, m) if half == 0 else slice(m, None)
+            Hh.set_correspondences(rt, p[sl], a[sl], None if b is None else b[sl], None if d is None else d[sl], w[sl])
+        Hp, gp, cp = Hh.accumulate(x_eval)
+        tot[0] += Hp; tot[1] += gp; tot[2] += cp
+        Hh.close()
+    np.testing.assert_allclose(tot[0], Hf, rtol=1e-11, atol=1e-11 * np.abs(Hf).max())
+    np.testing.assert_allclose(tot[1], gf, rtol=1e-11, atol=1e-11 * np.abs(gf).max())
+    assert abs(tot[2] - cf) < 1e-11 * cf
+    assert np.allclose(Hf, Hf.T) and np.all(np.linalg.eigvalsh(Hf) > 0)
+
+
+def test_k3_sample_against_oracle_1m(hip_module, prebuilt_1m):
+    """Side-channel costs of the full 1 M sweep, checked against the oracle on a 20 k sample."""
+    sets, x_true, x_eval = prebuilt_1m
+    H = hip_module.HipRegistration()
+    for rt in range(3):
+        H.set_correspondences(rt, *sets[rt])
+    H.accumulate(x_eval)
+    rng = np.random.default_rng(0)
+    for rt in range(3):
+        p, a, b, d, w = sets[rt]
+        pick = np.sort(rng.choice(len(p), min(len(p), 7000), replace=False))
+        O = ob.Oracle()
+        O.set_correspondences(rt, p[pick], a[pick], None if b is None else b[pick], None if d is None else d[pick], w[pick])
+        O.accumulate(x_eval)
+        np.testing.assert_allclose(H.get_costs(rt)[pick], O.get_costs(rt), rtol=1e-9, atol=1e-18)
+
+
+def test_solve_1m_known_answer(hip_module, prebuilt_1m):
+    sets, x_true, x_eval = prebuilt_1m
+    H = hip_module.HipRegistration()
+    for rt in range(3):
+        H.set_correspondences(rt, *sets[rt])
+    x, st = H.solve(x_eval)
+    assert np.linalg.norm(x[:3] - x_true[:3]) < 5e-4 and np.linalg.norm(x[3:] - x_true[3:]) < 2e-5
+    assert st["accepted_steps"] >= 2
+    x2, st2 = H.solve(x_eval)
+    assert np.array_equal(x, x2)                        # bit-reproducible
+
+
+def test_scan_match_1m_frame_properties(hip_module):
+    sc = synth.make_scene(seed=0, n_src=synth.M1_SRC, n_tgt=synth.M1_TGT)
+    cfg = hip_module.default_config(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+    H = hip_module.HipRegistration(cfg)
+    H.set_frames(sc.source, sc.target)
+    rc, T, st = H.scan_match(sc.T_pred)
+    assert rc == 0 and sum(st["n_corr"]) > 800_000
+    dt, dr = pose_delta(T, sc.T_true)
+    assert dt < 1e-3 and dr < 1e-4 and dt < pose_delta(sc.T_pred, sc.T_true)[0] / 10
+    for k in range(4):
+        c = H.get_correspondences(k, capacity=len(sc.source.cloud(k)))
+        assert len(c["idx"]) == st["n_corr"][k]
+        assert np.all(np.diff(c["idx"]) > 0)            # index order, no duplicates
+        w = H.get_weights(k)
+        assert np.all((w >= 0) & (w <= 1)) and st["bad_weights"] == 0
+        if k <= 1:
+            assert np.allclose(np.linalg.norm(c["a"], axis=1), 1.0, atol=1e-12)   # unit plane normals
+        if k == 2:
+            assert np.allclose(np.linalg.norm(c["a"] - c["b"], axis=1), 0.2, atol=1e-12)
+    rc, T2, st2 = H.scan_match(sc.T_pred)
+    assert np.array_equal(T, T2)
+    # oracle spot check of the builders on a 3 k-query sample of the 1 M-point planar cloud
+    O = ob.Oracle(ob.make_config(planar_maxnum=BIG)); O.set_target(0, sc.target.planar)
+    q = sc.source.planar[:3000] @ sc.T_pred[:3, :3].T + sc.T_pred[:3, 3]
+    hi, hd, hc = H.knn(0, q, 0.5, 5); oi, od, oc = O.knn(0, q, 0.5, 5)
+    assert np.array_equal(hc, oc) and np.array_equal(hi, oi) and np.array_equal(hd, od)
+    assert np.all(np.diff(hd, axis=1)[hi[:, 1:] >= 0] >= 0)                     # ascending distances

@@ -170,7 +170,7 @@ def make_scene(seed=0, n_src=SMALL_SRC, n_tgt=SMALL_TGT, noise=0.02, density=10.
     return Scene(source, target, T_true, T_pred, seed)
 
 
-def make_prebuilt(seed=1, n_plane=760_000, n_line=200_000, n_point=40_000, weights="ones"):
+def make_prebuilt(seed=1, n_plane=760_000, n_line=200_000, n_point=40_000, weights="ones", noise_scale=1.0):
     """Pre-built correspondence sets of SURVEY 8(d) config 3 (the K3 roofline run).
     Returns dict(res_type -> (p, a, b, d, w)), the true pose vector and an evaluation point."""
     rng = np.random.default_rng(seed)
@@ -188,15 +188,15 @@ def make_prebuilt(seed=1, n_plane=760_000, n_line=200_000, n_point=40_000, weigh
     out = {}
     p = src(n_plane); pw = p @ R.T + t
     nrm = unit(n_plane)
-    d = -(nrm * pw).sum(axis=1) + rng.normal(0, 0.05, n_plane)
+    d = -(nrm * pw).sum(axis=1) + noise_scale * rng.normal(0, 0.05, n_plane)
     out[0] = [p, nrm, None, d]
     p = src(n_line); pw = p @ R.T + t
     dirs = unit(n_line)
-    off = rng.normal(0, 0.05, (n_line, 3))
+    off = noise_scale * rng.normal(0, 0.05, (n_line, 3))
     mu = pw + off + dirs * rng.uniform(-0.3, 0.3, (n_line, 1))
     out[1] = [p, mu + 0.1 * dirs, mu - 0.1 * dirs, None]
     p = src(n_point); pw = p @ R.T + t
-    out[2] = [p, pw + rng.normal(0, 0.02, (n_point, 3)), None, None]
+    out[2] = [p, pw + noise_scale * rng.normal(0, 0.02, (n_point, 3)), None, None]
     for k, n in ((0, n_plane), (1, n_line), (2, n_point)):
         if weights == "ones":
             w = np.ones(n)
