@@ -1,0 +1,149 @@
+// hip_registration.hpp -- drop-in tloam::RegistrationInterface implementation backed by the MI355X
+// library (include/tloam_hip.h).  Header-only; link with -ltloam_hip.
+//
+// Replaces tloam::LocalRegistration (reference src/models/registration/registration.cpp) behind the same
+// plugin boundary (include/tloam/models/registration/registration_interface.hpp:40-48):
+//
+//     bool setInputSource(Frame&)                      registration.cpp:232-239
+//     bool setInputTarget(Frame&)                      registration.cpp:241-248
+//     bool scanMatching(Frame&, Isometry3d&, Isometry3d&)   registration.cpp:879-1133
+//     std::pair<double,double> getFitnessScore()       registration.cpp:257-296
+//
+// Selection mirrors FrontEnd::initRegistraton (front_end.cpp:155-167): add
+//     else if (method == "TLS_HIP") local_registration_ptr_ = std::make_shared<HipRegistration>(config_node["TLS"]);
+// (INTEGRATION.md has the full patch).
+//
+// The marshalling core is a template over the frame / pose types so that it can be compiled and tested
+// without Eigen, Open3D or ROS: it only needs
+//     frame.<kind>_feature->points_   : contiguous array of 3 doubles per point  (PointCloud2.hpp:396)
+//     pose.matrix().data()            : 16 doubles, column-major                 (Eigen::Isometry3d)
+// When the reference's registration_interface.hpp has been included first, the concrete
+// tloam::HipRegistration : RegistrationInterface is defined at the bottom of this file.
+#pragma once
+
+#include <cstddef>
+#include <cstdio>
+#include <utility>
+
+#include "../include/tloam_hip.h"
+
+namespace tloam_hip {
+
+// error convention of the reference: every method returns true; failures are asserts / ROS_WARN
+// (SURVEY 8(b)).  Here a failing status is logged and mapped to false / (0,0).
+inline bool ok(int status, const char* what, const tloam_ctx* ctx) {
+  if (status == TLOAM_OK) return true;
+  std::fprintf(stderr, "[tloam_hip] %s: %s %s\n", what, tloam_status_string(status), ctx ? tloam_last_error(ctx) : "");
+  return false;
+}
+
+// PointsAccessor<Cloud>::data(cloud) -> const double* (AoS xyz), ::size(cloud) -> number of points.
+// The default fits open3d::geometry::PointCloud2 (std::vector<Eigen::Vector3d> points_).
+template <class Cloud>
+struct PointsAccessor {
+  static const double* data(const Cloud& c) { return c.points_.empty() ? nullptr : reinterpret_cast<const double*>(c.points_.data()); }
+  static double* mutable_data(Cloud& c) { return c.points_.empty() ? nullptr : reinterpret_cast<double*>(c.points_.data()); }
+  static std::size_t size(const Cloud& c) { return c.points_.size(); }
+};
+
+template <class FrameT, class PoseT>
+class HipRegistrationCore {
+ public:
+  explicit HipRegistrationCore(const tloam_tls_config& cfg, int device_id = 0) {
+    status_ = tloam_create(&cfg, device_id, &ctx_);
+    ok(status_, "tloam_create", nullptr);
+  }
+  ~HipRegistrationCore() { tloam_destroy(ctx_); }
+  HipRegistrationCore(const HipRegistrationCore&) = delete;
+  HipRegistrationCore& operator=(const HipRegistrationCore&) = delete;
+
+  bool valid() const { return ctx_ != nullptr; }
+  tloam_ctx* context() { return ctx_; }
+  const tloam_stats& lastStats() const { return stats_; }
+
+  bool setInputSource(FrameT& f) { return upload(f, /*source=*/true); }
+  bool setInputTarget(FrameT& f) { return upload(f, /*source=*/false); }
+
+  bool scanMatching(FrameT& out_result, PoseT& predict_pose, PoseT& result_pose) {
+    if (!ctx_) return false;
+    auto& scan = *out_result.scan_cloud;
+    using Acc = PointsAccessor<typename std::remove_reference<decltype(scan)>::type>;
+    double result[16];
+    const int rc = tloam_scan_match(ctx_, predict_pose.matrix().data(), /*omega_perturb=*/nullptr, result,
+                                    Acc::mutable_data(scan), Acc::size(scan), &stats_);
+    if (!ok(rc, "tloam_scan_match", ctx_)) return false;
+    for (int i = 0; i < 16; ++i) result_pose.matrix().data()[i] = result[i];  // registration.cpp:1124
+    return true;
+  }
+
+  std::pair<double, double> getFitnessScore() {
+    double fitness = 0.0, rmse = 0.0;
+    if (!ctx_ || !ok(tloam_fitness(ctx_, &fitness, &rmse), "tloam_fitness", ctx_)) return {0.0, 0.0};
+    return {fitness, rmse};
+  }
+
+ private:
+  bool upload(FrameT& f, bool source) {
+    if (!ctx_) return false;
+    bool all = true;
+    auto put = [&](int kind, const auto& cloud_ptr) {
+      using Cloud = typename std::remove_reference<decltype(*cloud_ptr)>::type;
+      const int rc = source ? tloam_set_source(ctx_, kind, PointsAccessor<Cloud>::data(*cloud_ptr), PointsAccessor<Cloud>::size(*cloud_ptr))
+                            : tloam_set_target(ctx_, kind, PointsAccessor<Cloud>::data(*cloud_ptr), PointsAccessor<Cloud>::size(*cloud_ptr));
+      all = ok(rc, source ? "tloam_set_source" : "tloam_set_target", ctx_) && all;
+    };
+    put(TLOAM_KIND_PLANAR, f.planar_feature);   // registration.cpp:233-236 / :242-245
+    put(TLOAM_KIND_GROUND, f.ground_feature);
+    put(TLOAM_KIND_EDGE, f.edge_feature);
+    put(TLOAM_KIND_SPHERE, f.sphere_feature);
+    return all;
+  }
+
+  tloam_ctx* ctx_ = nullptr;
+  int status_ = TLOAM_OK;
+  tloam_stats stats_{};
+};
+
+}  // namespace tloam_hip
+
+// ---- concrete plugin, only where the reference's interface (Eigen + Open3D + yaml-cpp) is available ----
+#ifdef TLOAM_REGISTRATION_INTERFACE_HPP
+#include <yaml-cpp/yaml.h>
+namespace tloam {
+class HipRegistration : public RegistrationInterface {
+ public:
+  // same constructor argument as LocalRegistration (registration.cpp:182-206, initConfig :212-230)
+  explicit HipRegistration(const YAML::Node& node, int device_id = 0) : core_(fromYaml(node), device_id) {}
+  bool setInputSource(Frame& f) override { return core_.setInputSource(f); }
+  bool setInputTarget(Frame& f) override { return core_.setInputTarget(f); }
+  bool scanMatching(Frame& out, Eigen::Isometry3d& predict, Eigen::Isometry3d& result) override {
+    return core_.scanMatching(out, predict, result);
+  }
+  std::pair<double, double> getFitnessScore() override { return core_.getFitnessScore(); }
+
+ private:
+  static tloam_tls_config fromYaml(const YAML::Node& n) {
+    tloam_tls_config c;
+    tloam_default_config(&c);
+    c.k_corr = n["k_corr"].as<int>();
+    c.factor_num = n["factor_num"].as<int>();
+    c.edge_dist_thres = n["edge_dist_thres"].as<double>();
+    c.sphere_dist_thres = n["sphere_dist_thres"].as<double>();
+    c.planar_dist_thres = n["planar_dist_thres"].as<double>();
+    c.ground_dist_thres = n["ground_dist_thres"].as<double>();
+    c.edge_dir_thres = n["edge_dir_thres"].as<double>();
+    c.edge_maxnum = n["edge_maxnum"].as<int>();
+    c.sphere_maxnum = n["sphere_maxnum"].as<int>();
+    c.planar_maxnum = n["planar_maxnum"].as<int>();
+    c.ground_maxnum = n["ground_maxnum"].as<int>();
+    c.max_iterations = n["max_iterations"].as<int>();
+    c.cost_threshold = n["cost_threshold"].as<double>();
+    c.gnc_factor = n["gnc_factor"].as<double>();
+    c.noise_bound = n["noise_bound"].as<double>();
+    c.fitness_thres = n["fitness_thres"].as<double>();
+    return c;
+  }
+  tloam_hip::HipRegistrationCore<Frame, Eigen::Isometry3d> core_;
+};
+}  // namespace tloam
+#endif

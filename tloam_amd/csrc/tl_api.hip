@@ -121,7 +121,8 @@ struct tloam_ctx {
   KindData kd[kKinds];
   // concatenated per-source-slot arrays of the current scan_match
   DBuf<double> sx, sy, sz, w_src, rax, ray, raz, rbx, rby, rbz, rd;
-  DBuf<unsigned long long> flags, scan, scan_tmp;
+  DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
+  DBuf<int> tile_of_slot, tile_fill, qslot;
   SlotView sv{};
   CorrView cv{};
   DBuf<int> seg_n;
@@ -463,6 +464,7 @@ void tloam_destroy(tloam_ctx* c) {
   c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
   c->rax.release(); c->ray.release(); c->raz.release(); c->rbx.release(); c->rby.release(); c->rbz.release();
   c->rd.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
+  c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qslot.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
   c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
@@ -626,7 +628,15 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   GridView grids[kKinds];
   for (int k = 0; k < kKinds; ++k) grids[k] = c->kd[k].gv;
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
-  launch_build(c->sv, grids, bp, c->state.p, c->stream);
+  {
+    const size_t ntiles = (size_t)build_tile_count(grids);
+    HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
+    HIPC(c, c->tile_fill.reserve(ntiles)); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
+    HIPC(c, c->qslot.reserve(n_slots + 1));
+    HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
+  }
+  launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
+               c->qslot.p, c->scan_tmp.p, c->stream);
   launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream);
   const double* rank_counts = nullptr;
   if (c->nranks > 1) {

@@ -18,6 +18,8 @@
 // eig[2] > 3 eig[1], |dir.z| > 0.85, plane validity > 0.2, knn_dist > 0.2) are evaluated with
 // the same un-fused fp64 operation order as the CPU oracle, so a correspondence flips in/out on
 // the device only where it flips on the host.
+#include <algorithm>
+
 #include "tl_common.hpp"
 
 namespace tl {
@@ -235,12 +237,23 @@ void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int
 }
 
 // ================================================================================================
-//  K1: exact k-NN over the 27-cell neighbourhood, top-K kept sorted in registers
+//  K1: exact k-NN over the 27-cell neighbourhood, top-K kept sorted in registers.
+//  Candidates come from a "point source": the cell-sorted arrays in HBM (PtsGlobal) or a tile of them
+//  staged in LDS (PtsLds, see k_build_tiles).
 // ================================================================================================
+struct PtsGlobal {
+  const double *x, *y, *z;
+  const int* idx;
+  __device__ __forceinline__ double X(int j) const { return x[j]; }
+  __device__ __forceinline__ double Y(int j) const { return y[j]; }
+  __device__ __forceinline__ double Z(int j) const { return z[j]; }
+  __device__ __forceinline__ int I(int j) const { return idx[j]; }
+};
+
 template <int K>
 struct TopK {
   double d[K];
-  int j[K];  // position in the cell-sorted arrays
+  int j[K];  // position in the point source
 };
 
 // nanoflann L2_Simple_Adaptor: sum of squared differences accumulated in dimension order
@@ -252,14 +265,14 @@ __device__ __forceinline__ double sqdist(double qx, double qy, double qz, double
   return r;
 }
 
-template <int K>
-__device__ __forceinline__ void topk_insert(TopK<K>& tk, const int* __restrict__ gidx, double d, int j) {
+template <int K, class P>
+__device__ __forceinline__ void topk_insert(TopK<K>& tk, const P& pts, double d, int j) {
   // strict total order (d, original index): ties broken towards the lower target index
   auto less = [&](double da, int ja, double db, int jb) -> bool {
     if (da < db) return true;
     if (da > db) return false;
     if (jb < 0) return true;  // empty slot (both +inf cannot happen: da is finite)
-    return gidx[ja] < gidx[jb];
+    return pts.I(ja) < pts.I(jb);
   };
   if (!less(d, j, tk.d[K - 1], tk.j[K - 1])) return;
   bool placed = false;
@@ -278,15 +291,24 @@ __device__ __forceinline__ void topk_insert(TopK<K>& tk, const int* __restrict__
     }
   }
 }
-
 template <int K>
-__device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
+__device__ __forceinline__ void topk_clear(TopK<K>& tk) {
 #pragma unroll
   for (int m = 0; m < K; ++m) {
     tk.d[m] = __builtin_inf();
     tk.j[m] = -1;
   }
+}
+template <int K, class P>
+__device__ __forceinline__ void scan_range(const P& pts, int s, int e, double qx, double qy, double qz, TopK<K>& tk) {
+  for (int j = s; j < e; ++j) topk_insert<K, P>(tk, pts, sqdist(qx, qy, qz, pts.X(j), pts.Y(j), pts.Z(j)), j);
+}
+
+template <int K>
+__device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
+  topk_clear<K>(tk);
   if (g.n <= 0) return;
+  const PtsGlobal pts{g.gx, g.gy, g.gz, g.gidx};
   const int cx = cell_coord(qx, g.org[0], g.cell, g.dim[0]);
   const int cy = cell_coord(qy, g.org[1], g.cell, g.dim[1]);
   const int cz = cell_coord(qz, g.org[2], g.cell, g.dim[2]);
@@ -299,12 +321,7 @@ __device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy
     for (int y = cy - 1; y <= cy + 1; ++y) {
       if (y < 0 || y >= g.dim[1]) continue;
       const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
-      const int s = g.cell_start[base + x0];
-      const int e = g.cell_start[base + x1 + 1];
-      for (int j = s; j < e; ++j) {
-        const double d = sqdist(qx, qy, qz, g.gx[j], g.gy[j], g.gz[j]);
-        topk_insert<K>(tk, g.gidx, d, j);
-      }
+      scan_range<K, PtsGlobal>(pts, g.cell_start[base + x0], g.cell_start[base + x1 + 1], qx, qy, qz, tk);
     }
   }
 }
@@ -425,111 +442,387 @@ __device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
 }
 
 // ================================================================================================
-//  K1+K2 fused: one thread per source slot -> raw record + (counted, valid) flags
+//  K2: the per-query part of the four builders, given the k nearest neighbours (ascending distance)
 // ================================================================================================
+struct RawRec {
+  double a[3], b[3], d;
+  unsigned long long flag;  // low 32: counted, high 32: valid
+};
+
+// addSphereCostFactor registration.cpp:517-559
+template <class P>
+__device__ __forceinline__ void finish_sphere(const P& pts, const TopK<1>& tk, double radius, RawRec& r) {
+  const int cnt = radius_cut<1>(tk, radius);
+  const bool found = cnt > 0;
+  const bool skip = found && (tk.d[0] > 0.2);  // :536 squared distance vs 0.2 -> `continue`
+  const bool valid = found && !skip;
+  const bool counted = !skip;                    // :551 sphere_sum++ for every non-`continue`d point
+  if (valid) { r.a[0] = pts.X(tk.j[0]); r.a[1] = pts.Y(tk.j[0]); r.a[2] = pts.Z(tk.j[0]); }
+  r.flag = ((unsigned long long)(valid ? 1 : 0) << 32) | (unsigned long long)(counted ? 1 : 0);
+}
+
+// addEdgeCostFactor :427-505 (kind == edge) / addSurfCostFactor :571-635, addGroundCostFactor :714-778
+template <class P>
+__device__ __forceinline__ void finish_knn5(int kind, const P& pts, const TopK<5>& tk, double radius,
+                                            double edge_dir_thres, RawRec& r) {
+  const int cnt = radius_cut<5>(tk, radius);
+  bool valid = false;
+  double nx[5], ny[5], nz[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const bool in = m < cnt;
+    const int j = in ? tk.j[m] : 0;
+    nx[m] = in ? pts.X(j) : 0.0; ny[m] = in ? pts.Y(j) : 0.0; nz[m] = in ? pts.Z(j) : 0.0;
+  }
+  if (kind == TLOAM_KIND_EDGE) {
+    if (cnt > 3) {  // :445
+      double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        if (m < cnt) {  // :453-464, neighbours in ascending distance
+          const double x = nx[m], y = ny[m], z = nz[m];
+          cum[0] += x; cum[1] += y; cum[2] += z;
+          cum[3] += x * x; cum[4] += x * y; cum[5] += x * z;
+          cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;
+        }
+      }
+      const double nn = (double)cnt;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) cum[m] /= nn;  // :465
+      Sym3 M;
+      M.a[0][0] = cum[3] - cum[0] * cum[0];
+      M.a[1][1] = cum[6] - cum[1] * cum[1];
+      M.a[2][2] = cum[8] - cum[2] * cum[2];
+      M.a[0][1] = M.a[1][0] = cum[4] - cum[0] * cum[1];
+      M.a[0][2] = M.a[2][0] = cum[5] - cum[0] * cum[2];
+      M.a[1][2] = M.a[2][1] = cum[7] - cum[1] * cum[2];
+      double ev[3];
+      eig3_sym(M, ev);
+      const double dx = M.v[0][2], dy = M.v[1][2], dz = M.v[2][2];  // eigenvectors().col(2) :479
+      if (ev[2] > 3 * ev[1] && fabs(dz) > edge_dir_thres) {          // :481
+        r.a[0] = 0.1 * dx + cum[0];  r.a[1] = 0.1 * dy + cum[1];  r.a[2] = 0.1 * dz + cum[2];   // :483
+        r.b[0] = -0.1 * dx + cum[0]; r.b[1] = -0.1 * dy + cum[1]; r.b[2] = -0.1 * dz + cum[2];  // :484
+        valid = true;
+      }
+    }
+  } else {
+    if (cnt > 4) {  // :589 / :732  (all five neighbours inside the radius)
+      double plane[4];
+      fit_best_plane5(nx, ny, nz, plane);
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {  // :605-613 signed, no fabs
+        const double dis = plane[0] * nx[m] + plane[1] * ny[m] + plane[2] * nz[m] + plane[3];
+        if (dis > 0.2) ok = false;
+      }
+      if (ok) { r.a[0] = plane[0]; r.a[1] = plane[1]; r.a[2] = plane[2]; r.d = plane[3]; valid = true; }
+    }
+  }
+  // the cap tests (:448 / :592 / :735) only matter once num >= maxnum, and num counts ADDED factors:
+  // "added iff valid && #valid before < maxnum" (see launch_compact).
+  r.flag = valid ? ((1ull << 32) | 1ull) : 0ull;
+}
+
+__device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const RawRec& r) {
+  sv.flags[slot] = r.flag;
+  sv.rax[slot] = r.a[0]; sv.ray[slot] = r.a[1]; sv.raz[slot] = r.a[2];
+  sv.rbx[slot] = r.b[0]; sv.rby[slot] = r.b[1]; sv.rbz[slot] = r.b[2];
+  sv.rd[slot] = r.d;
+}
+
+// ================================================================================================
+//  K1+K2 driver, tiled.  The target grid of every kind is cut into TILES of 4x4x4 cells; the source
+//  points are bucketed by the tile their (transformed) cell falls into; ONE WAVE per non-empty tile
+//  stages the tile's 6x6x6-cell halo box (every candidate any of its queries can need) from HBM into
+//  LDS once -- coalesced -- and then each lane walks its own 27 cells out of LDS.
+//  Replaces the kd-tree walks of registration.cpp:444/:535/:588/:731.
+// ================================================================================================
+constexpr int kTile = 4;        // cells per tile edge
+constexpr int kHalo = kTile + 2;
+constexpr int kRows = kHalo * kHalo;   // (y,z) rows of the halo box
+constexpr int kLdsCap = 384;    // staged points per wave; denser boxes fall back to the HBM path
+
+struct TileMeta {
+  int tdim[kKinds][3];
+  int tile_base[kKinds + 1];  // concatenated tile index space over the 4 kinds
+};
 struct BuildArgs {
   SlotView sv;
   GridView grid[kKinds];
   BuildParams bp;
+  TileMeta tm;
 };
 
-__global__ __launch_bounds__(256) void k_build(BuildArgs A, const GnState* __restrict__ st) {
-  const int slot = blockIdx.x * 256 + threadIdx.x;
-  const int n_slots = A.sv.slot_off[kKinds];
-  if (slot >= n_slots) return;
+__device__ __forceinline__ int slot_kind(const SlotView& sv, int slot) {
   int kind = 0;
 #pragma unroll
-  for (int k = 1; k < kKinds; ++k) kind += (slot >= A.sv.slot_off[k]) ? 1 : 0;
-  unsigned long long flag = 0ull;
-  if (!A.bp.active[kind]) { A.sv.flags[slot] = 0ull; return; }
+  for (int k = 1; k < kKinds; ++k) kind += (slot >= sv.slot_off[k]) ? 1 : 0;
+  return kind;
+}
+
+// pass 1: tile of every source slot under the current pose; histogram of queries per tile
+__global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* __restrict__ st,
+                                                   int* __restrict__ tile_of_slot,
+                                                   unsigned long long* __restrict__ tile_cnt) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= A.sv.slot_off[kKinds]) return;
+  const int kind = slot_kind(A.sv, slot);
+  const GridView& g = A.grid[kind];
+  if (!A.bp.active[kind] || g.n <= 0) {  // inactive kind / empty target: no factor, nothing counted...
+    // ...except the sphere builder, whose counter also advances for points WITHOUT a neighbour (:551)
+    A.sv.flags[slot] = (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull;
+    tile_of_slot[slot] = -1;
+    return;
+  }
   const Pose T = st->T_cur;  // exp(se3_pose_)  registration.cpp:434/:524/:578/:721
   const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
+  // bucket by the cell clamped INTO the grid: every in-grid cell of the true 27-neighbourhood lies in
+  // that tile's halo box
+  const int cx = clampi(cell_coord(pw.x, g.org[0], g.cell, g.dim[0]), 0, g.dim[0] - 1);
+  const int cy = clampi(cell_coord(pw.y, g.org[1], g.cell, g.dim[1]), 0, g.dim[1] - 1);
+  const int cz = clampi(cell_coord(pw.z, g.org[2], g.cell, g.dim[2]), 0, g.dim[2] - 1);
+  const int t = A.tm.tile_base[kind] +
+                ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
+  tile_of_slot[slot] = t;
+  atomicAdd(&tile_cnt[t], 1ull);
+}
+// pass 2: slots grouped by tile (order inside a tile is irrelevant: every result goes to its own slot)
+__global__ __launch_bounds__(256) void k_query_scatter(int n_slots, const int* __restrict__ tile_of_slot,
+                                                       const unsigned long long* __restrict__ tile_scan,
+                                                       int* __restrict__ tile_fill, int* __restrict__ qslot) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n_slots) return;
+  const int t = tile_of_slot[slot];
+  if (t < 0) return;
+  qslot[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] = slot;
+}
+
+// LDS hand-off inside ONE wave (waves of a block run different tiles, so no __syncthreads here):
+// order this wave's LDS writes before its later LDS reads, and stop the compiler moving them
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct PtsLds {
+  const double *x, *y, *z;
+  const int* idx;
+  __device__ __forceinline__ double X(int j) const { return x[j]; }
+  __device__ __forceinline__ double Y(int j) const { return y[j]; }
+  __device__ __forceinline__ double Z(int j) const { return z[j]; }
+  __device__ __forceinline__ int I(int j) const { return idx[j]; }
+};
+
+// one query of tile-kind `kind` against point source `pts`, cell table given by `row_range`
+template <class P, class RowRange>
+__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const GridView& g, const Pose& T, int slot,
+                                          const P& pts, RowRange row_range) {
+  const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
+  const int cx = cell_coord(pw.x, g.org[0], g.cell, g.dim[0]);
+  const int cy = cell_coord(pw.y, g.org[1], g.cell, g.dim[1]);
+  const int cz = cell_coord(pw.z, g.org[2], g.cell, g.dim[2]);
+  int x0 = cx - 1, x1 = cx + 1;
+  if (x0 < 0) x0 = 0;
+  if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
+  RawRec r;
+  r.a[0] = r.a[1] = r.a[2] = r.b[0] = r.b[1] = r.b[2] = r.d = 0.0;
+  r.flag = 0ull;
   const double radius = A.bp.radius[kind];
-  double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
   if (kind == TLOAM_KIND_SPHERE) {
-    const GridView& g = A.grid[TLOAM_KIND_SPHERE];
     TopK<1> tk;
-    knn_grid<1>(g, pw.x, pw.y, pw.z, tk);
-    const int cnt = radius_cut<1>(tk, radius);
-    const bool found = cnt > 0;
-    const bool skip = found && (tk.d[0] > 0.2);   // :536 squared distance vs 0.2 -> `continue`
-    const bool valid = found && !skip;
-    const bool counted = !skip;                     // :551 sphere_sum++ for every non-`continue`d point
-    if (valid) { ra[0] = g.gx[tk.j[0]]; ra[1] = g.gy[tk.j[0]]; ra[2] = g.gz[tk.j[0]]; }
-    flag = ((unsigned long long)(valid ? 1 : 0) << 32) | (unsigned long long)(counted ? 1 : 0);
-  } else {
-    const GridView& g = A.grid[kind];
-    TopK<5> tk;
-    knn_grid<5>(g, pw.x, pw.y, pw.z, tk);
-    const int cnt = radius_cut<5>(tk, radius);
-    bool valid = false;
-    if (kind == TLOAM_KIND_EDGE) {
-      if (cnt > 3) {  // :445
-        double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-          if (m < cnt) {  // :453-464, neighbours in ascending distance
-            const double x = g.gx[tk.j[m]], y = g.gy[tk.j[m]], z = g.gz[tk.j[m]];
-            cum[0] += x; cum[1] += y; cum[2] += z;
-            cum[3] += x * x; cum[4] += x * y; cum[5] += x * z;
-            cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;
-          }
-        }
-        const double inv_n = (double)cnt;
-#pragma unroll
-        for (int m = 0; m < 9; ++m) cum[m] /= inv_n;  // :465
-        Sym3 M;
-        M.a[0][0] = cum[3] - cum[0] * cum[0];
-        M.a[1][1] = cum[6] - cum[1] * cum[1];
-        M.a[2][2] = cum[8] - cum[2] * cum[2];
-        M.a[0][1] = M.a[1][0] = cum[4] - cum[0] * cum[1];
-        M.a[0][2] = M.a[2][0] = cum[5] - cum[0] * cum[2];
-        M.a[1][2] = M.a[2][1] = cum[7] - cum[1] * cum[2];
-        double ev[3];
-        eig3_sym(M, ev);
-        const double dx = M.v[0][2], dy = M.v[1][2], dz = M.v[2][2];  // eigenvectors().col(2) :479
-        if (ev[2] > 3 * ev[1] && fabs(dz) > A.bp.edge_dir_thres) {   // :481
-          ra[0] = 0.1 * dx + cum[0];  ra[1] = 0.1 * dy + cum[1];  ra[2] = 0.1 * dz + cum[2];   // :483
-          rb[0] = -0.1 * dx + cum[0]; rb[1] = -0.1 * dy + cum[1]; rb[2] = -0.1 * dz + cum[2];  // :484
-          valid = true;
+    topk_clear<1>(tk);
+    if (x0 <= x1)
+      for (int z = cz - 1; z <= cz + 1; ++z) {
+        if (z < 0 || z >= g.dim[2]) continue;
+        for (int y = cy - 1; y <= cy + 1; ++y) {
+          if (y < 0 || y >= g.dim[1]) continue;
+          int s, e;
+          row_range(z, y, x0, x1, s, e);
+          scan_range<1, P>(pts, s, e, pw.x, pw.y, pw.z, tk);
         }
       }
-    } else {
-      if (cnt > 4) {  // :589 / :732  (all five neighbours inside the radius)
-        double nx[5], ny[5], nz[5];
-#pragma unroll
-        for (int m = 0; m < 5; ++m) { nx[m] = g.gx[tk.j[m]]; ny[m] = g.gy[tk.j[m]]; nz[m] = g.gz[tk.j[m]]; }
-        double plane[4];
-        fit_best_plane5(nx, ny, nz, plane);
-        bool ok = true;
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {  // :605-613 signed, no fabs
-          const double dis = plane[0] * nx[m] + plane[1] * ny[m] + plane[2] * nz[m] + plane[3];
-          if (dis > 0.2) ok = false;
+    finish_sphere<P>(pts, tk, radius, r);
+  } else {
+    TopK<5> tk;
+    topk_clear<5>(tk);
+    if (x0 <= x1)
+      for (int z = cz - 1; z <= cz + 1; ++z) {
+        if (z < 0 || z >= g.dim[2]) continue;
+        for (int y = cy - 1; y <= cy + 1; ++y) {
+          if (y < 0 || y >= g.dim[1]) continue;
+          int s, e;
+          row_range(z, y, x0, x1, s, e);
+          scan_range<5, P>(pts, s, e, pw.x, pw.y, pw.z, tk);
         }
-        if (ok) { ra[0] = plane[0]; ra[1] = plane[1]; ra[2] = plane[2]; rd = plane[3]; valid = true; }
+      }
+    finish_knn5<P>(kind, pts, tk, radius, A.bp.edge_dir_thres, r);
+  }
+  store_raw(A.sv, slot, r);
+}
+
+__global__ __launch_bounds__(256) void k_build_tiles(BuildArgs A, const GnState* __restrict__ st,
+                                                     const unsigned long long* __restrict__ tile_scan,
+                                                     const int* __restrict__ qslot) {
+  constexpr int kCs = kHalo + 1;                 // cell boundaries per row
+  constexpr int kEnt = kRows * kCs;              // 252 cell-table entries of a halo box
+  constexpr int kEntPerLane = (kEnt + 63) / 64;  // 4
+  constexpr int kCopyIters = kLdsCap / 64;
+  __shared__ double lx[4][kLdsCap], ly[4][kLdsCap], lz[4][kLdsCap];
+  __shared__ int lidx[4][kLdsCap];
+  __shared__ int lcs[4][kEnt];         // per row: LDS offsets of its (<= 6) cells + end
+  __shared__ int lroff[4][kRows + 1];  // per row: first LDS slot
+  __shared__ int lrgs[4][kRows];       // per row: first HBM slot
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave, W = gridDim.x * 4;
+  const int ntiles = A.tm.tile_base[kKinds];
+  const Pose T = st->T_cur;
+  double* sx = lx[wave]; double* sy = ly[wave]; double* sz = lz[wave];
+  int* sidx = lidx[wave]; int* cs = lcs[wave]; int* roff = lroff[wave]; int* rgs = lrgs[wave];
+  for (int t = gw; t < ntiles; t += W) {  // one tile per wave per pass; all of this is wave-uniform
+    const int q_beg = (int)tile_scan[t], q_end = (int)tile_scan[t + 1];
+    if (q_end <= q_beg) continue;
+    int kind = 0;
+#pragma unroll
+    for (int k = 1; k < kKinds; ++k) kind += (t >= A.tm.tile_base[k]) ? 1 : 0;
+    const GridView& g = A.grid[kind];
+    const int tloc = t - A.tm.tile_base[kind];
+    const int tdx = A.tm.tdim[kind][0], tdy = A.tm.tdim[kind][1];
+    const int tx = tloc % tdx, ty = (tloc / tdx) % tdy, tz = tloc / (tdx * tdy);
+    // halo box, clipped to the grid
+    const int bx0 = max(tx * kTile - 1, 0), bx1 = min(tx * kTile + kTile, g.dim[0] - 1);
+    const int by0 = max(ty * kTile - 1, 0), by1 = min(ty * kTile + kTile, g.dim[1] - 1);
+    const int bz0 = max(tz * kTile - 1, 0), bz1 = min(tz * kTile + kTile, g.dim[2] - 1);
+    const int nx = bx1 - bx0 + 1, ny = by1 - by0 + 1, nz = bz1 - bz0 + 1;
+    const int nrows = ny * nz;
+    wave_sync();  // the previous tile's LDS reads are done before its tables are overwritten
+    // ---- the box's cell table in ONE round trip: entry e = row * 7 + i  <-  cell_start[row_base + bx0 + i]
+    int ent[kEntPerLane];
+#pragma unroll
+    for (int m = 0; m < kEntPerLane; ++m) {
+      const int e = lane + 64 * m;
+      const int r = e / kCs, i = e - r * kCs;
+      ent[m] = 0;
+      if (r < nrows) {
+        const size_t rb = ((size_t)(bz0 + r / ny) * g.dim[1] + (by0 + r % ny)) * g.dim[0];
+        ent[m] = g.cell_start[rb + bx0 + min(i, nx)];
       }
     }
-    // the cap tests (:448 / :592 / :735) run on every point that reached them, i.e. that had
-    // >3 (>4) neighbours; but a `return` there only matters once num >= maxnum, and num counts
-    // ADDED factors, so "added iff valid && #valid before < maxnum" (see launch_compact).
-    flag = valid ? ((1ull << 32) | 1ull) : 0ull;
+#pragma unroll
+    for (int m = 0; m < kEntPerLane; ++m)
+      if (lane + 64 * m < kEnt) cs[lane + 64 * m] = ent[m];
+    wave_sync();
+    // ---- row extents -> LDS offsets (lane r owns row r)
+    int rs = 0, rc = 0;
+    if (lane < nrows) {
+      rs = cs[lane * kCs];
+      rc = cs[lane * kCs + nx] - rs;
+    }
+    int inc = rc;  // inclusive wave scan of the row counts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
+    }
+    const int total = __shfl(inc, 63, 64);
+    if (lane < nrows) {
+      roff[lane] = inc - rc;
+      rgs[lane] = rs;
+    }
+    if (lane == 0) roff[nrows] = total;
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < kEntPerLane; ++m) {  // HBM positions -> LDS positions
+      const int e = lane + 64 * m;
+      const int r = e / kCs;
+      if (r < nrows) cs[e] = ent[m] - rgs[r] + roff[r];
+    }
+    const bool staged = total <= kLdsCap;
+    if (staged) {
+      // ---- coalesced copy of the box's points HBM -> LDS: all loads of the tile in flight together
+      int gj[kCopyIters];
+#pragma unroll
+      for (int m = 0; m < kCopyIters; ++m) {
+        const int p = lane + 64 * m;
+        int lo = 0, hi = nrows;  // roff[lo] <= p < roff[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (roff[mid] <= p) lo = mid; else hi = mid;
+        }
+        gj[m] = (p < total) ? rgs[lo] + (p - roff[lo]) : -1;
+      }
+      double vx[kCopyIters], vy[kCopyIters], vz[kCopyIters];
+      int vi[kCopyIters];
+#pragma unroll
+      for (int m = 0; m < kCopyIters; ++m) {
+        const int j = max(gj[m], 0);
+        vx[m] = g.gx[j]; vy[m] = g.gy[j]; vz[m] = g.gz[j]; vi[m] = g.gidx[j];
+      }
+#pragma unroll
+      for (int m = 0; m < kCopyIters; ++m) {
+        const int p = lane + 64 * m;
+        if (gj[m] >= 0) { sx[p] = vx[m]; sy[p] = vy[m]; sz[p] = vz[m]; sidx[p] = vi[m]; }
+      }
+    }
+    wave_sync();  // staged points + tables visible to every lane of this wave (no cross-wave sharing)
+    const PtsLds lp{sx, sy, sz, sidx};
+    const PtsGlobal gp{g.gx, g.gy, g.gz, g.gidx};
+    for (int q0 = q_beg; q0 < q_end; q0 += 64) {
+      const int qi = q0 + lane;
+      if (qi < q_end) {
+        const int slot = qslot[qi];
+        if (staged) {
+          query_one<PtsLds>(A, kind, g, T, slot, lp, [&](int z, int y, int x0, int x1, int& s_, int& e_) {
+            const int r = (z - bz0) * ny + (y - by0);
+            s_ = cs[r * kCs + (x0 - bx0)];
+            e_ = cs[r * kCs + (x1 + 1 - bx0)];
+          });
+        } else {
+          query_one<PtsGlobal>(A, kind, g, T, slot, gp, [&](int z, int y, int x0, int x1, int& s_, int& e_) {
+            const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
+            s_ = g.cell_start[base + x0];
+            e_ = g.cell_start[base + x1 + 1];
+          });
+        }
+      }
+    }
   }
-  A.sv.flags[slot] = flag;
-  A.sv.rax[slot] = ra[0]; A.sv.ray[slot] = ra[1]; A.sv.raz[slot] = ra[2];
-  A.sv.rbx[slot] = rb[0]; A.sv.rby[slot] = rb[1]; A.sv.rbz[slot] = rb[2];
-  A.sv.rd[slot] = rd;
 }
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
-                  hipStream_t s) {
+                  int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
+                  int* qslot, unsigned long long* scan_tmp, hipStream_t s) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
   A.sv = sv;
-  for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
   A.bp = bp;
-  hipLaunchKernelGGL(k_build, dim3((n + 255) / 256), dim3(256), 0, s, A, st);
+  int base = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    A.grid[k] = grids[k];
+    A.tm.tile_base[k] = base;
+    for (int a = 0; a < 3; ++a) A.tm.tdim[k][a] = (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
+    base += A.tm.tdim[k][0] * A.tm.tdim[k][1] * A.tm.tdim[k][2];
+  }
+  A.tm.tile_base[kKinds] = base;
+  const int ntiles = base;
+  (void)hipMemsetAsync(tile_cnt, 0, sizeof(unsigned long long) * (size_t)(ntiles + 1), s);
+  (void)hipMemsetAsync(tile_fill, 0, sizeof(int) * (size_t)ntiles, s);
+  hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_cnt);
+  launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
+  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, tile_of_slot, tile_scan, tile_fill,
+                     qslot);
+  int blocks = (ntiles + 3) / 4;  // one tile per wave per pass; empty tiles cost two scalar loads
+  blocks = std::max(1, std::min(blocks, 8192));
+  hipLaunchKernelGGL(k_build_tiles, dim3(blocks), dim3(256), 0, s, A, st, tile_scan, qslot);
+}
+int build_tile_count(const GridView grids[kKinds]) {
+  int base = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    int t = 1;
+    for (int a = 0; a < 3; ++a) t *= (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
+    base += t;
+  }
+  return base;
 }
 
 // ================================================================================================
