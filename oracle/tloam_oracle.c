@@ -298,7 +298,8 @@ void orc_eig3_sym(const double cov[9], double ev[3], double V[9]) {
   for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-    if (off == 0.0) break;
+    double dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-36 * dia) break; /* off-diagonal mass below fp64 resolution of the eigenvalues */
     for (int p = 0; p < 2; ++p)
       for (int q = p + 1; q < 3; ++q) {
         double apq = A[p * 3 + q];

@@ -60,8 +60,8 @@ struct KindData {
   DBuf<double> tgt_aos, tx, ty, tz;
   bool tgt_set = false;
   // grid built at sm_begin (the deep copy KDTreeFlann::SetGeometry makes, :898-913)
-  DBuf<double> gx, gy, gz;
-  DBuf<int> gidx, cell_start, cell_of_pt, cell_fill;
+  DBuf<double4> gp;
+  DBuf<int> cell_start, cell_of_pt, cell_fill;
   DBuf<unsigned long long> cell_cnt, cell_scan;
   GridView gv{};
   bool grid_valid = false;
@@ -263,19 +263,17 @@ int plan_and_build_grid(tloam_ctx* c, int k, const GridPlan& gp, double radius) 
     ncell *= (size_t)g.dim[a];
   }
   g.n = n;
-  HIPC(c, K.gx.reserve(n)); HIPC(c, K.gy.reserve(n)); HIPC(c, K.gz.reserve(n));
-  HIPC(c, K.gidx.reserve(n)); HIPC(c, K.cell_of_pt.reserve(n));
+  HIPC(c, K.gp.reserve(n)); HIPC(c, K.cell_of_pt.reserve(n));
   HIPC(c, K.cell_start.reserve(ncell + 1)); HIPC(c, K.cell_fill.reserve(ncell));
   HIPC(c, K.cell_cnt.reserve(ncell)); HIPC(c, K.cell_scan.reserve(ncell));
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ncell)));
-  g.gx = K.gx.p; g.gy = K.gy.p; g.gz = K.gz.p; g.gidx = K.gidx.p; g.cell_start = K.cell_start.p;
+  g.gp = K.gp.p; g.cell_start = K.cell_start.p;
   HIPC(c, hipMemsetAsync(K.cell_cnt.p, 0, ncell * sizeof(unsigned long long), c->stream));
   HIPC(c, hipMemsetAsync(K.cell_fill.p, 0, ncell * sizeof(int), c->stream));
   launch_grid_count(K.tx.p, K.ty.p, K.tz.p, n, g, K.cell_cnt.p, K.cell_of_pt.p, c->stream);
   launch_exclusive_scan_u64(K.cell_cnt.p, K.cell_scan.p, ncell, c->scan_tmp.p, c->stream);
   launch_grid_finalize(K.cell_scan.p, ncell, n, K.cell_start.p, c->stream);
-  launch_grid_scatter(K.tx.p, K.ty.p, K.tz.p, n, K.cell_of_pt.p, K.cell_scan.p, K.cell_fill.p, K.gx.p, K.gy.p,
-                      K.gz.p, K.gidx.p, c->stream);
+  launch_grid_scatter(K.tx.p, K.ty.p, K.tz.p, n, K.cell_of_pt.p, K.cell_scan.p, K.cell_fill.p, K.gp.p, c->stream);
   K.grid_valid = true;
   return TLOAM_OK;
 }
@@ -455,7 +453,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
     K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
-    K.gx.release(); K.gy.release(); K.gz.release(); K.gidx.release(); K.cell_start.release();
+    K.gp.release(); K.cell_start.release();
     K.cell_of_pt.release(); K.cell_fill.release(); K.cell_cnt.release(); K.cell_scan.release();
     K.c_idx.release(); K.c_px.release(); K.c_py.release(); K.c_pz.release(); K.c_ax.release();
     K.c_ay.release(); K.c_az.release(); K.c_bx.release(); K.c_by.release(); K.c_bz.release();

@@ -2,7 +2,7 @@
 //
 // HBM layout (all fp64 SoA, one array per component, 256-B aligned, sized for 288 GB parts):
 //   source clouds   sx/sy/sz[k][n_src_local], GNC weights w_src[k][n]      (one slot per source point)
-//   target clouds   tx/ty/tz[k][n_tgt] (as given) + cell-sorted copy gx/gy/gz/gidx + cell table
+//   target clouds   tx/ty/tz[k][n_tgt] (as given) + cell-sorted packed copy gp[k] (x,y,z,idx) + cell table
 //   raw records     per source slot: a(3) b(3) d + flags        (written by the builder, K1+K2)
 //   compact set     one SoA segment per kind: idx, px py pz, ax ay az, [bx by bz], [d], w, cost
 //                   (streamed by K3; cost written back)
@@ -32,10 +32,8 @@ __host__ __device__ inline int res_type_of_kind(int kind) {
 
 // ---- uniform grid over a target cloud (the device stand-in for KDTreeFlann) -----------------
 struct GridView {
-  const double* gx;   // cell-sorted target coordinates
-  const double* gy;
-  const double* gz;
-  const int* gidx;    // original target index of each sorted entry
+  const double4* gp;  // cell-sorted targets, packed (x, y, z, original index as integer bits): ONE 32-byte
+                      // record per candidate, so a cell's points share cache lines
   const int* cell_start;  // ncell + 1
   double org[3];
   double inv_cell;    // 1 / cell
@@ -119,8 +117,7 @@ void launch_bbox(const double* x, const double* y, const double* z, int n, doubl
 void launch_grid_count(const double* x, const double* y, const double* z, int n, GridView g,
                        unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
 void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
-                         const unsigned long long* cell_scan, int* cell_fill, double* gx, double* gy,
-                         double* gz, int* gidx, hipStream_t s);
+                         const unsigned long long* cell_scan, int* cell_fill, double4* gp, hipStream_t s);
 void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start,
                           hipStream_t s);
 

@@ -175,8 +175,10 @@ void launch_bbox(const double* x, const double* y, const double* z, int n, doubl
   hipLaunchKernelGGL(k_bbox, dim3(64), dim3(256), 0, s, x, y, z, n, out6);
 }
 
-__device__ __forceinline__ int cell_coord(double v, double org, double cell, int dim) {
-  double f = floor((v - org) / cell);
+__device__ __forceinline__ int cell_coord(double v, double org, double inv_cell, int dim) {
+  // build and queries use this SAME function, so a point and a query always agree on cell boundaries;
+  // the 1e-6 slack of the cell size over the radius covers the rounding of the multiply
+  double f = floor((v - org) * inv_cell);
   f = fmax(f, -2.0);
   f = fmin(f, (double)dim + 1.0);
   return (int)f;
@@ -187,9 +189,9 @@ __global__ void k_grid_count(const double* __restrict__ x, const double* __restr
                              const double* __restrict__ z, int n, GridView g,
                              unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int cx = clampi(cell_coord(x[i], g.org[0], g.cell, g.dim[0]), 0, g.dim[0] - 1);
-    const int cy = clampi(cell_coord(y[i], g.org[1], g.cell, g.dim[1]), 0, g.dim[1] - 1);
-    const int cz = clampi(cell_coord(z[i], g.org[2], g.cell, g.dim[2]), 0, g.dim[2] - 1);
+    const int cx = clampi(cell_coord(x[i], g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
+    const int cy = clampi(cell_coord(y[i], g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
+    const int cz = clampi(cell_coord(z[i], g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
     const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
     cell_of_pt[i] = c;
     atomicAdd(&cell_cnt[c], 1ull);
@@ -204,24 +206,19 @@ void launch_grid_count(const double* x, const double* y, const double* z, int n,
 __global__ void k_grid_scatter(const double* __restrict__ x, const double* __restrict__ y,
                                const double* __restrict__ z, int n, const int* __restrict__ cell_of_pt,
                                const unsigned long long* __restrict__ cell_scan, int* __restrict__ cell_fill,
-                               double* __restrict__ gx, double* __restrict__ gy, double* __restrict__ gz,
-                               int* __restrict__ gidx) {
+                               double4* __restrict__ gp) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int c = cell_of_pt[i];
     const int pos = (int)cell_scan[c] + atomicAdd(&cell_fill[c], 1);
-    gx[pos] = x[i];
-    gy[pos] = y[i];
-    gz[pos] = z[i];
-    gidx[pos] = i;
+    gp[pos] = double4{x[i], y[i], z[i], __longlong_as_double((long long)i)};
   }
 }
 void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
-                         const unsigned long long* cell_scan, int* cell_fill, double* gx, double* gy,
-                         double* gz, int* gidx, hipStream_t s) {
+                         const unsigned long long* cell_scan, int* cell_fill, double4* gp, hipStream_t s) {
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, s, x, y, z, n, cell_of_pt, cell_scan,
-                     cell_fill, gx, gy, gz, gidx);
+                     cell_fill, gp);
 }
 __global__ void k_grid_finalize(const unsigned long long* __restrict__ cell_scan, size_t ncell, int n,
                                 int* __restrict__ cell_start) {
@@ -242,12 +239,11 @@ void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int
 //  staged in LDS (PtsLds, see k_build_tiles).
 // ================================================================================================
 struct PtsGlobal {
-  const double *x, *y, *z;
-  const int* idx;
-  __device__ __forceinline__ double X(int j) const { return x[j]; }
-  __device__ __forceinline__ double Y(int j) const { return y[j]; }
-  __device__ __forceinline__ double Z(int j) const { return z[j]; }
-  __device__ __forceinline__ int I(int j) const { return idx[j]; }
+  const double4* p;
+  __device__ __forceinline__ double X(int j) const { return p[j].x; }
+  __device__ __forceinline__ double Y(int j) const { return p[j].y; }
+  __device__ __forceinline__ double Z(int j) const { return p[j].z; }
+  __device__ __forceinline__ int I(int j) const { return (int)__double_as_longlong(p[j].w); }
 };
 
 template <int K>
@@ -265,30 +261,23 @@ __device__ __forceinline__ double sqdist(double qx, double qy, double qz, double
   return r;
 }
 
+// Branch-free sorted insertion: the candidate bubbles down the ascending list with one compare and
+// four selects per level, so a wave pays the same ~5 instructions per level whether or not any of its
+// lanes inserts (the branchy version made every wave run the long insert path on almost every
+// candidate).  Strict total order (d, original index): exact ties go to the lower target index; the
+// index is only fetched when two distances are bit-equal.
 template <int K, class P>
 __device__ __forceinline__ void topk_insert(TopK<K>& tk, const P& pts, double d, int j) {
-  // strict total order (d, original index): ties broken towards the lower target index
-  auto less = [&](double da, int ja, double db, int jb) -> bool {
-    if (da < db) return true;
-    if (da > db) return false;
-    if (jb < 0) return true;  // empty slot (both +inf cannot happen: da is finite)
-    return pts.I(ja) < pts.I(jb);
-  };
-  if (!less(d, j, tk.d[K - 1], tk.j[K - 1])) return;
-  bool placed = false;
 #pragma unroll
-  for (int m = K - 1; m >= 0; --m) {
-    if (!placed) {
-      const bool before_prev = (m > 0) && less(d, j, tk.d[m > 0 ? m - 1 : 0], tk.j[m > 0 ? m - 1 : 0]);
-      if (before_prev) {
-        tk.d[m] = tk.d[m - 1 >= 0 ? m - 1 : 0];
-        tk.j[m] = tk.j[m - 1 >= 0 ? m - 1 : 0];
-      } else {
-        tk.d[m] = d;
-        tk.j[m] = j;
-        placed = true;
-      }
-    }
+  for (int m = 0; m < K; ++m) {
+    bool before = d < tk.d[m];
+    if (d == tk.d[m]) before = (tk.j[m] < 0) || (pts.I(j) < pts.I(tk.j[m]));  // rare: exact tie
+    const double dm = tk.d[m];
+    const int jm = tk.j[m];
+    tk.d[m] = before ? d : dm;
+    tk.j[m] = before ? j : jm;
+    d = before ? dm : d;   // the displaced (larger) element carries on down the list
+    j = before ? jm : j;
   }
 }
 template <int K>
@@ -303,15 +292,30 @@ template <int K, class P>
 __device__ __forceinline__ void scan_range(const P& pts, int s, int e, double qx, double qy, double qz, TopK<K>& tk) {
   for (int j = s; j < e; ++j) topk_insert<K, P>(tk, pts, sqdist(qx, qy, qz, pts.X(j), pts.Y(j), pts.Z(j)), j);
 }
+// the same over the packed HBM records, two candidates per trip so that two 32-byte loads are in flight
+template <int K>
+__device__ __forceinline__ void scan_range(const PtsGlobal& pts, int s, int e, double qx, double qy, double qz,
+                                           TopK<K>& tk) {
+  int j = s;
+  for (; j + 1 < e; j += 2) {
+    const double4 a = pts.p[j], b = pts.p[j + 1];
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, a.x, a.y, a.z), j);
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, b.x, b.y, b.z), j + 1);
+  }
+  if (j < e) {
+    const double4 a = pts.p[j];
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, a.x, a.y, a.z), j);
+  }
+}
 
 template <int K>
 __device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
   topk_clear<K>(tk);
   if (g.n <= 0) return;
-  const PtsGlobal pts{g.gx, g.gy, g.gz, g.gidx};
-  const int cx = cell_coord(qx, g.org[0], g.cell, g.dim[0]);
-  const int cy = cell_coord(qy, g.org[1], g.cell, g.dim[1]);
-  const int cz = cell_coord(qz, g.org[2], g.cell, g.dim[2]);
+  const PtsGlobal pts{g.gp};
+  const int cx = cell_coord(qx, g.org[0], g.inv_cell, g.dim[0]);
+  const int cy = cell_coord(qy, g.org[1], g.inv_cell, g.dim[1]);
+  const int cz = cell_coord(qz, g.org[2], g.inv_cell, g.dim[2]);
   int x0 = cx - 1, x1 = cx + 1;
   if (x0 < 0) x0 = 0;
   if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
@@ -321,7 +325,7 @@ __device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy
     for (int y = cy - 1; y <= cy + 1; ++y) {
       if (y < 0 || y >= g.dim[1]) continue;
       const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
-      scan_range<K, PtsGlobal>(pts, g.cell_start[base + x0], g.cell_start[base + x1 + 1], qx, qy, qz, tk);
+      scan_range<K>(pts, g.cell_start[base + x0], g.cell_start[base + x1 + 1], qx, qy, qz, tk);
     }
   }
 }
@@ -430,7 +434,8 @@ __device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
     for (int j = 0; j < 3; ++j) m.v[i][j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     const double off = m.a[0][1] * m.a[0][1] + m.a[0][2] * m.a[0][2] + m.a[1][2] * m.a[1][2];
-    if (off == 0.0) break;
+    const double dia = m.a[0][0] * m.a[0][0] + m.a[1][1] * m.a[1][1] + m.a[2][2] * m.a[2][2];
+    if (off <= 1e-36 * dia) break;  // off-diagonal mass below fp64 resolution of the eigenvalues
     jacobi_rotate<0, 1>(m);
     jacobi_rotate<0, 2>(m);
     jacobi_rotate<1, 2>(m);
@@ -578,9 +583,9 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
   // bucket by the cell clamped INTO the grid: every in-grid cell of the true 27-neighbourhood lies in
   // that tile's halo box
-  const int cx = clampi(cell_coord(pw.x, g.org[0], g.cell, g.dim[0]), 0, g.dim[0] - 1);
-  const int cy = clampi(cell_coord(pw.y, g.org[1], g.cell, g.dim[1]), 0, g.dim[1] - 1);
-  const int cz = clampi(cell_coord(pw.z, g.org[2], g.cell, g.dim[2]), 0, g.dim[2] - 1);
+  const int cx = clampi(cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
+  const int cy = clampi(cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
+  const int cz = clampi(cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
   const int t = A.tm.tile_base[kind] +
                 ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
   tile_of_slot[slot] = t;
@@ -597,195 +602,57 @@ __global__ __launch_bounds__(256) void k_query_scatter(int n_slots, const int* _
   qslot[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] = slot;
 }
 
-// LDS hand-off inside ONE wave (waves of a block run different tiles, so no __syncthreads here):
-// order this wave's LDS writes before its later LDS reads, and stop the compiler moving them
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-struct PtsLds {
-  const double *x, *y, *z;
-  const int* idx;
-  __device__ __forceinline__ double X(int j) const { return x[j]; }
-  __device__ __forceinline__ double Y(int j) const { return y[j]; }
-  __device__ __forceinline__ double Z(int j) const { return z[j]; }
-  __device__ __forceinline__ int I(int j) const { return idx[j]; }
-};
-
-// one query of tile-kind `kind` against point source `pts`, cell table given by `row_range`
-template <class P, class RowRange>
-__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const GridView& g, const Pose& T, int slot,
-                                          const P& pts, RowRange row_range) {
+// One query against the HBM grid of its kind.  The nine (z,y) rows of the 27-cell neighbourhood are
+// resolved first (18 independent cell-table loads in flight), then scanned.
+__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, int slot) {
+  const GridView& g = A.grid[kind];
   const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
-  const int cx = cell_coord(pw.x, g.org[0], g.cell, g.dim[0]);
-  const int cy = cell_coord(pw.y, g.org[1], g.cell, g.dim[1]);
-  const int cz = cell_coord(pw.z, g.org[2], g.cell, g.dim[2]);
+  const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
+  const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
+  const int cz = cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]);
   int x0 = cx - 1, x1 = cx + 1;
   if (x0 < 0) x0 = 0;
   if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
-  RawRec r;
-  r.a[0] = r.a[1] = r.a[2] = r.b[0] = r.b[1] = r.b[2] = r.d = 0.0;
-  r.flag = 0ull;
+  int rs[9], re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int z = cz - 1 + r / 3, y = cy - 1 + r % 3;
+    const bool in = (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+    const size_t base = in ? ((size_t)z * g.dim[1] + y) * g.dim[0] : 0;
+    rs[r] = in ? g.cell_start[base + x0] : 0;
+    re[r] = in ? g.cell_start[base + x1 + 1] : 0;
+  }
+  const PtsGlobal pts{g.gp};
+  RawRec rec;
+  rec.a[0] = rec.a[1] = rec.a[2] = rec.b[0] = rec.b[1] = rec.b[2] = rec.d = 0.0;
+  rec.flag = 0ull;
   const double radius = A.bp.radius[kind];
   if (kind == TLOAM_KIND_SPHERE) {
     TopK<1> tk;
     topk_clear<1>(tk);
-    if (x0 <= x1)
-      for (int z = cz - 1; z <= cz + 1; ++z) {
-        if (z < 0 || z >= g.dim[2]) continue;
-        for (int y = cy - 1; y <= cy + 1; ++y) {
-          if (y < 0 || y >= g.dim[1]) continue;
-          int s, e;
-          row_range(z, y, x0, x1, s, e);
-          scan_range<1, P>(pts, s, e, pw.x, pw.y, pw.z, tk);
-        }
-      }
-    finish_sphere<P>(pts, tk, radius, r);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) scan_range<1>(pts, rs[r], re[r], pw.x, pw.y, pw.z, tk);
+    finish_sphere<PtsGlobal>(pts, tk, radius, rec);
   } else {
     TopK<5> tk;
     topk_clear<5>(tk);
-    if (x0 <= x1)
-      for (int z = cz - 1; z <= cz + 1; ++z) {
-        if (z < 0 || z >= g.dim[2]) continue;
-        for (int y = cy - 1; y <= cy + 1; ++y) {
-          if (y < 0 || y >= g.dim[1]) continue;
-          int s, e;
-          row_range(z, y, x0, x1, s, e);
-          scan_range<5, P>(pts, s, e, pw.x, pw.y, pw.z, tk);
-        }
-      }
-    finish_knn5<P>(kind, pts, tk, radius, A.bp.edge_dir_thres, r);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) scan_range<5>(pts, rs[r], re[r], pw.x, pw.y, pw.z, tk);
+    finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
   }
-  store_raw(A.sv, slot, r);
+  store_raw(A.sv, slot, rec);
 }
 
-__global__ __launch_bounds__(256) void k_build_tiles(BuildArgs A, const GnState* __restrict__ st,
-                                                     const unsigned long long* __restrict__ tile_scan,
+// pass 3: one thread per query, in TILE-SORTED order: the lanes of a wave query the same few cells, so
+// the packed candidate records they touch are shared through L1/L2 instead of being re-fetched from
+// HBM per query (the unsorted version moved ~30x the algorithmic bytes as 64-byte sectors).
+__global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
+                                                     const unsigned long long* __restrict__ n_sorted,
                                                      const int* __restrict__ qslot) {
-  constexpr int kCs = kHalo + 1;                 // cell boundaries per row
-  constexpr int kEnt = kRows * kCs;              // 252 cell-table entries of a halo box
-  constexpr int kEntPerLane = (kEnt + 63) / 64;  // 4
-  constexpr int kCopyIters = kLdsCap / 64;
-  __shared__ double lx[4][kLdsCap], ly[4][kLdsCap], lz[4][kLdsCap];
-  __shared__ int lidx[4][kLdsCap];
-  __shared__ int lcs[4][kEnt];         // per row: LDS offsets of its (<= 6) cells + end
-  __shared__ int lroff[4][kRows + 1];  // per row: first LDS slot
-  __shared__ int lrgs[4][kRows];       // per row: first HBM slot
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * 4 + wave, W = gridDim.x * 4;
-  const int ntiles = A.tm.tile_base[kKinds];
-  const Pose T = st->T_cur;
-  double* sx = lx[wave]; double* sy = ly[wave]; double* sz = lz[wave];
-  int* sidx = lidx[wave]; int* cs = lcs[wave]; int* roff = lroff[wave]; int* rgs = lrgs[wave];
-  for (int t = gw; t < ntiles; t += W) {  // one tile per wave per pass; all of this is wave-uniform
-    const int q_beg = (int)tile_scan[t], q_end = (int)tile_scan[t + 1];
-    if (q_end <= q_beg) continue;
-    int kind = 0;
-#pragma unroll
-    for (int k = 1; k < kKinds; ++k) kind += (t >= A.tm.tile_base[k]) ? 1 : 0;
-    const GridView& g = A.grid[kind];
-    const int tloc = t - A.tm.tile_base[kind];
-    const int tdx = A.tm.tdim[kind][0], tdy = A.tm.tdim[kind][1];
-    const int tx = tloc % tdx, ty = (tloc / tdx) % tdy, tz = tloc / (tdx * tdy);
-    // halo box, clipped to the grid
-    const int bx0 = max(tx * kTile - 1, 0), bx1 = min(tx * kTile + kTile, g.dim[0] - 1);
-    const int by0 = max(ty * kTile - 1, 0), by1 = min(ty * kTile + kTile, g.dim[1] - 1);
-    const int bz0 = max(tz * kTile - 1, 0), bz1 = min(tz * kTile + kTile, g.dim[2] - 1);
-    const int nx = bx1 - bx0 + 1, ny = by1 - by0 + 1, nz = bz1 - bz0 + 1;
-    const int nrows = ny * nz;
-    wave_sync();  // the previous tile's LDS reads are done before its tables are overwritten
-    // ---- the box's cell table in ONE round trip: entry e = row * 7 + i  <-  cell_start[row_base + bx0 + i]
-    int ent[kEntPerLane];
-#pragma unroll
-    for (int m = 0; m < kEntPerLane; ++m) {
-      const int e = lane + 64 * m;
-      const int r = e / kCs, i = e - r * kCs;
-      ent[m] = 0;
-      if (r < nrows) {
-        const size_t rb = ((size_t)(bz0 + r / ny) * g.dim[1] + (by0 + r % ny)) * g.dim[0];
-        ent[m] = g.cell_start[rb + bx0 + min(i, nx)];
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < kEntPerLane; ++m)
-      if (lane + 64 * m < kEnt) cs[lane + 64 * m] = ent[m];
-    wave_sync();
-    // ---- row extents -> LDS offsets (lane r owns row r)
-    int rs = 0, rc = 0;
-    if (lane < nrows) {
-      rs = cs[lane * kCs];
-      rc = cs[lane * kCs + nx] - rs;
-    }
-    int inc = rc;  // inclusive wave scan of the row counts
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += v;
-    }
-    const int total = __shfl(inc, 63, 64);
-    if (lane < nrows) {
-      roff[lane] = inc - rc;
-      rgs[lane] = rs;
-    }
-    if (lane == 0) roff[nrows] = total;
-    wave_sync();
-#pragma unroll
-    for (int m = 0; m < kEntPerLane; ++m) {  // HBM positions -> LDS positions
-      const int e = lane + 64 * m;
-      const int r = e / kCs;
-      if (r < nrows) cs[e] = ent[m] - rgs[r] + roff[r];
-    }
-    const bool staged = total <= kLdsCap;
-    if (staged) {
-      // ---- coalesced copy of the box's points HBM -> LDS: all loads of the tile in flight together
-      int gj[kCopyIters];
-#pragma unroll
-      for (int m = 0; m < kCopyIters; ++m) {
-        const int p = lane + 64 * m;
-        int lo = 0, hi = nrows;  // roff[lo] <= p < roff[hi]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (roff[mid] <= p) lo = mid; else hi = mid;
-        }
-        gj[m] = (p < total) ? rgs[lo] + (p - roff[lo]) : -1;
-      }
-      double vx[kCopyIters], vy[kCopyIters], vz[kCopyIters];
-      int vi[kCopyIters];
-#pragma unroll
-      for (int m = 0; m < kCopyIters; ++m) {
-        const int j = max(gj[m], 0);
-        vx[m] = g.gx[j]; vy[m] = g.gy[j]; vz[m] = g.gz[j]; vi[m] = g.gidx[j];
-      }
-#pragma unroll
-      for (int m = 0; m < kCopyIters; ++m) {
-        const int p = lane + 64 * m;
-        if (gj[m] >= 0) { sx[p] = vx[m]; sy[p] = vy[m]; sz[p] = vz[m]; sidx[p] = vi[m]; }
-      }
-    }
-    wave_sync();  // staged points + tables visible to every lane of this wave (no cross-wave sharing)
-    const PtsLds lp{sx, sy, sz, sidx};
-    const PtsGlobal gp{g.gx, g.gy, g.gz, g.gidx};
-    for (int q0 = q_beg; q0 < q_end; q0 += 64) {
-      const int qi = q0 + lane;
-      if (qi < q_end) {
-        const int slot = qslot[qi];
-        if (staged) {
-          query_one<PtsLds>(A, kind, g, T, slot, lp, [&](int z, int y, int x0, int x1, int& s_, int& e_) {
-            const int r = (z - bz0) * ny + (y - by0);
-            s_ = cs[r * kCs + (x0 - bx0)];
-            e_ = cs[r * kCs + (x1 + 1 - bx0)];
-          });
-        } else {
-          query_one<PtsGlobal>(A, kind, g, T, slot, gp, [&](int z, int y, int x0, int x1, int& s_, int& e_) {
-            const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
-            s_ = g.cell_start[base + x0];
-            e_ = g.cell_start[base + x1 + 1];
-          });
-        }
-      }
-    }
-  }
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= (int)*n_sorted) return;  // slots without a tile (inactive kinds) are not in qslot
+  const int slot = qslot[i];
+  query_one(A, slot_kind(A.sv, slot), st->T_cur, slot);
 }
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
@@ -811,9 +678,9 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
   hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, tile_of_slot, tile_scan, tile_fill,
                      qslot);
-  int blocks = (ntiles + 3) / 4;  // one tile per wave per pass; empty tiles cost two scalar loads
-  blocks = std::max(1, std::min(blocks, 8192));
-  hipLaunchKernelGGL(k_build_tiles, dim3(blocks), dim3(256), 0, s, A, st, tile_scan, qslot);
+  // every slot with a tile is in qslot[0 .. n_binned); n_binned <= n is only known on the device, so the
+  // launch covers n positions and the kernel bounds itself by the scanned total
+  hipLaunchKernelGGL(k_build_sorted, dim3((n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
 }
 int build_tile_count(const GridView grids[kKinds]) {
   int base = 0;
@@ -928,7 +795,7 @@ __global__ __launch_bounds__(256) void k_knn(GridView g, const double* __restric
     const bool in = (m < k) && (tk.d[m] < r2);
     cnt += in ? 1 : 0;
     if (m < k) {
-      out_idx[(size_t)i * k + m] = in ? g.gidx[tk.j[m]] : -1;
+      out_idx[(size_t)i * k + m] = in ? (int)__double_as_longlong(g.gp[tk.j[m]].w) : -1;
       out_d2[(size_t)i * k + m] = in ? tk.d[m] : 0.0;
     }
   }
