@@ -634,7 +634,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
   }
   launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-               c->qslot.p, c->scan_tmp.p, c->stream);
+               c->qslot.p, c->scan_tmp.p, /*rebin=*/iter == 0, c->stream);
   launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream);
   const double* rank_counts = nullptr;
   if (c->nranks > 1) {
@@ -664,7 +664,13 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   wp.mu = mu;
   wp.noise_bound_sq = c->noise_bound_sq;
   for (int k = 0; k < kKinds; ++k) wp.active[k] = bp.active[k];
-  const int wblocks = 64;
+  // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
+  int wblocks = 64;
+  {
+    size_t cap = 0;
+    for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
+    wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
+  }
   launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->stream);
   launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->sums16.p, c->stream);
   rc = allreduce(c, c->sums16.p, 16);

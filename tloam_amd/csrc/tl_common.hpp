@@ -130,7 +130,7 @@ struct BuildParams {
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  int* qslot, unsigned long long* scan_tmp, hipStream_t s);
+                  int* qslot, unsigned long long* scan_tmp, bool rebin, hipStream_t s);
 int build_tile_count(const GridView grids[kKinds]);  // size of the concatenated tile index space
 // cap + compaction (after the flag scan)
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,

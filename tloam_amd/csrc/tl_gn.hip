@@ -785,9 +785,11 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
                                                      const int* __restrict__ seg_n, double* __restrict__ sums16) {
   const int t = threadIdx.x;
-  double v[5];
+  double v[5] = {0, 0, 0, 0, 0};
+  for (int b = t; b < blocks; b += 64) {  // blocks <= 256: at most 4 rows per lane, fixed order
 #pragma unroll
-  for (int c = 0; c < 5; ++c) v[c] = (t < blocks) ? partial[t * 8 + c] : 0.0;
+    for (int c = 0; c < 5; ++c) v[c] += partial[b * 8 + c];
+  }
 #pragma unroll
   for (int c = 0; c < 5; ++c)
 #pragma unroll

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  int* qslot, unsigned long long* scan_tmp, hipStream_t s) {
+                  int* qslot, unsigned long long* scan_tmp, bool rebin, hipStream_t s) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -672,12 +672,17 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   }
   A.tm.tile_base[kKinds] = base;
   const int ntiles = base;
-  (void)hipMemsetAsync(tile_cnt, 0, sizeof(unsigned long long) * (size_t)(ntiles + 1), s);
-  (void)hipMemsetAsync(tile_fill, 0, sizeof(int) * (size_t)ntiles, s);
-  hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_cnt);
-  launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
-  hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, tile_of_slot, tile_scan, tile_fill,
-                     qslot);
+  if (rebin) {
+    // The processing ORDER only buys locality -- every query still searches its own exact 27 cells --
+    // so the tile sort is done once per frame (first outer iteration, predicted pose) and reused while
+    // the pose moves by centimetres.
+    (void)hipMemsetAsync(tile_cnt, 0, sizeof(unsigned long long) * (size_t)(ntiles + 1), s);
+    (void)hipMemsetAsync(tile_fill, 0, sizeof(int) * (size_t)ntiles, s);
+    hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_cnt);
+    launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
+    hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, tile_of_slot, tile_scan,
+                       tile_fill, qslot);
+  }
   // every slot with a tile is in qslot[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
   hipLaunchKernelGGL(k_build_sorted, dim3((n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
