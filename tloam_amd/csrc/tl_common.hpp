@@ -97,6 +97,7 @@ struct GnState {
   int bad_weights;
   int pad0;
   double kind_cost[kKinds];
+  double dbg[8];  // phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 
 // ---- host-callable launchers (defined in tl_nn.hip / tl_gn.hip) ------------------------------

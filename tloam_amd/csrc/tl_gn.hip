@@ -194,50 +194,45 @@ __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, 
   else seg.cost[j] = c0;
 }
 
-// All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment, software-pipelined: the loads of the
-// next DEPTH-1 chunks are in flight while the current one is evaluated.  Control flow is wave-uniform.
-#ifndef TLOAM_K3_DEPTH
-#define TLOAM_K3_DEPTH 2
-#endif
-template <int RES>
+// All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment.  DEPTH 2: software-pipelined, the loads of
+// the next chunk are in flight while the current one is evaluated (planes: 76 % of the bytes).  DEPTH 1:
+// plain load-then-evaluate (lines/points: keeps the register budget at 3 waves/SIMD).  Control flow is
+// wave-uniform.
+template <int RES, int DEPTH>
 __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, int n, int nchunks, int i0, int W,
                                               int lane, Acc& a) {
   if (i0 >= nchunks) return;
   const int m = (nchunks - i0 + W - 1) / W;  // chunks owned by this wave
   const int l2 = lane * 2;
 #define TL_J(t) ((i0 + (t) * W) * kChunk + l2)
-#if TLOAM_K3_DEPTH == 2
-  ChunkBuf<RES> b0, b1;
-  fetch<RES>(seg, TL_J(0), b0);
-  for (int t = 1;; t += 2) {
-    if (t >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b0, a); break; }
-    fetch<RES>(seg, TL_J(t), b1);
-    consume<RES>(T, seg, TL_J(t - 1), n, b0, a);
-    if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t), n, b1, a); break; }
-    fetch<RES>(seg, TL_J(t + 1), b0);
-    consume<RES>(T, seg, TL_J(t), n, b1, a);
+  if (DEPTH == 1) {
+    for (int t = 0; t < m; ++t) {
+      ChunkBuf<RES> b;
+      fetch<RES>(seg, TL_J(t), b);
+      consume<RES>(T, seg, TL_J(t), n, b, a);
+    }
+  } else {
+    ChunkBuf<RES> b0, b1;
+    fetch<RES>(seg, TL_J(0), b0);
+    for (int t = 1;; t += 2) {
+      if (t >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b0, a); break; }
+      fetch<RES>(seg, TL_J(t), b1);
+      consume<RES>(T, seg, TL_J(t - 1), n, b0, a);
+      if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t), n, b1, a); break; }
+      fetch<RES>(seg, TL_J(t + 1), b0);
+      consume<RES>(T, seg, TL_J(t), n, b1, a);
+    }
   }
-#else
-  ChunkBuf<RES> b0, b1, b2;
-  fetch<RES>(seg, TL_J(0), b0);
-  if (m == 1) { consume<RES>(T, seg, TL_J(0), n, b0, a); return; }
-  fetch<RES>(seg, TL_J(1), b1);
-  for (int t = 2;; t += 3) {
-    if (t >= m) { consume<RES>(T, seg, TL_J(t - 2), n, b0, a); consume<RES>(T, seg, TL_J(t - 1), n, b1, a); break; }
-    fetch<RES>(seg, TL_J(t), b2);
-    consume<RES>(T, seg, TL_J(t - 2), n, b0, a);
-    if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b1, a); consume<RES>(T, seg, TL_J(t), n, b2, a); break; }
-    fetch<RES>(seg, TL_J(t + 1), b0);
-    consume<RES>(T, seg, TL_J(t - 1), n, b1, a);
-    if (t + 2 >= m) { consume<RES>(T, seg, TL_J(t), n, b2, a); consume<RES>(T, seg, TL_J(t + 1), n, b0, a); break; }
-    fetch<RES>(seg, TL_J(t + 2), b1);
-    consume<RES>(T, seg, TL_J(t), n, b2, a);
-  }
-#endif
 #undef TL_J
 }
 
-__global__ __launch_bounds__(256, 2) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
+#ifndef TLOAM_K3_WAVES
+#define TLOAM_K3_WAVES 2  // 3+ waves/SIMD spills (measured 31-41 us vs 15.4 us)
+#endif
+#ifndef TLOAM_K3_LINE_DEPTH
+#define TLOAM_K3_LINE_DEPTH 2
+#endif
+__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
                                                         double* __restrict__ partials, int force) {
   __shared__ double red[4][32];
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
@@ -260,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void k3_accumulate(CorrView cv, GnState* __
     const int nchunks = (n + kChunk - 1) / kChunk;
     int i0 = (gw - first) % W;
     if (i0 < 0) i0 += W;
-    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE>(T, cv.k[k], n, nchunks, i0, W, lane, a);
-    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE>(T, cv.k[k], n, nchunks, i0, W, lane, a);
-    else sweep_segment<TLOAM_RES_POINT>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE, 2>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
     first = (first + nchunks) % W;
   }
   double v[32];
@@ -292,9 +287,10 @@ int k3_grid_for(int total_cap) {
   int waves = (total_cap + kChunk - 1) / kChunk;
   int blocks = (waves + 3) / 4;
   if (blocks < 1) blocks = 1;
-  if (blocks > 512) {
-    // two resident blocks per CU (8 waves); balance: every wave gets the same number of chunks
-    const int per_wave = (waves + 2048 - 1) / 2048;
+  const int resident = 256 * TLOAM_K3_WAVES;  // blocks of 4 waves that fit the chip at once
+  if (blocks > resident) {
+    // balance: every wave gets the same number of chunks
+    const int per_wave = (waves + resident * 4 - 1) / (resident * 4);
     const int need_waves = (waves + per_wave - 1) / per_wave;
     blocks = (need_waves + 3) / 4;
   }
@@ -315,25 +311,24 @@ void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool
 // ================================================================================================
 //  fixed-order reduction of the per-block rows (one block of 256 threads: 8 row groups x 32 columns)
 // ================================================================================================
-constexpr int kRedThreads = 256;
-__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[8][33]*/,
+constexpr int kRedThreads = 512;
+constexpr int kRedGroups = kRedThreads / 32;  // 16 row groups x 32 columns
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[16][33]*/,
                                             double* out32 /* LDS [32] */) {
   const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four independent chains keep loads in flight
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight independent chains: eight loads in flight per lane
   int b = grp;
-  for (; b + 24 < rows; b += 32) {
-    v0 += partials[(size_t)b * kAccStride + comp];
-    v1 += partials[(size_t)(b + 8) * kAccStride + comp];
-    v2 += partials[(size_t)(b + 16) * kAccStride + comp];
-    v3 += partials[(size_t)(b + 24) * kAccStride + comp];
+  for (; b + 7 * kRedGroups < rows; b += 8 * kRedGroups) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] += partials[(size_t)(b + u * kRedGroups) * kAccStride + comp];
   }
-  for (; b < rows; b += 8) v0 += partials[(size_t)b * kAccStride + comp];
-  lds[grp * 33 + comp] = (v0 + v1) + (v2 + v3);
+  for (; b < rows; b += kRedGroups) v[0] += partials[(size_t)b * kAccStride + comp];
+  lds[grp * 33 + comp] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
   if (threadIdx.x < 32) {
     double t = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += lds[g * 33 + threadIdx.x];
+    for (int g = 0; g < kRedGroups; ++g) t += lds[g * 33 + threadIdx.x];
     out32[threadIdx.x] = t;
   }
   __syncthreads();
@@ -341,7 +336,7 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
 
 __global__ __launch_bounds__(kRedThreads) void k_reduce(const double* __restrict__ partials, int rows,
                                                         const GnState* __restrict__ st, double* __restrict__ out48) {
-  __shared__ double lds[8 * 33];
+  __shared__ double lds[kRedGroups * 33];
   __shared__ double tot[32];
   (void)st;
   reduce_rows(partials, rows, lds, tot);
@@ -360,17 +355,117 @@ void launch_reduce(const double* partials, int grid, GnState* st, double* out48,
 //  "Plus" evaluations a step needs (candidate point on lane 0, Ceres' projected-gradient point on
 //  lane 1) run in lockstep and cost one.
 // ================================================================================================
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// Wave-wide sum / max in the VALU data-parallel-primitive network (row_shr 1,2,4,8, row_bcast 15, 31):
+// ~20 instructions and no LDS round trips, against six dependent ds_bpermute hops for a shuffle
+// butterfly (the step kernel does ~10 of these on its critical path).  Result broadcast from lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) {  // lanes without a source read 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+__device__ __forceinline__ double rdlane(double v, int lane_const) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wsum(double v) {
+  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row holds the row sum
+  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return rdlane(v, 63);
+}
+__device__ __forceinline__ double wmax(double v) {  // for non-negative values (0 is the identity)
+  v = fmax(v, dpp_fetch<0x111, 0xf>(v));
+  v = fmax(v, dpp_fetch<0x112, 0xf>(v));
+  v = fmax(v, dpp_fetch<0x114, 0xf>(v));
+  v = fmax(v, dpp_fetch<0x118, 0xf>(v));
+  v = fmax(v, dpp_fetch<0x142, 0xa>(v));
+  v = fmax(v, dpp_fetch<0x143, 0xc>(v));
+  return rdlane(v, 63);
 }
 __device__ __forceinline__ double lget(double v, int src) { return __shfl(v, src, 64); }
+
+// SE(3) exp / log / product for the step kernel: the same maps as tl_se3.hpp (sophus se3.hpp:761-785,
+// :223-256, :304-309) with the trigonometry folded -- one sincos of the half angle for exp
+// (cos t = 1 - 2 sin^2(t/2), sin t = 2 sin(t/2) cos(t/2)), none for log (for a unit quaternion
+// cot(theta/2) = w/|v|) -- equal to the literal forms to rounding (~1e-16), a third of the instructions.
+__device__ __forceinline__ Pose exp_fast(const double a[6]) {
+  const double ox = a[3], oy = a[4], oz = a[5];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  Pose T;
+  const Vec3 om{ox, oy, oz}, u{a[0], a[1], a[2]};
+  if (theta_sq < kSophusEps * kSophusEps) {
+    const double theta_po4 = theta_sq * theta_sq;
+    const double imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+    T.qw = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
+    const Vec3 t = rotate(T, u);
+    T.tx = t.x; T.ty = t.y; T.tz = t.z;
+    return T;
+  }
+  const double theta = sqrt(theta_sq);
+  double sh, ch;
+  sincos(0.5 * theta, &sh, &ch);
+  const double inv_theta = 1.0 / theta;
+  const double imag = sh * inv_theta;
+  T.qw = ch; T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
+  Vec3 t;
+  if (theta < kSophusEps) {
+    t = rotate(T, u);
+  } else {
+    const double c1 = 2.0 * imag * imag;                                       // (1 - cos t) / t^2
+    const double c2 = (theta - 2.0 * sh * ch) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
+    const Vec3 w1 = cross(om, u);
+    const Vec3 w2 = cross(om, w1);
+    t = u + c1 * w1 + c2 * w2;
+  }
+  T.tx = t.x; T.ty = t.y; T.tz = t.z;
+  return T;
+}
+__device__ __forceinline__ Pose compose_fast(const Pose& A, const Pose& B) {
+  Pose C;
+  C.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
+  C.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
+  C.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
+  C.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
+  const double il = 1.0 / sqrt(C.qw * C.qw + C.qx * C.qx + C.qy * C.qy + C.qz * C.qz);
+  C.qw *= il; C.qx *= il; C.qy *= il; C.qz *= il;
+  const Vec3 rt = rotate(A, Vec3{B.tx, B.ty, B.tz});
+  C.tx = A.tx + rt.x; C.ty = A.ty + rt.y; C.tz = A.tz + rt.z;
+  return C;
+}
+__device__ __forceinline__ void log_fast(const Pose& T, double a[6]) {
+  const double squared_n = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
+  const double w = T.qw;
+  double f, theta, c2;
+  if (squared_n < kSophusEps * kSophusEps) {
+    f = 2.0 / w - (2.0 / 3.0) * squared_n / (w * w * w);
+    theta = 2.0 * squared_n / w;
+    c2 = 1.0 / 12.0;
+  } else {
+    const double n = sqrt(squared_n);
+    if (fabs(w) < kSophusEps) {
+      f = (w > 0.0) ? kPi / n : -kPi / n;
+      theta = f * n;
+      c2 = 1.0 / (theta * theta);  // cos(theta/2) -> 0
+    } else {
+      f = 2.0 * atan(n / w) / n;
+      theta = f * n;
+      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : (1.0 - 0.5 * theta * w / n) / (theta * theta);
+    }
+  }
+  const Vec3 om{f * T.qx, f * T.qy, f * T.qz};
+  const Vec3 t{T.tx, T.ty, T.tz};
+  const Vec3 w1 = cross(om, t);
+  const Vec3 w2 = cross(om, w1);
+  const Vec3 ups = t + (-0.5) * w1 + c2 * w2;
+  a[0] = ups.x; a[1] = ups.y; a[2] = ups.z;
+  a[3] = om.x;  a[4] = om.y;  a[5] = om.z;
+}
 
 struct Vec2 { double x, y; };
 // minimum of 0.5 x^T B x + g^T x on |x| = r (dogleg_strategy.cc FindMinimumOnTrustRegionBoundary;
@@ -419,7 +514,7 @@ __device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, doubl
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const double pivot = lget(a, k * 7);
+    const double pivot = rdlane(a, k * 7);
     if (!(pivot > 0.0) || !isfinite(pivot)) ok = false;
     const double lkk = sqrt(pivot);
     if (L.ism && L.mj == k && L.mi >= k) a = (L.mi == k) ? lkk : a / lkk;
@@ -430,7 +525,7 @@ __device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, doubl
   // forward: L z = b
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const double zk = lget(b, k) / lget(a, k * 7);
+    const double zk = rdlane(b, k) / rdlane(a, k * 7);
     const double lik = lget(a, (L.isv ? L.lane : 0) * 6 + k);
     if (L.lane == k) b = zk;
     if (L.isv && L.lane > k) b -= lik * zk;
@@ -438,7 +533,7 @@ __device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, doubl
   // backward: L^T y = z
 #pragma unroll
   for (int k = 5; k >= 0; --k) {
-    const double yk = lget(b, k) / lget(a, k * 7);
+    const double yk = rdlane(b, k) / rdlane(a, k * 7);
     const double lki = lget(a, k * 6 + (L.isv ? L.lane : 0));
     if (L.lane == k) b = yk;
     if (L.isv && L.lane < k) b -= lki * yk;
@@ -456,7 +551,13 @@ __device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, doubl
 // cost-only and re-evaluates an accepted point with Jacobians -- same numbers, half the traffic.
 // The gradient-tolerance test of a freshly accepted point is evaluated together with the next
 // candidate and, if it fires, the speculative iteration is rolled back.
+#ifdef TLOAM_STEP_PROFILE
+#define TL_STAMP(i) if (lane == 0) st->dbg[i] = (double)__builtin_readcyclecounter();
+#else
+#define TL_STAMP(i)
+#endif
 __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const double* tot, int lane) {
+  TL_STAMP(1)
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   const int max_num_iterations = 4, max_consecutive_invalid = 5;
@@ -531,6 +632,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     if (radius <= min_trust_region_radius) { done = 1; break; }
     iteration++;
     iters++;
+    TL_STAMP(2)
     // ---- Jacobi-scaled system
     const double s_i = lget(S, L.mi), s_j = lget(S, L.mj);
     const double Hs = L.ism ? s_i * Hc * s_j : 0.0;
@@ -541,10 +643,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
       const double hkk = lget(Hs, vk * 7);
       D = L.isv ? sqrt(fmin(fmax(hkk, 1e-6), 1e32)) : 1.0;  // min_diagonal_ / max_diagonal_
       grad = gs / D;                                         // ComputeGradient
-      {                                                      // ComputeCauchyPoint
-        const double v = grad / D;
-        alpha = vdot(grad, grad) / quad_form(L, v, Hs, v);
-      }
+      // (ComputeCauchyPoint: alpha is only consumed by TRADITIONAL_DOGLEG; not needed for SUBSPACE_DOGLEG)
       // ComputeGaussNewtonStep: (Hs + mu D^2) y = gs ; on failure mu *= 10 while mu < max_mu (1.0)
       bool ok = false;
       double y = 0.0;
@@ -555,14 +654,26 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
         mu *= 10.0;
       }
       if (!ok) lin_ok = false;
-      else {
-        gnv = -D * y;
-        // ComputeSubspaceModel: orthonormal basis of span{grad, gn}, larger column first
-        const double n0 = sqrt(vdot(grad, grad)), n1 = sqrt(vdot(gnv, gnv));
-        if (n0 == 0.0 && n1 == 0.0) lin_ok = false;
-        else {
-          const bool gfirst = n0 >= n1;
-          const double nf = gfirst ? n0 : n1, ns = gfirst ? n1 : n0;
+      else gnv = -D * y;
+      subspace_1d = -1;  // ComputeSubspaceModel is deferred until a step actually leaves the trust region
+    }
+    TL_STAMP(3)
+    double step = 0.0;
+    bool valid = false;
+    const double gn2 = vdot(gnv, gnv);
+    if (lin_ok && gn2 == 0.0 && vdot(grad, grad) == 0.0) lin_ok = false;  // rank-0 subspace (Ceres: failure)
+    if (lin_ok) {  // ComputeSubspaceDoglegStep
+      const double gnn = sqrt(gn2);
+      if (gnn <= radius) {
+        step = gnv / D;
+        step_norm = gnn;
+      } else {
+        if (subspace_1d < 0) {
+          // ComputeSubspaceModel (first time this Gauss-Newton step is outside the region): orthonormal
+          // basis of span{grad, gn}, larger column first; g and B of the 2-D model
+          const double n0 = sqrt(vdot(grad, grad));
+          const bool gfirst = n0 >= gnn;
+          const double nf = gfirst ? n0 : gnn, ns = gfirst ? gnn : n0;
           const double first = gfirst ? grad : gnv, second = gfirst ? gnv : grad;
           const double u0 = first / nf;
           const double proj = vdot(u0, second);
@@ -583,28 +694,20 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
             sB3 = quad_form(L, v1, Hs, v1);
           }
         }
-      }
-    }
-    double step = 0.0;
-    bool valid = false;
-    if (lin_ok) {  // ComputeSubspaceDoglegStep
-      const double gnn = sqrt(vdot(gnv, gnv));
-      if (gnn <= radius) {
-        step = gnv / D;
-        step_norm = gnn;
-      } else if (subspace_1d) {
-        const double gnorm = sqrt(vdot(grad, grad));
-        step = -(radius / gnorm) * grad / D;
-        step_norm = radius;
-      } else {
-        const Vec2 m2 = min_on_circle(sB0, sB1, sB1, sB3, sg0, sg1, radius);
-        step = (U0 * m2.x + U1 * m2.y) / D;
+        if (subspace_1d) {
+          const double gnorm = sqrt(vdot(grad, grad));
+          step = -(radius / gnorm) * grad / D;
+        } else {
+          const Vec2 m2 = min_on_circle(sB0, sB1, sB1, sB3, sg0, sg1, radius);
+          step = (U0 * m2.x + U1 * m2.y) / D;
+        }
         step_norm = radius;
       }
       if (!L.isv) step = 0.0;
       mcc = -vdot(step, gs) - 0.5 * quad_form(L, step, Hs, step);  // model_cost_change_
       valid = mcc > 0.0;
     }
+    TL_STAMP(4)
     // ---- candidate Plus(x, delta) on lane 0 and projected-gradient point Plus(x, -g) on lane 1
     const double delta = valid ? step * S : 0.0;
     if (valid || need_gmax) {
@@ -615,9 +718,9 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
         const double gi = lget(gc, i), di = lget(delta, i);
         in[i] = (lane == 1) ? -gi : di;
       }
-      const Pose C = compose(se3_exp(in), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
+      const Pose C = compose_fast(exp_fast(in), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
       double out[6];
-      se3_log(C, out);
+      log_fast(C, out);
       double xc_new = 0.0, diff = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -651,6 +754,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     phase = PH_CAND;
     break;  // the next K3 sweep evaluates x_cand
   }
+  TL_STAMP(5)
   // ---- write back
   if (L.isv) {
     st->x[vk] = x; st->x_cand[vk] = xc; st->S[vk] = S; st->D[vk] = D; st->grad[vk] = grad; st->gn[vk] = gnv;
@@ -713,11 +817,17 @@ void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
 // single-GPU fast path: reduce the block rows and advance the minimiser in ONE launch
 __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* __restrict__ partials, int rows,
                                                                  GnState* __restrict__ st) {
-  __shared__ double lds[8 * 33];
+  __shared__ double lds[kRedGroups * 33];
   __shared__ double tot[32];
   if (st->done) return;
+#ifdef TLOAM_STEP_PROFILE
+  if (threadIdx.x == 0) st->dbg[0] = (double)__builtin_readcyclecounter();
+#endif
   reduce_rows(partials, rows, lds, tot);
   if (threadIdx.x < 64) gn_consume_wave(st, tot, threadIdx.x);
+#ifdef TLOAM_STEP_PROFILE
+  if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
+#endif
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
