@@ -317,12 +317,14 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials,
                                             double* out32 /* LDS [32] */) {
   const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight independent chains: eight loads in flight per lane
-  int b = grp;
-  for (; b + 7 * kRedGroups < rows; b += 8 * kRedGroups) {
+  for (int b0 = grp; b0 < rows; b0 += 8 * kRedGroups) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] += partials[(size_t)(b + u * kRedGroups) * kAccStride + comp];
+    for (int u = 0; u < 8; ++u) {  // predicated, so the tail also keeps eight loads in flight
+      const int r = b0 + u * kRedGroups;
+      const double x = partials[(size_t)min(r, rows - 1) * kAccStride + comp];
+      v[u] += (r < rows) ? x : 0.0;
+    }
   }
-  for (; b < rows; b += kRedGroups) v[0] += partials[(size_t)b * kAccStride + comp];
   lds[grp * 33 + comp] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
   if (threadIdx.x < 32) {

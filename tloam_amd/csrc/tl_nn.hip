@@ -543,9 +543,7 @@ __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const Ra
 //  Replaces the kd-tree walks of registration.cpp:444/:535/:588/:731.
 // ================================================================================================
 constexpr int kTile = 4;        // cells per tile edge
-constexpr int kHalo = kTile + 2;
-constexpr int kRows = kHalo * kHalo;   // (y,z) rows of the halo box
-constexpr int kLdsCap = 384;    // staged points per wave; denser boxes fall back to the HBM path
+constexpr int kQuadLimit = 131072;  // at most this many queries: four lanes per query (latency-bound regime)
 
 struct TileMeta {
   int tdim[kKinds][3];
@@ -602,26 +600,66 @@ __global__ __launch_bounds__(256) void k_query_scatter(int n_slots, const int* _
   qslot[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] = slot;
 }
 
-// One query against the HBM grid of its kind.  The nine (z,y) rows of the 27-cell neighbourhood are
-// resolved first (18 independent cell-table loads in flight), then scanned.
-__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, int slot) {
-  const GridView& g = A.grid[kind];
-  const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
+// One query against the HBM grid of its kind, by LPQ cooperating lanes (1 or 4).
+//   LPQ = 1: the lane resolves the nine (z,y) rows of the 27-cell neighbourhood (18 independent
+//            cell-table loads in flight) and scans them, two 32-byte candidate loads per trip.
+//   LPQ = 4: small frames are latency-bound (one wave per SIMD, a ~35-candidate dependent chain per
+//            query), so four adjacent lanes split the nine rows, walk their rows in parallel, and merge
+//            their sorted top-k lists with two xor-shuffle rounds; lane 0 of the quad finishes the fit.
+template <int K, int LPQ>
+__device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk) {
   const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
   const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
   const int cz = cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]);
   int x0 = cx - 1, x1 = cx + 1;
   if (x0 < 0) x0 = 0;
   if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
-  int rs[9], re[9];
+  constexpr int NR = (9 + LPQ - 1) / LPQ;  // rows per lane
+  int rs[NR], re[NR];
 #pragma unroll
-  for (int r = 0; r < 9; ++r) {
+  for (int i = 0; i < NR; ++i) {
+    const int r = sub + i * LPQ;
     const int z = cz - 1 + r / 3, y = cy - 1 + r % 3;
-    const bool in = (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+    const bool in = (r < 9) && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
     const size_t base = in ? ((size_t)z * g.dim[1] + y) * g.dim[0] : 0;
-    rs[r] = in ? g.cell_start[base + x0] : 0;
-    re[r] = in ? g.cell_start[base + x1 + 1] : 0;
+    rs[i] = in ? g.cell_start[base + x0] : 0;
+    re[i] = in ? g.cell_start[base + x1 + 1] : 0;
   }
+  topk_clear<K>(tk);
+  if (LPQ == 1) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) scan_range<K>(pts, rs[i], re[i], pw.x, pw.y, pw.z, tk);
+  } else {
+    int len = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) len = max(len, re[i] - rs[i]);
+    for (int s = 0; s < len; ++s) {  // step s: candidate s of each of this lane's rows, loads in flight together
+      double4 c[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) c[i] = pts.p[(rs[i] + s < re[i]) ? rs[i] + s : 0];
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (rs[i] + s < re[i])
+          topk_insert<K, PtsGlobal>(tk, pts, sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z), rs[i] + s);
+    }
+    // merge across the quad: after xor-1 and xor-2 every lane holds the exact global top-k
+#pragma unroll
+    for (int x = 1; x < LPQ; x <<= 1) {
+      double od[K];
+      int oj[K];
+#pragma unroll
+      for (int m = 0; m < K; ++m) { od[m] = __shfl_xor(tk.d[m], x, 64); oj[m] = __shfl_xor(tk.j[m], x, 64); }
+#pragma unroll
+      for (int m = 0; m < K; ++m)
+        if (oj[m] >= 0) topk_insert<K, PtsGlobal>(tk, pts, od[m], oj[m]);
+    }
+  }
+}
+
+template <int LPQ>
+__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, int slot, int sub) {
+  const GridView& g = A.grid[kind];
+  const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
   const PtsGlobal pts{g.gp};
   RawRec rec;
   rec.a[0] = rec.a[1] = rec.a[2] = rec.b[0] = rec.b[1] = rec.b[2] = rec.d = 0.0;
@@ -629,30 +667,28 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
   const double radius = A.bp.radius[kind];
   if (kind == TLOAM_KIND_SPHERE) {
     TopK<1> tk;
-    topk_clear<1>(tk);
-#pragma unroll
-    for (int r = 0; r < 9; ++r) scan_range<1>(pts, rs[r], re[r], pw.x, pw.y, pw.z, tk);
-    finish_sphere<PtsGlobal>(pts, tk, radius, rec);
+    knn_rows<1, LPQ>(g, pts, pw, sub, tk);
+    if (sub == 0) finish_sphere<PtsGlobal>(pts, tk, radius, rec);
   } else {
     TopK<5> tk;
-    topk_clear<5>(tk);
-#pragma unroll
-    for (int r = 0; r < 9; ++r) scan_range<5>(pts, rs[r], re[r], pw.x, pw.y, pw.z, tk);
-    finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
+    knn_rows<5, LPQ>(g, pts, pw, sub, tk);
+    if (sub == 0) finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
   }
-  store_raw(A.sv, slot, rec);
+  if (sub == 0) store_raw(A.sv, slot, rec);
 }
 
-// pass 3: one thread per query, in TILE-SORTED order: the lanes of a wave query the same few cells, so
-// the packed candidate records they touch are shared through L1/L2 instead of being re-fetched from
-// HBM per query (the unsorted version moved ~30x the algorithmic bytes as 64-byte sectors).
+// pass 3: the queries in TILE-SORTED order: the lanes of a wave query the same few cells, so the packed
+// candidate records they touch are shared through L1/L2 instead of being re-fetched from HBM per query
+// (the unsorted SoA version moved ~30x the algorithmic bytes as 64-byte sectors).
+template <int LPQ>
 __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
                                                      const unsigned long long* __restrict__ n_sorted,
                                                      const int* __restrict__ qslot) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= (int)*n_sorted) return;  // slots without a tile (inactive kinds) are not in qslot
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int i = t / LPQ, sub = t % LPQ;
+  if (i >= (int)*n_sorted) return;  // slots without a tile (inactive kinds) are not in qslot; quad-uniform
   const int slot = qslot[i];
-  query_one(A, slot_kind(A.sv, slot), st->T_cur, slot);
+  query_one<LPQ>(A, slot_kind(A.sv, slot), st->T_cur, slot, sub);
 }
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
@@ -685,7 +721,10 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   }
   // every slot with a tile is in qslot[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
-  hipLaunchKernelGGL(k_build_sorted, dim3((n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+  if (n <= kQuadLimit)
+    hipLaunchKernelGGL(k_build_sorted<4>, dim3((4 * n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+  else
+    hipLaunchKernelGGL(k_build_sorted<1>, dim3((n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
 }
 int build_tile_count(const GridView grids[kKinds]) {
   int base = 0;
