@@ -269,10 +269,9 @@ int plan_and_build_grid(tloam_ctx* c, int k, const GridPlan& gp, double radius) 
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ncell)));
   g.gp = K.gp.p; g.cell_start = K.cell_start.p;
   HIPC(c, hipMemsetAsync(K.cell_cnt.p, 0, ncell * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(K.cell_fill.p, 0, ncell * sizeof(int), c->stream));
   launch_grid_count(K.tx.p, K.ty.p, K.tz.p, n, g, K.cell_cnt.p, K.cell_of_pt.p, c->stream);
   launch_exclusive_scan_u64(K.cell_cnt.p, K.cell_scan.p, ncell, c->scan_tmp.p, c->stream);
-  launch_grid_finalize(K.cell_scan.p, ncell, n, K.cell_start.p, c->stream);
+  launch_grid_finalize(K.cell_scan.p, ncell, n, K.cell_start.p, K.cell_fill.p, c->stream);
   launch_grid_scatter(K.tx.p, K.ty.p, K.tz.p, n, K.cell_of_pt.p, K.cell_scan.p, K.cell_fill.p, K.gp.p, c->stream);
   K.grid_valid = true;
   return TLOAM_OK;

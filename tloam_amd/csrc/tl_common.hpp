@@ -119,7 +119,7 @@ void launch_grid_count(const double* x, const double* y, const double* z, int n,
                        unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
 void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
                          const unsigned long long* cell_scan, int* cell_fill, double4* gp, hipStream_t s);
-void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start,
+void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start, int* cell_fill,
                           hipStream_t s);
 
 struct BuildParams {

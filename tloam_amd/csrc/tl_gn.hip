@@ -232,20 +232,12 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
 #ifndef TLOAM_K3_LINE_DEPTH
 #define TLOAM_K3_LINE_DEPTH 2
 #endif
-__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
-                                                        double* __restrict__ partials, int force) {
-  __shared__ double red[4][32];
-  if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
-  const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
-  Acc a;
+// one full sweep of this wave's share of the four segments
+__device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int gw, int W, int lane, Acc& a) {
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
   a.pe = 1;  // 0.5 * 2^1 = 1
-  // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
-  // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * 4 + wave, W = gridDim.x * 4;
   // chunk g of the concatenated (planar | ground | edge | sphere) chunk list belongs to wave g % W:
   // within segment k the wave starts at i0 = (gw - first_k) mod W -- balanced across segments
   int first = 0;
@@ -260,6 +252,9 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
     else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
     first = (first + nchunks) % W;
   }
+}
+// wave total of the 28 sums: component c ends up (complete) in lanes 2c and 2c+1
+__device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
   double v[32];
 #pragma unroll
   for (int i = 0; i < 27; ++i) v[i] = a.v[i];
@@ -270,7 +265,20 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
   rs_step<8, 8>(v, lane);
   rs_step<4, 4>(v, lane);
   rs_step<2, 2>(v, lane);
-  const double tot = v[0] + __shfl_xor(v[0], 1, 64);
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
+__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
+                                                        double* __restrict__ partials, int force) {
+  __shared__ double red[4][32];
+  if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
+  const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
+  // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
+  // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Acc a;
+  sweep_all(cv, T, blockIdx.x * 4 + wave, gridDim.x * 4, lane, a);
+  const double tot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
   if (threadIdx.x < kAccStride)

@@ -114,6 +114,61 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add(unsigned long long* _
   for (int i = 0; i < kScanItems; ++i)
     if (base + i < n) out[base + i] += add;
 }
+// small inputs: ONE block walks the tiles carrying the running total (one launch instead of three)
+__global__ __launch_bounds__(kScanThreads) void k_scan_small(const unsigned long long* __restrict__ in,
+                                                             unsigned long long* __restrict__ out, size_t n) {
+  __shared__ unsigned long long wave_tot[kScanThreads / 64];
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t tile0 = 0; tile0 < n; tile0 += kScanTile) {
+    const size_t base = tile0 + (size_t)threadIdx.x * kScanItems;
+    unsigned long long v[kScanItems], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      v[i] = (base + i < n) ? in[base + i] : 0ull;
+      sum += v[i];
+    }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned long long wave_off = carry_s;
+    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+    unsigned long long run = wave_off + inc - sum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      if (base + i < n) out[base + i] = run;
+      run += v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == kScanThreads - 1) carry_s = wave_off + inc;
+    __syncthreads();
+  }
+}
+// medium inputs: every block sums the totals of the tiles before it itself (<= 1024 loads) -- two
+// launches instead of three
+__global__ __launch_bounds__(kScanThreads) void k_scan_add_direct(unsigned long long* __restrict__ out, size_t n,
+                                                                  const unsigned long long* __restrict__ tile_total) {
+  __shared__ unsigned long long red[kScanThreads / 64];
+  unsigned long long acc = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += kScanThreads) acc += tile_total[t];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  unsigned long long add = 0;
+  for (int w = 0; w < kScanThreads / 64; ++w) add += red[w];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) out[base + i] += add;
+}
 size_t scan_tmp_elems(size_t n) {
   size_t total = 0;
   while (n > 1) {
@@ -128,10 +183,16 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
                                unsigned long long* tmp, hipStream_t s) {
   if (n == 0) return;
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  if (tiles <= 8) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, s, in, out, n);
+    return;
+  }
   unsigned long long* totals = tmp;
   unsigned long long* totals_scan = tmp + tiles;
   hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals);
-  if (tiles > 1) {
+  if (tiles <= 1024) {
+    hipLaunchKernelGGL(k_scan_add_direct, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals);
+  } else {
     launch_exclusive_scan_u64(totals, totals_scan, tiles, tmp + 2 * tiles, s);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals_scan);
   }
@@ -221,16 +282,19 @@ void launch_grid_scatter(const double* x, const double* y, const double* z, int 
                      cell_fill, gp);
 }
 __global__ void k_grid_finalize(const unsigned long long* __restrict__ cell_scan, size_t ncell, int n,
-                                int* __restrict__ cell_start) {
+                                int* __restrict__ cell_start, int* __restrict__ cell_fill) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i <= ncell; i += stride) cell_start[i] = (i < ncell) ? (int)cell_scan[i] : n;
+  for (; i <= ncell; i += stride) {
+    cell_start[i] = (i < ncell) ? (int)cell_scan[i] : n;
+    if (i < ncell) cell_fill[i] = 0;  // the scatter's per-cell cursors (saves a memset launch)
+  }
 }
-void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start,
+void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start, int* cell_fill,
                           hipStream_t s) {
   int blocks = (int)((ncell + 256) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, cell_scan, ncell, n, cell_start);
+  hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, cell_scan, ncell, n, cell_start, cell_fill);
 }
 
 // ================================================================================================
