@@ -137,6 +137,8 @@ int build_tile_count(const GridView grids[kKinds]);  // size of the concatenated
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
                     const double* rank_counts, int rank, int nranks, hipStream_t s);
 void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s);
+// same correspondences, new outer iteration: re-capture the weights, zero the side-channel slots
+void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s);
 // generic hybrid search (tloam_knn / fitness)
 void launch_knn(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
                 double radius, int k, int* out_idx, double* out_d2, int* out_cnt, hipStream_t s);

@@ -211,7 +211,7 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
       fetch<RES>(seg, TL_J(t), b);
       consume<RES>(T, seg, TL_J(t), n, b, a);
     }
-  } else {
+  } else if (DEPTH == 2) {
     ChunkBuf<RES> b0, b1;
     fetch<RES>(seg, TL_J(0), b0);
     for (int t = 1;; t += 2) {
@@ -222,12 +222,31 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
       fetch<RES>(seg, TL_J(t + 1), b0);
       consume<RES>(T, seg, TL_J(t), n, b1, a);
     }
+  } else {  // DEPTH 3: two chunks of loads in flight behind the one being evaluated
+    ChunkBuf<RES> b0, b1, b2;
+    fetch<RES>(seg, TL_J(0), b0);
+    if (m > 1) fetch<RES>(seg, TL_J(1), b1);
+    for (int t = 0;; t += 3) {
+      // invariant: chunks t (b0) and t+1 (b1, if < m) are loaded or in flight
+      if (t + 2 < m) fetch<RES>(seg, TL_J(t + 2), b2);
+      consume<RES>(T, seg, TL_J(t), n, b0, a);
+      if (t + 1 >= m) break;
+      if (t + 3 < m) fetch<RES>(seg, TL_J(t + 3), b0);
+      consume<RES>(T, seg, TL_J(t + 1), n, b1, a);
+      if (t + 2 >= m) break;
+      if (t + 4 < m) fetch<RES>(seg, TL_J(t + 4), b1);
+      consume<RES>(T, seg, TL_J(t + 2), n, b2, a);
+      if (t + 3 >= m) break;
+    }
   }
 #undef TL_J
 }
 
 #ifndef TLOAM_K3_WAVES
 #define TLOAM_K3_WAVES 2  // 3+ waves/SIMD spills (measured 31-41 us vs 15.4 us)
+#endif
+#ifndef TLOAM_K3_PLANE_DEPTH
+#define TLOAM_K3_PLANE_DEPTH 2
 #endif
 #ifndef TLOAM_K3_LINE_DEPTH
 #define TLOAM_K3_LINE_DEPTH 2
@@ -247,7 +266,7 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int g
     const int nchunks = (n + kChunk - 1) / kChunk;
     int i0 = (gw - first) % W;
     if (i0 < 0) i0 += W;
-    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE, 2>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE, TLOAM_K3_PLANE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
     else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
     else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
     first = (first + nchunks) % W;

@@ -869,6 +869,29 @@ void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& b
   A.nranks = nranks;
   hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, A);
 }
+// Outer iteration with an unchanged pose: the factor list is the previous one.  What a fresh
+// AddResidualBlock pass would change is only the weight captured by value (registration.hpp:51,76,96) and
+// the zeroed residual slot (registration.cpp:1118-1121).
+__global__ __launch_bounds__(256) void k_refresh(SlotView sv, CorrView cv) {
+  const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) {
+    const int n = cv.seg_n[k];
+    const CorrSeg& seg = cv.k[k];
+    for (int i = tid; i < n; i += stride) {
+      seg.w[i] = sv.w_src[sv.slot_off[k] + (seg.idx[i] - sv.src_lo[k])];
+      seg.cost[i] = 0.0;
+    }
+  }
+}
+void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s) {
+  int cap = 0;
+  for (int k = 0; k < kKinds; ++k) cap += cv.k[k].cap;
+  int blocks = (cap + 255) / 256;
+  blocks = std::max(1, std::min(blocks, 2048));
+  hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(256), 0, s, sv, cv);
+}
+
 // per-rank `counted` totals -> row `rank` of a zeroed [nranks*4] buffer (summed by the all-reduce)
 __global__ void k_rank_counts(SlotView sv, double* rank_counts, int rank, int nranks) {
   const int t = threadIdx.x;
