@@ -142,6 +142,32 @@ __device__ __forceinline__ void rs_step(double (&v)[32], int lane) {
     v[i] = keep + __shfl_xor(send, D, 64);
   }
 }
+// The two widest steps (xor 32, xor 16: 24 of the 32 exchanges) on gfx950's v_permlane32_swap /
+// v_permlane16_swap: swapping the odd rows of A = v[i] with the even rows of B = v[i + N/2] and adding
+// gives every lane "own kept value + partner's sent value" in two VALU ops per 32-bit half -- no select,
+// no address arithmetic and no trip through the LDS crossbar.
+template <int N, int D>
+__device__ __forceinline__ void rs_step_swap(double (&v)[32]) {
+  static_assert(D == 32 || D == 16, "row swaps exist for 32- and 16-lane rows");
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const unsigned alo = (unsigned)__double2loint(v[i]), ahi = (unsigned)__double2hiint(v[i]);
+    const unsigned blo = (unsigned)__double2loint(v[i + N / 2]), bhi = (unsigned)__double2hiint(v[i + N / 2]);
+    double x, y;
+    if (D == 32) {
+      const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+      const auto hh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+      x = __hiloint2double((int)hh[0], (int)lo[0]);
+      y = __hiloint2double((int)hh[1], (int)lo[1]);
+    } else {
+      const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+      const auto hh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+      x = __hiloint2double((int)hh[0], (int)lo[0]);
+      y = __hiloint2double((int)hh[1], (int)lo[1]);
+    }
+    v[i] = x + y;
+  }
+}
 
 // One wave-chunk in flight: RES-dependent number of 16-byte streams per lane (plane 8, line 10,
 // point 7).  fetch() is branch-free -- every lane always issues every load (the segments are padded
@@ -200,7 +226,7 @@ __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, 
 // wave-uniform.
 template <int RES, int DEPTH>
 __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, int n, int nchunks, int i0, int W,
-                                              int lane, Acc& a) {
+                                              int lane, Acc& a, const ChunkBuf<RES>& pre, bool use_pre) {
   if (i0 >= nchunks) return;
   const int m = (nchunks - i0 + W - 1) / W;  // chunks owned by this wave
   const int l2 = lane * 2;
@@ -213,7 +239,8 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
     }
   } else if (DEPTH == 2) {
     ChunkBuf<RES> b0, b1;
-    fetch<RES>(seg, TL_J(0), b0);
+    if (use_pre) b0 = pre;  // chunk i0 was requested before the kernel even knew the segment sizes
+    else fetch<RES>(seg, TL_J(0), b0);
     for (int t = 1;; t += 2) {
       if (t >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b0, a); break; }
       fetch<RES>(seg, TL_J(t), b1);
@@ -252,7 +279,10 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
 #define TLOAM_K3_LINE_DEPTH 2
 #endif
 // one full sweep of this wave's share of the four segments
-__device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int gw, int W, int lane, Acc& a) {
+__device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int gw, int W, int lane, Acc& a,
+                                          const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
+  const ChunkBuf<TLOAM_RES_LINE> no_line{};
+  const ChunkBuf<TLOAM_RES_POINT> no_point{};
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
@@ -266,9 +296,10 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int g
     const int nchunks = (n + kChunk - 1) / kChunk;
     int i0 = (gw - first) % W;
     if (i0 < 0) i0 += W;
-    if (k <= TLOAM_KIND_GROUND) sweep_segment<TLOAM_RES_PLANE, TLOAM_K3_PLANE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
-    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
-    else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a);
+    if (k <= TLOAM_KIND_GROUND)
+      sweep_segment<TLOAM_RES_PLANE, TLOAM_K3_PLANE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, pre0, use_pre0 && k == 0);
+    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_line, false);
+    else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_point, false);
     first = (first + nchunks) % W;
   }
 }
@@ -279,8 +310,8 @@ __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
   for (int i = 0; i < 27; ++i) v[i] = a.v[i];
   v[27] = 0.5 * (log(a.pm) + (double)a.pe * 0.6931471805599453094);  // 0.5 * sum log(1+s)
   v[28] = v[29] = v[30] = v[31] = 0.0;
-  rs_step<32, 32>(v, lane);
-  rs_step<16, 16>(v, lane);
+  rs_step_swap<32, 32>(v);
+  rs_step_swap<16, 16>(v);
   rs_step<8, 8>(v, lane);
   rs_step<4, 4>(v, lane);
   rs_step<2, 2>(v, lane);
@@ -290,13 +321,20 @@ __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
 __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
                                                         double* __restrict__ partials, int force) {
   __shared__ double red[4][32];
-  if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
-  const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
   // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  // Speculative first fetch: the wave's first chunk of the planar segment is requested straight from the
+  // kernel arguments, BEFORE the dependent scalar loads of the state (done flag, pose, segment sizes)
+  // come back -- their latency overlaps the first HBM round trip.  The capacity bound keeps it in range.
+  ChunkBuf<TLOAM_RES_PLANE> pre;
+  const bool spec = (TLOAM_K3_PLANE_DEPTH == 2) && (gw + 1) * kChunk <= cv.k[0].cap;
+  if (spec) fetch<TLOAM_RES_PLANE>(cv.k[0], gw * kChunk + lane * 2, pre);
+  if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
+  const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
-  sweep_all(cv, T, blockIdx.x * 4 + wave, gridDim.x * 4, lane, a);
+  sweep_all(cv, T, gw, gridDim.x * 4, lane, a, pre, spec);
   const double tot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();

@@ -748,7 +748,12 @@ template <int LPQ>
 __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
                                                      const unsigned long long* __restrict__ n_sorted,
                                                      const int* __restrict__ qslot) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
+  // XCD-aware order: the dispatcher deals blocks round-robin to the 8 XCDs (each with a private L2), so
+  // physical block b is given logical position (b % 8) * (blocks / 8) + b / 8 -- every XCD then walks one
+  // CONTIGUOUS eighth of the tile-sorted queries and neighbouring tiles share target records in its L2
+  const int per_xcd = gridDim.x >> 3;  // the launch rounds the grid up to a multiple of 8
+  const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int t = lb * 64 + threadIdx.x;
   const int i = t / LPQ, sub = t % LPQ;
   if (i >= (int)*n_sorted) return;  // slots without a tile (inactive kinds) are not in qslot; quad-uniform
   const int slot = qslot[i];
@@ -785,10 +790,11 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   }
   // every slot with a tile is in qslot[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
+  auto grid8 = [](long long threads) { return (unsigned)(((threads + 63) / 64 + 7) / 8 * 8); };
   if (n <= kQuadLimit)
-    hipLaunchKernelGGL(k_build_sorted<4>, dim3((4 * n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
   else
-    hipLaunchKernelGGL(k_build_sorted<1>, dim3((n + 63) / 64), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
 }
 int build_tile_count(const GridView grids[kKinds]) {
   int base = 0;
