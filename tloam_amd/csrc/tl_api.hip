@@ -59,10 +59,8 @@ struct KindData {
   size_t n_tgt = 0;
   DBuf<double> tgt_aos, tx, ty, tz;
   bool tgt_set = false;
-  // grid built at sm_begin (the deep copy KDTreeFlann::SetGeometry makes, :898-913)
-  DBuf<double4> gp;
-  DBuf<int> cell_start, cell_of_pt, cell_fill;
-  DBuf<unsigned long long> cell_cnt, cell_scan;
+  // view into the shared search-grid buffers built at sm_begin (the deep copy KDTreeFlann::SetGeometry
+  // makes, :898-913)
   GridView gv{};
   bool grid_valid = false;
   // compact correspondence segment
@@ -71,6 +69,18 @@ struct KindData {
   size_t c_cap = 0;
   size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
 };
+
+struct GridBuffers {
+  DBuf<double4> gp;
+  DBuf<int> cell_start, cell_of_pt, cell_fill;
+  DBuf<unsigned long long> cell_cnt, cell_scan, scan_tmp;
+  DBuf<double> bbox;
+  void release() {
+    gp.release(); cell_start.release(); cell_of_pt.release(); cell_fill.release();
+    cell_cnt.release(); cell_scan.release(); scan_tmp.release(); bbox.release();
+  }
+};
+
 
 enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2 };
 
@@ -123,6 +133,7 @@ struct tloam_ctx {
   DBuf<double> sx, sy, sz, w_src, rax, ray, raz, rbx, rby, rbz, rd;
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<int> tile_of_slot, tile_fill, qslot;
+  GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
   SlotView sv{};
   CorrView cv{};
   DBuf<int> seg_n;
@@ -237,68 +248,79 @@ int reserve_seg(tloam_ctx* c, int k, size_t n) {
   return TLOAM_OK;
 }
 
-// (re)build the search grid of one kind from the target currently set
-struct GridPlan {
-  double lo[3], hi[3];
-};
-int plan_and_build_grid(tloam_ctx* c, int k, const GridPlan& gp, double radius) {
-  KindData& K = c->kd[k];
-  const int n = (int)K.n_tgt;
-  double cell = radius * (1.0 + 1e-6);
-  double dims[3];
-  for (;;) {
-    double cells = 1.0;
-    for (int a = 0; a < 3; ++a) {
-      dims[a] = floor((gp.hi[a] - gp.lo[a]) / cell) + 1.0;
-      cells *= dims[a];
-    }
-    if (cells <= 4.0e6) break;  // dense cell table bound (u64 histogram + scan per frame)
-    cell *= 1.25;
+// The four search grids share one set of buffers (points and cell tables concatenated), so that every
+// phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
+// scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
+// temporary one.
+// radius[k] <= 0: kind not rebuilt (its view is left empty).  One host synchronisation (bounding boxes).
+int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridView out[kKinds]) {
+  GridSet gs;
+  memset(&gs, 0, sizeof(gs));
+  size_t tgt_total = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    const KindData& K = c->kd[k];
+    const bool use = radius[k] > 0.0 && K.tgt_set && K.n_tgt > 0;
+    gs.tx[k] = K.tx.p; gs.ty[k] = K.ty.p; gs.tz[k] = K.tz.p;
+    gs.n[k] = use ? (int)K.n_tgt : 0;
+    gs.tgt_off[k] = (int)tgt_total;
+    tgt_total += (size_t)gs.n[k];
   }
-  GridView& g = K.gv;
-  g.cell = cell;
-  g.inv_cell = 1.0 / cell;
-  size_t ncell = 1;
-  for (int a = 0; a < 3; ++a) {
-    g.org[a] = gp.lo[a];
-    g.dim[a] = (int)dims[a];
-    ncell *= (size_t)g.dim[a];
-  }
-  g.n = n;
-  HIPC(c, K.gp.reserve(n)); HIPC(c, K.cell_of_pt.reserve(n));
-  HIPC(c, K.cell_start.reserve(ncell + 1)); HIPC(c, K.cell_fill.reserve(ncell));
-  HIPC(c, K.cell_cnt.reserve(ncell)); HIPC(c, K.cell_scan.reserve(ncell));
-  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ncell)));
-  g.gp = K.gp.p; g.cell_start = K.cell_start.p;
-  HIPC(c, hipMemsetAsync(K.cell_cnt.p, 0, ncell * sizeof(unsigned long long), c->stream));
-  launch_grid_count(K.tx.p, K.ty.p, K.tz.p, n, g, K.cell_cnt.p, K.cell_of_pt.p, c->stream);
-  launch_exclusive_scan_u64(K.cell_cnt.p, K.cell_scan.p, ncell, c->scan_tmp.p, c->stream);
-  launch_grid_finalize(K.cell_scan.p, ncell, n, K.cell_start.p, K.cell_fill.p, c->stream);
-  launch_grid_scatter(K.tx.p, K.ty.p, K.tz.p, n, K.cell_of_pt.p, K.cell_scan.p, K.cell_fill.p, K.gp.p, c->stream);
-  K.grid_valid = true;
-  return TLOAM_OK;
-}
-
-// bounding boxes of up to 4 target clouds with ONE host synchronisation
-int target_bboxes(tloam_ctx* c, const int* kinds, int nk, GridPlan* plans) {
-  HIPC(c, c->bbox_dev.reserve((size_t)kKinds * 64 * 6));
-  for (int i = 0; i < nk; ++i) {
-    KindData& K = c->kd[kinds[i]];
-    launch_bbox(K.tx.p, K.ty.p, K.tz.p, (int)K.n_tgt, c->bbox_dev.p + (size_t)i * 64 * 6, c->stream);
-  }
-  HIPC(c, hipMemcpyAsync(c->h_small, c->bbox_dev.p, sizeof(double) * (size_t)nk * 64 * 6, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, G.bbox.reserve((size_t)kKinds * 64 * 6));
+  launch_bbox_all(gs, G.bbox.p, c->stream);
+  HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kKinds * 64 * 6, hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < nk; ++i) {
-    GridPlan& p = plans[i];
-    for (int a = 0; a < 3; ++a) { p.lo[a] = 1e300; p.hi[a] = -1e300; }
+  long long cell_total = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int b = 0; b < 64; ++b) {
-      const double* row = c->h_small + ((size_t)i * 64 + b) * 6;
-      for (int a = 0; a < 3; ++a) {
-        p.lo[a] = std::min(p.lo[a], row[a]);
-        p.hi[a] = std::max(p.hi[a], row[3 + a]);
-      }
+      const double* row = c->h_small + ((size_t)k * 64 + b) * 6;
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], row[a]); hi[a] = std::max(hi[a], row[3 + a]); }
     }
+    GridView& g = out[k];
+    memset(&g, 0, sizeof(g));
+    gs.cell_base[k] = cell_total;
+    if (gs.n[k] == 0) { gs.ncell[k] = 0; gs.dim[k][0] = gs.dim[k][1] = gs.dim[k][2] = 1; gs.inv_cell[k] = 1.0; continue; }
+    double cell = radius[k] * (1.0 + 1e-6);  // every target within `radius` of a query lies in its 27 cells
+    double dims[3];
+    for (;;) {
+      double cells = 1.0;
+      for (int a = 0; a < 3; ++a) {
+        dims[a] = floor((hi[a] - lo[a]) / cell) + 1.0;
+        cells *= dims[a];
+      }
+      if (cells <= 4.0e6) break;  // dense cell table bound (u64 histogram + scan per frame)
+      cell *= 1.25;
+    }
+    g.cell = cell;
+    g.inv_cell = 1.0 / cell;
+    long long ncell = 1;
+    for (int a = 0; a < 3; ++a) {
+      g.org[a] = lo[a];
+      g.dim[a] = (int)dims[a];
+      ncell *= g.dim[a];
+      gs.org[k][a] = lo[a];
+      gs.dim[k][a] = g.dim[a];
+    }
+    g.n = gs.n[k];
+    gs.inv_cell[k] = g.inv_cell;
+    gs.ncell[k] = ncell;
+    cell_total += ncell;
   }
+  const size_t nc = (size_t)std::max<long long>(cell_total, 1);
+  HIPC(c, G.gp.reserve(std::max<size_t>(tgt_total, 1))); HIPC(c, G.cell_of_pt.reserve(std::max<size_t>(tgt_total, 1)));
+  HIPC(c, G.cell_start.reserve(nc + kKinds + 1)); HIPC(c, G.cell_fill.reserve(nc));
+  HIPC(c, G.cell_cnt.reserve(nc + 1)); HIPC(c, G.cell_scan.reserve(nc + 1));
+  HIPC(c, G.scan_tmp.reserve(scan_tmp_elems(nc + 1)));
+  for (int k = 0; k < kKinds; ++k) {
+    out[k].gp = G.gp.p + gs.tgt_off[k];
+    out[k].cell_start = G.cell_start.p + gs.cell_base[k] + k;
+  }
+  if (cell_total == 0) return TLOAM_OK;
+  HIPC(c, hipMemsetAsync(G.cell_cnt.p, 0, (nc + 1) * sizeof(unsigned long long), c->stream));
+  launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, c->stream);
+  launch_exclusive_scan_u64(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
+  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, G.cell_fill.p, c->stream);
+  launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.cell_fill.p, G.gp.p, c->stream);
   return TLOAM_OK;
 }
 
@@ -339,8 +361,8 @@ int harvest_k3_events(tloam_ctx* c, int working) {
 
 // one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
 // sweeps after a tolerance exit are no-op launches (GnState.done).
-int enqueue_solve(tloam_ctx* c) {
-  launch_solve_init(c->state.p, c->stream);
+int enqueue_solve(tloam_ctx* c, bool armed) {
+  if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   int max_sweeps = 5;
   if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) max_sweeps = atoi(e);  // debugging aid only
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -454,8 +476,6 @@ void tloam_destroy(tloam_ctx* c) {
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
     K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
-    K.gp.release(); K.cell_start.release();
-    K.cell_of_pt.release(); K.cell_fill.release(); K.cell_cnt.release(); K.cell_scan.release();
     K.c_idx.release(); K.c_px.release(); K.c_py.release(); K.c_pz.release(); K.c_ax.release();
     K.c_ay.release(); K.c_az.release(); K.c_bx.release(); K.c_by.release(); K.c_bz.release();
     K.c_d.release(); K.c_w.release(); K.c_cost.release();
@@ -465,7 +485,7 @@ void tloam_destroy(tloam_ctx* c) {
   c->rd.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
   c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qslot.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
-  c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release();
+  c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -540,16 +560,15 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   }
   int rc = ensure_common(c);
   if (rc != TLOAM_OK) return rc;
-  // ---- :889-915 four search structures over the submap clouds, one host sync for the 4 boxes
+  // ---- :889-915 four search structures over the submap clouds: one launch per build phase for all kinds,
+  //      one host sync (bounding boxes)
   {
-    int kinds[kKinds] = {0, 1, 2, 3};
-    GridPlan plans[kKinds];
-    rc = target_bboxes(c, kinds, kKinds, plans);
+    double radius[kKinds];
+    GridView views[kKinds];
+    for (int k = 0; k < kKinds; ++k) radius[k] = kind_radius(c->cfg, k);
+    rc = build_grids(c, c->grids, radius, views);
     if (rc != TLOAM_OK) return rc;
-    for (int k = 0; k < kKinds; ++k) {
-      rc = plan_and_build_grid(c, k, plans[k], kind_radius(c->cfg, k));
-      if (rc != TLOAM_OK) return rc;
-    }
+    for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
   }
   // ---- per-source-slot arrays (:931-949 weights = 1, residual slots = 0)
   size_t off = 0;
@@ -668,7 +687,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     if (c->mu <= 0) c->mu = 1e-10;
   }
   // ---- :1036-1047 ceres::Solve, device resident
-  rc = enqueue_solve(c);
+  rc = enqueue_solve(c, /*armed=*/true);  // by sm_begin / the previous iteration's finish kernel
   if (rc != TLOAM_OK) return rc;
   // ---- :1049-1086 thresholds + weight update, :1091-1094 cost sums
   const double mu = c->mu;
@@ -686,10 +705,14 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
   }
   launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->stream);
-  launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->sums16.p, c->stream);
-  rc = allreduce(c, c->sums16.p, 16);
-  if (rc != TLOAM_OK) return rc;
-  launch_outer_publish(c->sums16.p, c->state.p, c->stream);
+  if (c->nranks > 1) {
+    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->sums16.p, c->stream);
+    rc = allreduce(c, c->sums16.p, 16);
+    if (rc != TLOAM_OK) return rc;
+    launch_outer_publish(c->sums16.p, c->state.p, c->stream);
+  } else {
+    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->sums16.p, c->stream);  // + publish + re-arm
+  }
   const int evals_before = c->stats.gn_evaluations;
   HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
@@ -861,17 +884,17 @@ int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius,
     return TLOAM_OK;
   }
   int rc;
-  {  // a grid over the target currently set, sized for this radius
-    int kinds[1] = {kind};
-    GridPlan plan;
-    rc = target_bboxes(c, kinds, 1, &plan);
-    if (rc != TLOAM_OK) return rc;
-    rc = plan_and_build_grid(c, kind, plan, radius);
-    if (rc != TLOAM_OK) return rc;
+  GridBuffers tmp;  // a grid over the target currently set, sized for this radius; the scanMatching grids stay intact
+  GridView views[kKinds];
+  {
+    double radii[kKinds] = {0, 0, 0, 0};
+    radii[kind] = radius;
+    rc = build_grids(c, tmp, radii, views);
+    if (rc != TLOAM_OK) { tmp.release(); return rc; }
   }
   DBuf<double> qa, qx, qy, qz, d2;
   DBuf<int> idx, cnt;
-  auto cleanup = [&]() { qa.release(); qx.release(); qy.release(); qz.release(); d2.release(); idx.release(); cnt.release(); };
+  auto cleanup = [&]() { qa.release(); qx.release(); qy.release(); qz.release(); d2.release(); idx.release(); cnt.release(); tmp.release(); };
   hipError_t e = hipSuccess;
   if ((e = qa.reserve(3 * nq + 3)) != hipSuccess || (e = qx.reserve(nq + 1)) != hipSuccess ||
       (e = qy.reserve(nq + 1)) != hipSuccess || (e = qz.reserve(nq + 1)) != hipSuccess ||
@@ -884,7 +907,7 @@ int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius,
   if (nq > 0) {
     (void)hipMemcpyAsync(qa.p, q, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, c->stream);
     launch_aos_to_soa(qa.p, nq, qx.p, qy.p, qz.p, c->stream);
-    launch_knn(K.gv, qx.p, qy.p, qz.p, (int)nq, radius, k, idx.p, d2.p, cnt.p, c->stream);
+    launch_knn(views[kind], qx.p, qy.p, qz.p, (int)nq, radius, k, idx.p, d2.p, cnt.p, c->stream);
     (void)hipMemcpyAsync(out_idx, idx.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, c->stream);
     (void)hipMemcpyAsync(out_d2, d2.p, sizeof(double) * nq * k, hipMemcpyDeviceToHost, c->stream);
     (void)hipMemcpyAsync(out_cnt, cnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost, c->stream);
@@ -1001,7 +1024,7 @@ int tloam_solve(tloam_ctx* c, double se3[6], tloam_stats* stats) {
   HIPC(c, hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream));
   memcpy(c->h_small, se3, sizeof(double) * 6);
   HIPC(c, hipMemcpyAsync(c->state.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
-  int rc = enqueue_solve(c);
+  int rc = enqueue_solve(c, /*armed=*/false);
   if (rc != TLOAM_OK) return rc;
   HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));

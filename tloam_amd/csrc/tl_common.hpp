@@ -113,14 +113,26 @@ size_t scan_tmp_elems(size_t n);
 void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n,
                                unsigned long long* tmp, hipStream_t s);
 
-// grid build: bbox (host side from a small device reduction), histogram, scan, scatter
-void launch_bbox(const double* x, const double* y, const double* z, int n, double* out6, hipStream_t s);
-void launch_grid_count(const double* x, const double* y, const double* z, int n, GridView g,
-                       unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
-void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
-                         const unsigned long long* cell_scan, int* cell_fill, double4* gp, hipStream_t s);
-void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start, int* cell_fill,
-                          hipStream_t s);
+// grid build for all four kinds at once (one launch per phase, blockIdx.y = kind): bbox (finished on the
+// host), histogram over the CONCATENATED cell tables, one exclusive scan, finalize, scatter
+struct GridSet {
+  const double* tx[kKinds];
+  const double* ty[kKinds];
+  const double* tz[kKinds];
+  int n[kKinds];
+  int tgt_off[kKinds];          // offset of the kind's points in the concatenated point arrays
+  long long cell_base[kKinds];  // offset of the kind's cells in the concatenated cell arrays
+  long long ncell[kKinds];
+  double org[kKinds][3];
+  double inv_cell[kKinds];
+  int dim[kKinds][3];
+};
+void launch_bbox_all(const GridSet& gs, double* out /*[4][64][6]*/, hipStream_t s);
+void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
+void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, int* cell_fill,
+                              hipStream_t s);
+void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
+                             int* cell_fill, double4* gp, hipStream_t s);
 
 struct BuildParams {
   double radius[kKinds];

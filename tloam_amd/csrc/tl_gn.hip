@@ -840,11 +840,11 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
   }
 }
 
-__global__ void k_solve_init(GnState* st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  GnState& s = *st;
-  s.radius = 1e4;  // initial_trust_region_radius
-  s.mu = 1e-8;     // min_mu_
+// start-of-Solve values of the minimiser (Ceres defaults: initial_trust_region_radius 1e4, min_mu 1e-8);
+// the sweep point is the current pose
+__device__ __forceinline__ void arm_solver(GnState& s) {
+  s.radius = 1e4;
+  s.mu = 1e-8;
   s.reuse = 0;
   s.subspace_1d = 0;
   s.phase = PH_ITER0;
@@ -853,9 +853,13 @@ __global__ void k_solve_init(GnState* st) {
   s.step_successful = 1;
   s.done = 0;
   s.gmax = 1e300;
-  s.T_eval = se3_exp(s.x);
-  s.T_cur = s.T_eval;
-  s.Rt_eval = to_rt(s.T_eval);
+  s.T_eval = s.T_cur;
+  s.Rt_eval = to_rt(s.T_cur);
+}
+__global__ void k_solve_init(GnState* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->T_cur = se3_exp(st->x);
+  arm_solver(*st);
 }
 void launch_solve_init(GnState* st, hipStream_t s) { hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(64), 0, s, st); }
 
@@ -959,8 +963,22 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 
 // sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded.
 // One lane per partial row (blocks == 64), fixed shuffle tree.
+// publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
+// (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
+__device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t) {
+  if (t < 4) {
+    st->kind_cost[t] = sums16[t];
+    st->n_corr[t] = (int)sums16[4 + t];
+  }
+  if (t == 0) {
+    st->bad_weights += (int)sums16[8];
+    arm_solver(*st);
+  }
+}
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
-                                                     const int* __restrict__ seg_n, double* __restrict__ sums16) {
+                                                     const int* __restrict__ seg_n, double* __restrict__ sums16,
+                                                     GnState* st_or_null) {
+  __shared__ double sh[16];
   const int t = threadIdx.x;
   double v[5] = {0, 0, 0, 0, 0};
   for (int b = t; b < blocks; b += 64) {  // blocks <= 256: at most 4 rows per lane, fixed order
@@ -971,26 +989,24 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
   for (int c = 0; c < 5; ++c)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+  if (t < 16) sh[t] = 0.0;
+  __syncthreads();
   if (t == 0) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sums16[c] = v[c];
-    sums16[8] = v[4];
+    for (int c = 0; c < 4; ++c) sh[c] = v[c];
+    sh[8] = v[4];
   }
-  if (t >= 4 && t < 8) sums16[t] = (double)seg_n[t - 4];
-  if (t > 8 && t < 16) sums16[t] = 0.0;
+  if (t >= 4 && t < 8) sh[t] = (double)seg_n[t - 4];
+  __syncthreads();
+  if (t < 16) sums16[t] = sh[t];
+  if (st_or_null) publish_and_rearm(sh, st_or_null, t);  // single rank: no exchange in between
 }
-void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st, double* sums16,
+void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, double* sums16,
                          hipStream_t s) {
-  (void)st;
-  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16);
+  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null);
 }
 __global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st) {
-  const int t = threadIdx.x;
-  if (t < 4) {
-    st->kind_cost[t] = sums16[t];
-    st->n_corr[t] = (int)sums16[4 + t];
-  }
-  if (t == 0) st->bad_weights += (int)sums16[8];
+  publish_and_rearm(sums16, st, threadIdx.x);
 }
 void launch_outer_publish(const double* sums16, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_outer_publish, dim3(1), dim3(64), 0, s, sums16, st);

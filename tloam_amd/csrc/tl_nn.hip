@@ -201,10 +201,14 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 // ================================================================================================
 //  grid build
 // ================================================================================================
-// per-block min/max of a cloud; host finishes over <= 256 rows of 6
-__global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ x, const double* __restrict__ y,
-                                              const double* __restrict__ z, int n, double* __restrict__ out6) {
+// per-block min/max of every kind's cloud (blockIdx.y = kind); the host finishes over 64 rows of 6
+__global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict__ out) {
   __shared__ double red[4][6];
+  const int k = blockIdx.y;
+  const double* __restrict__ x = gs.tx[k];
+  const double* __restrict__ y = gs.ty[k];
+  const double* __restrict__ z = gs.tz[k];
+  const int n = gs.n[k];
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const double a = x[i], b = y[i], c = z[i];
@@ -229,11 +233,11 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ x, cons
   if (threadIdx.x < 6) {
     double v = red[0][threadIdx.x];
     for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
-    out6[blockIdx.x * 6 + threadIdx.x] = v;
+    out[((size_t)k * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;
   }
 }
-void launch_bbox(const double* x, const double* y, const double* z, int n, double* out6, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox, dim3(64), dim3(256), 0, s, x, y, z, n, out6);
+void launch_bbox_all(const GridSet& gs, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out);
 }
 
 __device__ __forceinline__ int cell_coord(double v, double org, double inv_cell, int dim) {
@@ -246,55 +250,68 @@ __device__ __forceinline__ int cell_coord(double v, double org, double inv_cell,
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ void k_grid_count(const double* __restrict__ x, const double* __restrict__ y,
-                             const double* __restrict__ z, int n, GridView g,
-                             unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt) {
+__global__ void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt) {
+  const int k = blockIdx.y;
+  const int n = gs.n[k];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int cx = clampi(cell_coord(x[i], g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
-    const int cy = clampi(cell_coord(y[i], g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
-    const int cz = clampi(cell_coord(z[i], g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
-    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-    cell_of_pt[i] = c;
-    atomicAdd(&cell_cnt[c], 1ull);
+    const int cx = clampi(cell_coord(gs.tx[k][i], gs.org[k][0], gs.inv_cell[k], gs.dim[k][0]), 0, gs.dim[k][0] - 1);
+    const int cy = clampi(cell_coord(gs.ty[k][i], gs.org[k][1], gs.inv_cell[k], gs.dim[k][1]), 0, gs.dim[k][1] - 1);
+    const int cz = clampi(cell_coord(gs.tz[k][i], gs.org[k][2], gs.inv_cell[k], gs.dim[k][2]), 0, gs.dim[k][2] - 1);
+    const int c = (cz * gs.dim[k][1] + cy) * gs.dim[k][0] + cx;
+    cell_of_pt[gs.tgt_off[k] + i] = c;
+    atomicAdd(&cell_cnt[gs.cell_base[k] + c], 1ull);
   }
 }
-void launch_grid_count(const double* x, const double* y, const double* z, int n, GridView g,
-                       unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s) {
-  int blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_grid_count, dim3(blocks), dim3(256), 0, s, x, y, z, n, g, cell_cnt, cell_of_pt);
+static int max_n(const GridSet& gs) {
+  int m = 1;
+  for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.n[k]);
+  return m;
 }
-__global__ void k_grid_scatter(const double* __restrict__ x, const double* __restrict__ y,
-                               const double* __restrict__ z, int n, const int* __restrict__ cell_of_pt,
-                               const unsigned long long* __restrict__ cell_scan, int* __restrict__ cell_fill,
-                               double4* __restrict__ gp) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int c = cell_of_pt[i];
-    const int pos = (int)cell_scan[c] + atomicAdd(&cell_fill[c], 1);
-    gp[pos] = double4{x[i], y[i], z[i], __longlong_as_double((long long)i)};
-  }
+void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s) {
+  int blocks = (max_n(gs) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_grid_count_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_cnt, cell_of_pt);
 }
-void launch_grid_scatter(const double* x, const double* y, const double* z, int n, const int* cell_of_pt,
-                         const unsigned long long* cell_scan, int* cell_fill, double4* gp, hipStream_t s) {
-  int blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_grid_scatter, dim3(blocks), dim3(256), 0, s, x, y, z, n, cell_of_pt, cell_scan,
-                     cell_fill, gp);
-}
-__global__ void k_grid_finalize(const unsigned long long* __restrict__ cell_scan, size_t ncell, int n,
-                                int* __restrict__ cell_start, int* __restrict__ cell_fill) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
+// cell_start of kind k lives at cell_start[cell_base[k] + k ...] (ncell + 1 entries per kind), relative to the
+// kind's own point block; also resets the scatter cursors
+__global__ void k_grid_finalize_all(GridSet gs, const unsigned long long* __restrict__ cell_scan,
+                                    int* __restrict__ cell_start, int* __restrict__ cell_fill) {
+  const int k = blockIdx.y;
+  const long long ncell = gs.ncell[k], base = gs.cell_base[k];
+  const unsigned long long first = cell_scan[base];
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i <= ncell; i += stride) {
-    cell_start[i] = (i < ncell) ? (int)cell_scan[i] : n;
-    if (i < ncell) cell_fill[i] = 0;  // the scatter's per-cell cursors (saves a memset launch)
+    cell_start[base + k + i] = (i < ncell) ? (int)(cell_scan[base + i] - first) : gs.n[k];
+    if (i < ncell) cell_fill[base + i] = 0;
   }
 }
-void launch_grid_finalize(const unsigned long long* cell_scan, size_t ncell, int n, int* cell_start, int* cell_fill,
-                          hipStream_t s) {
-  int blocks = (int)((ncell + 256) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_grid_finalize, dim3(blocks), dim3(256), 0, s, cell_scan, ncell, n, cell_start, cell_fill);
+void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, int* cell_fill,
+                              hipStream_t s) {
+  long long m = 1;
+  for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.ncell[k] + 1);
+  int blocks = (int)std::min<long long>((m + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_grid_finalize_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_scan, cell_start, cell_fill);
+}
+__global__ void k_grid_scatter_all(GridSet gs, const int* __restrict__ cell_of_pt,
+                                   const unsigned long long* __restrict__ cell_scan, int* __restrict__ cell_fill,
+                                   double4* __restrict__ gp) {
+  const int k = blockIdx.y;
+  const int n = gs.n[k];
+  const long long base = gs.cell_base[k];
+  const unsigned long long first = cell_scan[base];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = cell_of_pt[gs.tgt_off[k] + i];
+    const int pos = (int)(cell_scan[base + c] - first) + atomicAdd(&cell_fill[base + c], 1);
+    gp[gs.tgt_off[k] + pos] =
+        double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
+  }
+}
+void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
+                             int* cell_fill, double4* gp, hipStream_t s) {
+  int blocks = (max_n(gs) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_grid_scatter_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_scan, cell_fill, gp);
 }
 
 // ================================================================================================
