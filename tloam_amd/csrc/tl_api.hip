@@ -588,13 +588,6 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   c->sv.rax = c->rax.p; c->sv.ray = c->ray.p; c->sv.raz = c->raz.p;
   c->sv.rbx = c->rbx.p; c->sv.rby = c->rby.p; c->sv.rbz = c->rbz.p; c->sv.rd = c->rd.p;
   c->sv.flags = c->flags.p; c->sv.scan = c->scan.p;
-  for (int k = 0; k < kKinds; ++k) {
-    const KindData& K = c->kd[k];
-    launch_aos_to_soa(K.src_aos.p, K.n_src, c->sx.p + c->sv.slot_off[k], c->sy.p + c->sv.slot_off[k],
-                      c->sz.p + c->sv.slot_off[k], c->stream);
-  }
-  launch_fill_f64(c->w_src.p, off, 1.0, c->stream);
-  HIPC(c, hipMemsetAsync(c->flags.p + off, 0, sizeof(unsigned long long), c->stream));
   // ---- compact segments: at most min(n_src, maxnum) factors per kind
   size_t total_cap = 0;
   for (int k = 0; k < kKinds; ++k) {
@@ -606,13 +599,15 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   c->prebuilt = false;
   c->k3_grid = k3_grid_for((int)total_cap);
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
-  // ---- minimiser state: zero counters, upload `parameters`
-  HIPC(c, hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream));
-  HIPC(c, hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream));
-  memcpy(c->h_small, x, sizeof(double) * 6);
-  HIPC(c, hipMemcpyAsync(c->state.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));  // GnState.x is first
-  launch_solve_init(c->state.p, c->stream);  // T_cur = exp(x) for the first builder pass
-  HIPC(c, hipStreamSynchronize(c->stream));  // h_small is reused below
+  // ---- ONE launch: scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
+  //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve
+  {
+    FrameInit fi;
+    for (int k = 0; k < kKinds; ++k) { fi.src_aos[k] = c->kd[k].src_aos.p; fi.slot_off[k] = c->sv.slot_off[k]; }
+    fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
+    for (int i = 0; i < 6; ++i) fi.x[i] = x[i];
+    launch_frame_init(fi, c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p, c->stream);
+  }
   c->mu = 1.0;  // :961
   c->noise_bound_sq = c->cfg.noise_bound * c->cfg.noise_bound;
   if (c->noise_bound_sq < 1e-16) c->noise_bound_sq = 1e-2;  // :963-964

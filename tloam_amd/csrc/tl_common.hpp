@@ -140,6 +140,14 @@ struct BuildParams {
   int active[kKinds];
   double edge_dir_thres;
 };
+// start-of-frame initialisation, one launch
+struct FrameInit {
+  const double* src_aos[kKinds];
+  int slot_off[kKinds + 1];
+  double x[6];
+};
+void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, double* w_src,
+                       unsigned long long* flags, GnState* st, int* seg_n, hipStream_t s);
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
