@@ -34,6 +34,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
+# THIS command, summarised by scripts/pmc_summary.py with the gfx950 x2 FETCH_SIZE correction).  PMC counters
+# cannot be read from inside the process, so the line quotes the committed summary and says so.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_k3_bench_m1.json")
+
+
+def pmc_traffic(world):
+    if world != 1 or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        return float(d["traffic_bytes_per_launch_all"]), {
+            "source": "profiles/r01_pmc_k3_bench_m1.json (separate rocprofv3 --pmc passes of this command)",
+            "fetch_bytes_per_launch": d["fetch_bytes_per_launch_all"],
+            "write_bytes_per_launch": d["write_bytes_per_launch_all"],
+            "working_sweeps_traffic": d["traffic_bytes_per_launch_working"]}
+    except Exception:
+        return None, None
 
 
 def parse():
@@ -138,9 +156,10 @@ def main():
         alg_avg_launch = alg_launch * k3_n / max(k3_all_n, 1)
         achieved = alg_avg_launch / (k3_avg_all_us * 1e-6) / 1e9 if k3_all_n else 0.0
         achieved_work = alg_launch / (k3_avg_work_us * 1e-6) / 1e9 if k3_n else 0.0
-        roofline = {"kernel": "k3_accumulate", "bound": "hbm", "achieved": round(achieved, 1),
+        traffic, traffic_detail = pmc_traffic(world)
+        roofline = {"kernel": "k3_accumulate<false>", "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_us": round(k3_avg_all_us, 3), "launches": int(k3_all_n),
+                    "traffic": traffic, "traffic_detail": traffic_detail, "avg_launch_us": round(k3_avg_all_us, 3), "launches": int(k3_all_n),
                     "algorithmic_bytes_per_launch": alg_avg_launch,
                     "working_sweeps": {"launches": int(k3_n), "avg_launch_us": round(k3_avg_work_us, 3),
                                        "algorithmic_bytes_per_launch": alg_launch,

@@ -142,6 +142,7 @@ struct tloam_ctx {
   GnState* h_state = nullptr;  // pinned mirror
   double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
   int k3_grid = 1;
+  bool k3_single = false;
   bool prebuilt = false;
   // comm
   int rank = 0, nranks = 1;
@@ -332,11 +333,11 @@ int launch_k3_timed(tloam_ctx* c, bool force) {
       c->ev_pool.resize(old + 256);
       for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
     }
-    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, force, c->stream, c->ev_pool[c->ev_used],
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, force, c->stream, c->ev_pool[c->ev_used],
               c->ev_pool[c->ev_used + 1]);
     c->ev_used += 2;
   } else {
-    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, force, c->stream);
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, force, c->stream);
   }
   return TLOAM_OK;
 }
@@ -598,6 +599,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   }
   c->prebuilt = false;
   c->k3_grid = k3_grid_for((int)total_cap);
+  c->k3_single = k3_single_pass((int)total_cap, c->k3_grid);
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
   // ---- ONE launch: scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
   //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve
@@ -975,6 +977,7 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
     (void)nn;
   }
   c->k3_grid = k3_grid_for((int)total_cap);
+  c->k3_single = k3_single_pass((int)total_cap, c->k3_grid);
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
   return TLOAM_OK;
 }
@@ -1049,7 +1052,7 @@ int tloam_time_accumulate(tloam_ctx* c, const double se3[6], int launches, doubl
   HIPC(c, hipEventCreate(&e0));
   HIPC(c, hipEventCreate(&e1));
   HIPC(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; ++i) launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, true, c->stream);
+  for (int i = 0; i < launches; ++i) launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, true, c->stream);
   HIPC(c, hipEventRecord(e1, c->stream));
   HIPC(c, hipEventSynchronize(e1));
   float ms = 0.f;

@@ -167,7 +167,8 @@ void launch_fitness(const GridView& g, const double* qx, const double* qy, const
 
 // K3 and the minimiser
 int k3_grid_for(int total_cap);
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s,
+bool k3_single_pass(int total_cap, int grid);  // one wave per chunk (small sets) vs the streaming variant
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
 void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x

@@ -303,6 +303,40 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int g
     first = (first + nchunks) % W;
   }
 }
+// Small correspondence sets (KITTI caps: <= 5.9 k factors): the grid has one wave per chunk of the
+// concatenated (planar | ground | edge | sphere) list, so wave gw owns exactly chunk gw -- one fetch, one
+// evaluation, no chunk loop and no modulo distribution.  Same per-wave arithmetic as sweep_all.
+__device__ __forceinline__ void sweep_single(const CorrView& cv, const Rt& T, int gw, int lane, Acc& a,
+                                             const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
+#pragma unroll
+  for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
+  a.pm = 0.5;
+  a.pe = 1;
+  int g = gw;
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) {
+    const int n = cv.seg_n[k];
+    const int nchunks = (n + kChunk - 1) / kChunk;
+    if (g >= 0 && g < nchunks) {
+      const int j = g * kChunk + lane * 2;
+      if (k <= TLOAM_KIND_GROUND) {
+        ChunkBuf<TLOAM_RES_PLANE> b;
+        if (use_pre0 && k == 0) b = pre0;
+        else fetch<TLOAM_RES_PLANE>(cv.k[k], j, b);
+        consume<TLOAM_RES_PLANE>(T, cv.k[k], j, n, b, a);
+      } else if (k == TLOAM_KIND_EDGE) {
+        ChunkBuf<TLOAM_RES_LINE> b;
+        fetch<TLOAM_RES_LINE>(cv.k[k], j, b);
+        consume<TLOAM_RES_LINE>(T, cv.k[k], j, n, b, a);
+      } else {
+        ChunkBuf<TLOAM_RES_POINT> b;
+        fetch<TLOAM_RES_POINT>(cv.k[k], j, b);
+        consume<TLOAM_RES_POINT>(T, cv.k[k], j, n, b, a);
+      }
+    }
+    g -= nchunks;
+  }
+}
 // wave total of the 28 sums: component c ends up (complete) in lanes 2c and 2c+1
 __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
   double v[32];
@@ -318,6 +352,9 @@ __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
   return v[0] + __shfl_xor(v[0], 1, 64);
 }
 
+// SINGLE = false: the streaming variant (grid = the resident chip, every wave loops over its chunks with
+// software-pipelined loads).  SINGLE = true: small sets, one wave per chunk (sweep_single).
+template <bool SINGLE>
 __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
                                                         double* __restrict__ partials, int force) {
   __shared__ double red[4][32];
@@ -334,7 +371,8 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
-  sweep_all(cv, T, gw, gridDim.x * 4, lane, a, pre, spec);
+  if (SINGLE) sweep_single(cv, T, gw, lane, a, pre, spec);
+  else sweep_all(cv, T, gw, gridDim.x * 4, lane, a, pre, spec);
   const double tot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
@@ -361,15 +399,17 @@ int k3_grid_for(int total_cap) {
   }
   return blocks;
 }
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool force, hipStream_t s,
+// one wave per chunk: the grid (4 waves per block) covers every chunk the segments can hold
+bool k3_single_pass(int total_cap, int grid) { return (total_cap + kChunk - 1) / kChunk <= grid * 4; }
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop) {
+  auto kern = single ? k3_accumulate<true> : k3_accumulate<false>;
   if (ev_start && ev_stop) {
     // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
     // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
-    hipExtLaunchKernelGGL(k3_accumulate, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, cv, st, partials,
-                          force ? 1 : 0);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, cv, st, partials, force ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(k3_accumulate, dim3(grid), dim3(256), 0, s, cv, st, partials, force ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, cv, st, partials, force ? 1 : 0);
   }
 }
 
