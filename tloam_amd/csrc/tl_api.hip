@@ -130,9 +130,10 @@ struct tloam_ctx {
   hipStream_t stream = nullptr;
   KindData kd[kKinds];
   // concatenated per-source-slot arrays of the current scan_match
-  DBuf<double> sx, sy, sz, w_src, rax, ray, raz, rbx, rby, rbz, rd;
+  DBuf<double> sx, sy, sz, w_src, raw;
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
-  DBuf<int> tile_of_slot, tile_fill, qslot;
+  DBuf<int> tile_of_slot, tile_fill;
+  DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
   GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
   SlotView sv{};
   CorrView cv{};
@@ -482,9 +483,8 @@ void tloam_destroy(tloam_ctx* c) {
     K.c_d.release(); K.c_w.release(); K.c_cost.release();
   }
   c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
-  c->rax.release(); c->ray.release(); c->raz.release(); c->rbx.release(); c->rby.release(); c->rbz.release();
-  c->rd.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
-  c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qslot.release();
+  c->raw.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
+  c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qrec.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
   c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
@@ -581,13 +581,11 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   c->sv.slot_off[kKinds] = (int)off;
   const size_t ns = std::max<size_t>(off, 1);
   HIPC(c, c->sx.reserve(ns)); HIPC(c, c->sy.reserve(ns)); HIPC(c, c->sz.reserve(ns)); HIPC(c, c->w_src.reserve(ns));
-  HIPC(c, c->rax.reserve(ns)); HIPC(c, c->ray.reserve(ns)); HIPC(c, c->raz.reserve(ns));
-  HIPC(c, c->rbx.reserve(ns)); HIPC(c, c->rby.reserve(ns)); HIPC(c, c->rbz.reserve(ns)); HIPC(c, c->rd.reserve(ns));
+  HIPC(c, c->raw.reserve(ns * 8));
   HIPC(c, c->flags.reserve(ns + 1)); HIPC(c, c->scan.reserve(ns + 1));
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(ns + 1)));
   c->sv.sx = c->sx.p; c->sv.sy = c->sy.p; c->sv.sz = c->sz.p; c->sv.w_src = c->w_src.p;
-  c->sv.rax = c->rax.p; c->sv.ray = c->ray.p; c->sv.raz = c->raz.p;
-  c->sv.rbx = c->rbx.p; c->sv.rby = c->rby.p; c->sv.rbz = c->rbz.p; c->sv.rd = c->rd.p;
+  c->sv.raw = c->raw.p;
   c->sv.flags = c->flags.p; c->sv.scan = c->scan.p;
   // ---- compact segments: at most min(n_src, maxnum) factors per kind
   size_t total_cap = 0;
@@ -648,7 +646,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     const size_t ntiles = (size_t)build_tile_count(grids);
     HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
     HIPC(c, c->tile_fill.reserve(ntiles)); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
-    HIPC(c, c->qslot.reserve(n_slots + 1));
+    HIPC(c, c->qrec.reserve(n_slots + 1));
     HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
   }
   // The correspondence search is a pure function of (pose, clouds).  In the reference's GNC dynamics the
@@ -659,7 +657,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
                          !getenv("TLOAM_NO_BUILD_REUSE");
   if (!same_pose) {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-                 c->qslot.p, c->scan_tmp.p, /*rebin=*/iter == 0, c->stream);
+                 c->qrec.p, c->scan_tmp.p, /*rebin=*/iter == 0, c->stream);
     launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream);
     const double* rank_counts = nullptr;
     if (c->nranks > 1) {

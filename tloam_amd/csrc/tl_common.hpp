@@ -63,8 +63,10 @@ struct CorrView {
 struct SlotView {
   const double *sx, *sy, *sz;  // source points (sensor frame)
   double* w_src;               // GNC weights
-  // raw builder output
-  double *rax, *ray, *raz, *rbx, *rby, *rbz, *rd;
+  // raw builder output: one 64-byte record per slot (a[3], b[3], d, pad) -- K1 writes it with four 16-byte
+  // stores into ONE line (the seven separate SoA arrays cost a 32-byte sector per 8-byte scattered store:
+  // PMC WRITE_SIZE 269 MB per 1 M queries for 64 MB of records)
+  double* raw;
   unsigned long long* flags;   // low 32: counted, high 32: valid (then scanned in place -> exclusive prefix)
   unsigned long long* scan;    // exclusive scan of flags
   int slot_off[kKinds + 1];    // concatenated slot ranges per kind
@@ -151,7 +153,7 @@ void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, 
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  int* qslot, unsigned long long* scan_tmp, bool rebin, hipStream_t s);
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s);
 int build_tile_count(const GridView grids[kKinds]);  // size of the concatenated tile index space
 // cap + compaction (after the flag scan)
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,

@@ -361,6 +361,27 @@ __device__ __forceinline__ void topk_insert(TopK<K>& tk, const P& pts, double d,
     j = before ? jm : j;
   }
 }
+// Hot-loop variant: orders by distance only and REPORTS whether the candidate tied bit-exactly with a kept
+// distance; the caller then redoes that (rare) query with the exact (d, index) insertion above.  No branch,
+// no index fetch: 8 VALU ops per level instead of ~26 instructions with two exec-mask branches.
+// A NaN distance (masked-off candidate) compares false everywhere and falls through untouched.
+template <int K>
+__device__ __forceinline__ bool topk_insert_fast(TopK<K>& tk, double d, int j) {
+  bool tie = false;
+  const double d0 = d;  // the candidate itself (d becomes the displaced element further down the list)
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const bool before = d < tk.d[m];
+    tie |= (d0 == tk.d[m]);
+    const double dm = tk.d[m];
+    const int jm = tk.j[m];
+    tk.d[m] = before ? d : dm;
+    tk.j[m] = before ? j : jm;
+    d = before ? dm : d;
+    j = before ? jm : j;
+  }
+  return tie;
+}
 template <int K>
 __device__ __forceinline__ void topk_clear(TopK<K>& tk) {
 #pragma unroll
@@ -611,9 +632,12 @@ __device__ __forceinline__ void finish_knn5(int kind, const P& pts, const TopK<5
 
 __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const RawRec& r) {
   sv.flags[slot] = r.flag;
-  sv.rax[slot] = r.a[0]; sv.ray[slot] = r.a[1]; sv.raz[slot] = r.a[2];
-  sv.rbx[slot] = r.b[0]; sv.rby[slot] = r.b[1]; sv.rbz[slot] = r.b[2];
-  sv.rd[slot] = r.d;
+  if ((r.flag >> 32) == 0ull) return;  // no factor: the compaction never looks at the record
+  double2* q = reinterpret_cast<double2*>(sv.raw + (size_t)slot * 8);
+  q[0] = double2{r.a[0], r.a[1]};
+  q[1] = double2{r.a[2], r.b[0]};
+  q[2] = double2{r.b[1], r.b[2]};
+  q[3] = double2{r.d, 0.0};
 }
 
 // ================================================================================================
@@ -671,14 +695,17 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   atomicAdd(&tile_cnt[t], 1ull);
 }
 // pass 2: slots grouped by tile (order inside a tile is irrelevant: every result goes to its own slot)
-__global__ __launch_bounds__(256) void k_query_scatter(int n_slots, const int* __restrict__ tile_of_slot,
+// The sorted entry is a 32-byte record (x, y, z, slot): K1 then reads its queries coalesced instead of
+// chasing slot -> three scattered 8-byte loads.
+__global__ __launch_bounds__(256) void k_query_scatter(SlotView sv, const int* __restrict__ tile_of_slot,
                                                        const unsigned long long* __restrict__ tile_scan,
-                                                       int* __restrict__ tile_fill, int* __restrict__ qslot) {
+                                                       int* __restrict__ tile_fill, double4* __restrict__ qrec) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= n_slots) return;
+  if (slot >= sv.slot_off[kKinds]) return;
   const int t = tile_of_slot[slot];
   if (t < 0) return;
-  qslot[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] = slot;
+  qrec[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] =
+      double4{sv.sx[slot], sv.sy[slot], sv.sz[slot], __longlong_as_double((long long)slot)};
 }
 
 // One query against the HBM grid of its kind, by LPQ cooperating lanes (1 or 4).
@@ -688,7 +715,8 @@ __global__ __launch_bounds__(256) void k_query_scatter(int n_slots, const int* _
 //            query), so four adjacent lanes split the nine rows, walk their rows in parallel, and merge
 //            their sorted top-k lists with two xor-shuffle rounds; lane 0 of the quad finishes the fit.
 template <int K, int LPQ>
-__device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk) {
+__device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk,
+                                         int2* __restrict__ lds_rows) {
   const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
   const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
   const int cz = cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]);
@@ -708,8 +736,58 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
   }
   topk_clear<K>(tk);
   if (LPQ == 1) {
+    // FLATTENED walk: the lane's non-empty rows are queued in LDS ([row][lane], conflict-free) and consumed
+    // as ONE candidate stream, two candidates per trip.  The wave then runs max_lanes(total candidates)/2
+    // trips instead of sum_rows max_lanes(row length)/2 -- half the trips on the 1 M frame, where the lanes
+    // of a wave (one 4x4x4-cell tile) see very different row lengths.
+    const int lane = threadIdx.x & 63;
+    int nr = 0, total = 0;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) scan_range<K>(pts, rs[i], re[i], pw.x, pw.y, pw.z, tk);
+    for (int i = 0; i < NR; ++i) {
+      const int len = re[i] - rs[i];
+      if (len > 0) {
+        lds_rows[nr * 64 + lane] = int2{rs[i], re[i]};
+        ++nr;
+        total += len;
+      }
+    }
+    int j = 0, e = 0, r = 0;
+    int2 nx = (nr > 0) ? lds_rows[lane] : int2{0, 0};  // next row, pre-loaded
+    // (ballot, not a shuffle reduction: the kinds of a wave's lanes may differ, and only a ballot is
+    //  well-defined under the divergent kind branch)
+    bool tie = false;
+    const double nan = __builtin_nan("");
+    // next position of this lane's candidate stream (index 0 = a harmless in-range dummy when exhausted)
+    auto next = [&](int& jx, bool& vx) {
+      if (j >= e && r < nr) { j = nx.x; e = nx.y; ++r; nx = lds_rows[(r < nr ? r : 0) * 64 + lane]; }
+      vx = j < e;
+      jx = vx ? j : 0;
+      j += vx ? 1 : 0;
+    };
+    int ja, jb;
+    bool va, vb;
+    next(ja, va);
+    next(jb, vb);
+    double4 a = pts.p[ja], b = pts.p[jb];
+    for (int left = total; __any(left > 0); left -= 2) {
+      // software pipeline: the records of the NEXT trip are requested before this trip's two insertions
+      int ja2, jb2;
+      bool va2, vb2;
+      next(ja2, va2);
+      next(jb2, vb2);
+      const double4 a2 = pts.p[ja2], b2 = pts.p[jb2];
+      const double da = sqdist(pw.x, pw.y, pw.z, a.x, a.y, a.z), db = sqdist(pw.x, pw.y, pw.z, b.x, b.y, b.z);
+      tie |= topk_insert_fast<K>(tk, va ? da : nan, ja);
+      tie |= topk_insert_fast<K>(tk, vb ? db : nan, jb);
+      a = a2; b = b2; ja = ja2; jb = jb2; va = va2; vb = vb2;
+    }
+    if (tie) {  // bit-equal distances met: redo this query with the exact (d, original index) order
+      topk_clear<K>(tk);
+      for (int q = 0; q < nr; ++q) {
+        const int2 v = lds_rows[q * 64 + lane];
+        scan_range<K>(pts, v.x, v.y, pw.x, pw.y, pw.z, tk);
+      }
+    }
   } else {
     int len = 0;
 #pragma unroll
@@ -738,9 +816,10 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 }
 
 template <int LPQ>
-__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, int slot, int sub) {
+__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, const double4& q, int slot,
+                                          int sub, int2* __restrict__ lds_rows) {
   const GridView& g = A.grid[kind];
-  const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
+  const Vec3 pw = act(T, Vec3{q.x, q.y, q.z});
   const PtsGlobal pts{g.gp};
   RawRec rec;
   rec.a[0] = rec.a[1] = rec.a[2] = rec.b[0] = rec.b[1] = rec.b[2] = rec.d = 0.0;
@@ -748,11 +827,11 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
   const double radius = A.bp.radius[kind];
   if (kind == TLOAM_KIND_SPHERE) {
     TopK<1> tk;
-    knn_rows<1, LPQ>(g, pts, pw, sub, tk);
+    knn_rows<1, LPQ>(g, pts, pw, sub, tk, lds_rows);
     if (sub == 0) finish_sphere<PtsGlobal>(pts, tk, radius, rec);
   } else {
     TopK<5> tk;
-    knn_rows<5, LPQ>(g, pts, pw, sub, tk);
+    knn_rows<5, LPQ>(g, pts, pw, sub, tk, lds_rows);
     if (sub == 0) finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
   }
   if (sub == 0) store_raw(A.sv, slot, rec);
@@ -764,7 +843,7 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
 template <int LPQ>
 __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
                                                      const unsigned long long* __restrict__ n_sorted,
-                                                     const int* __restrict__ qslot) {
+                                                     const double4* __restrict__ qrec) {
   // XCD-aware order: the dispatcher deals blocks round-robin to the 8 XCDs (each with a private L2), so
   // physical block b is given logical position (b % 8) * (blocks / 8) + b / 8 -- every XCD then walks one
   // CONTIGUOUS eighth of the tile-sorted queries and neighbouring tiles share target records in its L2
@@ -772,14 +851,21 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
   const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int t = lb * 64 + threadIdx.x;
   const int i = t / LPQ, sub = t % LPQ;
-  if (i >= (int)*n_sorted) return;  // slots without a tile (inactive kinds) are not in qslot; quad-uniform
-  const int slot = qslot[i];
-  query_one<LPQ>(A, slot_kind(A.sv, slot), st->T_cur, slot, sub);
+  __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
+  // slots without a tile (inactive kinds) are not in qrec.  LPQ = 1 keeps the tail lanes alive (they take
+  // part in the wave-wide trip count) on a harmless duplicate of the last query; LPQ = 4 exits quad-uniformly.
+  const int ns = (int)*n_sorted;
+  if (LPQ != 1 && i >= ns) return;
+  if (ns <= 0) return;
+  const bool live = i < ns;
+  const double4 q = qrec[live ? i : ns - 1];
+  const int slot = (int)__double_as_longlong(q.w);
+  query_one<LPQ>(A, slot_kind(A.sv, slot), st->T_cur, q, slot, live ? sub : 1, lds_rows);
 }
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  int* qslot, unsigned long long* scan_tmp, bool rebin, hipStream_t s) {
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -802,16 +888,16 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     (void)hipMemsetAsync(tile_fill, 0, sizeof(int) * (size_t)ntiles, s);
     hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_cnt);
     launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
-    hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, tile_of_slot, tile_scan,
-                       tile_fill, qslot);
+    hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
+                       tile_fill, qrec);
   }
-  // every slot with a tile is in qslot[0 .. n_binned); n_binned <= n is only known on the device, so the
+  // every slot with a tile is in qrec[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
   auto grid8 = [](long long threads) { return (unsigned)(((threads + 63) / 64 + 7) / 8 * 8); };
   if (n <= kQuadLimit)
-    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
   else
-    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qslot);
+    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
 }
 int build_tile_count(const GridView grids[kKinds]) {
   int base = 0;
@@ -872,9 +958,14 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
   const int local = slot - A.sv.slot_off[kind];
   seg.idx[pos] = local + A.sv.src_lo[kind];
   seg.px[pos] = A.sv.sx[slot]; seg.py[pos] = A.sv.sy[slot]; seg.pz[pos] = A.sv.sz[slot];
-  seg.ax[pos] = A.sv.rax[slot]; seg.ay[pos] = A.sv.ray[slot]; seg.az[pos] = A.sv.raz[slot];
-  if (kind == TLOAM_KIND_EDGE) { seg.bx[pos] = A.sv.rbx[slot]; seg.by[pos] = A.sv.rby[slot]; seg.bz[pos] = A.sv.rbz[slot]; }
-  if (kind <= TLOAM_KIND_GROUND) seg.d[pos] = A.sv.rd[slot];
+  const double2* q = reinterpret_cast<const double2*>(A.sv.raw + (size_t)slot * 8);
+  const double2 q0 = q[0], q1 = q[1];
+  seg.ax[pos] = q0.x; seg.ay[pos] = q0.y; seg.az[pos] = q1.x;
+  if (kind == TLOAM_KIND_EDGE) {
+    const double2 q2 = q[2];
+    seg.bx[pos] = q1.y; seg.by[pos] = q2.x; seg.bz[pos] = q2.y;
+  }
+  if (kind <= TLOAM_KIND_GROUND) seg.d[pos] = q[3].x;
   seg.w[pos] = A.sv.w_src[slot];  // weight captured by value at construction (registration.hpp:51,76,96)
   seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
 }
