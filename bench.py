@@ -7,12 +7,19 @@
 A *step* is ONE full `scan_match` (LocalRegistration::scanMatching, registration.cpp:879-1133 -- the
 bracket the reference times at front_end.cpp:320-322: grid build, 4 outer GNC iterations of
 [correspondence search + Ceres-configured solve + weight update]) over one synthetic frame pair
-whose eight feature clouds are already resident in HBM.  Workload (BASELINE.json configs[2]/[3]):
-the synthetic 1 M-correspondence frame -- 1 M source points / 1 M target points, all three residual
-types -- STRONG-scaled over N GPUs: the source points are sharded in contiguous index blocks, the
-targets are replicated, and every GN sweep ends in one RCCL all-reduce of the 6x6/6x1 normal
-equations (48 doubles) over xGMI.  `value` = GN iterations (residual+Jacobian sweep + all-reduce +
-6x6 dogleg step + pose update) per second of wall time, whole job; `ms_per_step` = ms/frame.
+whose eight feature clouds are already resident in HBM.  Workload (BASELINE.json configs[2]): the
+synthetic 1 M-correspondence frame -- 1 M source points / 1 M target points, all three residual types.
+`value` = GN iterations (residual+Jacobian sweep + 6x6 dogleg step + pose update) per second of wall
+time, whole job; `ms_per_step` = ms/frame.
+
+N > 1 (one process per GPU).  The reference runs ONE scanMatching per LiDAR frame, frames are independent
+units, so the headline scales the way BASELINE.json configs[4] does: every rank registers its OWN
+1 M frame (seed + rank) with no data-path collective -- `"scaling": "weak"`, value = sum of the ranks'
+GN iterations / max-over-ranks time.  The path's one real exchange step -- ONE frame's source points
+sharded in contiguous index blocks over the N GPUs, targets replicated, one RCCL all-reduce of the
+6x6/6x1 normal equations (48 doubles) over xGMI per GN sweep (BASELINE.json configs[3]) -- is timed in
+the same run and reported beside it as "sharded_1m" (strong scaling of one frame; 20 dependent
+all-reduces per ~2 ms frame bound it).
 The KITTI-density frame (configs[1], ~10 k source / ~85 k target points, reference caps) is timed on
 rank 0 at N=1 and reported under "kitti_density" in the same line.
 
@@ -73,7 +80,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    multi = world > 1
+    # TLOAM_BENCH_FORCE_MULTI=1 (under torchrun, WORLD_SIZE=1): drive the N>1 code path -- process group,
+    # replica aggregation and the RCCL-sharded block -- on a single-GPU box
+    multi = world > 1 or os.environ.get("TLOAM_BENCH_FORCE_MULTI") == "1"
 
     import torch  # plumbing only: process group, barrier, device sync (imported first so that one HIP runtime is shared)
     from tloam_amd import registration as reg
@@ -103,13 +112,9 @@ def main():
         n_src, n_tgt = synth.KITTI_SRC, synth.KITTI_TGT
         cfg = reg.default_config()
         wl_name = "synthetic KITTI-density frame (9.4k src / 83.5k tgt pts, reference caps 2500/2000/1200/200)"
-    scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
+    scene = synth.make_scene(seed=args.seed + rank, n_src=n_src, n_tgt=n_tgt)   # every rank: its own frame
 
     H = reg.HipRegistration(cfg, device=local_rank)
-    if multi:
-        uid = [reg.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        H.comm_init_rccl(rank, world, uid[0])
     H.set_frames(scene.source, scene.target)   # inputs resident in HBM before the timed region
     H.k3_timer(reset=True)                      # arm per-launch HIP events around K3
 
@@ -134,20 +139,25 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        gi = torch.tensor([float(gn_iters)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(gi, op=dist.ReduceOp.SUM)     # whole-job GN iterations
+        gn_iters_job = float(gi.item())
+    else:
+        gn_iters_job = float(gn_iters)
     k3_us, k3_n, k3_bytes_job = H.k3_timer()          # working sweeps
     k3_all_us, k3_all_n = H.k3_timer_all()              # every K3 launch incl. no-ops after a tolerance exit
 
     out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = gn_iters / elapsed
+        ms_per_step = elapsed / args.steps * 1e3      # one step = one frame on every rank
+        value = gn_iters_job / elapsed
         # pose sanity (not timed): the solve must land near the generating pose
         D = np.linalg.inv(T) @ scene.T_true
         pose_err_m = float(np.linalg.norm(D[:3, 3]))
         # ---- roofline of the dominant streaming kernel K3 (per launch, this rank's shard)
         n_corr = st["n_corr"]  # job-wide counts (all-reduced)
         alg_job = 72.0 * (n_corr[0] + n_corr[1]) + 88.0 * n_corr[2] + 64.0 * n_corr[3]
-        alg_launch = alg_job / world      # contiguous shards: this rank streams 1/N of the set
+        alg_launch = alg_job              # rank 0's own frame (replica mode: no sharding in the headline)
         # HIP event pairs bound to each K3 dispatch (hipExtLaunchKernelGGL): elapsed = kernel duration.
         # `achieved` uses the SAME population a kernel trace averages over -- every k3_accumulate
         # launch, the no-op launches enqueued after a solver tolerance exit included (bytes: 0).
@@ -160,6 +170,7 @@ def main():
         roofline = {"kernel": "k3_accumulate<false>", "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_detail": traffic_detail, "avg_launch_us": round(k3_avg_all_us, 3), "launches": int(k3_all_n),
+                    "launch_sampling": "HIP event pair on every 3rd K3 launch of the timed region",
                     "algorithmic_bytes_per_launch": alg_avg_launch,
                     "working_sweeps": {"launches": int(k3_n), "avg_launch_us": round(k3_avg_work_us, 3),
                                        "algorithmic_bytes_per_launch": alg_launch,
@@ -169,15 +180,26 @@ def main():
             "metric": "gauss_newton_iters_per_sec", "value": round(value, 2), "unit": "GN iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name, "step": "one scan_match (ms_per_step = ms/frame)",
                        "gn_iters_per_frame": gn_iters / args.steps, "n_corr": n_corr,
                        "outer_iterations": st["outer_iterations"],
-                       "parallelism": f"source points sharded x{world}, targets replicated, 1 RCCL all-reduce(48 f64) per GN sweep" if multi else "1 GPU",
+                       "frames_per_step": world,
+                       "parallelism": (f"{world} independent frames, one per GPU, no data-path collective (replicas); "
+                                       "the sharded single-frame path is reported under sharded_1m") if multi else "1 GPU",
                        "pose_err_vs_truth_m": pose_err_m},
             "roofline": roofline,
         }
     H.close()
+
+    # ---------------- N > 1: ONE frame sharded over the ranks (strong scaling, RCCL all-reduce per sweep) ----------------
+    if multi:
+        sharded = sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier)
+        if rank == 0:
+            sharded["replica_ms_per_frame"] = out["ms_per_step"]
+            if "ms_per_frame" in sharded:
+                sharded["speedup_vs_one_gpu_frame"] = round(out["ms_per_step"] / sharded["ms_per_frame"], 3)
+            out["sharded_1m"] = sharded
 
     # ---------------- KITTI-density frame + CPU baseline: rank 0, N = 1 only ----------------
     if rank == 0 and not multi:
@@ -209,6 +231,65 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier):
+    """BASELINE.json configs[3]: the SAME frame on every rank, source points sharded in contiguous index
+    blocks, targets replicated, one RCCL all-reduce of 48 doubles per GN sweep (native librccl on the
+    compute stream).  Any failure is reported in the block instead of taking the headline down."""
+    res = {"workload": "one 1M-correspondence frame, source points sharded x%d, targets replicated, "
+                       "1 RCCL all-reduce (48 f64) per GN sweep" % world, "scaling": "strong", "n_gpus": world}
+    H = None
+    try:
+        scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
+        H = reg.HipRegistration(cfg, device=local_rank)
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [reg.rccl_unique_id()]
+            except Exception as e:  # noqa: BLE001
+                uid = [e]
+        dist.broadcast_object_list(uid, src=0)
+        init_err = None
+        try:
+            if isinstance(uid[0], Exception):
+                raise uid[0]
+            H.comm_init_rccl(rank, world, uid[0])
+            H.set_frames(scene.source, scene.target)
+        except Exception as e:  # noqa: BLE001
+            init_err = e
+        # every rank learns whether ALL ranks initialised before anyone enqueues a collective
+        flag = torch.tensor([0.0 if init_err is None else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) != 0.0:
+            raise RuntimeError(f"sharded-path initialisation failed on some rank ({init_err})")
+        ok = 1.0
+        for _ in range(max(args.warmup, 1)):
+            rc, T, st = H.scan_match(scene.T_pred)
+            ok = ok if rc == 0 else 0.0
+        barrier()
+        t0 = time.perf_counter()
+        it = 0
+        for _ in range(args.steps):
+            rc, T, st = H.scan_match(scene.T_pred)
+            ok = ok if rc == 0 else 0.0
+            it += st["gn_evaluations"]
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt, -ok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0].item())
+        if float(tt[1].item()) != -1.0:
+            raise RuntimeError("scan_match failed on at least one rank")
+        D = np.linalg.inv(T) @ scene.T_true
+        res.update({"ms_per_frame": round(dt / args.steps * 1e3, 4), "gn_iters_per_sec": round(it / dt, 2),
+                    "n_corr": st["n_corr"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3]))})
+    except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+        res["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if H is not None:
+            H.close()
+    return res
 
 
 def cpu_baseline(scene, cfg, args):

@@ -188,6 +188,9 @@ int tloam_k3_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* launche
 int tloam_k3_timer_all(tloam_ctx* ctx, double* total_us, int64_t* launches);
 /* debugging aid: raw copy of the device-resident minimiser state; returns its size in doubles */
 int tloam_debug_state(tloam_ctx* ctx, double* out, int n_doubles);
+/* development aid: the per-block partial rows of the last K3 launch (32 doubles per block); returns the
+ * number of rows.  Columns 28..31 carry in-kernel timestamps in builds with -DTLOAM_K3_PROFILE. */
+int tloam_debug_partials(tloam_ctx* ctx, double* out, int n_doubles);
 
 /* ---- multi-GPU: correspondence set sharded over ranks, one all-reduce per sweep --------
  * (nothing in the reference).  Call before set_source / set_correspondences.

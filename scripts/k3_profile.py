@@ -1,0 +1,35 @@
+"""In-kernel timeline of K3 on the 1 M pre-built set.  Needs a profiling build:
+   TLOAM_EXTRA_HIPCC_FLAGS=-DTLOAM_K3_PROFILE python -m tloam_amd.build --force
+Wave 0 of every block stamps s_memtime at entry, after the state load, after the sweep and after the block
+reduction; printed as a distribution over blocks."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tloam_amd import registration as reg, synth
+sets, x_true, x_eval = synth.make_prebuilt(seed=1, weights="timing")
+H = reg.HipRegistration()
+for rt in range(3):
+    p, a, b, d, w = sets[rt]
+    H.set_correspondences(rt, p, a, b, d, w)
+us = [H.time_accumulate(x_eval, 50) for _ in range(3)]
+print("K3 us/launch", us)
+H.time_accumulate(x_eval, 1)
+L = H.L
+buf = np.zeros(4096 * 32)
+nb = L.tloam_debug_partials(H.h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size)
+rows = buf[: nb * 32].reshape(nb, 32)
+wc = rows[:, 28]                                # wall clock (10 ns ticks, low 32 bits) at entry
+wdur = np.floor(rows[:, 31] / 65536.0)          # wall-clock ticks entry -> end of block
+rows[:, 31] -= wdur * 65536.0
+tick_ns = (wdur * 10.0).sum() / (rows[:, 29] + rows[:, 30] + rows[:, 31]).sum()
+print("s_memtime tick = %.3f ns" % tick_ns)
+t0 = (wc - wc.min()) * 10.0 / tick_ns
+ld, sw, rd = rows[:, 29], rows[:, 30], rows[:, 31]
+end = t0 + ld + sw + rd
+def q(v): return "min %.0f p50 %.0f p90 %.0f max %.0f" % (v.min(), np.median(v), np.percentile(v, 90), v.max())
+print("blocks", nb, "(ticks of s_memtime)")
+print("start offset :", q(t0))
+print("state load   :", q(ld))
+print("sweep        :", q(sw))
+print("reduce+store :", q(rd))
+print("end          :", q(end), " -> span", end.max())

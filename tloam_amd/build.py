@@ -16,6 +16,7 @@ OUT = os.path.join(HERE, "libtloam_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("TLOAM_EXTRA_HIPCC_FLAGS", "").split()  # development aid (-DTLOAM_K3_PROFILE ...)
 UNITS = [
     # K1/K2: un-fused fp64 so the discontinuous gates see the oracle's operation order
     ("tl_nn.hip", ["-ffp-contract=off"]),

@@ -365,20 +365,39 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
   // Speculative first fetch: the wave's first chunk of the planar segment is requested straight from the
   // kernel arguments, BEFORE the dependent scalar loads of the state (done flag, pose, segment sizes)
   // come back -- their latency overlaps the first HBM round trip.  The capacity bound keeps it in range.
+#ifdef TLOAM_K3_PROFILE
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long wc0 = wall_clock64();  // 100 MHz, one base for the whole device
+#endif
   ChunkBuf<TLOAM_RES_PLANE> pre;
   const bool spec = (TLOAM_K3_PLANE_DEPTH == 2) && (gw + 1) * kChunk <= cv.k[0].cap;
   if (spec) fetch<TLOAM_RES_PLANE>(cv.k[0], gw * kChunk + lane * 2, pre);
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
+#ifdef TLOAM_K3_PROFILE
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
   if (SINGLE) sweep_single(cv, T, gw, lane, a, pre, spec);
   else sweep_all(cv, T, gw, gridDim.x * 4, lane, a, pre, spec);
+#ifdef TLOAM_K3_PROFILE
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
   const double tot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
   if (threadIdx.x < kAccStride)
     partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+#ifdef TLOAM_K3_PROFILE
+  if (threadIdx.x == 0) {  // development aid (scripts/k3_profile.py): wave 0's timeline in the spare columns
+    const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+    double* row = partials + (size_t)blockIdx.x * kAccStride;
+    row[28] = (double)(wc0 & 0xffffffffull); row[29] = (double)(ts1 - ts0); row[30] = (double)(ts2 - ts1);
+    row[31] = (double)(ts3 - ts2) + 65536.0 * (double)(wall_clock64() - wc0);
+  }
+#endif
 }
 
 int k3_grid_for(int total_cap) {

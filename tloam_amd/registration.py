@@ -108,6 +108,7 @@ def load_library():
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
+        "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
         "tloam_rccl_unique_id": (C.c_int, [vp]),
         "tloam_comm_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "tloam_comm_init_callback": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]),
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = (
     "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_scan_match", "tloam_sm_begin",
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_solve",
-    "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
+    "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_init_callback", "tloam_shard_range", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
 )
 
