@@ -72,11 +72,11 @@ struct KindData {
 
 struct GridBuffers {
   DBuf<double4> gp;
-  DBuf<int> cell_start, cell_of_pt, cell_fill;
+  DBuf<int> cell_start, cell_of_pt, rank_of_pt;
   DBuf<unsigned long long> cell_cnt, cell_scan, scan_tmp;
   DBuf<double> bbox;
   void release() {
-    gp.release(); cell_start.release(); cell_of_pt.release(); cell_fill.release();
+    gp.release(); cell_start.release(); cell_of_pt.release(); rank_of_pt.release();
     cell_cnt.release(); cell_scan.release(); scan_tmp.release(); bbox.release();
   }
 };
@@ -313,7 +313,7 @@ int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridV
   }
   const size_t nc = (size_t)std::max<long long>(cell_total, 1);
   HIPC(c, G.gp.reserve(std::max<size_t>(tgt_total, 1))); HIPC(c, G.cell_of_pt.reserve(std::max<size_t>(tgt_total, 1)));
-  HIPC(c, G.cell_start.reserve(nc + kKinds + 1)); HIPC(c, G.cell_fill.reserve(nc));
+  HIPC(c, G.cell_start.reserve(nc + kKinds + 1)); HIPC(c, G.rank_of_pt.reserve(tgt_total + 1));
   HIPC(c, G.cell_cnt.reserve(nc + 1)); HIPC(c, G.cell_scan.reserve(nc + 1));
   HIPC(c, G.scan_tmp.reserve(scan_tmp_elems(nc + 1)));
   for (int k = 0; k < kKinds; ++k) {
@@ -322,10 +322,10 @@ int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridV
   }
   if (cell_total == 0) return TLOAM_OK;
   HIPC(c, hipMemsetAsync(G.cell_cnt.p, 0, (nc + 1) * sizeof(unsigned long long), c->stream));
-  launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, c->stream);
+  launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream);
   launch_exclusive_scan_u64(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
-  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, G.cell_fill.p, c->stream);
-  launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.cell_fill.p, G.gp.p, c->stream);
+  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, c->stream);
+  launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.rank_of_pt.p, G.gp.p, c->stream);
   return TLOAM_OK;
 }
 
@@ -659,7 +659,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   {
     const size_t ntiles = (size_t)build_tile_count(grids);
     HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
-    HIPC(c, c->tile_fill.reserve(ntiles)); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
+    HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)ntiles, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
     HIPC(c, c->qrec.reserve(n_slots + 1));
     HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
   }

@@ -130,11 +130,11 @@ struct GridSet {
   int dim[kKinds][3];
 };
 void launch_bbox_all(const GridSet& gs, double* out /*[4][64][6]*/, hipStream_t s);
-void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s);
-void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, int* cell_fill,
-                              hipStream_t s);
+void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
+                           hipStream_t s);
+void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, hipStream_t s);
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
-                             int* cell_fill, double4* gp, hipStream_t s);
+                             const int* rank_of_pt, double4* gp, hipStream_t s);
 
 struct BuildParams {
   double radius[kKinds];

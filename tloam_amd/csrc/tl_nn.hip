@@ -250,7 +250,8 @@ __device__ __forceinline__ int cell_coord(double v, double org, double inv_cell,
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt) {
+__global__ void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt,
+                                 int* __restrict__ rank_of_pt) {
   const int k = blockIdx.y;
   const int n = gs.n[k];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -259,7 +260,8 @@ __global__ void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ ce
     const int cz = clampi(cell_coord(gs.tz[k][i], gs.org[k][2], gs.inv_cell[k], gs.dim[k][2]), 0, gs.dim[k][2] - 1);
     const int c = (cz * gs.dim[k][1] + cy) * gs.dim[k][0] + cx;
     cell_of_pt[gs.tgt_off[k] + i] = c;
-    atomicAdd(&cell_cnt[gs.cell_base[k] + c], 1ull);
+    // the one atomic of the build: the histogram count doubles as the point's rank inside its cell
+    rank_of_pt[gs.tgt_off[k] + i] = (int)atomicAdd(&cell_cnt[gs.cell_base[k] + c], 1ull);
   }
 }
 static int max_n(const GridSet& gs) {
@@ -267,15 +269,16 @@ static int max_n(const GridSet& gs) {
   for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.n[k]);
   return m;
 }
-void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, hipStream_t s) {
+void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
+                           hipStream_t s) {
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_grid_count_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_cnt, cell_of_pt);
+  hipLaunchKernelGGL(k_grid_count_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_cnt, cell_of_pt, rank_of_pt);
 }
 // cell_start of kind k lives at cell_start[cell_base[k] + k ...] (ncell + 1 entries per kind), relative to the
-// kind's own point block; also resets the scatter cursors
+// kind's own point block
 __global__ void k_grid_finalize_all(GridSet gs, const unsigned long long* __restrict__ cell_scan,
-                                    int* __restrict__ cell_start, int* __restrict__ cell_fill) {
+                                    int* __restrict__ cell_start) {
   const int k = blockIdx.y;
   const long long ncell = gs.ncell[k], base = gs.cell_base[k];
   const unsigned long long first = cell_scan[base];
@@ -283,35 +286,33 @@ __global__ void k_grid_finalize_all(GridSet gs, const unsigned long long* __rest
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i <= ncell; i += stride) {
     cell_start[base + k + i] = (i < ncell) ? (int)(cell_scan[base + i] - first) : gs.n[k];
-    if (i < ncell) cell_fill[base + i] = 0;
   }
 }
-void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, int* cell_fill,
-                              hipStream_t s) {
+void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, hipStream_t s) {
   long long m = 1;
   for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.ncell[k] + 1);
   int blocks = (int)std::min<long long>((m + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_grid_finalize_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_scan, cell_start, cell_fill);
+  hipLaunchKernelGGL(k_grid_finalize_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_scan, cell_start);
 }
 __global__ void k_grid_scatter_all(GridSet gs, const int* __restrict__ cell_of_pt,
-                                   const unsigned long long* __restrict__ cell_scan, int* __restrict__ cell_fill,
-                                   double4* __restrict__ gp) {
+                                   const unsigned long long* __restrict__ cell_scan,
+                                   const int* __restrict__ rank_of_pt, double4* __restrict__ gp) {
   const int k = blockIdx.y;
   const int n = gs.n[k];
   const long long base = gs.cell_base[k];
   const unsigned long long first = cell_scan[base];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int c = cell_of_pt[gs.tgt_off[k] + i];
-    const int pos = (int)(cell_scan[base + c] - first) + atomicAdd(&cell_fill[base + c], 1);
+    const int pos = (int)(cell_scan[base + c] - first) + rank_of_pt[gs.tgt_off[k] + i];
     gp[gs.tgt_off[k] + pos] =
         double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
   }
 }
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
-                             int* cell_fill, double4* gp, hipStream_t s) {
+                             const int* rank_of_pt, double4* gp, hipStream_t s) {
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_grid_scatter_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_scan, cell_fill, gp);
+  hipLaunchKernelGGL(k_grid_scatter_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_scan, rank_of_pt, gp);
 }
 
 // ================================================================================================
@@ -670,7 +671,7 @@ __device__ __forceinline__ int slot_kind(const SlotView& sv, int slot) {
 
 // pass 1: tile of every source slot under the current pose; histogram of queries per tile
 __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* __restrict__ st,
-                                                   int* __restrict__ tile_of_slot,
+                                                   int* __restrict__ tile_of_slot, int* __restrict__ rank_in_tile,
                                                    unsigned long long* __restrict__ tile_cnt) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= A.sv.slot_off[kKinds]) return;
@@ -692,19 +693,19 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   const int t = A.tm.tile_base[kind] +
                 ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
   tile_of_slot[slot] = t;
-  atomicAdd(&tile_cnt[t], 1ull);
+  rank_in_tile[slot] = (int)atomicAdd(&tile_cnt[t], 1ull);  // the one atomic of the sort: count AND rank
 }
 // pass 2: slots grouped by tile (order inside a tile is irrelevant: every result goes to its own slot)
 // The sorted entry is a 32-byte record (x, y, z, slot): K1 then reads its queries coalesced instead of
 // chasing slot -> three scattered 8-byte loads.
 __global__ __launch_bounds__(256) void k_query_scatter(SlotView sv, const int* __restrict__ tile_of_slot,
                                                        const unsigned long long* __restrict__ tile_scan,
-                                                       int* __restrict__ tile_fill, double4* __restrict__ qrec) {
+                                                       const int* __restrict__ rank_in_tile, double4* __restrict__ qrec) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= sv.slot_off[kKinds]) return;
   const int t = tile_of_slot[slot];
   if (t < 0) return;
-  qrec[(int)tile_scan[t] + atomicAdd(&tile_fill[t], 1)] =
+  qrec[(int)tile_scan[t] + rank_in_tile[slot]] =
       double4{sv.sx[slot], sv.sy[slot], sv.sz[slot], __longlong_as_double((long long)slot)};
 }
 
@@ -885,8 +886,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     // so the tile sort is done once per frame (first outer iteration, predicted pose) and reused while
     // the pose moves by centimetres.
     (void)hipMemsetAsync(tile_cnt, 0, sizeof(unsigned long long) * (size_t)(ntiles + 1), s);
-    (void)hipMemsetAsync(tile_fill, 0, sizeof(int) * (size_t)ntiles, s);
-    hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_cnt);
+    hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
     launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
     hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
                        tile_fill, qrec);
