@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--workload", default="m1", choices=["m1", "kitti"], help="m1 = 1 M-correspondence frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kitti", action="store_true")
+    ap.add_argument("--kitti-frames", type=int, default=200, help="length of the KITTI-density sequence block")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -203,29 +204,12 @@ def main():
 
     # ---------------- KITTI-density frame + CPU baseline: rank 0, N = 1 only ----------------
     if rank == 0 and not multi:
+        kitti_seq = None
         if not args.no_kitti and args.workload == "m1":
-            sk = synth.make_scene(seed=args.seed, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
-            Hk = reg.HipRegistration(reg.default_config(), device=local_rank)
-            Hk.set_frames(sk.source, sk.target)
-            for _ in range(5):
-                Hk.scan_match(sk.T_pred)
-            torch.cuda.synchronize()
-            nk, it = 100, 0
-            t0 = time.perf_counter()
-            for _ in range(nk):
-                rc, Tk, stk = Hk.scan_match(sk.T_pred)
-                it += stk["gn_evaluations"]
-            dtk = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for _ in range(20):
-                Hk.set_frames(sk.source, sk.target)
-            dt_up = (time.perf_counter() - t0) / 20
-            out["kitti_density"] = {"ms_per_frame": round(dtk / nk * 1e3, 4), "gn_iters_per_sec": round(it / dtk, 1),
-                                    "n_corr": stk["n_corr"], "frames": nk,
-                                    "ms_per_frame_incl_pcie_upload": round((dtk / nk + dt_up) * 1e3, 4)}
-            Hk.close()
+            kitti_seq = kitti_sequence(args, reg, synth, torch, local_rank)
+            out["kitti_density"] = kitti_seq["report"]
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cfg, args)
+            out["cpu_baseline"] = cpu_baseline(scene, cfg, args, kitti_seq)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:
@@ -292,7 +276,60 @@ def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world,
     return res
 
 
-def cpu_baseline(scene, cfg, args):
+def kitti_frame(synth, seed, f):
+    """Frame f of the synthetic KITTI-density sequence (BASELINE.json configs[1]): an independent procedural
+    scan pair per frame (seed + f), ego pose advancing ~0.8 m / 10 mrad per frame along a gentle arc, the
+    constant-velocity prediction off by ~1.6 cm / 3 mrad."""
+    rng = np.random.default_rng(1000003 * seed + f)
+    yaw = 0.3 + 0.01 * f
+    true_se3 = (0.8 * np.cos(0.01 * f) * (1 + f * 0.0), 0.8 * np.sin(0.01 * f), 0.02, 0.002, 0.003, yaw % 3.0)
+    pred_err = tuple(rng.normal(0.0, 0.016 / np.sqrt(3), 3)) + tuple(rng.normal(0.0, 0.003 / np.sqrt(3), 3))
+    return synth.make_scene(seed=seed + f, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, true_se3=true_se3,
+                            pred_err=pred_err)
+
+
+def kitti_sequence(args, reg, synth, torch, device):
+    """KITTI-density sequence on one GPU: per frame the eight clouds are handed over (PCIe), then ONE
+    scan_match is timed with the clouds resident (the bracket of front_end.cpp:320-322)."""
+    nf = args.kitti_frames
+    H = reg.HipRegistration(reg.default_config(), device=device)
+    warm = kitti_frame(synth, args.seed, 0)
+    H.set_frames(warm.source, warm.target)
+    for _ in range(5):
+        H.scan_match(warm.T_pred)
+    ms, ms_up, it, terr, poses = [], [], 0, [], {}
+    n_corr = None
+    for f in range(nf):
+        sc = kitti_frame(synth, args.seed, f)
+        t0 = time.perf_counter()
+        H.set_frames(sc.source, sc.target)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rc, T, st = H.scan_match(sc.T_pred)
+        t2 = time.perf_counter()
+        if rc != 0:
+            raise SystemExit(f"KITTI-density frame {f}: scan_match failed: {reg.STATUS.get(rc, rc)}")
+        ms.append((t2 - t1) * 1e3)
+        ms_up.append((t2 - t0) * 1e3)
+        it += st["gn_evaluations"]
+        D = np.linalg.inv(T) @ sc.T_true
+        terr.append(float(np.linalg.norm(D[:3, 3])))
+        n_corr = st["n_corr"]
+        if f < 8:
+            poses[f] = T
+    H.close()
+    ms = np.array(ms)
+    rep = {"workload": "synthetic KITTI-density sequence (9.4k src / 83.5k tgt pts per frame, reference caps 2500/2000/1200/200)",
+           "frames": nf, "ms_per_frame": round(float(ms.mean()), 4), "ms_per_frame_p50": round(float(np.median(ms)), 4),
+           "ms_per_frame_p99": round(float(np.percentile(ms, 99)), 4),
+           "gn_iters_per_sec": round(it / (ms.sum() * 1e-3), 1), "gn_iters_per_frame": round(it / nf, 2),
+           "ms_per_frame_incl_pcie_upload": round(float(np.mean(ms_up)), 4),
+           "n_corr_last_frame": n_corr,
+           "pose_err_vs_truth_m": {"mean": round(float(np.mean(terr)), 6), "max": round(float(np.max(terr)), 6)}}
+    return {"report": rep, "poses": poses}
+
+
+def cpu_baseline(scene, cfg, args, kitti_seq=None):
     """The oracle (a dependency-free port of the reference's Ceres-configured solve, NOT Ceres) on the
     host cores, threaded in the reference's shape: 4 builder threads (registration.cpp:976-1020),
     evaluation on hardware_concurrency()/2 threads (:184, :1044).  Bounded sample: ONE scan_match of
@@ -306,9 +343,40 @@ def cpu_baseline(scene, cfg, args):
     t0 = time.perf_counter()
     rc, T, st = O.scan_match(scene.T_pred)
     dt = time.perf_counter() - t0
-    return {"value": round(st["gn_evaluations"] / dt, 3), "unit": "GN iter/s", "cores": max(4, eval_threads),
-            "host_cores": cores, "kind": "port", "ms_per_frame": round(dt * 1e3, 2),
-            "sample": "1 scan_match of the same frame (C oracle, -O3, OpenMP: 4 builder threads, eval on cores/2)"}
+    res = {"value": round(st["gn_evaluations"] / dt, 3), "unit": "GN iter/s", "cores": max(4, eval_threads),
+           "host_cores": cores, "kind": "port", "ms_per_frame": round(dt * 1e3, 2),
+           "sample": "1 scan_match of the same 1M frame + the first 8 KITTI-density frames "
+                     "(C oracle, -O3, OpenMP: 4 builder threads, eval on cores/2)"}
+    if kitti_seq is not None:
+        # the same port on the first frames of the KITTI-density sequence: CPU ms/frame beside the GPU's, and
+        # the pose the GPU returned for those frames checked against it (the oracle as the checker)
+        from tloam_amd import registration as reg
+        from tloam_amd import synth
+        kc = reg.default_config()
+        ko = ob.make_config(**{f: getattr(kc, f) for f, _ in kc._fields_ if f != "reserved0"})
+        K = ob.Oracle(ko, builder_threads=4, eval_threads=eval_threads)
+        K1 = ob.Oracle(ko, builder_threads=1, eval_threads=1)   # and single-threaded (both shapes)
+        tms, tms1, dts, drs, its = [], [], [], [], 0
+        for f, T_gpu in sorted(kitti_seq["poses"].items()):
+            sc = kitti_frame(synth, args.seed, f)
+            K1.set_frames(sc.source, sc.target)
+            t0 = time.perf_counter()
+            K1.scan_match(sc.T_pred)
+            tms1.append((time.perf_counter() - t0) * 1e3)
+            K.set_frames(sc.source, sc.target)
+            t0 = time.perf_counter()
+            rc, T_cpu, stc = K.scan_match(sc.T_pred)
+            tms.append((time.perf_counter() - t0) * 1e3)
+            its += stc["gn_evaluations"]
+            D = np.linalg.inv(T_cpu) @ T_gpu
+            dts.append(float(np.linalg.norm(D[:3, 3])))
+            drs.append(float(np.arccos(np.clip((np.trace(D[:3, :3]) - 1.0) / 2.0, -1.0, 1.0))))
+        if tms:
+            res["kitti_density"] = {"frames": len(tms), "ms_per_frame": round(float(np.mean(tms)), 3),
+                                    "ms_per_frame_1_thread": round(float(np.mean(tms1)), 3),
+                                    "gn_iters_per_sec": round(its / (sum(tms) * 1e-3), 1),
+                                    "gpu_vs_port_pose_delta": {"max_dt_m": max(dts), "max_dR_rad": max(drs)}}
+    return res
 
 
 if __name__ == "__main__":
