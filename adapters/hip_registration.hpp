@@ -76,6 +76,30 @@ class HipRegistrationCore {
     return true;
   }
 
+  // ---- device-resident submap (optional; replaces the body of FrontEnd::updateSubmap, front_end.cpp:201-275,
+  //      and of the first-frame branch :283-304).  The clouds are the ones the reference builds on the CPU
+  //      anyway -- SelectByIndex(planar/sphere_submap_index), current_scan.edge/ground_feature -- and the
+  //      resulting submap becomes the registration target without coming back to the host.
+  template <class CloudPtr>
+  bool submapInit(const tloam_submap_config& cfg, const CloudPtr& planar_submap, const CloudPtr& sphere_submap,
+                  const CloudPtr& edge, const CloudPtr& ground) {
+    using Acc = PointsAccessor<typename std::remove_reference<decltype(*planar_submap)>::type>;
+    return ctx_ && ok(tloam_submap_init(ctx_, &cfg, Acc::data(*planar_submap), Acc::size(*planar_submap),
+                                        Acc::data(*sphere_submap), Acc::size(*sphere_submap), Acc::data(*edge),
+                                        Acc::size(*edge), Acc::data(*ground), Acc::size(*ground)),
+                      "tloam_submap_init", ctx_);
+  }
+  template <class CloudPtr>
+  bool submapUpdate(PoseT& lidar_odom_pose, const CloudPtr& planar_submap, const CloudPtr& sphere_submap,
+                    const CloudPtr& edge_scan, const CloudPtr& ground_scan) {
+    using Acc = PointsAccessor<typename std::remove_reference<decltype(*planar_submap)>::type>;
+    return ctx_ && ok(tloam_submap_update(ctx_, lidar_odom_pose.matrix().data(), Acc::data(*planar_submap),
+                                          Acc::size(*planar_submap), Acc::data(*sphere_submap), Acc::size(*sphere_submap),
+                                          Acc::data(*edge_scan), Acc::size(*edge_scan), Acc::data(*ground_scan),
+                                          Acc::size(*ground_scan)),
+                      "tloam_submap_update", ctx_);
+  }
+
   std::pair<double, double> getFitnessScore() {
     double fitness = 0.0, rmse = 0.0;
     if (!ctx_ || !ok(tloam_fitness(ctx_, &fitness, &rmse), "tloam_fitness", ctx_)) return {0.0, 0.0};
@@ -120,6 +144,8 @@ class HipRegistration : public RegistrationInterface {
     return core_.scanMatching(out, predict, result);
   }
   std::pair<double, double> getFitnessScore() override { return core_.getFitnessScore(); }
+  // beyond the interface: the device-resident submap entry points
+  tloam_hip::HipRegistrationCore<Frame, Eigen::Isometry3d>& core() { return core_; }
 
  private:
   static tloam_tls_config fromYaml(const YAML::Node& n) {

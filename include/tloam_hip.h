@@ -192,6 +192,39 @@ int tloam_debug_state(tloam_ctx* ctx, double* out, int n_doubles);
  * number of rows.  Columns 28..31 carry in-kernel timestamps in builds with -DTLOAM_K3_PROFILE. */
 int tloam_debug_partials(tloam_ctx* ctx, double* out, int n_doubles);
 
+/* ---- submap maintenance on the device ---------------------------------------
+ * FrontEnd::updateSubmap (front_end.cpp:201-275) and the first-frame branch of updateLidarOdometry
+ * (front_end.cpp:283-304) restated on the device, so that the four target clouds never leave HBM between
+ * frames: Transform (PointCloud2.cpp:71-75) -> += (:96-132) -> Crop (:551-559) -> VoxelDownSample (:358-403).
+ * The result is installed as the registration target (the reference's setInputTarget(submap),
+ * front_end.cpp:267) without a host round trip.  Quirk kept: the sphere submap is rebuilt from the PLANAR
+ * frame buffer (front_end.cpp:221 iterates submap_planar_buffer).  Voxels are emitted in order of first
+ * occurrence (the reference's order is std::unordered_map's, i.e. unspecified). */
+typedef struct tloam_submap_config {
+  int32_t planar_frame_size;        /* lidar_odometry.yaml:13  (3)   */
+  int32_t sphere_frame_size;        /* lidar_odometry.yaml:12  (3)   */
+  double edge_crop_box_length;      /* lidar_odometry.yaml:16  (100) */
+  double ground_crop_box_length;    /* lidar_odometry.yaml:17  (100) */
+  double edge_down_sample_submap;   /* lidar_odometry.yaml:9   (0.3) */
+  double ground_down_sample_submap; /* lidar_odometry.yaml:7   (0.45)*/
+  double ground_down_sample;        /* lidar_odometry.yaml:6   (0.3), first frame only (front_end.cpp:287) */
+} tloam_submap_config;
+void tloam_submap_default_config(tloam_submap_config* cfg);
+/* first frame (front_end.cpp:283-304): edge += edge cloud; ground += ground cloud->VoxelDownSample(
+ * ground_down_sample); planar / sphere += the submap selections; setInputTarget(submap). */
+int tloam_submap_init(tloam_ctx* ctx, const tloam_submap_config* cfg, const double* planar_submap_xyz, size_t n_planar,
+                      const double* sphere_submap_xyz, size_t n_sphere, const double* edge_xyz, size_t n_edge,
+                      const double* ground_xyz, size_t n_ground);
+/* every later frame (front_end.cpp:201-275) with lidar_odom_pose = pose_colmajor: planar/sphere frame
+ * buffers, edge/ground accumulate -> crop around the pose's translation -> voxel grid; setInputTarget. */
+int tloam_submap_update(tloam_ctx* ctx, const double pose_colmajor[16], const double* planar_submap_xyz,
+                        size_t n_planar, const double* sphere_submap_xyz, size_t n_sphere,
+                        const double* edge_scan_xyz, size_t n_edge, const double* ground_scan_xyz, size_t n_ground);
+/* the target cloud of `kind` as the device holds it (AoS out); n receives the size even when capacity is
+ * too small (then nothing is copied and TLOAM_E_INVALID is returned) */
+int tloam_get_target(tloam_ctx* ctx, int kind, size_t capacity, size_t* n, double* xyz_aos);
+
+
 /* ---- multi-GPU: correspondence set sharded over ranks, one all-reduce per sweep --------
  * (nothing in the reference).  Call before set_source / set_correspondences.
  * (a) native RCCL over xGMI: unique_id = the 128 bytes of an ncclUniqueId made on rank 0

@@ -63,8 +63,8 @@ def make_config(**over) -> TlsConfig:
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "tloam_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "tloam_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -266,3 +266,100 @@ def knn_brute(targets, q, radius, k):
     cnt = lib().orc_knn_hybrid_brute(_dp(t), int(len(t)), _dp(qq), C.c_double(radius), int(k), _ip(idx), _dp(d2))
     cnt = max(cnt, 0)
     return idx[:cnt], d2[:cnt]
+
+
+# ---------------------------------------------------------------------------------------------------
+#  submap maintenance (oracle/submap_oracle.c; front_end.cpp:201-275, :283-304)
+# ---------------------------------------------------------------------------------------------------
+class SubmapConfig(C.Structure):
+    """== tloam_submap_config (include/tloam_hip.h)."""
+    _fields_ = [("planar_frame_size", C.c_int32), ("sphere_frame_size", C.c_int32),
+                ("edge_crop_box_length", C.c_double), ("ground_crop_box_length", C.c_double),
+                ("edge_down_sample_submap", C.c_double), ("ground_down_sample_submap", C.c_double),
+                ("ground_down_sample", C.c_double)]
+
+
+SUBMAP_DEFAULTS = dict(planar_frame_size=3, sphere_frame_size=3, edge_crop_box_length=100.0,
+                       ground_crop_box_length=100.0, edge_down_sample_submap=0.3, ground_down_sample_submap=0.45,
+                       ground_down_sample=0.3)
+
+
+def make_submap_config(**over) -> SubmapConfig:
+    cfg = SubmapConfig()
+    vals = dict(SUBMAP_DEFAULTS)
+    vals.update(over)
+    for k, v in vals.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def pc_transform(M, xyz):
+    a = _aos(xyz).copy()
+    m = np.ascontiguousarray(np.asarray(M, float).reshape(4, 4).T.ravel())  # column-major
+    lib().orc_pc_transform(_dp(m), _dp(a), C.c_size_t(len(a)))
+    return a
+
+
+def pc_crop(xyz, lo, hi):
+    a = _aos(xyz)
+    out = np.empty_like(a)
+    L = lib()
+    L.orc_pc_crop.restype = C.c_size_t
+    n = L.orc_pc_crop(_dp(a), C.c_size_t(len(a)), _dp(np.asarray(lo, float)), _dp(np.asarray(hi, float)), _dp(out))
+    return out[:n].copy()
+
+
+def pc_voxel_down_sample(xyz, voxel):
+    a = _aos(xyz)
+    out = np.empty((max(len(a), 1), 3))
+    L = lib()
+    L.orc_pc_voxel_down_sample.restype = C.c_long
+    n = L.orc_pc_voxel_down_sample(_dp(a), C.c_size_t(len(a)), C.c_double(voxel), _dp(out))
+    if n < 0:
+        raise ValueError("[VoxelDownSample] voxel_size is too small / <= 0")
+    return out[:n].copy()
+
+
+class OracleSubmap:
+    """FrontEnd's submap object (front_end.cpp:201-275, :283-304), same call surface as the HIP side."""
+
+    def __init__(self, cfg: SubmapConfig | None = None):
+        self.L = lib()
+        self.L.orc_submap_create.restype = C.c_void_p
+        self.L.orc_submap_create.argtypes = [C.POINTER(SubmapConfig)]
+        self.L.orc_submap_destroy.argtypes = [C.c_void_p]
+        self.L.orc_submap_destroy.restype = None
+        self.cfg = cfg or make_submap_config()
+        self.h = C.c_void_p(self.L.orc_submap_create(C.byref(self.cfg)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orc_submap_destroy(self.h)
+            self.h = C.c_void_p()
+
+    @staticmethod
+    def _args(clouds):
+        out = []
+        keep = []
+        for c in clouds:
+            a = _aos(c)
+            keep.append(a)
+            out += [_dp(a), C.c_size_t(len(a))]
+        return out, keep
+
+    def init(self, planar, sphere, edge, ground):
+        args, keep = self._args((planar, sphere, edge, ground))
+        return self.L.orc_submap_init(self.h, *args)
+
+    def update(self, pose, planar, sphere, edge, ground):
+        m = np.ascontiguousarray(np.asarray(pose, float).reshape(4, 4).T.ravel())
+        args, keep = self._args((planar, sphere, edge, ground))
+        return self.L.orc_submap_update(self.h, _dp(m), *args)
+
+    def get(self, kind):
+        n = C.c_size_t(0)
+        self.L.orc_submap_get(self.h, int(kind), C.c_size_t(0), C.byref(n), None)
+        out = np.empty((max(n.value, 1), 3))
+        rc = self.L.orc_submap_get(self.h, int(kind), C.c_size_t(n.value), C.byref(n), _dp(out))
+        assert rc == 0 or n.value == 0
+        return out[: n.value].copy()

@@ -535,3 +535,80 @@ class NpRegistration:
                 fit += hit.sum() / len(self.src[k])
                 rmse += math.sqrt((d[hit] ** 2).sum() / hit.sum())
         return fit, rmse
+
+
+# ---------------------------------------------------------------------------------------------------
+#  Submap maintenance, restated independently of oracle/submap_oracle.c:
+#  front_end.cpp:201-275, :283-304; PointCloud2.cpp:71-75, :96-132, :358-403, :551-559.
+#  Voxel output order: first occurrence (python dicts keep insertion order) -- the reference's is
+#  std::unordered_map's, i.e. unspecified.
+# ---------------------------------------------------------------------------------------------------
+def pc_transform(T, pts):
+    """Open3D TransformPoints: new = T (x, y, z, 1), p = new[:3] / new[3]; rows accumulated left to right."""
+    pts = np.asarray(pts, float).reshape(-1, 3)
+    T = np.asarray(T, float)
+    out = np.empty_like(pts)
+    r = [((T[a, 0] * pts[:, 0] + T[a, 1] * pts[:, 1]) + T[a, 2] * pts[:, 2]) + T[a, 3] * 1.0 for a in range(4)]
+    for a in range(3):
+        out[:, a] = r[a] / r[3]
+    return out
+
+
+def pc_crop(pts, lo, hi):
+    pts = np.asarray(pts, float).reshape(-1, 3)
+    keep = np.all((pts >= np.asarray(lo)) & (pts <= np.asarray(hi)), axis=1)
+    return pts[keep]
+
+
+def pc_voxel_down_sample(pts, voxel):
+    pts = np.asarray(pts, float).reshape(-1, 3)
+    if len(pts) == 0:
+        return pts.copy()
+    vmin = pts.min(axis=0) - voxel * 0.5
+    idx = np.floor((pts - vmin) / voxel).astype(np.int64)
+    acc = {}
+    for i in range(len(pts)):           # AddPoint in index order
+        key = (int(idx[i, 0]), int(idx[i, 1]), int(idx[i, 2]))
+        e = acc.get(key)
+        if e is None:
+            acc[key] = [pts[i].copy(), 1]
+        else:
+            e[0] = e[0] + pts[i]
+            e[1] += 1
+    return np.array([s / float(n) for s, n in acc.values()]).reshape(-1, 3)
+
+
+class NpSubmap:
+    def __init__(self, planar_frame_size=3, sphere_frame_size=3, edge_crop_box_length=100.0,
+                 ground_crop_box_length=100.0, edge_down_sample_submap=0.3, ground_down_sample_submap=0.45,
+                 ground_down_sample=0.3):
+        self.cfg = dict(planar_frame_size=planar_frame_size, sphere_frame_size=sphere_frame_size,
+                        edge_crop_box_length=edge_crop_box_length, ground_crop_box_length=ground_crop_box_length,
+                        edge_down_sample_submap=edge_down_sample_submap,
+                        ground_down_sample_submap=ground_down_sample_submap, ground_down_sample=ground_down_sample)
+        self.planar_ring, self.sphere_ring = [], []
+        self.cloud = [np.zeros((0, 3)) for _ in range(4)]
+
+    def init(self, planar, sphere, edge, ground):          # front_end.cpp:283-304
+        self.cloud[KIND_EDGE] = np.asarray(edge, float).reshape(-1, 3).copy()
+        self.cloud[KIND_GROUND] = pc_voxel_down_sample(ground, self.cfg["ground_down_sample"])
+        self.cloud[KIND_PLANAR] = np.asarray(planar, float).reshape(-1, 3).copy()
+        self.cloud[KIND_SPHERE] = np.asarray(sphere, float).reshape(-1, 3).copy()
+
+    def update(self, pose, planar, sphere, edge, ground):  # front_end.cpp:201-275
+        pose = np.asarray(pose, float)
+        self.sphere_ring.append((pose.copy(), np.asarray(sphere, float).reshape(-1, 3).copy()))
+        self.planar_ring.append((pose.copy(), np.asarray(planar, float).reshape(-1, 3).copy()))
+        self.sphere_ring = self.sphere_ring[-self.cfg["sphere_frame_size"]:]
+        self.planar_ring = self.planar_ring[-self.cfg["planar_frame_size"]:]
+        both = np.concatenate([pc_transform(T, c) for T, c in self.planar_ring]) if self.planar_ring else np.zeros((0, 3))
+        self.cloud[KIND_SPHERE] = both.copy()   # :221 iterates submap_planar_buffer
+        self.cloud[KIND_PLANAR] = both.copy()
+        t = pose[:3, 3]
+        for kind, scan, L, vox in ((KIND_EDGE, edge, self.cfg["edge_crop_box_length"], self.cfg["edge_down_sample_submap"]),
+                                   (KIND_GROUND, ground, self.cfg["ground_crop_box_length"], self.cfg["ground_down_sample_submap"])):
+            allp = np.concatenate([self.cloud[kind], pc_transform(pose, scan)])
+            self.cloud[kind] = pc_voxel_down_sample(pc_crop(allp, t - L, t + L), vox)
+
+    def get(self, kind):
+        return self.cloud[kind]

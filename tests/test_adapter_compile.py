@@ -37,9 +37,14 @@ int main() {
   Frame out;
   const bool c = reg.scanMatching(out, pred, res);
   auto fit = reg.getFitnessScore();
-  std::printf("gpu=%d set=%d,%d match=%d fitness=%g\n", (int)have_gpu, (int)a, (int)b, (int)c, fit.first);
+  // the device-resident submap entry points marshal the same cloud type (front_end.cpp:201-275 / :283-304)
+  tloam_submap_config scfg; tloam_submap_default_config(&scfg);
+  const bool s0 = reg.submapInit(scfg, f.planar_feature, f.sphere_feature, f.edge_feature, f.ground_feature);
+  const bool s1 = reg.submapUpdate(pred, f.planar_feature, f.sphere_feature, f.edge_feature, f.ground_feature);
+  std::printf("gpu=%d set=%d,%d match=%d fitness=%g submap=%d,%d\n", (int)have_gpu, (int)a, (int)b, (int)c, fit.first,
+              (int)s0, (int)s1);
   // without a device every call must report failure (no CPU fallback); with one they must all succeed
-  return (have_gpu ? (a && b && c) : (!a && !b && !c)) ? 0 : 1;
+  return (have_gpu ? (a && b && c && s0 && s1) : (!a && !b && !c && !s0 && !s1)) ? 0 : 1;
 }
 '''
 

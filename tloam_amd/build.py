@@ -20,6 +20,7 @@ COMMON += os.environ.get("TLOAM_EXTRA_HIPCC_FLAGS", "").split()  # development a
 UNITS = [
     # K1/K2: un-fused fp64 so the discontinuous gates see the oracle's operation order
     ("tl_nn.hip", ["-ffp-contract=off"]),
+    ("tl_submap.hip", ["-ffp-contract=off"]),   # voxel indices / means in the oracle's operation order
     ("tl_gn.hip", []),
     ("tl_api.hip", []),
 ]

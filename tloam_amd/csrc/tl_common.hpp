@@ -167,6 +167,31 @@ void launch_knn(const GridView& g, const double* qx, const double* qy, const dou
 void launch_fitness(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
                     double radius, double* partial /*[blocks*2]*/, int blocks, hipStream_t s);
 
+// ---- device-resident submap maintenance (tl_submap.hip; front_end.cpp:201-275) ----------------
+struct VoxelJob {
+  const double *x, *y, *z;   // input cloud, SoA
+  size_t n;
+  double lo[3], hi[3];       // crop box, inclusive (+-inf: no crop)
+  double voxel;              // voxel size
+  unsigned long long mask;   // hash-table capacity - 1 (power of two >= 2 n)
+};
+struct VoxelWork {           // scratch, sized by the caller (see voxel_table_size)
+  double* min_partial;       // [256][3]
+  double* vmin;              // [3] voxel_min_bound
+  unsigned long long *keys, *cnt, *off;   // [cap + 1]
+  int *slot_of_pt, *urank, *members, *sorted;  // [n]
+  unsigned long long *leader, *leader_scan;    // [n + 1]
+  unsigned long long* scan_tmp;
+  int* overflow;             // set when a voxel index leaves [0, 2^21)
+};
+size_t voxel_table_size(size_t n);
+void launch_transform_to_soa(const double* aos, size_t n, const double M[16], double* ox, double* oy, double* oz,
+                             hipStream_t s);
+void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
+                  hipStream_t s);
+void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);
+void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s);
+
 // K3 and the minimiser
 int k3_grid_for(int total_cap);
 bool k3_single_pass(int total_cap, int grid);  // one wave per chunk (small sets) vs the streaming variant

@@ -1,0 +1,239 @@
+// tl_submap.hip -- device-resident submap maintenance: the target side of the path.
+//
+// Replaces, for the four submap clouds handed to setInputTarget, the CPU chain of FrontEnd::updateSubmap
+// (front_end.cpp:201-275):
+//     cloud->Transform(pose)                       PointCloud2.cpp:71-75   (Open3D TransformPoints)
+//     *submap += cloud                             PointCloud2.cpp:96-132  (append, index order kept)
+//     submap->Crop(box)                            PointCloud2.cpp:551-559 (inclusive bounds, index order kept)
+//           ->VoxelDownSample(voxel)               PointCloud2.cpp:358-403 (per-voxel mean, accumulated in
+//                                                                            index order; AccumulatedPoint :246-291)
+// so that the submap never leaves HBM between frames: the result is written straight into the SoA target
+// arrays the search grids are built from.
+//
+// VoxelDownSample emits its voxels in std::unordered_map iteration order, which is implementation-defined;
+// this restatement (device AND oracle) emits them in order of FIRST OCCURRENCE (ascending smallest member
+// index).  The scan-matching result does not depend on the order of the target points (exact k-NN, ties by
+// index are measure-zero after averaging).
+//
+// Voxel membership uses an open-addressing hash table keyed by the packed voxel coordinates
+// (ix | iy << 21 | iz << 42); per-voxel member lists are ordered by index with a rank-by-counting pass so the
+// floating-point accumulation order is the reference's (ascending index).  Compiled with -ffp-contract=off.
+#include "tl_common.hpp"
+
+namespace tl {
+
+namespace {
+constexpr unsigned long long kEmpty = ~0ull;
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+struct Mat16 { double m[16]; };  // column-major 4x4
+
+// Open3D TransformPoints: new = T * (x, y, z, 1); point = new.head<3>() / new(3).  Each row is accumulated
+// left to right (assumed upstream behaviour: Open3D is not under /root/reference).
+__global__ void k_transform_to_soa(const double* __restrict__ aos, size_t n, Mat16 M, double* __restrict__ ox,
+                                   double* __restrict__ oy, double* __restrict__ oz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+  double r[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) r[a] = ((M.m[a] * x + M.m[4 + a] * y) + M.m[8 + a] * z) + M.m[12 + a] * 1.0;
+  ox[i] = r[0] / r[3];
+  oy[i] = r[1] / r[3];
+  oz[i] = r[2] / r[3];
+}
+
+__global__ void k_copy3(const double* __restrict__ ax, const double* __restrict__ ay, const double* __restrict__ az,
+                        size_t n, double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ox[i] = ax[i]; oy[i] = ay[i]; oz[i] = az[i];
+}
+
+__global__ void k_soa_to_aos(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                             size_t n, double* __restrict__ aos) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
+}
+
+__device__ __forceinline__ bool in_box(const VoxelJob& J, double x, double y, double z) {
+  // AxisAlignedBoundingBox::GetPointIndicesWithinBoundingBox: inclusive on both sides
+  return x >= J.lo[0] && x <= J.hi[0] && y >= J.lo[1] && y <= J.hi[1] && z >= J.lo[2] && z <= J.hi[2];
+}
+
+// GetMinBound() of the cropped cloud, block partials
+__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][3]*/) {
+  __shared__ double sm[3][256];
+  double m[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (size_t)gridDim.x * 256) {
+    const double x = J.x[i], y = J.y[i], z = J.z[i];
+    if (in_box(J, x, y, z)) { m[0] = fmin(m[0], x); m[1] = fmin(m[1], y); m[2] = fmin(m[2], z); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = m[a];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sm[threadIdx.x][0];
+}
+// voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); an empty cloud has min bound (0, 0, 0)
+__global__ void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel, double* __restrict__ vmin) {
+  const int a = threadIdx.x;
+  if (a >= 3) return;
+  double m = __builtin_inf();
+  for (int b = 0; b < blocks; ++b) m = fmin(m, partial[b * 3 + a]);
+  if (!(m < __builtin_inf())) m = 0.0;
+  vmin[a] = m - voxel * 0.5;
+}
+
+__global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// voxel of every in-box point -> hash slot; the counting atomic also hands out an (arbitrary) member rank
+__global__ __launch_bounds__(256) void k_vox_insert(VoxelJob J, const double* __restrict__ vmin,
+                                                    unsigned long long* __restrict__ keys,
+                                                    unsigned long long* __restrict__ cnt, int* __restrict__ slot_of_pt,
+                                                    int* __restrict__ urank, int* __restrict__ overflow) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.n) return;
+  const double x = J.x[i], y = J.y[i], z = J.z[i];
+  if (!in_box(J, x, y, z)) { slot_of_pt[i] = -1; return; }
+  // ref_coord = (p - voxel_min_bound) / voxel_size; index = int(floor(ref_coord))   (:380-383)
+  const long long ix = (long long)floor((x - vmin[0]) / J.voxel);
+  const long long iy = (long long)floor((y - vmin[1]) / J.voxel);
+  const long long iz = (long long)floor((z - vmin[2]) / J.voxel);
+  if (ix < 0 || iy < 0 || iz < 0 || ix >= (1ll << 21) || iy >= (1ll << 21) || iz >= (1ll << 21)) {
+    *overflow = 1;  // "[VoxelDownSample] voxel_size is too small." (:370-372)
+    slot_of_pt[i] = -1;
+    return;
+  }
+  const unsigned long long key = (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42);
+  unsigned long long h = mix64(key) & J.mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&keys[h], kEmpty, key);
+    if (prev == kEmpty || prev == key) break;
+    h = (h + 1) & J.mask;
+  }
+  slot_of_pt[i] = (int)h;
+  urank[i] = (int)atomicAdd(&cnt[h], 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_vox_scatter(size_t n, const int* __restrict__ slot_of_pt,
+                                                     const int* __restrict__ urank,
+                                                     const unsigned long long* __restrict__ off, int* __restrict__ members) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int h = slot_of_pt[i];
+  if (h < 0) return;
+  members[off[h] + (unsigned long long)urank[i]] = (int)i;
+}
+
+// rank of every point among its voxel's members in INDEX order (the order AddPoint is called in, :379-385);
+// the first member is the voxel's leader
+__global__ __launch_bounds__(256) void k_vox_order(size_t n, const int* __restrict__ slot_of_pt,
+                                                   const unsigned long long* __restrict__ off,
+                                                   const unsigned long long* __restrict__ cnt,
+                                                   const int* __restrict__ members, int* __restrict__ sorted,
+                                                   unsigned long long* __restrict__ leader) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  if (i == n) { leader[n] = 0ull; return; }  // scan terminator
+  const int h = slot_of_pt[i];
+  if (h < 0) { leader[i] = 0ull; return; }
+  const unsigned long long o = off[h];
+  const int m = (int)cnt[h];
+  int r = 0;
+  for (int q = 0; q < m; ++q) r += (members[o + q] < (int)i) ? 1 : 0;
+  sorted[o + r] = (int)i;
+  leader[i] = (r == 0) ? 1ull : 0ull;
+}
+
+// AccumulatedPoint: point_ += p in index order, GetAveragePoint = point_ / double(num) (:253-272)
+__global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, const int* __restrict__ slot_of_pt,
+                                                        const unsigned long long* __restrict__ off,
+                                                        const unsigned long long* __restrict__ cnt,
+                                                        const int* __restrict__ sorted,
+                                                        const unsigned long long* __restrict__ leader_scan,
+                                                        double* __restrict__ ox, double* __restrict__ oy,
+                                                        double* __restrict__ oz) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= J.n) return;
+  const int h = slot_of_pt[i];
+  if (h < 0) return;
+  const unsigned long long pos = leader_scan[i];
+  if (leader_scan[i + 1] == pos) return;  // not a leader
+  const unsigned long long o = off[h];
+  const int m = (int)cnt[h];
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int q = 0; q < m; ++q) {
+    const int j = sorted[o + q];
+    sx += J.x[j]; sy += J.y[j]; sz += J.z[j];
+  }
+  const double dn = (double)m;
+  ox[pos] = sx / dn; oy[pos] = sy / dn; oz[pos] = sz / dn;
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+}  // namespace
+
+void launch_transform_to_soa(const double* aos, size_t n, const double M[16], double* ox, double* oy, double* oz,
+                             hipStream_t s) {
+  if (n == 0) return;
+  Mat16 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = M[i];
+  hipLaunchKernelGGL(k_transform_to_soa, dim3(blocks_for(n)), dim3(256), 0, s, aos, n, m, ox, oy, oz);
+}
+void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
+                  hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_copy3, dim3(blocks_for(n)), dim3(256), 0, s, ax, ay, az, n, ox, oy, oz);
+}
+void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(blocks_for(n)), dim3(256), 0, s, x, y, z, n, aos);
+}
+
+size_t voxel_table_size(size_t n) {
+  size_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+// Crop(box) -> VoxelDownSample(voxel) of the SoA cloud in J, written to (ox, oy, oz); the number of output
+// points lands in W.leader_scan[J.n] (device).  No host synchronisation.
+void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s) {
+  const size_t n = J.n;
+  constexpr int kMinBlocks = 256;
+  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial);
+  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(64), 0, s, W.min_partial, kMinBlocks, J.voxel, W.vmin);
+  const size_t cap = (size_t)J.mask + 1;
+  hipLaunchKernelGGL(k_fill_u64, dim3(blocks_for(cap)), dim3(256), 0, s, W.keys, cap, kEmpty);
+  (void)hipMemsetAsync(W.cnt, 0, sizeof(unsigned long long) * (cap + 1), s);
+  if (n > 0)
+    hipLaunchKernelGGL(k_vox_insert, dim3(blocks_for(n)), dim3(256), 0, s, J, W.vmin, W.keys, W.cnt, W.slot_of_pt,
+                       W.urank, W.overflow);
+  launch_exclusive_scan_u64(W.cnt, W.off, cap + 1, W.scan_tmp, s);
+  if (n > 0)
+    hipLaunchKernelGGL(k_vox_scatter, dim3(blocks_for(n)), dim3(256), 0, s, n, W.slot_of_pt, W.urank, W.off, W.members);
+  hipLaunchKernelGGL(k_vox_order, dim3(blocks_for(n + 1)), dim3(256), 0, s, n, W.slot_of_pt, W.off, W.cnt, W.members,
+                     W.sorted, W.leader);
+  launch_exclusive_scan_u64(W.leader, W.leader_scan, n + 1, W.scan_tmp, s);
+  if (n > 0)
+    hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n)), dim3(256), 0, s, J, W.slot_of_pt, W.off, W.cnt, W.sorted,
+                       W.leader_scan, ox, oy, oz);
+}
+
+}  // namespace tl

@@ -30,6 +30,14 @@ STATUS = {0: "TLOAM_OK", -1: "TLOAM_E_INVALID", -2: "TLOAM_E_TOO_FEW_POINTS", -3
           -4: "TLOAM_E_HIP", -5: "TLOAM_E_RCCL", -6: "TLOAM_E_NOT_READY", -7: "TLOAM_E_WEIGHT_RANGE"}
 
 
+class SubmapConfig(C.Structure):
+    """tloam_submap_config: the submap keys of config/mapping/lidar_odometry.yaml:6-17."""
+    _fields_ = [("planar_frame_size", C.c_int32), ("sphere_frame_size", C.c_int32),
+                ("edge_crop_box_length", C.c_double), ("ground_crop_box_length", C.c_double),
+                ("edge_down_sample_submap", C.c_double), ("ground_down_sample_submap", C.c_double),
+                ("ground_down_sample", C.c_double)]
+
+
 class TlsConfig(C.Structure):
     """tloam_tls_config: the 16 keys of the `TLS:` block (config/mapping/lidar_odometry.yaml:23-39)."""
     _fields_ = [
@@ -109,6 +117,10 @@ def load_library():
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
         "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
+        "tloam_submap_default_config": (None, [C.POINTER(SubmapConfig)]),
+        "tloam_submap_init": (C.c_int, [vp, C.POINTER(SubmapConfig), dp, sz, dp, sz, dp, sz, dp, sz]),
+        "tloam_submap_update": (C.c_int, [vp, dp, dp, sz, dp, sz, dp, sz, dp, sz]),
+        "tloam_get_target": (C.c_int, [vp, C.c_int, sz, C.POINTER(sz), dp]),
         "tloam_rccl_unique_id": (C.c_int, [vp]),
         "tloam_comm_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "tloam_comm_init_callback": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]),
@@ -130,7 +142,8 @@ EXPORTED_SYMBOLS = (
     "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_scan_match", "tloam_sm_begin",
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_solve",
-    "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
+    "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
+    "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_init_callback", "tloam_shard_range", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
 )
 
@@ -291,6 +304,35 @@ class HipRegistration:
         rc = self.L.tloam_sm_end(self.h, _dp(res), C.byref(st))
         return rc, res.reshape(4, 4).T.copy(), st.as_dict()
 
+    # ---- device-resident submap (FrontEnd::updateSubmap, front_end.cpp:201-275 / :283-304)
+    def submap_init(self, planar, sphere, edge, ground, cfg: SubmapConfig | None = None):
+        cl = [_aos(x) for x in (planar, sphere, edge, ground)]
+        args = []
+        for a in cl:
+            args += [_dp(a), len(a)]
+        rc = self.L.tloam_submap_init(self.h, C.byref(cfg) if cfg is not None else None, *args)
+        self._check(rc, "tloam_submap_init")
+        return rc
+
+    def submap_update(self, pose, planar, sphere, edge, ground):
+        m = np.ascontiguousarray(np.asarray(pose, float).reshape(4, 4).T.ravel())  # column-major
+        cl = [_aos(x) for x in (planar, sphere, edge, ground)]
+        args = []
+        for a in cl:
+            args += [_dp(a), len(a)]
+        rc = self.L.tloam_submap_update(self.h, _dp(m), *args)
+        self._check(rc, "tloam_submap_update")
+        return rc
+
+    def get_target(self, kind):
+        n = C.c_size_t(0)
+        self.L.tloam_get_target(self.h, int(kind), 0, C.byref(n), None)
+        out = np.zeros((max(n.value, 1), 3))
+        if n.value:
+            self._check(self.L.tloam_get_target(self.h, int(kind), n.value, C.byref(n), _dp(out)), "tloam_get_target")
+        self._n[("t", kind)] = n.value
+        return out[: n.value].copy()
+
     def fitness(self):
         f, r = C.c_double(0), C.c_double(0)
         rc = self.L.tloam_fitness(self.h, C.byref(f), C.byref(r))
@@ -394,6 +436,14 @@ def rccl_unique_id() -> bytes:
     if rc != 0:
         raise TloamHipError(f"tloam_rccl_unique_id: {STATUS.get(rc, rc)}")
     return buf.raw
+
+
+def default_submap_config(**over) -> SubmapConfig:
+    cfg = SubmapConfig()
+    load_library().tloam_submap_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
 
 
 def make_registration(method: str, cfg: TlsConfig | None = None, device: int = 0):
