@@ -72,82 +72,107 @@ void launch_fill_i32(int* p, size_t n, int v, hipStream_t s) {
 // ================================================================================================
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
+constexpr int kScanTile = kScanThreads * kScanItems;   // 2048 elements per block, 512 per wave
+constexpr int kScanPer = 4;                            // consecutive elements per lane within a row
+constexpr int kScanRowElems = 64 * kScanPer;           // 256 elements = 2 KiB per wave row
+constexpr int kScanRows = kScanTile / (kScanThreads / 64) / kScanRowElems;   // rows per wave (2)
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_tile(const unsigned long long* __restrict__ in,
-                                                            unsigned long long* __restrict__ out, size_t n,
-                                                            unsigned long long* __restrict__ tile_total) {
-  __shared__ unsigned long long wave_tot[kScanThreads / 64];
-  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
-  unsigned long long v[kScanItems];
-  unsigned long long sum = 0;
+// Wave-level exclusive scan of ROWS x 256 consecutive elements starting at `wbase`: lane l holds the four
+// elements 4l .. 4l+3 of each row, so a wave instruction covers 2 KiB (16 cache lines) and one shuffle scan
+// serves 256 elements.  The fully blocked layout (8-16 consecutive elements per thread) made every wave
+// instruction touch 32-64 different lines, serialised by the texture addresser: 11.9 us for a 9.4 k-element
+// scan.  Returns the wave total; out[row i, 4l + j] = ex[i] + a[i][0] + .. + a[i][j-1].
+template <int ROWS>
+__device__ __forceinline__ unsigned long long wave_scan_rows(const unsigned long long* __restrict__ in, size_t n,
+                                                             size_t wbase, int lane, unsigned long long (&ex)[ROWS],
+                                                             unsigned long long (&a)[ROWS][kScanPer]) {
 #pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    v[i] = (base + i < n) ? in[base + i] : 0ull;
-    sum += v[i];
-  }
-  // inclusive scan of `sum` across the wave (64 lanes)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long inc = sum;
+  for (int i = 0; i < ROWS; ++i)
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    unsigned long long t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wave_tot[wave] = inc;
-  __syncthreads();
-  unsigned long long wave_off = 0;
-  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-  unsigned long long run = wave_off + inc - sum;
-#pragma unroll
-  for (int i = 0; i < kScanItems; ++i) {
-    if (base + i < n) out[base + i] = run;
-    run += v[i];
-  }
-  if (threadIdx.x == kScanThreads - 1) tile_total[blockIdx.x] = wave_off + inc;
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_add(unsigned long long* __restrict__ out, size_t n,
-                                                           const unsigned long long* __restrict__ tile_off) {
-  const unsigned long long add = tile_off[blockIdx.x];
-  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
-#pragma unroll
-  for (int i = 0; i < kScanItems; ++i)
-    if (base + i < n) out[base + i] += add;
-}
-// small inputs: ONE block walks the tiles carrying the running total (one launch instead of three)
-__global__ __launch_bounds__(kScanThreads) void k_scan_small(const unsigned long long* __restrict__ in,
-                                                             unsigned long long* __restrict__ out, size_t n) {
-  __shared__ unsigned long long wave_tot[kScanThreads / 64];
-  __shared__ unsigned long long carry_s;
-  if (threadIdx.x == 0) carry_s = 0ull;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (size_t tile0 = 0; tile0 < n; tile0 += kScanTile) {
-    const size_t base = tile0 + (size_t)threadIdx.x * kScanItems;
-    unsigned long long v[kScanItems], sum = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-      v[i] = (base + i < n) ? in[base + i] : 0ull;
-      sum += v[i];
+    for (int j = 0; j < kScanPer; ++j) {  // unconditional (clamped) loads: all in flight together
+      const size_t idx = wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j;
+      const unsigned long long x = in[idx < n ? idx : n - 1];
+      a[i][j] = idx < n ? x : 0ull;
     }
-    unsigned long long inc = sum;
+  unsigned long long carry = 0;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    unsigned long long s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) s += a[i][j];
+    unsigned long long inc = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned long long t = __shfl_up(inc, off, 64);
       if (lane >= off) inc += t;
     }
-    if (lane == 63) wave_tot[wave] = inc;
+    ex[i] = carry + inc - s;
+    carry += __shfl(inc, 63, 64);
+  }
+  return carry;
+}
+template <int ROWS>
+__device__ __forceinline__ void wave_store_rows(unsigned long long* __restrict__ out, size_t n, size_t wbase, int lane,
+                                                unsigned long long add, const unsigned long long (&ex)[ROWS],
+                                                const unsigned long long (&a)[ROWS][kScanPer]) {
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    unsigned long long run = add + ex[i];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+      const size_t idx = wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j;
+      if (idx < n) out[idx] = run;
+      run += a[i][j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile(const unsigned long long* __restrict__ in,
+                                                            unsigned long long* __restrict__ out, size_t n,
+                                                            unsigned long long* __restrict__ tile_total) {
+  __shared__ unsigned long long wave_tot[kScanThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t wbase = (size_t)blockIdx.x * kScanTile + (size_t)wave * (kScanRows * kScanRowElems);
+  unsigned long long ex[kScanRows], a[kScanRows][kScanPer];
+  const unsigned long long tot = wave_scan_rows<kScanRows>(in, n, wbase, lane, ex, a);
+  if (lane == 0) wave_tot[wave] = tot;
+  __syncthreads();
+  unsigned long long wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  wave_store_rows<kScanRows>(out, n, wbase, lane, wave_off, ex, a);
+  if (threadIdx.x == kScanThreads - 1) tile_total[blockIdx.x] = wave_off + tot;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(unsigned long long* __restrict__ out, size_t n,
+                                                           const unsigned long long* __restrict__ tile_off) {
+  const unsigned long long add = tile_off[blockIdx.x];
+  const size_t base = (size_t)blockIdx.x * kScanTile + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + (size_t)i * kScanThreads < n) out[base + (size_t)i * kScanThreads] += add;
+}
+// small inputs (<= 16 Ki elements, e.g. the flag scan of a KITTI-size frame): ONE block of 1024 threads, a
+// single pass with every load in flight at once
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallRows = 4;                                   // 1024 elements per wave
+constexpr int kSmallTile = (kSmallThreads / 64) * kSmallRows * kScanRowElems;  // 16384
+__global__ __launch_bounds__(kSmallThreads) void k_scan_small(const unsigned long long* __restrict__ in,
+                                                              unsigned long long* __restrict__ out, size_t n) {
+  __shared__ unsigned long long wave_tot[kSmallThreads / 64];
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t tile0 = 0; tile0 < n; tile0 += kSmallTile) {
+    const size_t wbase = tile0 + (size_t)wave * (kSmallRows * kScanRowElems);
+    unsigned long long ex[kSmallRows], a[kSmallRows][kScanPer];
+    const unsigned long long tot = wave_scan_rows<kSmallRows>(in, n, wbase, lane, ex, a);
+    if (lane == 0) wave_tot[wave] = tot;
     __syncthreads();
     unsigned long long wave_off = carry_s;
     for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-    unsigned long long run = wave_off + inc - sum;
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-      if (base + i < n) out[base + i] = run;
-      run += v[i];
-    }
+    wave_store_rows<kSmallRows>(out, n, wbase, lane, wave_off, ex, a);
     __syncthreads();
-    if (threadIdx.x == kScanThreads - 1) carry_s = wave_off + inc;
+    if (threadIdx.x == kSmallThreads - 1) carry_s = wave_off + tot;
     __syncthreads();
   }
 }
@@ -164,10 +189,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add_direct(unsigned long 
   __syncthreads();
   unsigned long long add = 0;
   for (int w = 0; w < kScanThreads / 64; ++w) add += red[w];
-  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  const size_t base = (size_t)blockIdx.x * kScanTile + threadIdx.x;
 #pragma unroll
   for (int i = 0; i < kScanItems; ++i)
-    if (base + i < n) out[base + i] += add;
+    if (base + (size_t)i * kScanThreads < n) out[base + (size_t)i * kScanThreads] += add;
 }
 size_t scan_tmp_elems(size_t n) {
   size_t total = 0;
@@ -183,8 +208,8 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
                                unsigned long long* tmp, hipStream_t s) {
   if (n == 0) return;
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
-  if (tiles <= 8) {
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, s, in, out, n);
+  if (n <= (size_t)kSmallTile) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kSmallThreads), 0, s, in, out, n);
     return;
   }
   unsigned long long* totals = tmp;
