@@ -131,3 +131,22 @@ def test_prebuilt_accumulate_and_solve(hip_module):
            (so["gn_iterations"], so["accepted_steps"], so["gn_evaluations"])
     # known answer: the solve lands on the generating pose (noise 2-5 cm over ~10 k blocks)
     assert np.linalg.norm(xh[:3] - x_true[:3]) < 5e-3 and np.linalg.norm(xh[3:] - x_true[3:]) < 2e-4
+
+
+def test_build_reuse_is_exact(hip_module, monkeypatch):
+    """An outer iteration that starts from a bit-identical pose reuses the previous correspondence records
+    instead of re-running K1/K2; switching the reuse off (development knob) must not change a single bit."""
+    sc = synth.make_scene(seed=11, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    H1 = hip_module.HipRegistration()
+    H1.set_frames(sc.source, sc.target)
+    rc1, T1, st1 = H1.scan_match(sc.T_pred)
+    monkeypatch.setenv("TLOAM_NO_BUILD_REUSE", "1")      # read once, when the context is created
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    rc2, T2, st2 = H2.scan_match(sc.T_pred)
+    assert rc1 == rc2 == 0
+    assert np.array_equal(T1, T2)
+    assert st1["n_corr"] == st2["n_corr"] and st1["gn_evaluations"] == st2["gn_evaluations"]
+    for k in range(4):
+        assert np.array_equal(H1.get_weights(k), H2.get_weights(k))
+    H1.close(); H2.close()

@@ -169,6 +169,8 @@ struct tloam_ctx {
   double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
   int k3_grid = 1;
   bool k3_single = false;
+  int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
+  bool dbg_no_build_reuse = false;
   bool prebuilt = false;
   // comm
   int rank = 0, nranks = 1;
@@ -403,7 +405,7 @@ int harvest_k3_events(tloam_ctx* c, int working) {
 int enqueue_solve(tloam_ctx* c, bool armed) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   int max_sweeps = 5;
-  if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) max_sweeps = atoi(e);  // debugging aid only
+  if (c->dbg_max_sweeps > 0) max_sweeps = c->dbg_max_sweeps;  // TLOAM_DEBUG_MAX_SWEEPS, debugging aid only
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     int rc = launch_k3_timed(c, false);
     if (rc != TLOAM_OK) return rc;
@@ -491,6 +493,8 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   if (!c) return TLOAM_E_INVALID;
   c->cfg = *cfg;
   c->device = device_id;
+  if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) c->dbg_max_sweeps = atoi(e);
+  c->dbg_no_build_reuse = getenv("TLOAM_NO_BUILD_REUSE") != nullptr;
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
@@ -694,7 +698,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   // neighbour list, fit and gate -- is bit-identical to the previous outer iteration: then only the
   // captured weights and the zeroed side-channel slots of the compact set have to be refreshed.
   const bool same_pose = iter > 0 && c->have_build && memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) == 0 &&
-                         !getenv("TLOAM_NO_BUILD_REUSE");
+                         !c->dbg_no_build_reuse;
   if (!same_pose) {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
                  c->qrec.p, c->scan_tmp.p, /*rebin=*/iter == 0, c->stream);

@@ -342,8 +342,8 @@ void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const uns
 
 // ================================================================================================
 //  K1: exact k-NN over the 27-cell neighbourhood, top-K kept sorted in registers.
-//  Candidates come from a "point source": the cell-sorted arrays in HBM (PtsGlobal) or a tile of them
-//  staged in LDS (PtsLds, see k_build_tiles).
+//  Candidates come from the cell-sorted packed records in HBM (PtsGlobal); the L1/L2 reuse comes from the
+//  tile-sorted query order (an LDS-staged tile variant was measured and rejected).
 // ================================================================================================
 struct PtsGlobal {
   const double4* p;
@@ -667,10 +667,10 @@ __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const Ra
 }
 
 // ================================================================================================
-//  K1+K2 driver, tiled.  The target grid of every kind is cut into TILES of 4x4x4 cells; the source
-//  points are bucketed by the tile their (transformed) cell falls into; ONE WAVE per non-empty tile
-//  stages the tile's 6x6x6-cell halo box (every candidate any of its queries can need) from HBM into
-//  LDS once -- coalesced -- and then each lane walks its own 27 cells out of LDS.
+//  K1+K2 driver.  The target grid of every kind is cut into TILES of 4x4x4 cells; the source points are
+//  bucketed by the tile their (transformed) cell falls into (a counting sort, once per frame) and the
+//  queries are then processed in tile order, so the lanes of a wave walk the same few cells and share the
+//  packed candidate records through L1/L2.  Every query still searches its own exact 27 cells.
 //  Replaces the kd-tree walks of registration.cpp:444/:535/:588/:731.
 // ================================================================================================
 constexpr int kTile = 4;        // cells per tile edge
@@ -710,8 +710,7 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   }
   const Pose T = st->T_cur;  // exp(se3_pose_)  registration.cpp:434/:524/:578/:721
   const Vec3 pw = act(T, Vec3{A.sv.sx[slot], A.sv.sy[slot], A.sv.sz[slot]});
-  // bucket by the cell clamped INTO the grid: every in-grid cell of the true 27-neighbourhood lies in
-  // that tile's halo box
+  // bucket by the cell clamped INTO the grid (queries outside the grid sort with its border tiles)
   const int cx = clampi(cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
   const int cy = clampi(cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
   const int cz = clampi(cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
