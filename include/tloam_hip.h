@@ -225,6 +225,38 @@ int tloam_submap_update(tloam_ctx* ctx, const double pose_colmajor[16], const do
 int tloam_get_target(tloam_ctx* ctx, int kind, size_t capacity, size_t* n, double* xyz_aos);
 
 
+/* ---- PCA feature extraction on the device ------------------------------------
+ * featureExtract::calculatePCAInfo (src/models/feature_extraction/feature_extract.cpp:47-122) and
+ * featureExtract::extractPlanarSphere (:133-197): hybrid k-NN (r, K) of every point in its own cloud,
+ * 3x3 covariance from nine cumulants, ascending eigen decomposition, cvr / flatness / sphericity, then the
+ * planar / sphere candidate lists ranked by flatness (descending; ties by ascending index -- the reference's
+ * std::sort is unstable there).  Quirks kept: the sphere lists are ranked by FLATNESS (:162) and hold sort
+ * RANKS, not point indices (:186,:188).  K <= 20. */
+typedef struct tloam_feature_config {
+  double radius;               /* feature.yaml: radius 0.2 */
+  int32_t K;                   /* 20 */
+  int32_t min_neigh;           /* 10 */
+  int32_t planar_num;          /* 500 */
+  int32_t sphere_num;          /* 300 */
+  double cvr_scan;             /* 0.25 */
+  double cvr_submap;           /* 0.15 */
+  double planar_scan_thres;    /* 0.75 */
+  double planar_submap_thres;  /* 0.65 */
+  double planar_vertic_thres;  /* 0.25 */
+} tloam_feature_config;
+void tloam_feature_default_config(tloam_feature_config* cfg);
+/* per-point PCAInfo (feature_extract.hpp:33-39); any output pointer may be NULL.  Points that are skipped
+ * (no more than min_neigh neighbours) keep the value-initialised zeros of the reference; neigh_index is
+ * n x K, padded with -1. */
+int tloam_pca_info(tloam_ctx* ctx, const tloam_feature_config* cfg, const double* xyz_aos, size_t n,
+                   double* flatness, double* cvr, double* sphericity, double* normal_aos, int32_t* num_sum,
+                   int32_t* neigh_index);
+/* the four index lists of extractPlanarSphere; each output array must hold n entries */
+int tloam_extract_planar_sphere(tloam_ctx* ctx, const tloam_feature_config* cfg, const double* xyz_aos, size_t n,
+                                int32_t* planar_scan_index, size_t* n_planar_scan, int32_t* planar_submap_index,
+                                size_t* n_planar_submap, int32_t* sphere_scan_index, size_t* n_sphere_scan,
+                                int32_t* sphere_submap_index, size_t* n_sphere_submap);
+
 /* ---- multi-GPU: correspondence set sharded over ranks, one all-reduce per sweep --------
  * (nothing in the reference).  Call before set_source / set_correspondences.
  * (a) native RCCL over xGMI: unique_id = the 128 bytes of an ncclUniqueId made on rank 0

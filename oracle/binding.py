@@ -363,3 +363,56 @@ class OracleSubmap:
         rc = self.L.orc_submap_get(self.h, int(kind), C.c_size_t(n.value), C.byref(n), _dp(out))
         assert rc == 0 or n.value == 0
         return out[: n.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+#  PCA feature extraction (tloam_oracle.c: orc_pca_info / orc_extract_planar_sphere;
+#  feature_extract.cpp:47-122, :133-197)
+# ---------------------------------------------------------------------------------------------------
+class FeatureConfig(C.Structure):
+    """== tloam_feature_config (include/tloam_hip.h)."""
+    _fields_ = [("radius", C.c_double), ("K", C.c_int32), ("min_neigh", C.c_int32), ("planar_num", C.c_int32),
+                ("sphere_num", C.c_int32), ("cvr_scan", C.c_double), ("cvr_submap", C.c_double),
+                ("planar_scan_thres", C.c_double), ("planar_submap_thres", C.c_double),
+                ("planar_vertic_thres", C.c_double)]
+
+
+FEATURE_DEFAULTS = dict(radius=0.2, K=20, min_neigh=10, planar_num=500, sphere_num=300, cvr_scan=0.25,
+                        cvr_submap=0.15, planar_scan_thres=0.75, planar_submap_thres=0.65, planar_vertic_thres=0.25)
+
+
+def make_feature_config(**over) -> FeatureConfig:
+    cfg = FeatureConfig()
+    vals = dict(FEATURE_DEFAULTS)
+    vals.update(over)
+    for k, v in vals.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def pca_info(xyz, cfg: FeatureConfig | None = None):
+    cfg = cfg or make_feature_config()
+    a = _aos(xyz)
+    n, K = len(a), cfg.K
+    out = dict(flatness=np.zeros(n), cvr=np.zeros(n), sphericity=np.zeros(n), normal=np.zeros((max(n, 1), 3)),
+               num_sum=np.zeros(n, np.int32), neigh=np.zeros((max(n, 1), K), np.int32))
+    rc = lib().orc_pca_info(C.byref(cfg), _dp(a), C.c_size_t(n), _dp(out["flatness"]), _dp(out["cvr"]),
+                            _dp(out["sphericity"]), _dp(out["normal"]), _ip(out["num_sum"]), _ip(out["neigh"]))
+    assert rc == 0, rc
+    out["normal"] = out["normal"][:n]
+    out["neigh"] = out["neigh"][:n]
+    return out
+
+
+def extract_planar_sphere(xyz, cfg: FeatureConfig | None = None):
+    cfg = cfg or make_feature_config()
+    a = _aos(xyz)
+    n = len(a)
+    lists = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+    cnt = [C.c_size_t(0) for _ in range(4)]
+    args = []
+    for l, c in zip(lists, cnt):
+        args += [_ip(l), C.byref(c)]
+    rc = lib().orc_extract_planar_sphere(C.byref(cfg), _dp(a), C.c_size_t(n), *args)
+    assert rc == 0, rc
+    return tuple(l[: c.value].copy() for l, c in zip(lists, cnt))

@@ -612,3 +612,69 @@ class NpSubmap:
 
     def get(self, kind):
         return self.cloud[kind]
+
+
+# ---------------------------------------------------------------------------------------------------
+#  PCA feature extraction, restated independently of the C oracle:
+#  feature_extract.cpp:47-122 (calculatePCAInfo), :133-197 (extractPlanarSphere).
+#  Brute-force exact hybrid search and LAPACK's eigh (the C oracle / device use a cyclic Jacobi), so the
+#  per-point values agree to rounding, the index lists exactly (away from threshold ties).
+# ---------------------------------------------------------------------------------------------------
+FEATURE_DEFAULTS = dict(radius=0.2, K=20, min_neigh=10, planar_num=500, sphere_num=300, cvr_scan=0.25,
+                        cvr_submap=0.15, planar_scan_thres=0.75, planar_submap_thres=0.65, planar_vertic_thres=0.25)
+
+
+def pca_info(pts, **over):
+    cfg = dict(FEATURE_DEFAULTS); cfg.update(over)
+    pts = np.asarray(pts, float).reshape(-1, 3)
+    n, K, r2 = len(pts), cfg["K"], cfg["radius"] ** 2
+    out = dict(flatness=np.zeros(n), cvr=np.zeros(n), sphericity=np.zeros(n), normal=np.zeros((n, 3)),
+               num_sum=np.zeros(n, np.int32), neigh=-np.ones((n, K), np.int32))
+    ids = np.arange(n)
+    for i in range(n):
+        d = pts - pts[i]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # nanoflann L2_Simple order
+        order = np.lexsort((ids, d2))[:K]
+        order = order[d2[order] < r2]                                        # SearchHybrid: k-NN, then the radius cut
+        if len(order) == 0 or len(order) <= cfg["min_neigh"]:
+            continue
+        q = pts[order]
+        cum = np.zeros(9)
+        for p in q:                                                          # cumulants in neighbour order
+            cum += [p[0], p[1], p[2], p[0] * p[0], p[0] * p[1], p[0] * p[2], p[1] * p[1], p[1] * p[2], p[2] * p[2]]
+        cum /= float(len(q))
+        cov = np.array([[cum[3] - cum[0] * cum[0], cum[4] - cum[0] * cum[1], cum[5] - cum[0] * cum[2]],
+                        [0, cum[6] - cum[1] * cum[1], cum[7] - cum[1] * cum[2]],
+                        [0, 0, cum[8] - cum[2] * cum[2]]])
+        cov = cov + np.triu(cov, 1).T
+        ev, V = np.linalg.eigh(cov)                                          # ascending
+        s = ev.sum()
+        out["normal"][i] = V[:, 0]
+        out["cvr"][i] = 0.0 if s == 0.0 else ev[0] / s
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out["flatness"][i] = (ev[1] - ev[0]) / ev[2]
+            out["sphericity"][i] = ev[0] / ev[2]
+        out["num_sum"][i] = len(order)
+        out["neigh"][i, :len(order)] = order
+    return out
+
+
+def extract_planar_sphere(pts, **over):
+    cfg = dict(FEATURE_DEFAULTS); cfg.update(over)
+    info = pca_info(pts, **over)
+    fl, cv, nz = info["flatness"], info["cvr"], np.abs(info["normal"][:, 2])
+    planar, sphere = [], []
+    for i in range(len(fl)):
+        if fl[i] > cfg["planar_submap_thres"] and nz[i] < cfg["planar_vertic_thres"]:
+            planar.append((fl[i], i))
+        elif cv[i] > cfg["cvr_submap"]:
+            nb = info["neigh"][i, :info["num_sum"][i]]
+            if not np.any(cv[i] < cv[nb]):
+                sphere.append((fl[i], i))                                    # :162 pairs the FLATNESS
+    planar.sort(key=lambda t: (-t[0], t[1]))
+    sphere.sort(key=lambda t: (-t[0], t[1]))
+    ps = [i for r, (f, i) in enumerate(planar) if r < cfg["planar_num"] or f > cfg["planar_scan_thres"]]
+    pm = [i for f, i in planar]
+    ss = [r for r, (f, i) in enumerate(sphere) if r < cfg["sphere_num"] or f > cfg["cvr_scan"]]   # ranks (:186)
+    sm = list(range(len(sphere)))                                                                  # ranks (:188)
+    return (np.array(ps, np.int32), np.array(pm, np.int32), np.array(ss, np.int32), np.array(sm, np.int32)), info

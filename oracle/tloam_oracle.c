@@ -1403,3 +1403,109 @@ int orc_solve(orc_ctx* c, double se3[6], tloam_stats* stats) {
   if (stats) *stats = st;
   return TLOAM_OK;
 }
+
+
+/* ==========================================================================
+ *  PCA feature extraction -- TEST INFRASTRUCTURE like the rest of this file.
+ *  featureExtract::calculatePCAInfo     feature_extract.cpp:47-122
+ *  featureExtract::extractPlanarSphere  feature_extract.cpp:133-197
+ *  "parity unpinned": no reference test covers it; Eigen::SelfAdjointEigenSolver is restated by the same
+ *  cyclic Jacobi as above (ascending eigenvalues; the sign of normal_dir is immaterial, only |z| is used).
+ * ========================================================================== */
+#define ORC_FEAT_MAXK 20
+int orc_pca_info(const tloam_feature_config* cfg, const double* xyz, size_t n, double* flatness, double* cvr,
+                 double* sphericity, double* normal, int32_t* num_sum, int32_t* neigh) {
+  if (!cfg || cfg->K < 3 || cfg->K > ORC_FEAT_MAXK || !(cfg->radius >= 0.0)) return TLOAM_E_INVALID; /* assert :55 */
+  const int K = cfg->K;
+  orc_grid g;
+  memset(&g, 0, sizeof(g));
+  if (n > 0 && cfg->radius > 0.0) grid_build(&g, xyz, (int)n, cfg->radius);
+  for (size_t i = 0; i < n; ++i) {
+    /* value-initialised PCAInfo (pca_info_.resize, :59) */
+    if (flatness) flatness[i] = 0.0;
+    if (cvr) cvr[i] = 0.0;
+    if (sphericity) sphericity[i] = 0.0;
+    if (normal) normal[3 * i] = normal[3 * i + 1] = normal[3 * i + 2] = 0.0;
+    if (num_sum) num_sum[i] = 0;
+    if (neigh) for (int m = 0; m < K; ++m) neigh[i * (size_t)K + m] = -1;
+    int idx[ORC_FEAT_MAXK];
+    double d2[ORC_FEAT_MAXK];
+    const int cnt = (cfg->radius > 0.0) ? grid_knn_hybrid(&g, xyz + 3 * i, cfg->radius, K, idx, d2) : 0; /* :71 */
+    if (cnt <= 0) continue;
+    if (cnt <= cfg->min_neigh) continue; /* :72 */
+    double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < cnt; ++m) { /* :80-91, neighbours in ascending distance */
+      const double* p = xyz + 3 * (size_t)idx[m];
+      cum[0] += p[0]; cum[1] += p[1]; cum[2] += p[2];
+      cum[3] += p[0] * p[0]; cum[4] += p[0] * p[1]; cum[5] += p[0] * p[2];
+      cum[6] += p[1] * p[1]; cum[7] += p[1] * p[2]; cum[8] += p[2] * p[2];
+    }
+    for (int m = 0; m < 9; ++m) cum[m] /= (double)cnt; /* :92 */
+    double cov[9];
+    cov[0] = cum[3] - cum[0] * cum[0];
+    cov[4] = cum[6] - cum[1] * cum[1];
+    cov[8] = cum[8] - cum[2] * cum[2];
+    cov[1] = cov[3] = cum[4] - cum[0] * cum[1];
+    cov[2] = cov[6] = cum[5] - cum[0] * cum[2];
+    cov[5] = cov[7] = cum[7] - cum[1] * cum[2];
+    double ev[3], V[9];
+    orc_eig3_sym(cov, ev, V);
+    const double sum = (ev[0] + ev[1]) + ev[2]; /* Eigen sum(): left to right for a 3-vector */
+    if (normal) { normal[3 * i] = V[0]; normal[3 * i + 1] = V[3]; normal[3 * i + 2] = V[6]; } /* eigenvectors().col(0) */
+    if (cvr) cvr[i] = (sum == 0.0) ? 0.0 : ev[0] / sum;                 /* :109-114 */
+    if (flatness) flatness[i] = (ev[1] - ev[0]) / ev[2];                /* :116 */
+    if (sphericity) sphericity[i] = ev[0] / ev[2];                      /* :117 */
+    if (num_sum) num_sum[i] = cnt;
+    if (neigh) for (int m = 0; m < cnt; ++m) neigh[i * (size_t)K + m] = idx[m];
+  }
+  grid_free(&g);
+  return TLOAM_OK;
+}
+
+typedef struct { double f; int32_t idx; } feat_pair;
+static int feat_cmp(const void* a, const void* b) { /* descending flatness; ties: ascending index (stable order) */
+  const feat_pair* x = (const feat_pair*)a; const feat_pair* y = (const feat_pair*)b;
+  if (x->f > y->f) return -1;
+  if (x->f < y->f) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+int orc_extract_planar_sphere(const tloam_feature_config* cfg, const double* xyz, size_t n, int32_t* planar_scan,
+                              size_t* n_ps, int32_t* planar_submap, size_t* n_pm, int32_t* sphere_scan, size_t* n_ss,
+                              int32_t* sphere_submap, size_t* n_sm) {
+  if (!cfg || !n_ps || !n_pm || !n_ss || !n_sm) return TLOAM_E_INVALID;
+  *n_ps = *n_pm = *n_ss = *n_sm = 0;
+  if (n == 0) return TLOAM_OK; /* "cloud_in_ does not contain points" -> calculatePCAInfo false, lists stay empty */
+  const int K = cfg->K;
+  double* fl = (double*)malloc(sizeof(double) * n);
+  double* cv = (double*)malloc(sizeof(double) * n);
+  double* nr = (double*)malloc(sizeof(double) * 3 * n);
+  int32_t* ns = (int32_t*)malloc(sizeof(int32_t) * n);
+  int32_t* ng = (int32_t*)malloc(sizeof(int32_t) * n * (size_t)(K > 0 ? K : 1));
+  int rc = orc_pca_info(cfg, xyz, n, fl, cv, NULL, nr, ns, ng);
+  if (rc != TLOAM_OK) { free(fl); free(cv); free(nr); free(ns); free(ng); return rc; }
+  feat_pair* planar = (feat_pair*)malloc(sizeof(feat_pair) * n);
+  feat_pair* sphere = (feat_pair*)malloc(sizeof(feat_pair) * n);
+  size_t np = 0, nsph = 0;
+  for (size_t id = 0; id < n; ++id) { /* :149-165; cur_index of a skipped point is 0, but such a point is never selected */
+    if (fl[id] > cfg->planar_submap_thres && fabs(nr[3 * id + 2]) < cfg->planar_vertic_thres) {
+      planar[np].f = fl[id]; planar[np].idx = (int32_t)id; ++np;
+    } else if (cv[id] > cfg->cvr_submap) {
+      int max_uniform = 1;
+      for (int m = 0; m < ns[id]; ++m)
+        if (cv[id] < cv[ng[id * (size_t)K + m]]) { max_uniform = 0; break; }
+      if (max_uniform) { sphere[nsph].f = fl[id]; sphere[nsph].idx = (int32_t)id; ++nsph; } /* :162 pairs FLATNESS */
+    }
+  }
+  qsort(planar, np, sizeof(feat_pair), feat_cmp);   /* :168-174 */
+  qsort(sphere, nsph, sizeof(feat_pair), feat_cmp);
+  for (size_t id = 0; id < np; ++id) {              /* :178-183 */
+    if (id < (size_t)cfg->planar_num || planar[id].f > cfg->planar_scan_thres) planar_scan[(*n_ps)++] = planar[id].idx;
+    planar_submap[(*n_pm)++] = planar[id].idx;
+  }
+  for (size_t id = 0; id < nsph; ++id) {            /* :185-190: the RANK id is stored, not the point index */
+    if (id < (size_t)cfg->sphere_num || sphere[id].f > cfg->cvr_scan) sphere_scan[(*n_ss)++] = (int32_t)id;
+    sphere_submap[(*n_sm)++] = (int32_t)id;
+  }
+  free(planar); free(sphere); free(fl); free(cv); free(nr); free(ns); free(ng);
+  return TLOAM_OK;
+}

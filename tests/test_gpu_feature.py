@@ -1,0 +1,78 @@
+"""-m gpu: PCA feature extraction on the device (tloam_pca_info / tloam_extract_planar_sphere, SURVEY 8(f)
+next-2) against the CPU restatement -- the same grid search, (distance, index) order and Jacobi eigen solve,
+so every per-point value and every index list is compared bit for bit -- through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tloam_amd import synth_submap as ss
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1500), (1, 4000), (2, 12000)])
+def test_pca_info_bit_exact(hip_module, seed, n):
+    p = ss.feature_cloud(seed, n=n)
+    H = hip_module.HipRegistration()
+    g = H.pca_info(p)
+    o = ob.pca_info(p)
+    assert _same(g["num_sum"], o["num_sum"])
+    assert _same(g["neigh"], o["neigh"])
+    for k in ("flatness", "cvr", "sphericity", "normal"):
+        assert _same(g[k], o[k]), (k, np.nanmax(np.abs(g[k] - o[k])))
+    assert (o["num_sum"] > 0).sum() > 0.8 * n
+    H.close()
+
+
+@pytest.mark.parametrize("seed,cfg", [(0, {}), (1, dict(planar_num=40, sphere_num=3)),
+                                      (2, dict(K=12, min_neigh=6, radius=0.15, planar_scan_thres=0.9, cvr_scan=0.05)),
+                                      (3, dict(planar_vertic_thres=2.0, cvr_submap=0.01))])
+def test_index_lists_bit_exact(hip_module, seed, cfg):
+    p = ss.feature_cloud(seed, n=5000)
+    H = hip_module.HipRegistration()
+    g = H.extract_planar_sphere(p, hip_module.default_feature_config(**cfg))
+    o = ob.extract_planar_sphere(p, ob.make_feature_config(**cfg))
+    for i, name in enumerate(("planar_scan", "planar_submap", "sphere_scan", "sphere_submap")):
+        assert _same(g[i], o[i]), (name, len(g[i]), len(o[i]))
+    assert len(o[1]) > 100
+    H.close()
+
+
+def test_hip_against_golden(hip_module):
+    from test_feature_oracle import check_against_golden
+    H = hip_module.HipRegistration()
+    check_against_golden(lambda p, cfg: H.pca_info(p, hip_module.default_feature_config(**cfg)),
+                         lambda p, cfg: H.extract_planar_sphere(p, hip_module.default_feature_config(**cfg)))
+    H.close()
+
+
+def test_degenerate_inputs(hip_module):
+    H = hip_module.HipRegistration()
+    line = np.column_stack([np.linspace(0, 0.1, 11), np.zeros(11), np.zeros(11)])
+    dup = np.repeat(np.array([[1.0, 2.0, 3.0]]), 30, axis=0)
+    for cloud in (line, line[:10], dup, np.array([[0.0, 0.0, 0.0]])):
+        g, o = H.pca_info(cloud), ob.pca_info(cloud)
+        for k in g:
+            assert _same(g[k], o[k]), k
+        gl, ol = H.extract_planar_sphere(cloud), ob.extract_planar_sphere(cloud)
+        assert all(_same(a, b) for a, b in zip(gl, ol))
+    assert all(len(x) == 0 for x in H.extract_planar_sphere(np.zeros((0, 3))))
+    with pytest.raises(hip_module.TloamHipError):
+        H.pca_info(line, hip_module.default_feature_config(K=21))          # K <= 20 on the device
+    H.close()
+
+
+def test_feature_lists_feed_the_submap(hip_module):
+    """The three widened rows chained: extract on the device, select the clouds, update the device submap."""
+    p = ss.feature_cloud(5, n=6000)
+    H = hip_module.HipRegistration()
+    ps, pm, s_scan, s_sub = H.extract_planar_sphere(p)
+    cl = ss.frame_clouds(5, 0, n=(10, 10, 300, 400))
+    H.submap_init(p[pm], p[s_sub], cl[2], cl[3])
+    H.submap_update(ss.frame_pose(1), p[pm], p[s_sub], cl[2], cl[3])
+    assert len(H.get_target(0)) == len(pm) and len(H.get_target(3)) == len(pm)    # sphere submap <- planar buffer
+    H.close()

@@ -21,10 +21,11 @@ UNITS = [
     # K1/K2: un-fused fp64 so the discontinuous gates see the oracle's operation order
     ("tl_nn.hip", ["-ffp-contract=off"]),
     ("tl_submap.hip", ["-ffp-contract=off"]),   # voxel indices / means in the oracle's operation order
+    ("tl_feature.hip", ["-ffp-contract=off"]),  # PCA gates (flatness / cvr thresholds) like the oracle
     ("tl_gn.hip", []),
     ("tl_api.hip", []),
 ]
-HEADERS = ["tl_common.hpp", "tl_se3.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
+HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
 
 
 def _hipcc():

@@ -192,6 +192,22 @@ void launch_copy3(const double* ax, const double* ay, const double* az, size_t n
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);
 void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s);
 
+// ---- PCA feature extraction (tl_feature.hip; feature_extract.cpp:47-197) -----------------------
+struct FeatArgs {
+  GridView g;                 // grid over the cloud itself (cell >= radius)
+  const double *x, *y, *z;    // the cloud, SoA, original order
+  int n;
+  double radius;
+  int K, min_neigh;
+  double *flatness, *cvr, *sphericity, *normal;  // [n], [n], [n], [3n] AoS
+  int *num_sum, *neigh;                          // [n], [n * K] (-1 padded)
+};
+struct FeatSelect { double cvr_submap, planar_submap_thres, planar_vertic_thres; };
+void launch_pca_info(const FeatArgs& A, hipStream_t s);
+void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long long* flags, unsigned long long* scan,
+                        unsigned long long* scan_tmp, double* pf, int* pidx, double* sf, int* sidx, double* pf_sorted,
+                        int* pidx_sorted, double* sf_sorted, int* sidx_sorted, int* rank, hipStream_t s);
+
 // K3 and the minimiser
 int k3_grid_for(int total_cap);
 bool k3_single_pass(int total_cap, int grid);  // one wave per chunk (small sets) vs the streaming variant

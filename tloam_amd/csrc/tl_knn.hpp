@@ -1,0 +1,256 @@
+// tl_knn.hpp -- device-side building blocks shared by the translation units that search the uniform grid
+// (tl_nn.hip: K1/K2 of scanMatching; tl_feature.hip: PCA feature extraction): cell indexing, the sorted
+// top-K list with exact (distance, index) order, the 27-cell walk, fitBestPlane and the 3x3 symmetric eigen
+// solve.  Include only from TUs compiled with -ffp-contract=off (the gates that consume these results are
+// discontinuous and must see the oracle's un-fused fp64 operation order).
+#pragma once
+
+#include "tl_common.hpp"
+
+namespace tl {
+
+__device__ __forceinline__ int cell_coord(double v, double org, double inv_cell, int dim) {
+  // build and queries use this SAME function, so a point and a query always agree on cell boundaries;
+  // the 1e-6 slack of the cell size over the radius covers the rounding of the multiply
+  double f = floor((v - org) * inv_cell);
+  f = fmax(f, -2.0);
+  f = fmin(f, (double)dim + 1.0);
+  return (int)f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ================================================================================================
+//  K1: exact k-NN over the 27-cell neighbourhood, top-K kept sorted in registers.
+//  Candidates come from the cell-sorted packed records in HBM (PtsGlobal); the L1/L2 reuse comes from the
+//  tile-sorted query order (an LDS-staged tile variant was measured and rejected).
+// ================================================================================================
+struct PtsGlobal {
+  const double4* p;
+  __device__ __forceinline__ double X(int j) const { return p[j].x; }
+  __device__ __forceinline__ double Y(int j) const { return p[j].y; }
+  __device__ __forceinline__ double Z(int j) const { return p[j].z; }
+  __device__ __forceinline__ int I(int j) const { return (int)__double_as_longlong(p[j].w); }
+};
+
+template <int K>
+struct TopK {
+  double d[K];
+  int j[K];  // position in the point source
+};
+
+// nanoflann L2_Simple_Adaptor: sum of squared differences accumulated in dimension order
+__device__ __forceinline__ double sqdist(double qx, double qy, double qz, double x, double y, double z) {
+  const double d0 = qx - x, d1 = qy - y, d2 = qz - z;
+  double r = d0 * d0;
+  r += d1 * d1;
+  r += d2 * d2;
+  return r;
+}
+
+// Branch-free sorted insertion: the candidate bubbles down the ascending list with one compare and
+// four selects per level, so a wave pays the same ~5 instructions per level whether or not any of its
+// lanes inserts (the branchy version made every wave run the long insert path on almost every
+// candidate).  Strict total order (d, original index): exact ties go to the lower target index; the
+// index is only fetched when two distances are bit-equal.
+template <int K, class P>
+__device__ __forceinline__ void topk_insert(TopK<K>& tk, const P& pts, double d, int j) {
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    bool before = d < tk.d[m];
+    if (d == tk.d[m]) before = (tk.j[m] < 0) || (pts.I(j) < pts.I(tk.j[m]));  // rare: exact tie
+    const double dm = tk.d[m];
+    const int jm = tk.j[m];
+    tk.d[m] = before ? d : dm;
+    tk.j[m] = before ? j : jm;
+    d = before ? dm : d;   // the displaced (larger) element carries on down the list
+    j = before ? jm : j;
+  }
+}
+// Hot-loop variant: orders by distance only and REPORTS whether the candidate tied bit-exactly with a kept
+// distance; the caller then redoes that (rare) query with the exact (d, index) insertion above.  No branch,
+// no index fetch: 8 VALU ops per level instead of ~26 instructions with two exec-mask branches.
+// A NaN distance (masked-off candidate) compares false everywhere and falls through untouched.
+template <int K>
+__device__ __forceinline__ bool topk_insert_fast(TopK<K>& tk, double d, int j) {
+  bool tie = false;
+  const double d0 = d;  // the candidate itself (d becomes the displaced element further down the list)
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const bool before = d < tk.d[m];
+    tie |= (d0 == tk.d[m]);
+    const double dm = tk.d[m];
+    const int jm = tk.j[m];
+    tk.d[m] = before ? d : dm;
+    tk.j[m] = before ? j : jm;
+    d = before ? dm : d;
+    j = before ? jm : j;
+  }
+  return tie;
+}
+template <int K>
+__device__ __forceinline__ void topk_clear(TopK<K>& tk) {
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    tk.d[m] = __builtin_inf();
+    tk.j[m] = -1;
+  }
+}
+template <int K, class P>
+__device__ __forceinline__ void scan_range(const P& pts, int s, int e, double qx, double qy, double qz, TopK<K>& tk) {
+  for (int j = s; j < e; ++j) topk_insert<K, P>(tk, pts, sqdist(qx, qy, qz, pts.X(j), pts.Y(j), pts.Z(j)), j);
+}
+// the same over the packed HBM records, two candidates per trip so that two 32-byte loads are in flight
+template <int K>
+__device__ __forceinline__ void scan_range(const PtsGlobal& pts, int s, int e, double qx, double qy, double qz,
+                                           TopK<K>& tk) {
+  int j = s;
+  for (; j + 1 < e; j += 2) {
+    const double4 a = pts.p[j], b = pts.p[j + 1];
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, a.x, a.y, a.z), j);
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, b.x, b.y, b.z), j + 1);
+  }
+  if (j < e) {
+    const double4 a = pts.p[j];
+    topk_insert<K, PtsGlobal>(tk, pts, sqdist(qx, qy, qz, a.x, a.y, a.z), j);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
+  topk_clear<K>(tk);
+  if (g.n <= 0) return;
+  const PtsGlobal pts{g.gp};
+  const int cx = cell_coord(qx, g.org[0], g.inv_cell, g.dim[0]);
+  const int cy = cell_coord(qy, g.org[1], g.inv_cell, g.dim[1]);
+  const int cz = cell_coord(qz, g.org[2], g.inv_cell, g.dim[2]);
+  int x0 = cx - 1, x1 = cx + 1;
+  if (x0 < 0) x0 = 0;
+  if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
+  if (x0 > x1) return;
+  for (int z = cz - 1; z <= cz + 1; ++z) {
+    if (z < 0 || z >= g.dim[2]) continue;
+    for (int y = cy - 1; y <= cy + 1; ++y) {
+      if (y < 0 || y >= g.dim[1]) continue;
+      const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
+      scan_range<K>(pts, g.cell_start[base + x0], g.cell_start[base + x1 + 1], qx, qy, qz, tk);
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ int radius_cut(const TopK<K>& tk, double radius) {
+  const double r2 = radius * radius;
+  int cnt = 0;
+#pragma unroll
+  for (int m = 0; m < K; ++m) cnt += (tk.d[m] < r2) ? 1 : 0;  // sorted ascending => prefix
+  return cnt;
+}
+
+// ================================================================================================
+//  K2 helpers: fitBestPlane (registration.cpp:303-368) and the 3x3 symmetric eigen solve that stands
+//  in for Eigen::SelfAdjointEigenSolver (registration.cpp:476-479) -- cyclic Jacobi, all indices
+//  compile-time so the 3x3 work stays in VGPRs.
+// ================================================================================================
+__device__ __forceinline__ void fit_best_plane5(const double px[5], const double py[5], const double pz[5],
+                                                double plane[4]) {
+  const double total = 5.0;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { c0 += px[i]; c1 += py[i]; c2 += pz[i]; }
+  c0 /= total; c1 /= total; c2 /= total;
+  double xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double a = px[i] - c0, b = py[i] - c1, g = pz[i] - c2;
+    xx += a * a; xy += a * b; xz += a * g; yy += b * b; yz += b * g; zz += g * g;
+  }
+  xx /= total; xy /= total; xz /= total; yy /= total; yz /= total; zz /= total;
+  double w0 = 0, w1 = 0, w2 = 0;
+  {
+    const double det_x = yy * zz - yz * yz;
+    const double a0 = det_x, a1 = xz * yz - xy * zz, a2 = xy * yz - xz * yy;
+    double w = det_x * det_x;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  {
+    const double det_y = xx * zz - xz * xz;
+    const double a0 = xz * yz - xy * zz, a1 = det_y, a2 = xy * xz - yz * xx;
+    double w = det_y * det_y;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  {
+    const double det_z = xx * yy - xy * xy;
+    const double a0 = xy * yz - xz * yy, a1 = xy * xz - yz * xx, a2 = det_z;
+    double w = det_z * det_z;
+    if (w0 * a0 + w1 * a1 + w2 * a2 < 0.0) w = -w;
+    w0 += a0 * w; w1 += a1 * w; w2 += a2 * w;
+  }
+  const double norm = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+  if (norm == 0.0) { plane[0] = plane[1] = plane[2] = plane[3] = 0.0; return; }
+  w0 /= norm; w1 /= norm; w2 /= norm;
+  plane[0] = w0; plane[1] = w1; plane[2] = w2;
+  plane[3] = -(w0 * c0 + w1 * c1 + w2 * c2);
+}
+
+struct Sym3 {
+  double a[3][3];
+  double v[3][3];
+};
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(Sym3& m) {
+  const double apq = m.a[P][Q];
+  if (apq == 0.0) return;
+  const double app = m.a[P][P], aqq = m.a[Q][Q];
+  const double tau = (aqq - app) / (2.0 * apq);
+  const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
+  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double akp = m.a[k][P], akq = m.a[k][Q];
+    m.a[k][P] = cs * akp - sn * akq;
+    m.a[k][Q] = sn * akp + cs * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double apk = m.a[P][k], aqk = m.a[Q][k];
+    m.a[P][k] = cs * apk - sn * aqk;
+    m.a[Q][k] = sn * apk + cs * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double vkp = m.v[k][P], vkq = m.v[k][Q];
+    m.v[k][P] = cs * vkp - sn * vkq;
+    m.v[k][Q] = sn * vkp + cs * vkq;
+  }
+}
+template <int J>
+__device__ __forceinline__ void sort_swap(double ev[3], Sym3& m) {
+  if (ev[J] > ev[J + 1]) {
+    const double t = ev[J]; ev[J] = ev[J + 1]; ev[J + 1] = t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double tv = m.v[k][J]; m.v[k][J] = m.v[k][J + 1]; m.v[k][J + 1] = tv; }
+  }
+}
+// eigenvalues ascending in ev, unit eigenvectors in the columns of m.v
+__device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m.v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = m.a[0][1] * m.a[0][1] + m.a[0][2] * m.a[0][2] + m.a[1][2] * m.a[1][2];
+    const double dia = m.a[0][0] * m.a[0][0] + m.a[1][1] * m.a[1][1] + m.a[2][2] * m.a[2][2];
+    if (off <= 1e-36 * dia) break;  // off-diagonal mass below fp64 resolution of the eigenvalues
+    jacobi_rotate<0, 1>(m);
+    jacobi_rotate<0, 2>(m);
+    jacobi_rotate<1, 2>(m);
+  }
+  ev[0] = m.a[0][0]; ev[1] = m.a[1][1]; ev[2] = m.a[2][2];
+  sort_swap<0>(ev, m);
+  sort_swap<1>(ev, m);
+  sort_swap<0>(ev, m);
+}
+
+}  // namespace tl

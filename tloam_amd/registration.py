@@ -38,6 +38,14 @@ class SubmapConfig(C.Structure):
                 ("ground_down_sample", C.c_double)]
 
 
+class FeatureConfig(C.Structure):
+    """tloam_feature_config: the `feature:` block of config/mapping/feature.yaml."""
+    _fields_ = [("radius", C.c_double), ("K", C.c_int32), ("min_neigh", C.c_int32), ("planar_num", C.c_int32),
+                ("sphere_num", C.c_int32), ("cvr_scan", C.c_double), ("cvr_submap", C.c_double),
+                ("planar_scan_thres", C.c_double), ("planar_submap_thres", C.c_double),
+                ("planar_vertic_thres", C.c_double)]
+
+
 class TlsConfig(C.Structure):
     """tloam_tls_config: the 16 keys of the `TLS:` block (config/mapping/lidar_odometry.yaml:23-39)."""
     _fields_ = [
@@ -121,6 +129,10 @@ def load_library():
         "tloam_submap_init": (C.c_int, [vp, C.POINTER(SubmapConfig), dp, sz, dp, sz, dp, sz, dp, sz]),
         "tloam_submap_update": (C.c_int, [vp, dp, dp, sz, dp, sz, dp, sz, dp, sz]),
         "tloam_get_target": (C.c_int, [vp, C.c_int, sz, C.POINTER(sz), dp]),
+        "tloam_feature_default_config": (None, [C.POINTER(FeatureConfig)]),
+        "tloam_pca_info": (C.c_int, [vp, C.POINTER(FeatureConfig), dp, sz, dp, dp, dp, dp, ip, ip]),
+        "tloam_extract_planar_sphere": (C.c_int, [vp, C.POINTER(FeatureConfig), dp, sz, ip, C.POINTER(sz), ip,
+                                                  C.POINTER(sz), ip, C.POINTER(sz), ip, C.POINTER(sz)]),
         "tloam_rccl_unique_id": (C.c_int, [vp]),
         "tloam_comm_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "tloam_comm_init_callback": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]),
@@ -143,7 +155,8 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_solve",
     "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
-    "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
+    "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
+    "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_init_callback", "tloam_shard_range", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
 )
 
@@ -333,6 +346,34 @@ class HipRegistration:
         self._n[("t", kind)] = n.value
         return out[: n.value].copy()
 
+    # ---- PCA feature extraction (featureExtract::calculatePCAInfo / extractPlanarSphere)
+    def pca_info(self, xyz, cfg: FeatureConfig | None = None):
+        cfg = cfg or default_feature_config()
+        a = _aos(xyz)
+        n, K = len(a), cfg.K
+        out = dict(flatness=np.zeros(n), cvr=np.zeros(n), sphericity=np.zeros(n), normal=np.zeros((max(n, 1), 3)),
+                   num_sum=np.zeros(n, np.int32), neigh=np.zeros((max(n, 1), K), np.int32))
+        rc = self.L.tloam_pca_info(self.h, C.byref(cfg), _dp(a), n, _dp(out["flatness"]), _dp(out["cvr"]),
+                                   _dp(out["sphericity"]), _dp(out["normal"]), _ip(out["num_sum"]), _ip(out["neigh"]))
+        self._check(rc, "tloam_pca_info")
+        out["normal"] = out["normal"][:n]
+        out["neigh"] = out["neigh"][:n]
+        return out
+
+    def extract_planar_sphere(self, xyz, cfg: FeatureConfig | None = None):
+        """-> (planar_scan_index, planar_submap_index, sphere_scan_index, sphere_submap_index)"""
+        cfg = cfg or default_feature_config()
+        a = _aos(xyz)
+        n = len(a)
+        lists = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+        cnt = [C.c_size_t(0) for _ in range(4)]
+        args = []
+        for l, k in zip(lists, cnt):
+            args += [_ip(l), C.byref(k)]
+        rc = self.L.tloam_extract_planar_sphere(self.h, C.byref(cfg), _dp(a), n, *args)
+        self._check(rc, "tloam_extract_planar_sphere")
+        return tuple(l[: k.value].copy() for l, k in zip(lists, cnt))
+
     def fitness(self):
         f, r = C.c_double(0), C.c_double(0)
         rc = self.L.tloam_fitness(self.h, C.byref(f), C.byref(r))
@@ -436,6 +477,14 @@ def rccl_unique_id() -> bytes:
     if rc != 0:
         raise TloamHipError(f"tloam_rccl_unique_id: {STATUS.get(rc, rc)}")
     return buf.raw
+
+
+def default_feature_config(**over) -> FeatureConfig:
+    cfg = FeatureConfig()
+    load_library().tloam_feature_default_config(C.byref(cfg))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
 
 
 def default_submap_config(**over) -> SubmapConfig:

@@ -43,3 +43,19 @@ def frame_clouds(seed, f, n=(600, 120, 1500, 2500), extent=40.0):
     a = rng.uniform(0, 2 * np.pi, n_ground)
     ground = np.column_stack([r * np.cos(a), r * np.sin(a), -1.73 + rng.normal(0, 0.02, n_ground)])
     return tuple(np.ascontiguousarray(c.astype(np.float32).astype(np.float64)) for c in (planar, sphere, edge, ground))
+
+
+def feature_cloud(seed, n=3000):
+    """A small scan-like cloud for the PCA feature path: a wall and a ground patch dense enough for the
+    r = 0.2 m / K = 20 search (planar candidates), compact blobs (high-curvature / sphere candidates) and sparse
+    clutter (too few neighbours -> skipped), float32-rounded."""
+    r = np.random.default_rng(4243 * seed + 17)
+    nw, ng = n // 2, n // 3
+    s = np.sqrt(nw / 750.0)                       # ~300 points per square metre on the wall
+    wall = np.column_stack([r.uniform(-s, s, nw), 2.0 + r.normal(0, 0.004, nw), r.uniform(-0.5 * s, 0.75 * s, nw)])
+    g = np.sqrt(ng / 1200.0)
+    ground = np.column_stack([r.uniform(-g, g, ng), r.uniform(-g, g, ng), -1.7 + r.normal(0, 0.004, ng)])
+    nb = max((n - nw - ng) // 50, 1)
+    blobs = np.concatenate([c + r.normal(0, 0.04, (40, 3)) for c in r.uniform(-2, 2, (nb, 3)) + [0, -3.0, 0]])
+    clutter = r.uniform(-6, 6, (max(n - nw - ng - 40 * nb, 1), 3))
+    return np.ascontiguousarray(np.concatenate([wall, ground, blobs, clutter]).astype(np.float32).astype(np.float64))
