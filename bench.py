@@ -208,6 +208,8 @@ def main():
         if not args.no_kitti and args.workload == "m1":
             kitti_seq = kitti_sequence(args, reg, synth, torch, local_rank)
             out["kitti_density"] = kitti_seq["report"]
+        if not args.no_kitti and args.workload == "m1":
+            out["adjacent_rows"] = adjacent_rows(args, reg, torch, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cfg, args, kitti_seq)
     if rank == 0:
@@ -327,6 +329,36 @@ def kitti_sequence(args, reg, synth, torch, device):
            "n_corr_last_frame": n_corr,
            "pose_err_vs_truth_m": {"mean": round(float(np.mean(terr)), 6), "max": round(float(np.max(terr)), 6)}}
     return {"report": rep, "poses": poses}
+
+
+def adjacent_rows(args, reg, torch, device):
+    """The rows either side of the path, timed on the GPU at KITTI-like sizes: the device-resident
+    submap update (FrontEnd::updateSubmap) and the PCA feature extraction (extractPlanarSphere).  Reported
+    beside the headline, never part of `value`."""
+    from tloam_amd import synth_submap as ss
+    H = reg.HipRegistration(reg.default_config(), device=device)
+    H.submap_init(*ss.frame_clouds(args.seed, 0, n=(4000, 500, 7000, 30000), extent=60.0))
+    ts = []
+    for f in range(1, 40):
+        cl = ss.frame_clouds(args.seed, f, n=(4000, 500, 2000, 4000), extent=60.0)
+        T = ss.frame_pose(f)
+        t0 = time.perf_counter()
+        H.submap_update(T, *cl)
+        ts.append(time.perf_counter() - t0)
+    sizes = [len(H.get_target(k)) for k in range(4)]
+    cloud = ss.feature_cloud(args.seed, n=100000)
+    for _ in range(2):
+        H.extract_planar_sphere(cloud)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        lists = H.extract_planar_sphere(cloud)
+    tf = (time.perf_counter() - t0) / 5
+    H.close()
+    return {"submap_update_ms": round(float(np.mean(ts[-20:])) * 1e3, 4), "submap_points": sizes,
+            "feature_extract_ms": round(tf * 1e3, 4), "feature_cloud_points": int(len(cloud)),
+            "feature_lists": [int(len(x)) for x in lists],
+            "note": "host call to host return, incl. the upload of the per-scan clouds / the cloud and the list download"}
 
 
 def cpu_baseline(scene, cfg, args, kitti_seq=None):
