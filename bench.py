@@ -39,6 +39,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory (the ROCm 7 default here; with =0 the KITTI-density frame goes from 0.56 to
+# 0.69 ms): set before the HIP runtime initialises so a different default cannot silently change the numbers
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of

@@ -96,6 +96,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise TloamHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in HBM (effective if HIP is not up yet)
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     sz = C.c_size_t
