@@ -91,7 +91,7 @@ void tloam_default_config(tloam_tls_config* cfg);
 /* What one scan_match (or one outer GNC iteration) did. */
 typedef struct tloam_stats {
   int32_t outer_iterations;       /* GNC iterations executed (<= max_iterations)              */
-  int32_t gn_evaluations;         /* residual+Jacobian sweeps (K3 launches that did work)     */
+  int32_t gn_evaluations;         /* solver evaluations (Ceres `Evaluate` calls of the minimiser) */
   int32_t gn_iterations;          /* trust-region iterations attempted (<= 4 per outer)       */
   int32_t accepted_steps;         /* ... of which accepted                                    */
   int32_t n_corr[TLOAM_NUM_KINDS];/* factors added in the LAST outer iteration, per kind      */
@@ -101,6 +101,11 @@ typedef struct tloam_stats {
   double mu;                      /* GNC mu after the last update (:1089)                      */
   double solver_cost;             /* Ceres-style cost 0.5*sum(rho) at the final iterate        */
   double se3[6];                  /* final tangent vector `parameters` (registration.hpp:328)  */
+  int32_t gn_sweeps;              /* residual+Jacobian sweeps actually executed (K3 launches that did
+                                   * work): <= gn_evaluations -- an evaluation of a point that is bit-identical
+                                   * to the one just evaluated (a rejected step retried inside a halved trust
+                                   * region) is served from the totals already on the device */
+  int32_t reserved1;
 } tloam_stats;
 
 typedef struct tloam_ctx tloam_ctx;

@@ -37,6 +37,7 @@ class Stats(C.Structure):
         ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
         ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
         ("se3", C.c_double * 6),
+        ("gn_sweeps", C.c_int32), ("reserved1", C.c_int32),
     ]
 
     def as_dict(self):
@@ -44,7 +45,7 @@ class Stats(C.Structure):
                     gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
                     n_corr=list(self.n_corr), converged_early=self.converged_early,
                     kind_cost=list(self.kind_cost), mu=self.mu, solver_cost=self.solver_cost,
-                    se3=np.array(self.se3))
+                    se3=np.array(self.se3), gn_sweeps=self.gn_sweeps)
 
 
 DEFAULTS = dict(k_corr=10, factor_num=4, edge_dist_thres=1.0, edge_dir_thres=0.85, edge_maxnum=1200,

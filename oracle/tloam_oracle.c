@@ -1028,6 +1028,7 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
   /* IterationZero */
   evaluate(c, x, 1, &cur);
   st->gn_evaluations++;
+  st->gn_sweeps++; /* the CPU restatement executes every evaluation */
   double x_cost = cur.cost;
   double S[6];
   for (int i = 0; i < 6; ++i) S[i] = 1.0 / (1.0 + sqrt(cur.H[i * 6 + i])); /* jacobi_scaling, iteration 0 only */
@@ -1076,6 +1077,7 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
     orc_normal cand;
     evaluate(c, x_cand, 0, &cand);
     st->gn_evaluations++;
+    st->gn_sweeps++;
     double candidate_cost = cand.cost;
     /* ParameterToleranceReached */
     double dx[6];

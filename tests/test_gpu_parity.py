@@ -150,3 +150,55 @@ def test_build_reuse_is_exact(hip_module, monkeypatch):
     for k in range(4):
         assert np.array_equal(H1.get_weights(k), H2.get_weights(k))
     H1.close(); H2.close()
+
+
+def test_evaluation_reuse_is_exact(hip_module, monkeypatch):
+    """The minimiser serves the evaluation of a bit-identical point from the totals already on the device
+    (gn_sweeps <= gn_evaluations).  With the reuse switched off every evaluation runs its own sweep; pose,
+    counters, weights and side-channel costs must not change by a single bit."""
+    sc = synth.make_scene(seed=12, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    H1 = hip_module.HipRegistration()
+    H1.set_frames(sc.source, sc.target)
+    rc1, T1, st1 = H1.scan_match(sc.T_pred)
+    monkeypatch.setenv("TLOAM_NO_EVAL_REUSE", "1")       # read once, when the context is created
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    rc2, T2, st2 = H2.scan_match(sc.T_pred)
+    assert rc1 == rc2 == 0
+    assert np.array_equal(T1, T2)
+    for k in ("gn_evaluations", "gn_iterations", "accepted_steps", "n_corr", "outer_iterations"):
+        assert st1[k] == st2[k], k
+    assert st2["gn_sweeps"] == st2["gn_evaluations"]
+    assert st1["gn_sweeps"] < st1["gn_evaluations"], "this scene retries rejected steps (SURVEY A.13)"
+    assert np.array_equal(st1["kind_cost"], st2["kind_cost"])
+    for k in range(4):
+        assert np.array_equal(H1.get_weights(k), H2.get_weights(k))
+    # and the oracle executes every evaluation: same evaluation count
+    O = ob.Oracle()
+    O.set_frames(sc.source, sc.target)
+    rc, To, sto = O.scan_match(sc.T_pred)
+    assert sto["gn_evaluations"] == st1["gn_evaluations"] and sto["gn_sweeps"] == sto["gn_evaluations"]
+    H1.close(); H2.close()
+
+
+@pytest.mark.parametrize("planned", ["1", "2", "5"])
+def test_sweep_budget_top_up_is_exact(hip_module, monkeypatch, planned):
+    """Only as many sweeps as a Solve is expected to need are enqueued; the weight update / finish kernels
+    are gated on the minimiser having terminated and the host tops the Solve up otherwise.  Forcing the budget
+    (development knob) exercises the top-up path: nothing may change."""
+    sc = synth.make_scene(seed=13, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    H1 = hip_module.HipRegistration()
+    H1.set_frames(sc.source, sc.target)
+    ref = [H1.scan_match(sc.T_pred) for _ in range(2)][-1]        # second frame: learned budgets in use
+    monkeypatch.setenv("TLOAM_PLANNED_SWEEPS", planned)
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    got = H2.scan_match(sc.T_pred)
+    assert ref[0] == got[0] == 0
+    assert np.array_equal(ref[1], got[1])
+    for k in ("gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "n_corr", "outer_iterations", "bad_weights"):
+        assert ref[2][k] == got[2][k], k
+    assert np.array_equal(ref[2]["kind_cost"], got[2]["kind_cost"])
+    for k in range(4):
+        assert np.array_equal(H1.get_weights(k), H2.get_weights(k))
+    H1.close(); H2.close()

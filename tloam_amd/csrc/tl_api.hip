@@ -186,6 +186,9 @@ struct tloam_ctx {
   bool k3_single = false;
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
+  bool dbg_no_eval_reuse = false;
+  int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
+  std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames
   bool prebuilt = false;
   // comm
   int rank = 0, nranks = 1;
@@ -427,11 +430,10 @@ int harvest_k3_events(tloam_ctx* c, int working) {
 
 // one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
 // sweeps after a tolerance exit are no-op launches (GnState.done).
-int enqueue_solve(tloam_ctx* c, bool armed) {
+constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
+int enqueue_solve(tloam_ctx* c, bool armed, int sweeps) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
-  int max_sweeps = 5;
-  if (c->dbg_max_sweeps > 0) max_sweeps = c->dbg_max_sweeps;  // TLOAM_DEBUG_MAX_SWEEPS, debugging aid only
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
     int rc = launch_k3_timed(c, false);
     if (rc != TLOAM_OK) return rc;
     if (c->nranks > 1) {
@@ -520,6 +522,8 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->device = device_id;
   if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) c->dbg_max_sweeps = atoi(e);
   c->dbg_no_build_reuse = getenv("TLOAM_NO_BUILD_REUSE") != nullptr;
+  c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
+  if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
@@ -674,6 +678,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     for (int k = 0; k < kKinds; ++k) { fi.src_aos[k] = c->kd[k].src_aos.p; fi.slot_off[k] = c->sv.slot_off[k]; }
     fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
     for (int i = 0; i < 6; ++i) fi.x[i] = x[i];
+    fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
     launch_frame_init(fi, c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p, c->stream);
   }
   c->mu = 1.0;  // :961
@@ -751,8 +756,15 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     c->mu = 1 / (2 * max_residual / c->noise_bound_sq - 1.0);
     if (c->mu <= 0) c->mu = 1e-10;
   }
-  // ---- :1036-1047 ceres::Solve, device resident
-  rc = enqueue_solve(c, /*armed=*/true);  // by sm_begin / the previous iteration's finish kernel
+  // ---- :1036-1047 ceres::Solve, device resident.  Only as many sweeps as this outer iteration needed in the
+  //      last three frames are enqueued (typically 2 of 5 from the second iteration on: the retried rejected steps
+  //      are served by the evaluation reuse); the weight update and the finish kernel are gated on the
+  //      minimiser having terminated, and raise `incomplete` otherwise -- then the Solve is topped up.
+  if ((int)c->planned_sweeps.size() < 3 * (iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), kSolveSweeps);
+  int* hist = &c->planned_sweeps[3 * (size_t)iter];  // budget = the most this iteration needed in the last 3 frames
+  int planned = std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
+  if (c->dbg_planned_sweeps > 0) planned = std::min(c->dbg_planned_sweeps, kSolveSweeps);
+  rc = enqueue_solve(c, /*armed=*/true, planned);  // armed by sm_begin / the previous iteration's finish kernel
   if (rc != TLOAM_OK) return rc;
   // ---- :1049-1086 thresholds + weight update, :1091-1094 cost sums
   const double mu = c->mu;
@@ -769,25 +781,38 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
     wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
   }
-  launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->stream);
-  if (c->nranks > 1) {
-    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->sums16.p, c->stream);
-    rc = allreduce(c, c->sums16.p, 16);
+  const int sweeps_before = c->stats.gn_sweeps;
+  for (int attempt = 0;; ++attempt) {
+    launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
+    if (c->nranks > 1) {
+      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, c->stream);
+      rc = allreduce(c, c->sums16.p, 16);
+      if (rc != TLOAM_OK) return rc;
+      launch_outer_publish(c->sums16.p, c->state.p, c->stream);
+    } else {
+      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, c->stream);  // + publish + re-arm
+    }
+    HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (!c->h_state->incomplete) break;
+    if (attempt > 0 || planned >= kSolveSweeps) {
+      c->last_error = "the minimiser did not terminate within its evaluation budget";
+      return TLOAM_E_INVALID;
+    }
+    rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps - planned);  // top up, then weights + finish again
     if (rc != TLOAM_OK) return rc;
-    launch_outer_publish(c->sums16.p, c->state.p, c->stream);
-  } else {
-    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->sums16.p, c->stream);  // + publish + re-arm
   }
-  const int evals_before = c->stats.gn_evaluations;
-  HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
   const GnState& S = *c->h_state;
-  rc = harvest_k3_events(c, S.gn_evaluations - evals_before);
+  hist = &c->planned_sweeps[3 * (size_t)iter];
+  hist[2] = hist[1]; hist[1] = hist[0];
+  hist[0] = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
+  rc = harvest_k3_events(c, S.gn_sweeps - sweeps_before);
   if (rc != TLOAM_OK) return rc;
   c->mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
   tloam_stats& st = c->stats;
   st.outer_iterations = iter + 1;
   st.gn_evaluations = S.gn_evaluations;
+  st.gn_sweeps = S.gn_sweeps;
   st.gn_iterations = S.gn_iterations;
   st.accepted_steps = S.accepted_steps;
   st.reserved0 = S.bad_weights;
@@ -1398,17 +1423,22 @@ int tloam_solve(tloam_ctx* c, double se3[6], tloam_stats* stats) {
   HIPC(c, hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream));
   memcpy(c->h_small, se3, sizeof(double) * 6);
   HIPC(c, hipMemcpyAsync(c->state.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
-  int rc = enqueue_solve(c, /*armed=*/false);
+  if (c->dbg_no_eval_reuse) {
+    static const int one = 1;
+    HIPC(c, hipMemcpyAsync(&c->state.p->no_eval_reuse, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = enqueue_solve(c, /*armed=*/false, c->dbg_max_sweeps > 0 ? c->dbg_max_sweeps : kSolveSweeps);
   if (rc != TLOAM_OK) return rc;
   HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
   const GnState& S = *c->h_state;
-  rc = harvest_k3_events(c, S.gn_evaluations);
+  rc = harvest_k3_events(c, S.gn_sweeps);
   if (rc != TLOAM_OK) return rc;
   memcpy(se3, S.x, sizeof(double) * 6);
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->gn_evaluations = S.gn_evaluations;
+    stats->gn_sweeps = S.gn_sweeps;
     stats->gn_iterations = S.gn_iterations;
     stats->accepted_steps = S.accepted_steps;
     stats->solver_cost = S.x_cost;

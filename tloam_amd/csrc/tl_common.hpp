@@ -94,10 +94,14 @@ struct GnState {
   int phase, iteration, invalid, step_successful, done;
   // counters (whole scan_match)
   int gn_evaluations, gn_iterations, accepted_steps;
+  int gn_sweeps;      // sweeps actually consumed (<= gn_evaluations, see gn_consume_wave)
+  int no_eval_reuse;  // development knob (TLOAM_NO_EVAL_REUSE): every evaluation runs its own sweep
   // outer-loop bookkeeping written by the finish kernel
   int n_corr[kKinds];
   int bad_weights;
   int pad0;
+  int incomplete;     // set by the gated weight/finish kernels when the Solve had not terminated yet
+  int pad2;
   double kind_cost[kKinds];
   double dbg[8];  // phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
@@ -147,6 +151,7 @@ struct FrameInit {
   const double* src_aos[kKinds];
   int slot_off[kKinds + 1];
   double x[6];
+  int no_eval_reuse;  // development knob, copied into the state
 };
 void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, double* w_src,
                        unsigned long long* flags, GnState* st, int* seg_n, hipStream_t s);
@@ -223,10 +228,11 @@ struct WeightParams {
   double th1, th2, mu, noise_bound_sq;
   int active[kKinds];
 };
+// (gated on st->done: see k_weights)
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
-                    int blocks, hipStream_t s);
-void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st, double* sums8,
-                         hipStream_t s);
+                    int blocks, const GnState* st, hipStream_t s);
+void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
+                         double* sums8, hipStream_t s);
 void launch_outer_publish(const double* sums8, GnState* st, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
 

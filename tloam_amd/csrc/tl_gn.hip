@@ -713,6 +713,17 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
   const int ui = L.mi < L.mj ? L.mi : L.mj, uj = L.mi < L.mj ? L.mj : L.mi;
   const double Hn = L.ism ? tot[ui * 6 - (ui * (ui - 1)) / 2 + (uj - ui)] : 0.0;
   const double gn_new = L.isv ? tot[21 + vk] : 0.0;
+  const int sweeps = st->gn_sweeps + 1;
+  const bool eval_reuse = st->no_eval_reuse == 0;
+  // Evaluation reuse: when the minimiser asks for the evaluation of a point that is bit-identical to the one
+  // whose totals are in `tot` -- a rejected step retried inside the halved trust region re-creates exactly the
+  // same candidate (four times per Solve from the second outer iteration on) -- the answer is
+  // already here: count the evaluation and go round again instead of waiting for another sweep.  Residuals,
+  // Jacobians and side-channel costs are pure functions of the point, so nothing observable changes.
+  for (;;) {
+  const double xc_held = xc;        // the point `tot` was evaluated at (PH_CAND)
+  const Pose T_held = T_eval;
+  const int phase_in = phase;
   bool need_gmax = false;
   if (phase == PH_ITER0) {
     x_cost = cost;
@@ -880,6 +891,13 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     phase = PH_CAND;
     break;  // the next K3 sweep evaluates x_cand
   }
+  if (done || !eval_reuse || phase_in != PH_CAND || phase != PH_CAND) break;
+  const bool same_pose = T_eval.qw == T_held.qw && T_eval.qx == T_held.qx && T_eval.qy == T_held.qy &&
+                         T_eval.qz == T_held.qz && T_eval.tx == T_held.tx && T_eval.ty == T_held.ty &&
+                         T_eval.tz == T_held.tz;
+  if (!same_pose || !__all((!L.isv || xc == xc_held) ? 1 : 0)) break;
+  evals++;  // served from the totals in hand
+  }
   TL_STAMP(5)
   // ---- write back
   if (L.isv) {
@@ -891,6 +909,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     st->phase = phase; st->iteration = iteration; st->invalid = invalid; st->step_successful = step_successful;
     st->reuse = reuse; st->subspace_1d = subspace_1d; st->done = done;
     st->gn_evaluations = evals; st->gn_iterations = iters; st->accepted_steps = accepted;
+    st->gn_sweeps = sweeps;
     st->x_cost = x_cost; st->x_norm = x_norm; st->gmax = gmax; st->model_cost_change = mcc;
     st->radius = radius; st->mu = mu; st->alpha = alpha; st->step_norm = step_norm;
     st->sg[0] = sg0; st->sg[1] = sg1; st->sB[0] = sB0; st->sB[1] = sB1; st->sB[2] = sB1; st->sB[3] = sB3;
@@ -948,6 +967,7 @@ __global__ __launch_bounds__(256) void k_frame_init(FrameInit fi, double* __rest
 #pragma unroll
       for (int i = 0; i < 6; ++i) st->x[i] = fi.x[i];
       st->T_cur = se3_exp(st->x);
+      st->no_eval_reuse = fi.no_eval_reuse;
       arm_solver(*st);
     }
   }
@@ -1009,8 +1029,12 @@ struct WeightArgs {
   SlotView sv;
   WeightParams wp;
 };
-__global__ __launch_bounds__(256) void k_weights(WeightArgs A, double* __restrict__ partial) {
+// Gate: the host enqueues only as many sweeps as the Solve is expected to need; if the minimiser has not
+// terminated yet (st->done == 0) the weight update and the finish kernel do nothing, the finish kernel raises
+// st->incomplete, and the host tops the Solve up and runs them again.
+__global__ __launch_bounds__(256) void k_weights(WeightArgs A, double* __restrict__ partial, const GnState* __restrict__ st) {
   __shared__ double red[4][8];
+  if (!st->done) return;
   double sum[kKinds] = {0, 0, 0, 0};
   double bad = 0.0;
   const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
@@ -1050,12 +1074,12 @@ __global__ __launch_bounds__(256) void k_weights(WeightArgs A, double* __restric
   }
 }
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial, int blocks,
-                    hipStream_t s) {
+                    const GnState* st, hipStream_t s) {
   WeightArgs A;
   A.cv = cv;
   A.sv = sv;
   A.wp = wp;
-  hipLaunchKernelGGL(k_weights, dim3(blocks), dim3(256), 0, s, A, partial);
+  hipLaunchKernelGGL(k_weights, dim3(blocks), dim3(256), 0, s, A, partial, st);
 }
 
 // sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded.
@@ -1069,14 +1093,19 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
   }
   if (t == 0) {
     st->bad_weights += (int)sums16[8];
+    st->incomplete = 0;
     arm_solver(*st);
   }
 }
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
                                                      const int* __restrict__ seg_n, double* __restrict__ sums16,
-                                                     GnState* st_or_null) {
+                                                     GnState* st_or_null, GnState* gate) {
   __shared__ double sh[16];
   const int t = threadIdx.x;
+  if (!gate->done) {  // the Solve is still running: nothing to finish yet (see k_weights)
+    if (t == 0) gate->incomplete = 1;
+    return;
+  }
   double v[5] = {0, 0, 0, 0, 0};
   for (int b = t; b < blocks; b += 64) {  // blocks <= 256: at most 4 rows per lane, fixed order
 #pragma unroll
@@ -1098,11 +1127,12 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
   if (t < 16) sums16[t] = sh[t];
   if (st_or_null) publish_and_rearm(sh, st_or_null, t);  // single rank: no exchange in between
 }
-void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, double* sums16,
-                         hipStream_t s) {
-  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null);
+void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
+                         double* sums16, hipStream_t s) {
+  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate);
 }
 __global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st) {
+  if (!st->done) return;  // gated like k_outer_finish (which raised st->incomplete)
   publish_and_rearm(sums16, st, threadIdx.x);
 }
 void launch_outer_publish(const double* sums16, GnState* st, hipStream_t s) {
