@@ -720,6 +720,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
   // same candidate (four times per Solve from the second outer iteration on) -- the answer is
   // already here: count the evaluation and go round again instead of waiting for another sweep.  Residuals,
   // Jacobians and side-channel costs are pure functions of the point, so nothing observable changes.
+  bool gn_inside = false;  // this launch already produced the candidate of the current (reused) Gauss-Newton step
   for (;;) {
   const double xc_held = xc;        // the point `tot` was evaluated at (PH_CAND)
   const Pose T_held = T_eval;
@@ -769,6 +770,15 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
     if (radius <= min_trust_region_radius) { done = 1; break; }
     iteration++;
     iters++;
+    // A rejected step retried with the dogleg data reused (reuse == 1) whose Gauss-Newton point is still inside
+    // the halved region yields, input for input, the candidate this launch has just built: x_cand, T_eval and
+    // the model cost change are already right -- skip the 6x6 work and the exp/log.
+    if (reuse && gn_inside && step_norm <= radius && !need_gmax) {
+      invalid = 0;
+      phase = PH_CAND;
+      break;
+    }
+    gn_inside = false;
     TL_STAMP(2)
     // ---- Jacobi-scaled system
     const double s_i = lget(S, L.mi), s_j = lget(S, L.mj);
@@ -804,6 +814,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
       if (gnn <= radius) {
         step = gnv / D;
         step_norm = gnn;
+        gn_inside = true;
       } else {
         if (subspace_1d < 0) {
           // ComputeSubspaceModel (first time this Gauss-Newton step is outside the region): orthonormal
@@ -881,6 +892,7 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
       }
     }
     if (!valid) {  // HandleInvalidStep -> DoglegStrategy::StepIsInvalid
+      gn_inside = false;
       if (++invalid >= max_consecutive_invalid) { done = 1; break; }
       mu *= 10.0;
       reuse = 0;
