@@ -776,13 +776,18 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   for (int k = 0; k < kKinds; ++k) wp.active[k] = bp.active[k];
   // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
   int wblocks = 64;
+  bool small_set = false;
   {
     size_t cap = 0;
     for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
     wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
+    small_set = cap <= 16384;  // one 1024-thread block does weights + sums + publish in a single launch
   }
   const int sweeps_before = c->stats.gn_sweeps;
   for (int attempt = 0;; ++attempt) {
+    if (c->nranks == 1 && small_set) {
+      launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, c->stream);
+    } else {
     launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
     if (c->nranks > 1) {
       launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, c->stream);
@@ -791,6 +796,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
       launch_outer_publish(c->sums16.p, c->state.p, c->stream);
     } else {
       launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, c->stream);  // + publish + re-arm
+    }
     }
     HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));

@@ -234,6 +234,9 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
                          double* sums8, hipStream_t s);
 void launch_outer_publish(const double* sums8, GnState* st, hipStream_t s);
+// weights + finish in one launch for small single-rank sets
+void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
+                                 double* sums16, GnState* st, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
 
 }  // namespace tl

@@ -1139,6 +1139,68 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
   if (t < 16) sums16[t] = sh[t];
   if (st_or_null) publish_and_rearm(sh, st_or_null, t);  // single rank: no exchange in between
 }
+// Small sets on one rank (KITTI caps: <= 5.9 k factors): weight update, cost sums, publish and re-arm in ONE
+// launch of one 1024-thread block -- the frame is a chain of launch-latency-bound kernels, every boundary
+// removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
+// folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
+__global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, const int* __restrict__ seg_n,
+                                                               double* __restrict__ sums16, GnState* st) {
+  __shared__ double red[16][8];
+  __shared__ double sh[16];
+  if (!st->done) {  // gate, see k_weights
+    if (threadIdx.x == 0) st->incomplete = 1;
+    return;
+  }
+  double sum[kKinds] = {0, 0, 0, 0};
+  double bad = 0.0;
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) {
+    const int n = A.cv.seg_n[k];
+    const CorrSeg& seg = A.cv.k[k];
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const double c = seg.cost[i];
+      sum[k] += c;
+      if (!A.wp.active[k]) continue;
+      if (c == 0) continue;                          // :862
+      double w;
+      if (c >= A.wp.th1) w = 0.0;                    // :865
+      else if (c <= A.wp.th2) w = 1.0;               // :867
+      else {
+        w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+        if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+      }
+      const int slot = A.sv.slot_off[k] + (seg.idx[i] - A.sv.src_lo[k]);
+      A.sv.w_src[slot] = w;
+    }
+  }
+  double v[5] = {sum[0], sum[1], sum[2], sum[3], bad};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    if (lane == 0) red[wave][i] = v[i];
+  }
+  if (threadIdx.x < 16) sh[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+    sh[threadIdx.x < 4 ? threadIdx.x : 8] = t;
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 68) sh[threadIdx.x - 60] = (double)seg_n[threadIdx.x - 64];
+  __syncthreads();
+  if (threadIdx.x < 16) sums16[threadIdx.x] = sh[threadIdx.x];
+  if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x);
+}
+void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
+                                 double* sums16, GnState* st, hipStream_t s) {
+  WeightArgs A;
+  A.cv = cv;
+  A.sv = sv;
+  A.wp = wp;
+  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st);
+}
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
                          double* sums16, hipStream_t s) {
   hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate);
