@@ -630,8 +630,17 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
   // XCD-aware order: the dispatcher deals blocks round-robin to the 8 XCDs (each with a private L2), so
   // physical block b is given logical position (b % 8) * (blocks / 8) + b / 8 -- every XCD then walks one
   // CONTIGUOUS eighth of the tile-sorted queries and neighbouring tiles share target records in its L2
-  const int per_xcd = gridDim.x >> 3;  // the launch rounds the grid up to a multiple of 8
-  const int lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  // ... in CHUNKS: a contiguous eighth per XCD would hand whole kinds to single XCDs (planar to XCDs 0-3, the
+  // edge kind with its 3x3 eigen solves to XCD 6-7) and the slowest XCD sets the kernel time; instead XCD x takes
+  // the chunks x, x + 8, x + 16, ... of kXcdChunk consecutive blocks (1024 tile-sorted queries: still local).
+  constexpr int kXcdChunk = 16;
+  const int xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3;
+  const int lb0 = ((in_xcd / kXcdChunk) * 8 + xcd) * kXcdChunk + in_xcd % kXcdChunk;  // grid: a multiple of 8 chunks
+  // ... and BACK TO FRONT: the sorted list ends with the edge kind (most candidates, eigen solve per query); the
+  // expensive blocks are dispatched first so that the cheap ones fill the tail (longest-processing-time first)
+  const int nblk = (int)(((long long)*n_sorted * LPQ + 63) / 64);
+  if (lb0 >= nblk) return;  // whole block past the end (grid rounded up)
+  const int lb = nblk - 1 - lb0;
   const int t = lb * 64 + threadIdx.x;
   const int i = t / LPQ, sub = t % LPQ;
   __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
@@ -675,7 +684,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   }
   // every slot with a tile is in qrec[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
-  auto grid8 = [](long long threads) { return (unsigned)(((threads + 63) / 64 + 7) / 8 * 8); };
+  auto grid8 = [](long long threads) { return (unsigned)(((threads + 63) / 64 + 127) / 128 * 128); };  // 8 XCDs x kXcdChunk
   if (n <= kQuadLimit)
     hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
   else
