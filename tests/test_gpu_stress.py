@@ -1,6 +1,6 @@
 """-m gpu: randomised parity sweep -- HIP vs the C oracle over seeded scenes and configurations (caps binding,
 factor_num, more outer iterations, outliers, large prediction errors); final pose, minimiser counters, per-kind
-correspondence index lists and weights.  scripts/stress_parity.py runs the same over hundreds of seeds."""
+correspondence index lists and weights.  tests/tools/stress_parity.py runs the same over hundreds of seeds."""
 import numpy as np
 import pytest
 

@@ -1,6 +1,6 @@
 """Timing probe: PCA feature extraction of a ~100 k-point scan-like cloud, device vs the C restatement."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tloam_amd import registration as reg, synth_submap as ss
 from oracle import binding as ob

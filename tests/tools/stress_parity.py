@@ -1,7 +1,7 @@
 """Randomised parity sweep (not part of the test suite): HIP vs the C oracle over many seeded scenes and
 configurations -- final pose, counters, per-kind correspondence index lists and weights."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tloam_amd import registration as reg, synth
 from oracle import binding as ob

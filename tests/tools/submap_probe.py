@@ -1,6 +1,6 @@
 """Timing probe: device submap update at KITTI-like sizes vs the CPU restatement."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tloam_amd import registration as reg, synth_submap as ss
 from oracle import binding as ob
