@@ -24,8 +24,10 @@ UNITS = [
     ("tl_feature.hip", ["-ffp-contract=off"]),  # PCA gates (flatness / cvr thresholds) like the oracle
     ("tl_gn.hip", []),
     ("tl_api.hip", []),
+    ("tl_api_submap.hip", []),
+    ("tl_api_feature.hip", []),
 ]
-HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
+HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", "tl_ctx.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
 
 
 def _hipcc():

@@ -5,85 +5,13 @@
 // every per-point / per-correspondence computation is a HIP kernel (tl_nn.hip, tl_gn.hip).
 // There is no CPU fallback: without a usable device every computing entry point returns
 // TLOAM_E_HIP.
-#include <dlfcn.h>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <algorithm>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "tl_common.hpp"
+#include "tl_ctx.hpp"
 
 using namespace tl;
 
 struct Uid128 { char bytes[128]; };  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-//  grow-only device buffer
-// ------------------------------------------------------------------------------------------------
-template <class T>
-struct DBuf {
-  T* p = nullptr;
-  size_t cap = 0;  // elements
-  hipError_t reserve(size_t n) {
-    if (n <= cap) return hipSuccess;
-    size_t want = std::max(n, cap + cap / 2);
-    want = (want + 63) & ~size_t(63);
-    T* q = nullptr;
-    hipError_t e = hipMalloc((void**)&q, want * sizeof(T) + 256);
-    if (e != hipSuccess) return e;
-    if (p) (void)hipFree(p);
-    p = q;
-    cap = want;
-    return hipSuccess;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-struct KindData {
-  // source (this rank's block)
-  size_t n_src_full = 0, src_lo = 0, n_src = 0;
-  DBuf<double> src_aos;
-  bool src_set = false;
-  // target as given by set_target
-  size_t n_tgt = 0;
-  DBuf<double> tgt_aos, tx, ty, tz;
-  bool tgt_set = false;
-  // view into the shared search-grid buffers built at sm_begin (the deep copy KDTreeFlann::SetGeometry
-  // makes, :898-913)
-  GridView gv{};
-  bool grid_valid = false;
-  // compact correspondence segment
-  DBuf<int> c_idx;
-  DBuf<double> c_px, c_py, c_pz, c_ax, c_ay, c_az, c_bx, c_by, c_bz, c_d, c_w, c_cost;
-  size_t c_cap = 0;
-  size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
-};
-
-struct GridBuffers {
-  DBuf<double4> gp;
-  DBuf<int> cell_start, cell_of_pt, rank_of_pt;
-  DBuf<unsigned long long> cell_cnt, cell_scan, scan_tmp;
-  DBuf<double> bbox;
-  void release() {
-    gp.release(); cell_start.release(); cell_of_pt.release(); rank_of_pt.release();
-    cell_cnt.release(); cell_scan.release(); scan_tmp.release(); bbox.release();
-  }
-};
-
-
-enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2 };
-
 // ---- RCCL, loaded at run time so the library also loads where librccl is absent ----------------
 struct RcclApi {
   void* handle = nullptr;
@@ -124,109 +52,7 @@ constexpr int kNcclFloat64 = 8;  // ncclDataType_t ncclFloat64 (rccl.h)
 constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
 }  // namespace
 
-// ---- device-resident submap (front_end.cpp:201-275): frame buffers + scratch of the crop/voxel pipeline ----
-struct RingFrame {
-  DBuf<double> aos;   // the frame's cloud, sensor frame, as handed over
-  size_t n = 0;
-  double pose[16];
-};
-struct SubmapState {
-  bool inited = false;
-  tloam_submap_config cfg;
-  std::vector<RingFrame*> planar_ring, sphere_ring;  // oldest first (std::deque in the reference)
-  DBuf<double> in_aos, wx, wy, wz, min_partial, vmin;
-  DBuf<unsigned long long> keys, cnt, off, leader, leader_scan, scan_tmp, counts;
-  DBuf<int> slot_of_pt, urank, members, sorted, overflow;
-  void release() {
-    for (auto* f : planar_ring) { f->aos.release(); delete f; }
-    for (auto* f : sphere_ring) { f->aos.release(); delete f; }
-    planar_ring.clear(); sphere_ring.clear();
-    in_aos.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
-    keys.release(); cnt.release(); off.release(); leader.release(); leader_scan.release(); scan_tmp.release();
-    counts.release(); slot_of_pt.release(); urank.release(); members.release(); sorted.release(); overflow.release();
-    inited = false;
-  }
-};
-
-// scratch of the PCA feature path (grow-only, kept across calls)
-struct FeatBuffers {
-  DBuf<double> aos, x, y, z, flatness, cvr, sphericity, normal, pf, sf, pfs, sfs;
-  DBuf<int> num_sum, neigh, pidx, sidx, pidxs, sidxs, rank;
-  DBuf<unsigned long long> flags, scan, scan_tmp;
-  GridBuffers grid;
-  void release() {
-    aos.release(); x.release(); y.release(); z.release(); flatness.release(); cvr.release(); sphericity.release();
-    normal.release(); pf.release(); sf.release(); pfs.release(); sfs.release(); num_sum.release(); neigh.release();
-    pidx.release(); sidx.release(); pidxs.release(); sidxs.release(); rank.release(); flags.release(); scan.release();
-    scan_tmp.release(); grid.release();
-  }
-};
-
-struct tloam_ctx {
-  tloam_tls_config cfg;
-  SubmapState submap;
-  FeatBuffers feat;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  KindData kd[kKinds];
-  // concatenated per-source-slot arrays of the current scan_match
-  DBuf<double> sx, sy, sz, w_src, raw;
-  DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
-  DBuf<int> tile_of_slot, tile_fill;
-  DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
-  GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
-  SlotView sv{};
-  CorrView cv{};
-  DBuf<int> seg_n;
-  DBuf<double> partials, red48, sums16, wpart, rank_counts, se3_dev, bbox_dev, misc;
-  DBuf<GnState> state;
-  GnState* h_state = nullptr;  // pinned mirror
-  double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
-  int k3_grid = 1;
-  bool k3_single = false;
-  int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
-  bool dbg_no_build_reuse = false;
-  bool dbg_no_eval_reuse = false;
-  int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
-  std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames
-  bool prebuilt = false;
-  // comm
-  int rank = 0, nranks = 1;
-  CommMode comm = COMM_NONE;
-  tloam_allreduce_fn cb = nullptr;
-  void* cb_user = nullptr;
-  void* nccl_comm = nullptr;
-  // scanMatching host state
-  bool active = false;
-  bool have_build = false;   // the compact set matches build_x
-  double build_x[6] = {0, 0, 0, 0, 0, 0};
-  int iter = 0;
-  double mu = 1.0, noise_bound_sq = 1e-4;
-  double prev_cost[kKinds], cur_cost[kKinds];
-  tloam_stats stats;
-  // K3 timing (bench roofline)
-  bool k3_timing = false;
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  std::vector<int> ev_batch_idx;   // position of each sampled launch inside its batch (solve)
-  int batch_launches = 0;          // K3 launches enqueued since the last harvest
-  long long k3_seq = 0;            // all K3 launches of this context
-  double k3_total_us = 0.0, k3_all_us = 0.0;  // working sweeps only / every K3 launch incl. no-ops
-  int64_t k3_launches = 0, k3_all_launches = 0;
-  double k3_alg_bytes = 0.0;  // algorithmic bytes of ONE sweep over the current set
-  std::string last_error;
-};
-
 namespace {
-
-#define HIPC(ctx, expr)                                                                 \
-  do {                                                                                  \
-    hipError_t _e = (expr);                                                             \
-    if (_e != hipSuccess) {                                                             \
-      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);            \
-      return TLOAM_E_HIP;                                                               \
-    }                                                                                   \
-  } while (0)
 
 double kind_radius(const tloam_tls_config& c, int k) {
   switch (k) {
@@ -298,13 +124,14 @@ int reserve_seg(tloam_ctx* c, int k, size_t n) {
   return TLOAM_OK;
 }
 
+}  // namespace
+
+namespace tlh {
 // The four search grids share one set of buffers (points and cell tables concatenated), so that every
 // phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
 // scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
 // temporary one.
 // radius[k] <= 0: kind not rebuilt (its view is left empty).  One host synchronisation (bounding boxes).
-// clouds: up to four SoA clouds (x, y, z, n) -- the registered targets, or any other cloud (feature extraction)
-struct CloudRef { const double *x, *y, *z; size_t n; };
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], const CloudRef clouds[kKinds],
                      GridView out[kKinds]) {
   GridSet gs;
@@ -383,6 +210,9 @@ int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridV
   }
   return build_grids_over(c, G, radius, clouds, out);
 }
+}  // namespace tlh
+
+namespace {
 
 // K3 launch; when the bench armed the timer, with a HIP event pair bound to the dispatch itself
 // Every kK3SampleStride-th launch carries the pair (stride 3 is coprime to the 5 sweeps of a Solve and the 20 of
@@ -876,314 +706,6 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     launch_transform_cloud(c->misc.p, n_scan, result, c->stream);
     HIPC(c, hipMemcpyAsync(scan_xyz, c->misc.p, sizeof(double) * 3 * n_scan, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-  }
-  return TLOAM_OK;
-}
-
-// ---- submap maintenance on the device (front_end.cpp:201-275, :283-304) ---------------------------
-void tloam_submap_default_config(tloam_submap_config* cfg) {
-  if (!cfg) return;
-  cfg->planar_frame_size = 3;
-  cfg->sphere_frame_size = 3;
-  cfg->edge_crop_box_length = 100.0;
-  cfg->ground_crop_box_length = 100.0;
-  cfg->edge_down_sample_submap = 0.3;
-  cfg->ground_down_sample_submap = 0.45;
-  cfg->ground_down_sample = 0.3;
-}
-
-namespace {
-int submap_reserve_work(tloam_ctx* c, size_t n) {
-  SubmapState& S = c->submap;
-  const size_t m = std::max<size_t>(n, 1), cap = voxel_table_size(m);
-  HIPC(c, S.min_partial.reserve(256 * 3)); HIPC(c, S.vmin.reserve(8)); HIPC(c, S.counts.reserve(8));
-  HIPC(c, S.overflow.reserve(8));
-  HIPC(c, S.keys.reserve(cap + 1)); HIPC(c, S.cnt.reserve(cap + 1)); HIPC(c, S.off.reserve(cap + 1));
-  HIPC(c, S.slot_of_pt.reserve(m)); HIPC(c, S.urank.reserve(m)); HIPC(c, S.members.reserve(m)); HIPC(c, S.sorted.reserve(m));
-  HIPC(c, S.leader.reserve(m + 1)); HIPC(c, S.leader_scan.reserve(m + 1));
-  HIPC(c, S.scan_tmp.reserve(scan_tmp_elems(std::max(cap + 1, m + 1))));
-  return TLOAM_OK;
-}
-// target[kind] <- VoxelDownSample(Crop(cloud (wx, wy, wz)[0..n), box), voxel); the output size goes to counts[slot]
-int submap_crop_voxel(tloam_ctx* c, int kind, size_t n, const double lo[3], const double hi[3], double voxel, int slot) {
-  SubmapState& S = c->submap;
-  KindData& K = c->kd[kind];
-  int rc = submap_reserve_work(c, n);
-  if (rc != TLOAM_OK) return rc;
-  const size_t m = std::max<size_t>(n, 1);
-  HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
-  VoxelJob J;
-  J.x = S.wx.p; J.y = S.wy.p; J.z = S.wz.p;
-  J.n = n;
-  for (int a = 0; a < 3; ++a) { J.lo[a] = lo[a]; J.hi[a] = hi[a]; }
-  J.voxel = voxel;
-  J.mask = voxel_table_size(m) - 1;
-  VoxelWork W;
-  W.min_partial = S.min_partial.p; W.vmin = S.vmin.p;
-  W.keys = S.keys.p; W.cnt = S.cnt.p; W.off = S.off.p;
-  W.slot_of_pt = S.slot_of_pt.p; W.urank = S.urank.p; W.members = S.members.p; W.sorted = S.sorted.p;
-  W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
-  launch_crop_voxel(J, W, K.tx.p, K.ty.p, K.tz.p, c->stream);
-  HIPC(c, hipMemcpyAsync(S.counts.p + slot, S.leader_scan.p + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                         c->stream));
-  return TLOAM_OK;
-}
-int submap_upload(tloam_ctx* c, const double* xyz, size_t n) {  // host AoS -> in_aos (device)
-  SubmapState& S = c->submap;
-  HIPC(c, S.in_aos.reserve(3 * std::max<size_t>(n, 1)));
-  if (n > 0) HIPC(c, hipMemcpyAsync(S.in_aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-  return TLOAM_OK;
-}
-int submap_finish(tloam_ctx* c, size_t* n_edge, size_t* n_ground) {  // the ONE host sync of an update
-  SubmapState& S = c->submap;
-  unsigned long long h[2] = {0, 0};
-  int ov = 0;
-  HIPC(c, hipMemcpyAsync(h, S.counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipMemcpyAsync(&ov, S.overflow.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
-  if (ov) {
-    c->last_error = "[VoxelDownSample] voxel_size is too small.";  // PointCloud2.cpp:370-372
-    return TLOAM_E_INVALID;
-  }
-  *n_edge = (size_t)h[0];
-  *n_ground = (size_t)h[1];
-  return TLOAM_OK;
-}
-const double kNoLo[3] = {-INFINITY, -INFINITY, -INFINITY}, kNoHi[3] = {INFINITY, INFINITY, INFINITY};
-}  // namespace
-
-int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double* planar, size_t n_planar,
-                      const double* sphere, size_t n_sphere, const double* edge, size_t n_edge, const double* ground,
-                      size_t n_ground) {
-  if (!c || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
-    return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
-  SubmapState& S = c->submap;
-  S.release();
-  if (cfg) S.cfg = *cfg;
-  else tloam_submap_default_config(&S.cfg);
-  if (S.cfg.planar_frame_size < 1 || S.cfg.sphere_frame_size < 1 || !(S.cfg.edge_down_sample_submap > 0.0) ||
-      !(S.cfg.ground_down_sample_submap > 0.0) || !(S.cfg.ground_down_sample > 0.0))
-    return TLOAM_E_INVALID;  // "[VoxelDownSample] voxel_size <= 0." (PointCloud2.cpp:361-363)
-  // :286 / :290-291 submap += cloud on empty submaps: the clouds as given
-  int rc = tloam_set_target(c, TLOAM_KIND_EDGE, edge, n_edge);
-  if (rc == TLOAM_OK) rc = tloam_set_target(c, TLOAM_KIND_PLANAR, planar, n_planar);
-  if (rc == TLOAM_OK) rc = tloam_set_target(c, TLOAM_KIND_SPHERE, sphere, n_sphere);
-  if (rc != TLOAM_OK) return rc;
-  // :287 ground += ground->VoxelDownSample(ground_down_sample)
-  rc = submap_upload(c, ground, n_ground);
-  if (rc != TLOAM_OK) return rc;
-  const size_t m = std::max<size_t>(n_ground, 1);
-  HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
-  launch_aos_to_soa(S.in_aos.p, n_ground, S.wx.p, S.wy.p, S.wz.p, c->stream);
-  rc = submap_reserve_work(c, n_ground);
-  if (rc != TLOAM_OK) return rc;
-  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
-  rc = submap_crop_voxel(c, TLOAM_KIND_GROUND, n_ground, kNoLo, kNoHi, S.cfg.ground_down_sample, 1);
-  if (rc != TLOAM_OK) return rc;
-  size_t ne = 0, ng = 0;
-  rc = submap_finish(c, &ne, &ng);
-  if (rc != TLOAM_OK) return rc;
-  c->kd[TLOAM_KIND_GROUND].n_tgt = ng;
-  c->kd[TLOAM_KIND_GROUND].tgt_set = true;
-  S.inited = true;
-  return TLOAM_OK;
-}
-
-int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
-                        const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
-                        const double* ground, size_t n_ground) {
-  if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
-    return TLOAM_E_INVALID;
-  SubmapState& S = c->submap;
-  if (!S.inited) return TLOAM_E_NOT_READY;
-  HIPC(c, hipSetDevice(c->device));
-  // :202-218 push the frame into both buffers, keep the newest *_frame_size
-  auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep) -> int {
-    RingFrame* f = nullptr;
-    if ((int)ring.size() >= keep) {  // recycle the frame that falls out
-      f = ring.front();
-      ring.erase(ring.begin());
-      while ((int)ring.size() >= keep) { ring.front()->aos.release(); delete ring.front(); ring.erase(ring.begin()); }
-    } else {
-      f = new RingFrame();
-    }
-    ring.push_back(f);
-    f->n = n;
-    memcpy(f->pose, pose, sizeof(double) * 16);
-    HIPC(c, f->aos.reserve(3 * std::max<size_t>(n, 1)));
-    if (n > 0) HIPC(c, hipMemcpyAsync(f->aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    return TLOAM_OK;
-  };
-  int rc = push(S.sphere_ring, sphere, n_sphere, S.cfg.sphere_frame_size);
-  if (rc == TLOAM_OK) rc = push(S.planar_ring, planar, n_planar, S.cfg.planar_frame_size);
-  if (rc != TLOAM_OK) return rc;
-  // :220-243 both submaps are rebuilt from submap_planar_buffer (the sphere loop iterates the PLANAR buffer)
-  size_t total = 0;
-  for (auto* f : S.planar_ring) total += f->n;
-  for (int kind : {TLOAM_KIND_SPHERE, TLOAM_KIND_PLANAR}) {
-    KindData& K = c->kd[kind];
-    const size_t m = std::max<size_t>(total, 1);
-    HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
-    size_t off = 0;
-    for (auto* f : S.planar_ring) {
-      launch_transform_to_soa(f->aos.p, f->n, f->pose, K.tx.p + off, K.ty.p + off, K.tz.p + off, c->stream);
-      off += f->n;
-    }
-    K.n_tgt = total;
-    K.tgt_set = true;
-  }
-  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
-  // :246-264 edge / ground: submap += scan->Transform(pose); Crop(pose.translation() +- L)->VoxelDownSample
-  struct Acc { int kind; const double* xyz; size_t n; double L, voxel; int slot; };
-  const Acc accs[2] = {{TLOAM_KIND_EDGE, edge, n_edge, S.cfg.edge_crop_box_length, S.cfg.edge_down_sample_submap, 0},
-                       {TLOAM_KIND_GROUND, ground, n_ground, S.cfg.ground_crop_box_length, S.cfg.ground_down_sample_submap, 1}};
-  for (const Acc& A : accs) {
-    KindData& K = c->kd[A.kind];
-    const size_t n_old = K.tgt_set ? K.n_tgt : 0, n_in = n_old + A.n, m = std::max<size_t>(n_in, 1);
-    HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
-    launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old, S.wx.p, S.wy.p, S.wz.p, c->stream);
-    rc = submap_upload(c, A.xyz, A.n);
-    if (rc != TLOAM_OK) return rc;
-    launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + n_old, S.wy.p + n_old, S.wz.p + n_old, c->stream);
-    double lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) { lo[a] = pose[12 + a] - A.L; hi[a] = pose[12 + a] + A.L; }  // :250-254, :259-262
-    HIPC(c, hipStreamSynchronize(c->stream));  // the work cloud is complete before the target buffers may be regrown
-    rc = submap_crop_voxel(c, A.kind, n_in, lo, hi, A.voxel, A.slot);
-    if (rc != TLOAM_OK) return rc;
-  }
-  size_t ne = 0, ng = 0;
-  rc = submap_finish(c, &ne, &ng);
-  if (rc != TLOAM_OK) return rc;
-  c->kd[TLOAM_KIND_EDGE].n_tgt = ne;
-  c->kd[TLOAM_KIND_GROUND].n_tgt = ng;
-  c->kd[TLOAM_KIND_EDGE].tgt_set = c->kd[TLOAM_KIND_GROUND].tgt_set = true;
-  return TLOAM_OK;
-}
-
-int tloam_get_target(tloam_ctx* c, int kind, size_t capacity, size_t* n, double* xyz) {
-  if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
-  const KindData& K = c->kd[kind];
-  *n = K.tgt_set ? K.n_tgt : 0;
-  if (*n == 0) return TLOAM_OK;
-  if (capacity < *n || !xyz) return TLOAM_E_INVALID;
-  HIPC(c, c->misc.reserve(3 * *n));
-  launch_soa_to_aos(K.tx.p, K.ty.p, K.tz.p, *n, c->misc.p, c->stream);
-  HIPC(c, hipMemcpyAsync(xyz, c->misc.p, sizeof(double) * 3 * *n, hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
-  return TLOAM_OK;
-}
-
-// ---- PCA feature extraction (feature_extract.cpp:47-122, :133-197) --------------------------------
-void tloam_feature_default_config(tloam_feature_config* cfg) {
-  if (!cfg) return;
-  cfg->radius = 0.2; cfg->K = 20; cfg->min_neigh = 10; cfg->planar_num = 500; cfg->sphere_num = 300;
-  cfg->cvr_scan = 0.25; cfg->cvr_submap = 0.15; cfg->planar_scan_thres = 0.75; cfg->planar_submap_thres = 0.65;
-  cfg->planar_vertic_thres = 0.25;
-}
-
-namespace {
-// calculatePCAInfo on the device; the per-point arrays stay in F
-int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz, size_t n, FeatBuffers& F, FeatArgs* out) {
-  if (cfg.K < 3 || cfg.K > 20 || !(cfg.radius >= 0.0)) return TLOAM_E_INVALID;  // assert(r_ >= 0.0 && K_ >= 3) :55
-  const size_t m = std::max<size_t>(n, 1);
-  HIPC(c, F.aos.reserve(3 * m)); HIPC(c, F.x.reserve(m)); HIPC(c, F.y.reserve(m)); HIPC(c, F.z.reserve(m));
-  HIPC(c, F.flatness.reserve(m)); HIPC(c, F.cvr.reserve(m)); HIPC(c, F.sphericity.reserve(m)); HIPC(c, F.normal.reserve(3 * m));
-  HIPC(c, F.num_sum.reserve(m)); HIPC(c, F.neigh.reserve(m * (size_t)cfg.K));
-  if (n > 0) {
-    HIPC(c, hipMemcpyAsync(F.aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    launch_aos_to_soa(F.aos.p, n, F.x.p, F.y.p, F.z.p, c->stream);
-  }
-  GridView views[kKinds];
-  double radii[kKinds] = {cfg.radius, 0, 0, 0};
-  CloudRef clouds[kKinds] = {{F.x.p, F.y.p, F.z.p, n}, {nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0},
-                             {nullptr, nullptr, nullptr, 0}};
-  int rc = build_grids_over(c, F.grid, radii, clouds, views);  // KDTreeFlann::SetGeometry(cloud) :57
-  if (rc != TLOAM_OK) return rc;
-  FeatArgs A;
-  A.g = views[0];
-  A.x = F.x.p; A.y = F.y.p; A.z = F.z.p;
-  A.n = (int)n;
-  A.radius = cfg.radius; A.K = cfg.K; A.min_neigh = cfg.min_neigh;
-  A.flatness = F.flatness.p; A.cvr = F.cvr.p; A.sphericity = F.sphericity.p; A.normal = F.normal.p;
-  A.num_sum = F.num_sum.p; A.neigh = F.neigh.p;
-  launch_pca_info(A, c->stream);
-  *out = A;
-  return TLOAM_OK;
-}
-}  // namespace
-
-int tloam_pca_info(tloam_ctx* c, const tloam_feature_config* cfg, const double* xyz, size_t n, double* flatness,
-                   double* cvr, double* sphericity, double* normal, int32_t* num_sum, int32_t* neigh) {
-  if (!c || !cfg || (n > 0 && !xyz) || n > (size_t)INT32_MAX) return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
-  FeatBuffers& F = c->feat;
-  FeatArgs A;
-  int rc = feature_pca(c, *cfg, xyz, n, F, &A);
-  if (rc == TLOAM_OK && n > 0) {
-    hipError_t e = hipSuccess;
-    auto get = [&](void* dst, const void* src, size_t bytes) {
-      if (dst && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
-    };
-    get(flatness, F.flatness.p, sizeof(double) * n); get(cvr, F.cvr.p, sizeof(double) * n);
-    get(sphericity, F.sphericity.p, sizeof(double) * n); get(normal, F.normal.p, sizeof(double) * 3 * n);
-    get(num_sum, F.num_sum.p, sizeof(int) * n); get(neigh, F.neigh.p, sizeof(int) * n * (size_t)cfg->K);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { c->last_error = hipGetErrorString(e); rc = TLOAM_E_HIP; }
-  }
-  (void)hipStreamSynchronize(c->stream);
-  return rc;
-}
-
-int tloam_extract_planar_sphere(tloam_ctx* c, const tloam_feature_config* cfg, const double* xyz, size_t n,
-                                int32_t* planar_scan, size_t* n_ps, int32_t* planar_submap, size_t* n_pm,
-                                int32_t* sphere_scan, size_t* n_ss, int32_t* sphere_submap, size_t* n_sm) {
-  if (!c || !cfg || (n > 0 && !xyz) || n > (size_t)INT32_MAX || !n_ps || !n_pm || !n_ss || !n_sm) return TLOAM_E_INVALID;
-  *n_ps = *n_pm = *n_ss = *n_sm = 0;
-  if (n == 0) return TLOAM_OK;  // "cloud_in_ does not contain points" (:50-53): the lists stay empty
-  if (!planar_scan || !planar_submap || !sphere_scan || !sphere_submap) return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
-  FeatBuffers& F = c->feat;
-  FeatArgs A;
-  int rc = feature_pca(c, *cfg, xyz, n, F, &A);
-  std::vector<double> pf, sf;
-  std::vector<int> pidx, sidx;
-  unsigned long long total = 0;
-  if (rc == TLOAM_OK) {
-    hipError_t e = hipSuccess;
-    if ((e = F.flags.reserve(n + 1)) == hipSuccess && (e = F.scan.reserve(n + 1)) == hipSuccess &&
-        (e = F.scan_tmp.reserve(scan_tmp_elems(n + 1))) == hipSuccess && (e = F.pf.reserve(n)) == hipSuccess &&
-        (e = F.sf.reserve(n)) == hipSuccess && (e = F.pfs.reserve(n)) == hipSuccess && (e = F.sfs.reserve(n)) == hipSuccess &&
-        (e = F.pidx.reserve(n)) == hipSuccess && (e = F.sidx.reserve(n)) == hipSuccess &&
-        (e = F.pidxs.reserve(n)) == hipSuccess && (e = F.sidxs.reserve(n)) == hipSuccess &&
-        (e = F.rank.reserve(2 * n)) == hipSuccess) {
-      const FeatSelect S{cfg->cvr_submap, cfg->planar_submap_thres, cfg->planar_vertic_thres};
-      launch_feat_select(A, S, F.flags.p, F.scan.p, F.scan_tmp.p, F.pf.p, F.pidx.p, F.sf.p, F.sidx.p, F.pfs.p, F.pidxs.p,
-                         F.sfs.p, F.sidxs.p, F.rank.p, c->stream);
-      e = hipMemcpyAsync(&total, F.scan.p + n, sizeof(total), hipMemcpyDeviceToHost, c->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-      const size_t np = (size_t)(total >> 32), ns = (size_t)(total & 0xffffffffull);
-      pf.resize(np); pidx.resize(np); sf.resize(ns); sidx.resize(ns);
-      if (e == hipSuccess && np) e = hipMemcpy(pf.data(), F.pfs.p, sizeof(double) * np, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && np) e = hipMemcpy(pidx.data(), F.pidxs.p, sizeof(int) * np, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && ns) e = hipMemcpy(sf.data(), F.sfs.p, sizeof(double) * ns, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && ns) e = hipMemcpy(sidx.data(), F.sidxs.p, sizeof(int) * ns, hipMemcpyDeviceToHost);
-    }
-    if (e != hipSuccess) { c->last_error = hipGetErrorString(e); rc = TLOAM_E_HIP; }
-  }
-  (void)hipStreamSynchronize(c->stream);
-  if (rc != TLOAM_OK) return rc;
-  // :178-190 on the ranked lists
-  for (size_t id = 0; id < pf.size(); ++id) {
-    if (id < (size_t)std::max(cfg->planar_num, 0) || pf[id] > cfg->planar_scan_thres) planar_scan[(*n_ps)++] = pidx[id];
-    planar_submap[(*n_pm)++] = pidx[id];
-  }
-  for (size_t id = 0; id < sf.size(); ++id) {  // the RANK is stored, not the point index (:186, :188)
-    if (id < (size_t)std::max(cfg->sphere_num, 0) || sf[id] > cfg->cvr_scan) sphere_scan[(*n_ss)++] = (int32_t)id;
-    sphere_submap[(*n_sm)++] = (int32_t)id;
   }
   return TLOAM_OK;
 }

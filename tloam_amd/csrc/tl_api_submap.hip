@@ -1,0 +1,207 @@
+// tl_api_submap.hip -- C ABI of the device-resident submap (include/tloam_hip.h: tloam_submap_*, tloam_get_target):
+// FrontEnd::updateSubmap (front_end.cpp:201-275) and the first-frame branch (:283-304) driven on the device
+// (kernels in tl_submap.hip).  The result is written straight into the SoA target arrays of the context.
+#include "tl_ctx.hpp"
+
+using namespace tl;
+
+extern "C" {
+
+// ---- submap maintenance on the device (front_end.cpp:201-275, :283-304) ---------------------------
+void tloam_submap_default_config(tloam_submap_config* cfg) {
+  if (!cfg) return;
+  cfg->planar_frame_size = 3;
+  cfg->sphere_frame_size = 3;
+  cfg->edge_crop_box_length = 100.0;
+  cfg->ground_crop_box_length = 100.0;
+  cfg->edge_down_sample_submap = 0.3;
+  cfg->ground_down_sample_submap = 0.45;
+  cfg->ground_down_sample = 0.3;
+}
+
+namespace {
+int submap_reserve_work(tloam_ctx* c, size_t n) {
+  SubmapState& S = c->submap;
+  const size_t m = std::max<size_t>(n, 1), cap = voxel_table_size(m);
+  HIPC(c, S.min_partial.reserve(256 * 3)); HIPC(c, S.vmin.reserve(8)); HIPC(c, S.counts.reserve(8));
+  HIPC(c, S.overflow.reserve(8));
+  HIPC(c, S.keys.reserve(cap + 1)); HIPC(c, S.cnt.reserve(cap + 1)); HIPC(c, S.off.reserve(cap + 1));
+  HIPC(c, S.slot_of_pt.reserve(m)); HIPC(c, S.urank.reserve(m)); HIPC(c, S.members.reserve(m)); HIPC(c, S.sorted.reserve(m));
+  HIPC(c, S.leader.reserve(m + 1)); HIPC(c, S.leader_scan.reserve(m + 1));
+  HIPC(c, S.scan_tmp.reserve(scan_tmp_elems(std::max(cap + 1, m + 1))));
+  return TLOAM_OK;
+}
+// target[kind] <- VoxelDownSample(Crop(cloud (wx, wy, wz)[0..n), box), voxel); the output size goes to counts[slot]
+int submap_crop_voxel(tloam_ctx* c, int kind, size_t n, const double lo[3], const double hi[3], double voxel, int slot) {
+  SubmapState& S = c->submap;
+  KindData& K = c->kd[kind];
+  int rc = submap_reserve_work(c, n);
+  if (rc != TLOAM_OK) return rc;
+  const size_t m = std::max<size_t>(n, 1);
+  HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
+  VoxelJob J;
+  J.x = S.wx.p; J.y = S.wy.p; J.z = S.wz.p;
+  J.n = n;
+  for (int a = 0; a < 3; ++a) { J.lo[a] = lo[a]; J.hi[a] = hi[a]; }
+  J.voxel = voxel;
+  J.mask = voxel_table_size(m) - 1;
+  VoxelWork W;
+  W.min_partial = S.min_partial.p; W.vmin = S.vmin.p;
+  W.keys = S.keys.p; W.cnt = S.cnt.p; W.off = S.off.p;
+  W.slot_of_pt = S.slot_of_pt.p; W.urank = S.urank.p; W.members = S.members.p; W.sorted = S.sorted.p;
+  W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
+  launch_crop_voxel(J, W, K.tx.p, K.ty.p, K.tz.p, c->stream);
+  HIPC(c, hipMemcpyAsync(S.counts.p + slot, S.leader_scan.p + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                         c->stream));
+  return TLOAM_OK;
+}
+int submap_upload(tloam_ctx* c, const double* xyz, size_t n) {  // host AoS -> in_aos (device)
+  SubmapState& S = c->submap;
+  HIPC(c, S.in_aos.reserve(3 * std::max<size_t>(n, 1)));
+  if (n > 0) HIPC(c, hipMemcpyAsync(S.in_aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  return TLOAM_OK;
+}
+int submap_finish(tloam_ctx* c, size_t* n_edge, size_t* n_ground) {  // the ONE host sync of an update
+  SubmapState& S = c->submap;
+  unsigned long long h[2] = {0, 0};
+  int ov = 0;
+  HIPC(c, hipMemcpyAsync(h, S.counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(&ov, S.overflow.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  if (ov) {
+    c->last_error = "[VoxelDownSample] voxel_size is too small.";  // PointCloud2.cpp:370-372
+    return TLOAM_E_INVALID;
+  }
+  *n_edge = (size_t)h[0];
+  *n_ground = (size_t)h[1];
+  return TLOAM_OK;
+}
+const double kNoLo[3] = {-INFINITY, -INFINITY, -INFINITY}, kNoHi[3] = {INFINITY, INFINITY, INFINITY};
+}  // namespace
+
+int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double* planar, size_t n_planar,
+                      const double* sphere, size_t n_sphere, const double* edge, size_t n_edge, const double* ground,
+                      size_t n_ground) {
+  if (!c || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
+    return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  SubmapState& S = c->submap;
+  S.release();
+  if (cfg) S.cfg = *cfg;
+  else tloam_submap_default_config(&S.cfg);
+  if (S.cfg.planar_frame_size < 1 || S.cfg.sphere_frame_size < 1 || !(S.cfg.edge_down_sample_submap > 0.0) ||
+      !(S.cfg.ground_down_sample_submap > 0.0) || !(S.cfg.ground_down_sample > 0.0))
+    return TLOAM_E_INVALID;  // "[VoxelDownSample] voxel_size <= 0." (PointCloud2.cpp:361-363)
+  // :286 / :290-291 submap += cloud on empty submaps: the clouds as given
+  int rc = tloam_set_target(c, TLOAM_KIND_EDGE, edge, n_edge);
+  if (rc == TLOAM_OK) rc = tloam_set_target(c, TLOAM_KIND_PLANAR, planar, n_planar);
+  if (rc == TLOAM_OK) rc = tloam_set_target(c, TLOAM_KIND_SPHERE, sphere, n_sphere);
+  if (rc != TLOAM_OK) return rc;
+  // :287 ground += ground->VoxelDownSample(ground_down_sample)
+  rc = submap_upload(c, ground, n_ground);
+  if (rc != TLOAM_OK) return rc;
+  const size_t m = std::max<size_t>(n_ground, 1);
+  HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
+  launch_aos_to_soa(S.in_aos.p, n_ground, S.wx.p, S.wy.p, S.wz.p, c->stream);
+  rc = submap_reserve_work(c, n_ground);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
+  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
+  rc = submap_crop_voxel(c, TLOAM_KIND_GROUND, n_ground, kNoLo, kNoHi, S.cfg.ground_down_sample, 1);
+  if (rc != TLOAM_OK) return rc;
+  size_t ne = 0, ng = 0;
+  rc = submap_finish(c, &ne, &ng);
+  if (rc != TLOAM_OK) return rc;
+  c->kd[TLOAM_KIND_GROUND].n_tgt = ng;
+  c->kd[TLOAM_KIND_GROUND].tgt_set = true;
+  S.inited = true;
+  return TLOAM_OK;
+}
+
+int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
+                        const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
+                        const double* ground, size_t n_ground) {
+  if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
+    return TLOAM_E_INVALID;
+  SubmapState& S = c->submap;
+  if (!S.inited) return TLOAM_E_NOT_READY;
+  HIPC(c, hipSetDevice(c->device));
+  // :202-218 push the frame into both buffers, keep the newest *_frame_size
+  auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep) -> int {
+    RingFrame* f = nullptr;
+    if ((int)ring.size() >= keep) {  // recycle the frame that falls out
+      f = ring.front();
+      ring.erase(ring.begin());
+      while ((int)ring.size() >= keep) { ring.front()->aos.release(); delete ring.front(); ring.erase(ring.begin()); }
+    } else {
+      f = new RingFrame();
+    }
+    ring.push_back(f);
+    f->n = n;
+    memcpy(f->pose, pose, sizeof(double) * 16);
+    HIPC(c, f->aos.reserve(3 * std::max<size_t>(n, 1)));
+    if (n > 0) HIPC(c, hipMemcpyAsync(f->aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    return TLOAM_OK;
+  };
+  int rc = push(S.sphere_ring, sphere, n_sphere, S.cfg.sphere_frame_size);
+  if (rc == TLOAM_OK) rc = push(S.planar_ring, planar, n_planar, S.cfg.planar_frame_size);
+  if (rc != TLOAM_OK) return rc;
+  // :220-243 both submaps are rebuilt from submap_planar_buffer (the sphere loop iterates the PLANAR buffer)
+  size_t total = 0;
+  for (auto* f : S.planar_ring) total += f->n;
+  for (int kind : {TLOAM_KIND_SPHERE, TLOAM_KIND_PLANAR}) {
+    KindData& K = c->kd[kind];
+    const size_t m = std::max<size_t>(total, 1);
+    HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
+    size_t off = 0;
+    for (auto* f : S.planar_ring) {
+      launch_transform_to_soa(f->aos.p, f->n, f->pose, K.tx.p + off, K.ty.p + off, K.tz.p + off, c->stream);
+      off += f->n;
+    }
+    K.n_tgt = total;
+    K.tgt_set = true;
+  }
+  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
+  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
+  // :246-264 edge / ground: submap += scan->Transform(pose); Crop(pose.translation() +- L)->VoxelDownSample
+  struct Acc { int kind; const double* xyz; size_t n; double L, voxel; int slot; };
+  const Acc accs[2] = {{TLOAM_KIND_EDGE, edge, n_edge, S.cfg.edge_crop_box_length, S.cfg.edge_down_sample_submap, 0},
+                       {TLOAM_KIND_GROUND, ground, n_ground, S.cfg.ground_crop_box_length, S.cfg.ground_down_sample_submap, 1}};
+  for (const Acc& A : accs) {
+    KindData& K = c->kd[A.kind];
+    const size_t n_old = K.tgt_set ? K.n_tgt : 0, n_in = n_old + A.n, m = std::max<size_t>(n_in, 1);
+    HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
+    launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old, S.wx.p, S.wy.p, S.wz.p, c->stream);
+    rc = submap_upload(c, A.xyz, A.n);
+    if (rc != TLOAM_OK) return rc;
+    launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + n_old, S.wy.p + n_old, S.wz.p + n_old, c->stream);
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = pose[12 + a] - A.L; hi[a] = pose[12 + a] + A.L; }  // :250-254, :259-262
+    HIPC(c, hipStreamSynchronize(c->stream));  // the work cloud is complete before the target buffers may be regrown
+    rc = submap_crop_voxel(c, A.kind, n_in, lo, hi, A.voxel, A.slot);
+    if (rc != TLOAM_OK) return rc;
+  }
+  size_t ne = 0, ng = 0;
+  rc = submap_finish(c, &ne, &ng);
+  if (rc != TLOAM_OK) return rc;
+  c->kd[TLOAM_KIND_EDGE].n_tgt = ne;
+  c->kd[TLOAM_KIND_GROUND].n_tgt = ng;
+  c->kd[TLOAM_KIND_EDGE].tgt_set = c->kd[TLOAM_KIND_GROUND].tgt_set = true;
+  return TLOAM_OK;
+}
+
+int tloam_get_target(tloam_ctx* c, int kind, size_t capacity, size_t* n, double* xyz) {
+  if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  const KindData& K = c->kd[kind];
+  *n = K.tgt_set ? K.n_tgt : 0;
+  if (*n == 0) return TLOAM_OK;
+  if (capacity < *n || !xyz) return TLOAM_E_INVALID;
+  HIPC(c, c->misc.reserve(3 * *n));
+  launch_soa_to_aos(K.tx.p, K.ty.p, K.tz.p, *n, c->misc.p, c->stream);
+  HIPC(c, hipMemcpyAsync(xyz, c->misc.p, sizeof(double) * 3 * *n, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
+}  // extern "C"

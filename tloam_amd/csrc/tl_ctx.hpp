@@ -1,0 +1,196 @@
+// tl_ctx.hpp -- host-side context of the C ABI (include/tloam_hip.h), shared by the API translation units
+// (tl_api.hip: registration path, tl_api_submap.hip: device-resident submap, tl_api_feature.hip: PCA features).
+#pragma once
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tl_common.hpp"
+
+
+namespace tlh {
+using namespace tl;
+
+
+// ------------------------------------------------------------------------------------------------
+//  grow-only device buffer
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    size_t want = std::max(n, cap + cap / 2);
+    want = (want + 63) & ~size_t(63);
+    T* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, want * sizeof(T) + 256);
+    if (e != hipSuccess) return e;
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct KindData {
+  // source (this rank's block)
+  size_t n_src_full = 0, src_lo = 0, n_src = 0;
+  DBuf<double> src_aos;
+  bool src_set = false;
+  // target as given by set_target
+  size_t n_tgt = 0;
+  DBuf<double> tgt_aos, tx, ty, tz;
+  bool tgt_set = false;
+  // view into the shared search-grid buffers built at sm_begin (the deep copy KDTreeFlann::SetGeometry
+  // makes, :898-913)
+  GridView gv{};
+  bool grid_valid = false;
+  // compact correspondence segment
+  DBuf<int> c_idx;
+  DBuf<double> c_px, c_py, c_pz, c_ax, c_ay, c_az, c_bx, c_by, c_bz, c_d, c_w, c_cost;
+  size_t c_cap = 0;
+  size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
+};
+
+struct GridBuffers {
+  DBuf<double4> gp;
+  DBuf<int> cell_start, cell_of_pt, rank_of_pt;
+  DBuf<unsigned long long> cell_cnt, cell_scan, scan_tmp;
+  DBuf<double> bbox;
+  void release() {
+    gp.release(); cell_start.release(); cell_of_pt.release(); rank_of_pt.release();
+    cell_cnt.release(); cell_scan.release(); scan_tmp.release(); bbox.release();
+  }
+};
+
+
+enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2 };
+
+// ---- device-resident submap (front_end.cpp:201-275): frame buffers + scratch of the crop/voxel pipeline ----
+struct RingFrame {
+  DBuf<double> aos;   // the frame's cloud, sensor frame, as handed over
+  size_t n = 0;
+  double pose[16];
+};
+struct SubmapState {
+  bool inited = false;
+  tloam_submap_config cfg;
+  std::vector<RingFrame*> planar_ring, sphere_ring;  // oldest first (std::deque in the reference)
+  DBuf<double> in_aos, wx, wy, wz, min_partial, vmin;
+  DBuf<unsigned long long> keys, cnt, off, leader, leader_scan, scan_tmp, counts;
+  DBuf<int> slot_of_pt, urank, members, sorted, overflow;
+  void release() {
+    for (auto* f : planar_ring) { f->aos.release(); delete f; }
+    for (auto* f : sphere_ring) { f->aos.release(); delete f; }
+    planar_ring.clear(); sphere_ring.clear();
+    in_aos.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
+    keys.release(); cnt.release(); off.release(); leader.release(); leader_scan.release(); scan_tmp.release();
+    counts.release(); slot_of_pt.release(); urank.release(); members.release(); sorted.release(); overflow.release();
+    inited = false;
+  }
+};
+
+// scratch of the PCA feature path (grow-only, kept across calls)
+struct FeatBuffers {
+  DBuf<double> aos, x, y, z, flatness, cvr, sphericity, normal, pf, sf, pfs, sfs;
+  DBuf<int> num_sum, neigh, pidx, sidx, pidxs, sidxs, rank;
+  DBuf<unsigned long long> flags, scan, scan_tmp;
+  GridBuffers grid;
+  void release() {
+    aos.release(); x.release(); y.release(); z.release(); flatness.release(); cvr.release(); sphericity.release();
+    normal.release(); pf.release(); sf.release(); pfs.release(); sfs.release(); num_sum.release(); neigh.release();
+    pidx.release(); sidx.release(); pidxs.release(); sidxs.release(); rank.release(); flags.release(); scan.release();
+    scan_tmp.release(); grid.release();
+  }
+};
+
+// up to four SoA clouds (x, y, z, n) a search grid is built over -- the registered targets, or any other cloud
+struct CloudRef { const double *x, *y, *z; size_t n; };
+}  // namespace tlh
+
+using namespace tlh;
+
+struct tloam_ctx {
+  tloam_tls_config cfg;
+  SubmapState submap;
+  FeatBuffers feat;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  KindData kd[kKinds];
+  // concatenated per-source-slot arrays of the current scan_match
+  DBuf<double> sx, sy, sz, w_src, raw;
+  DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
+  DBuf<int> tile_of_slot, tile_fill;
+  DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
+  GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
+  SlotView sv{};
+  CorrView cv{};
+  DBuf<int> seg_n;
+  DBuf<double> partials, red48, sums16, wpart, rank_counts, se3_dev, bbox_dev, misc;
+  DBuf<GnState> state;
+  GnState* h_state = nullptr;  // pinned mirror
+  double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
+  int k3_grid = 1;
+  bool k3_single = false;
+  int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
+  bool dbg_no_build_reuse = false;
+  bool dbg_no_eval_reuse = false;
+  int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
+  std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames
+  bool prebuilt = false;
+  // comm
+  int rank = 0, nranks = 1;
+  CommMode comm = COMM_NONE;
+  tloam_allreduce_fn cb = nullptr;
+  void* cb_user = nullptr;
+  void* nccl_comm = nullptr;
+  // scanMatching host state
+  bool active = false;
+  bool have_build = false;   // the compact set matches build_x
+  double build_x[6] = {0, 0, 0, 0, 0, 0};
+  int iter = 0;
+  double mu = 1.0, noise_bound_sq = 1e-4;
+  double prev_cost[kKinds], cur_cost[kKinds];
+  tloam_stats stats;
+  // K3 timing (bench roofline)
+  bool k3_timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int> ev_batch_idx;   // position of each sampled launch inside its batch (solve)
+  int batch_launches = 0;          // K3 launches enqueued since the last harvest
+  long long k3_seq = 0;            // all K3 launches of this context
+  double k3_total_us = 0.0, k3_all_us = 0.0;  // working sweeps only / every K3 launch incl. no-ops
+  int64_t k3_launches = 0, k3_all_launches = 0;
+  double k3_alg_bytes = 0.0;  // algorithmic bytes of ONE sweep over the current set
+  std::string last_error;
+};
+
+#define HIPC(ctx, expr)                                                                 \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);            \
+      return TLOAM_E_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+namespace tlh {
+// tl_api.hip
+int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
+                     tl::GridView out[tl::kKinds]);
+int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], tl::GridView out[tl::kKinds]);
+}  // namespace tlh
