@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 1
+#define TLOAM_ABI_VERSION 2  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
