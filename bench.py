@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kitti", action="store_true")
     ap.add_argument("--kitti-frames", type=int, default=200, help="length of the KITTI-density sequence block")
+    ap.add_argument("--loop-frames", type=int, default=150, help="length of the device odometry-loop block")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -218,6 +219,7 @@ def main():
             out["kitti_density"] = kitti_seq["report"]
         if not args.no_kitti and args.workload == "m1":
             out["adjacent_rows"] = adjacent_rows(args, reg, torch, local_rank)
+            out["odometry_loop"] = odometry_loop(args, reg, torch, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cfg, args, kitti_seq)
     if rank == 0:
@@ -369,6 +371,47 @@ def adjacent_rows(args, reg, torch, device):
             "feature_extract_ms": round(tf * 1e3, 4), "feature_cloud_points": int(len(cloud)),
             "feature_lists": [int(len(x)) for x in lists],
             "note": "host call to host return, incl. the upload of the per-scan clouds / the cloud and the list download"}
+
+
+def odometry_loop(args, reg, torch, device):
+    """SURVEY 8(d) config 2 in miniature: the whole inner loop of FrontEnd::updateLidarOdometry
+    (front_end.cpp:278-337) on the device over a CONSISTENT synthetic street -- per frame setInputSource (the four
+    scan clouds cross PCIe), scanMatching against the device-resident submap, updateSubmap with the pose just
+    found.  The targets never leave HBM.  Reports ms per frame and the drift against the generator's trajectory."""
+    from tloam_amd import synth_world as sw
+    nf = args.loop_frames
+    W = sw.make_world(seed=args.seed)
+    Ts = sw.trajectory(nf + 1)
+    scans = [sw.scan(W, Ts[f], args.seed, f) for f in range(nf + 1)]      # generated outside the timed loop
+    H = reg.HipRegistration(reg.default_config(), device=device)
+    s0 = scans[0]
+    H.submap_init(s0[0], s0[3], s0[2], s0[1])
+    est = [np.eye(4)]
+    ms, errs, its = [], [], 0
+    for f in range(1, nf + 1):
+        sc = scans[f]
+        pred = est[-1] @ (np.linalg.inv(est[-2]) @ est[-1] if len(est) > 1 else np.eye(4))   # front_end.cpp:329-330
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(4):
+            H.set_source(k, sc[k])
+        rc, T, st = H.scan_match(pred)
+        if rc != 0:
+            raise SystemExit(f"odometry loop frame {f}: {reg.STATUS.get(rc, rc)}")
+        H.submap_update(T, sc[0], sc[3], sc[2], sc[1])
+        ms.append((time.perf_counter() - t0) * 1e3)
+        est.append(T)
+        its += st["gn_sweeps"]
+        errs.append(float(np.linalg.norm((np.linalg.inv(T) @ Ts[f])[:3, 3])))
+    sizes = [len(H.get_target(k)) for k in range(4)]
+    H.close()
+    ms = np.array(ms[5:])                                                  # first frames: buffers still growing
+    return {"workload": "consistent synthetic street, %d frames, 0.8 m / frame; per frame: set_source x4 + scan_match "
+                        "+ submap_update (device-resident submap)" % nf,
+            "ms_per_frame": round(float(ms.mean()), 4), "ms_per_frame_p50": round(float(np.median(ms)), 4),
+            "ms_per_frame_p99": round(float(np.percentile(ms, 99)), 4), "gn_iters_per_frame": round(its / nf, 2),
+            "submap_points_end": sizes, "path_length_m": round(float(np.linalg.norm(Ts[nf][:3, 3])), 2),
+            "final_position_error_m": round(errs[-1], 4), "max_position_error_m": round(max(errs), 4)}
 
 
 def cpu_baseline(scene, cfg, args, kitti_seq=None):
