@@ -170,6 +170,8 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
   for (const Acc& A : accs) {
     KindData& K = c->kd[A.kind];
     const size_t n_old = K.tgt_set ? K.n_tgt : 0, n_in = n_old + A.n, m = std::max<size_t>(n_in, 1);
+    if (S.wx.cap < m || S.in_aos.cap < 3 * std::max<size_t>(A.n, 1))
+      HIPC(c, hipStreamSynchronize(c->stream));  // about to regrow a buffer the previous cloud's kernels may still read
     HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
     launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old, S.wx.p, S.wy.p, S.wz.p, c->stream);
     rc = submap_upload(c, A.xyz, A.n);
@@ -177,7 +179,13 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
     launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + n_old, S.wy.p + n_old, S.wz.p + n_old, c->stream);
     double lo[3], hi[3];
     for (int a = 0; a < 3; ++a) { lo[a] = pose[12 + a] - A.L; hi[a] = pose[12 + a] + A.L; }  // :250-254, :259-262
-    HIPC(c, hipStreamSynchronize(c->stream));  // the work cloud is complete before the target buffers may be regrown
+    {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
+       // only then -- in steady state the capacities suffice and the update runs without a host wait
+      const size_t m_in = std::max<size_t>(n_in, 1);
+      if (K.tx.cap < m_in || S.slot_of_pt.cap < m_in || S.keys.cap < voxel_table_size(m_in) + 1 ||
+          S.leader.cap < m_in + 1)
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
     rc = submap_crop_voxel(c, A.kind, n_in, lo, hi, A.voxel, A.slot);
     if (rc != TLOAM_OK) return rc;
   }
