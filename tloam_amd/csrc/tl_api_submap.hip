@@ -50,9 +50,8 @@ int submap_crop_voxel(tloam_ctx* c, int kind, size_t n, const double lo[3], cons
   W.keys = S.keys.p; W.cnt = S.cnt.p; W.off = S.off.p;
   W.slot_of_pt = S.slot_of_pt.p; W.urank = S.urank.p; W.members = S.members.p; W.sorted = S.sorted.p;
   W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
+  W.n_out = S.counts.p + slot;
   launch_crop_voxel(J, W, K.tx.p, K.ty.p, K.tz.p, c->stream);
-  HIPC(c, hipMemcpyAsync(S.counts.p + slot, S.leader_scan.p + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                         c->stream));
   return TLOAM_OK;
 }
 int submap_upload(tloam_ctx* c, const double* xyz, size_t n) {  // host AoS -> in_aos (device)
@@ -149,17 +148,21 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
   // :220-243 both submaps are rebuilt from submap_planar_buffer (the sphere loop iterates the PLANAR buffer)
   size_t total = 0;
   for (auto* f : S.planar_ring) total += f->n;
-  for (int kind : {TLOAM_KIND_SPHERE, TLOAM_KIND_PLANAR}) {
-    KindData& K = c->kd[kind];
+  {
+    KindData& P = c->kd[TLOAM_KIND_PLANAR];
+    KindData& Q = c->kd[TLOAM_KIND_SPHERE];
     const size_t m = std::max<size_t>(total, 1);
-    HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
+    if (P.tx.cap < m || Q.tx.cap < m) HIPC(c, hipStreamSynchronize(c->stream));  // regrowth: nothing may be in flight
+    HIPC(c, P.tx.reserve(m)); HIPC(c, P.ty.reserve(m)); HIPC(c, P.tz.reserve(m));
+    HIPC(c, Q.tx.reserve(m)); HIPC(c, Q.ty.reserve(m)); HIPC(c, Q.tz.reserve(m));
     size_t off = 0;
-    for (auto* f : S.planar_ring) {
-      launch_transform_to_soa(f->aos.p, f->n, f->pose, K.tx.p + off, K.ty.p + off, K.tz.p + off, c->stream);
+    for (auto* f : S.planar_ring) {  // one launch per buffered frame writes both submaps
+      launch_transform_to_soa2(f->aos.p, f->n, f->pose, P.tx.p + off, P.ty.p + off, P.tz.p + off, Q.tx.p + off,
+                               Q.ty.p + off, Q.tz.p + off, c->stream);
       off += f->n;
     }
-    K.n_tgt = total;
-    K.tgt_set = true;
+    P.n_tgt = Q.n_tgt = total;
+    P.tgt_set = Q.tgt_set = true;
   }
   HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
   HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));

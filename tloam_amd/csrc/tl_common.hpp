@@ -188,10 +188,13 @@ struct VoxelWork {           // scratch, sized by the caller (see voxel_table_si
   unsigned long long *leader, *leader_scan;    // [n + 1]
   unsigned long long* scan_tmp;
   int* overflow;             // set when a voxel index leaves [0, 2^21)
+  unsigned long long* n_out; // receives the size of the down-sampled cloud
 };
 size_t voxel_table_size(size_t n);
 void launch_transform_to_soa(const double* aos, size_t n, const double M[16], double* ox, double* oy, double* oz,
                              hipStream_t s);
+void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], double* ax, double* ay, double* az,
+                              double* bx, double* by, double* bz, hipStream_t s);
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s);
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);

@@ -49,6 +49,21 @@ __global__ void k_transform_to_soa(const double* __restrict__ aos, size_t n, Mat
   oz[i] = r[2] / r[3];
 }
 
+// the same transformed cloud written to TWO outputs (the sphere submap is rebuilt from the planar buffer too)
+__global__ void k_transform_to_soa2(const double* __restrict__ aos, size_t n, Mat16 M, double* __restrict__ ax,
+                                    double* __restrict__ ay, double* __restrict__ az, double* __restrict__ bx,
+                                    double* __restrict__ by, double* __restrict__ bz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+  double r[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) r[a] = ((M.m[a] * x + M.m[4 + a] * y) + M.m[8 + a] * z) + M.m[12 + a] * 1.0;
+  const double px = r[0] / r[3], py = r[1] / r[3], pz = r[2] / r[3];
+  ax[i] = px; ay[i] = py; az[i] = pz;
+  bx[i] = px; by[i] = py; bz[i] = pz;
+}
+
 __global__ void k_copy3(const double* __restrict__ ax, const double* __restrict__ ay, const double* __restrict__ az,
                         size_t n, double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,8 +84,15 @@ __device__ __forceinline__ bool in_box(const VoxelJob& J, double x, double y, do
 }
 
 // GetMinBound() of the cropped cloud, block partials
-__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][3]*/) {
+__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][3]*/,
+                                                 unsigned long long* __restrict__ keys,
+                                                 unsigned long long* __restrict__ cnt) {
   __shared__ double sm[3][256];
+  // the same launch empties the hash table of this job (keys = empty, cnt = 0 incl. the scan terminator)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= J.mask + 1; i += (size_t)gridDim.x * 256) {
+    if (i <= J.mask) keys[i] = kEmpty;
+    cnt[i] = 0ull;
+  }
   double m[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (size_t)gridDim.x * 256) {
     const double x = J.x[i], y = J.y[i], z = J.z[i];
@@ -95,11 +117,6 @@ __global__ void k_vox_min_final(const double* __restrict__ partial, int blocks, 
   for (int b = 0; b < blocks; ++b) m = fmin(m, partial[b * 3 + a]);
   if (!(m < __builtin_inf())) m = 0.0;
   vmin[a] = m - voxel * 0.5;
-}
-
-__global__ void k_fill_u64(unsigned long long* p, size_t n, unsigned long long v) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
 }
 
 // voxel of every in-box point -> hash slot; the counting atomic also hands out an (arbitrary) member rank
@@ -168,8 +185,9 @@ __global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, const int* _
                                                         const int* __restrict__ sorted,
                                                         const unsigned long long* __restrict__ leader_scan,
                                                         double* __restrict__ ox, double* __restrict__ oy,
-                                                        double* __restrict__ oz) {
+                                                        double* __restrict__ oz, unsigned long long* __restrict__ n_out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *n_out = leader_scan[J.n];  // number of voxels = size of the down-sampled cloud
   if (i >= J.n) return;
   const int h = slot_of_pt[i];
   if (h < 0) return;
@@ -196,6 +214,13 @@ void launch_transform_to_soa(const double* aos, size_t n, const double M[16], do
   for (int i = 0; i < 16; ++i) m.m[i] = M[i];
   hipLaunchKernelGGL(k_transform_to_soa, dim3(blocks_for(n)), dim3(256), 0, s, aos, n, m, ox, oy, oz);
 }
+void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], double* ax, double* ay, double* az,
+                              double* bx, double* by, double* bz, hipStream_t s) {
+  if (n == 0) return;
+  Mat16 m;
+  for (int i = 0; i < 16; ++i) m.m[i] = M[i];
+  hipLaunchKernelGGL(k_transform_to_soa2, dim3(blocks_for(n)), dim3(256), 0, s, aos, n, m, ax, ay, az, bx, by, bz);
+}
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s) {
   if (n == 0) return;
@@ -217,11 +242,9 @@ size_t voxel_table_size(size_t n) {
 void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s) {
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
-  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial);
+  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt);
   hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(64), 0, s, W.min_partial, kMinBlocks, J.voxel, W.vmin);
   const size_t cap = (size_t)J.mask + 1;
-  hipLaunchKernelGGL(k_fill_u64, dim3(blocks_for(cap)), dim3(256), 0, s, W.keys, cap, kEmpty);
-  (void)hipMemsetAsync(W.cnt, 0, sizeof(unsigned long long) * (cap + 1), s);
   if (n > 0)
     hipLaunchKernelGGL(k_vox_insert, dim3(blocks_for(n)), dim3(256), 0, s, J, W.vmin, W.keys, W.cnt, W.slot_of_pt,
                        W.urank, W.overflow);
@@ -231,9 +254,8 @@ void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double
   hipLaunchKernelGGL(k_vox_order, dim3(blocks_for(n + 1)), dim3(256), 0, s, n, W.slot_of_pt, W.off, W.cnt, W.members,
                      W.sorted, W.leader);
   launch_exclusive_scan_u64(W.leader, W.leader_scan, n + 1, W.scan_tmp, s);
-  if (n > 0)
-    hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n)), dim3(256), 0, s, J, W.slot_of_pt, W.off, W.cnt, W.sorted,
-                       W.leader_scan, ox, oy, oz);
+  hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n + 1)), dim3(256), 0, s, J, W.slot_of_pt, W.off, W.cnt, W.sorted,
+                     W.leader_scan, ox, oy, oz, W.n_out);
 }
 
 }  // namespace tl
