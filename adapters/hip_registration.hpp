@@ -22,8 +22,10 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <utility>
+#include <vector>
 
 #include "../include/tloam_hip.h"
 
@@ -98,6 +100,29 @@ class HipRegistrationCore {
                                           Acc::data(*edge_scan), Acc::size(*edge_scan), Acc::data(*ground_scan),
                                           Acc::size(*ground_scan)),
                       "tloam_submap_update", ctx_);
+  }
+
+  // ---- PCA feature extraction (optional; featureExtract::extractPlanarSphere, feature_extract.cpp:133-197): the four
+  //      index vectors of the reference's signature, filled from the device lists.
+  template <class Cloud>
+  bool extractPlanarSphere(const tloam_feature_config& cfg, const Cloud& cloud, std::vector<std::size_t>& planar_scan_index,
+                           std::vector<std::size_t>& planar_submap_index, std::vector<std::size_t>& sphere_scan_index,
+                           std::vector<std::size_t>& sphere_submap_index) {
+    if (!ctx_) return false;
+    using Acc = PointsAccessor<Cloud>;
+    const std::size_t n = Acc::size(cloud);
+    std::vector<std::int32_t> buf(4 * (n ? n : 1));
+    std::size_t cnt[4] = {0, 0, 0, 0};
+    const int rc = tloam_extract_planar_sphere(ctx_, &cfg, Acc::data(cloud), n, buf.data(), &cnt[0], buf.data() + n, &cnt[1],
+                                               buf.data() + 2 * n, &cnt[2], buf.data() + 3 * n, &cnt[3]);
+    if (!ok(rc, "tloam_extract_planar_sphere", ctx_)) return false;
+    std::vector<std::size_t>* out[4] = {&planar_scan_index, &planar_submap_index, &sphere_scan_index, &sphere_submap_index};
+    for (int l = 0; l < 4; ++l) {
+      out[l]->clear();  // the reference appends to vectors it has just swapped empty (front_end.cpp:299-302)
+      out[l]->reserve(cnt[l]);
+      for (std::size_t i = 0; i < cnt[l]; ++i) out[l]->push_back(static_cast<std::size_t>(buf[l * n + i]));
+    }
+    return true;
   }
 
   std::pair<double, double> getFitnessScore() {

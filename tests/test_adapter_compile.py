@@ -41,10 +41,14 @@ int main() {
   tloam_submap_config scfg; tloam_submap_default_config(&scfg);
   const bool s0 = reg.submapInit(scfg, f.planar_feature, f.sphere_feature, f.edge_feature, f.ground_feature);
   const bool s1 = reg.submapUpdate(pred, f.planar_feature, f.sphere_feature, f.edge_feature, f.ground_feature);
-  std::printf("gpu=%d set=%d,%d match=%d fitness=%g submap=%d,%d\n", (int)have_gpu, (int)a, (int)b, (int)c, fit.first,
-              (int)s0, (int)s1);
+  // ... and the PCA feature extraction fills the reference's four index vectors
+  tloam_feature_config fcfg; tloam_feature_default_config(&fcfg);
+  std::vector<std::size_t> ps, pm, ss, sm;
+  const bool e0 = reg.extractPlanarSphere(fcfg, *f.planar_feature, ps, pm, ss, sm);
+  std::printf("gpu=%d set=%d,%d match=%d fitness=%g submap=%d,%d feature=%d\n", (int)have_gpu, (int)a, (int)b, (int)c,
+              fit.first, (int)s0, (int)s1, (int)e0);
   // without a device every call must report failure (no CPU fallback); with one they must all succeed
-  return (have_gpu ? (a && b && c && s0 && s1) : (!a && !b && !c && !s0 && !s1)) ? 0 : 1;
+  return (have_gpu ? (a && b && c && s0 && s1 && e0) : (!a && !b && !c && !s0 && !s1 && !e0)) ? 0 : 1;
 }
 '''
 
