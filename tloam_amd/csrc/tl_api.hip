@@ -258,6 +258,37 @@ int harvest_k3_events(tloam_ctx* c, int working) {
   return TLOAM_OK;
 }
 
+// Result of an outer iteration on the host.  With the mirror the finish kernel has been handed
+// {pinned state, sequence number}: poll the number (a word in host memory the device writes last); the stream
+// is only queried now and then, to notice a failed launch instead of spinning forever.  Otherwise, or if the
+// stream drained without the number arriving, copy the state and synchronise.
+HostMirror next_mirror(tloam_ctx* c) {
+  HostMirror hm;
+  hm.out = c->h_state_dev;
+  hm.seq = hm.out ? ++c->mirror_seq : 0ull;
+  return hm;
+}
+int wait_state(tloam_ctx* c, const HostMirror& hm) {
+  if (hm.out) {
+    const unsigned long long* p = &c->h_state->host_seq;
+    for (unsigned spins = 1;; ++spins) {
+      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == hm.seq) return TLOAM_OK;
+      if ((spins & 0x7ffu) == 0) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) {
+          if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == hm.seq) return TLOAM_OK;
+          break;  // drained, nothing arrived: read it the slow way
+        }
+        if (e != hipErrorNotReady) HIPC(c, e);
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
 // one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
@@ -356,10 +387,16 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostMalloc((void**)&c->h_small, sizeof(double) * 4096, hipHostMallocDefault) != hipSuccess) {
     delete c;
     return TLOAM_E_HIP;
+  }
+  memset(c->h_state, 0, sizeof(GnState));
+  c->no_host_mirror = getenv("TLOAM_NO_HOST_MIRROR") != nullptr;
+  if (!c->no_host_mirror && hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    c->h_state_dev = nullptr;  // no device view of the pinned state: fall back to copy + synchronise
   }
   if (ensure_common(c) != TLOAM_OK) { tloam_destroy(c); return TLOAM_E_HIP; }
   (void)hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream);
@@ -509,6 +546,14 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
     for (int i = 0; i < 6; ++i) fi.x[i] = x[i];
     fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
+    {
+      GridView gviews[kKinds];
+      for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
+      const size_t ntiles = (size_t)build_tile_count(gviews);
+      HIPC(c, c->tile_cnt.reserve(ntiles + 1));
+      fi.tile_cnt = c->tile_cnt.p;
+      fi.n_tile_cnt = (int)ntiles + 1;
+    }
     launch_frame_init(fi, c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p, c->stream);
   }
   c->mu = 1.0;  // :961
@@ -571,7 +616,9 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
       if (rc != TLOAM_OK) return rc;
       rank_counts = c->rank_counts.p;
     }
-    HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
+    // seg_n: every kind with slots and a positive cap is rewritten by the compaction, the others keep the 0 of
+    // k_frame_init; only a sharded rank can find its cap already filled by the lower ranks and write nothing
+    if (c->nranks > 1) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
     launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->stream);
     memcpy(c->build_x, c->stats.se3, sizeof(c->build_x));
     c->have_build = true;
@@ -615,21 +662,22 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   }
   const int sweeps_before = c->stats.gn_sweeps;
   for (int attempt = 0;; ++attempt) {
+    const HostMirror hm = next_mirror(c);
     if (c->nranks == 1 && small_set) {
-      launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, c->stream);
+      launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, hm, c->stream);
     } else {
     launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
     if (c->nranks > 1) {
-      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, c->stream);
+      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, hm, c->stream);
       rc = allreduce(c, c->sums16.p, 16);
       if (rc != TLOAM_OK) return rc;
-      launch_outer_publish(c->sums16.p, c->state.p, c->stream);
+      launch_outer_publish(c->sums16.p, c->state.p, hm, c->stream);
     } else {
-      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, c->stream);  // + publish + re-arm
+      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, hm, c->stream);  // + publish + re-arm
     }
     }
-    HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    rc = wait_state(c, hm);
+    if (rc != TLOAM_OK) return rc;
     if (!c->h_state->incomplete) break;
     if (attempt > 0 || planned >= kSolveSweeps) {
       c->last_error = "the minimiser did not terminate within its evaluation budget";

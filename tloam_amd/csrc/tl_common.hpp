@@ -104,6 +104,14 @@ struct GnState {
   int pad2;
   double kind_cost[kKinds];
   double dbg[8];  // phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
+  unsigned long long host_seq;  // LAST member: sequence number of the host mirror (see HostMirror)
+};
+// End of an outer iteration: the finish kernel copies the state into pinned host memory and then stores the
+// sequence number, so the host reads the result by polling one word instead of paying a copy kernel plus a
+// stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).  out == nullptr: off.
+struct HostMirror {
+  GnState* out;
+  unsigned long long seq;
 };
 
 // ---- host-callable launchers (defined in tl_nn.hip / tl_gn.hip) ------------------------------
@@ -152,6 +160,8 @@ struct FrameInit {
   int slot_off[kKinds + 1];
   double x[6];
   int no_eval_reuse;  // development knob, copied into the state
+  unsigned long long* tile_cnt;  // query-tile histogram of the first builder pass, zeroed here (n_tile_cnt entries)
+  int n_tile_cnt;
 };
 void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, double* w_src,
                        unsigned long long* flags, GnState* st, int* seg_n, hipStream_t s);
@@ -235,11 +245,11 @@ struct WeightParams {
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
                     int blocks, const GnState* st, hipStream_t s);
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
-                         double* sums8, hipStream_t s);
-void launch_outer_publish(const double* sums8, GnState* st, hipStream_t s);
+                         double* sums8, HostMirror hm, hipStream_t s);
+void launch_outer_publish(const double* sums8, GnState* st, HostMirror hm, hipStream_t s);
 // weights + finish in one launch for small single-rank sets
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
-                                 double* sums16, GnState* st, hipStream_t s);
+                                 double* sums16, GnState* st, HostMirror hm, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
 
 }  // namespace tl

@@ -149,6 +149,9 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
+  bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
+  tl::GnState* h_state_dev = nullptr;   // device address of the pinned host state (HostMirror target)
+  unsigned long long mirror_seq = 0;
   int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
   std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames
   bool prebuilt = false;

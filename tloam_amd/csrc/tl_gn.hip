@@ -969,6 +969,7 @@ __global__ __launch_bounds__(256) void k_frame_init(FrameInit fi, double* __rest
     sx[slot] = a[0]; sy[slot] = a[1]; sz[slot] = a[2];
     w_src[slot] = 1.0;
   }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < fi.n_tile_cnt; i += gridDim.x * 256) fi.tile_cnt[i] = 0ull;
   if (blockIdx.x == 0) {
     constexpr int kWords = (int)(sizeof(GnState) / sizeof(double));
     for (int i = threadIdx.x; i < kWords; i += 256) reinterpret_cast<double*>(st)[i] = 0.0;
@@ -1098,6 +1099,19 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 // One lane per partial row (blocks == 64), fixed shuffle tree.
 // publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
 // (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
+// Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
+// state writes are done: words first, system-scope fence, then the sequence number.
+__device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads) {
+  if (!hm.out) return;
+  __syncthreads();
+  constexpr int kWords = (int)(sizeof(GnState) / 8) - 1;  // everything but host_seq
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(st);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(hm.out);
+  for (int i = tid; i < kWords; i += nthreads) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&hm.out->host_seq, hm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t) {
   if (t < 4) {
     st->kind_cost[t] = sums16[t];
@@ -1111,11 +1125,12 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
 }
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
                                                      const int* __restrict__ seg_n, double* __restrict__ sums16,
-                                                     GnState* st_or_null, GnState* gate) {
+                                                     GnState* st_or_null, GnState* gate, HostMirror hm) {
   __shared__ double sh[16];
   const int t = threadIdx.x;
   if (!gate->done) {  // the Solve is still running: nothing to finish yet (see k_weights)
     if (t == 0) gate->incomplete = 1;
+    if (st_or_null) mirror_to_host(gate, hm, t, 64);
     return;
   }
   double v[5] = {0, 0, 0, 0, 0};
@@ -1137,18 +1152,22 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
   if (t >= 4 && t < 8) sh[t] = (double)seg_n[t - 4];
   __syncthreads();
   if (t < 16) sums16[t] = sh[t];
-  if (st_or_null) publish_and_rearm(sh, st_or_null, t);  // single rank: no exchange in between
+  if (st_or_null) {  // single rank: no exchange in between
+    publish_and_rearm(sh, st_or_null, t);
+    mirror_to_host(st_or_null, hm, t, 64);
+  }
 }
 // Small sets on one rank (KITTI caps: <= 5.9 k factors): weight update, cost sums, publish and re-arm in ONE
 // launch of one 1024-thread block -- the frame is a chain of launch-latency-bound kernels, every boundary
 // removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
 // folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
 __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, const int* __restrict__ seg_n,
-                                                               double* __restrict__ sums16, GnState* st) {
+                                                               double* __restrict__ sums16, GnState* st, HostMirror hm) {
   __shared__ double red[16][8];
   __shared__ double sh[16];
   if (!st->done) {  // gate, see k_weights
     if (threadIdx.x == 0) st->incomplete = 1;
+    mirror_to_host(st, hm, threadIdx.x, 1024);
     return;
   }
   double sum[kKinds] = {0, 0, 0, 0};
@@ -1192,25 +1211,26 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
   __syncthreads();
   if (threadIdx.x < 16) sums16[threadIdx.x] = sh[threadIdx.x];
   if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x);
+  mirror_to_host(st, hm, threadIdx.x, 1024);
 }
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
-                                 double* sums16, GnState* st, hipStream_t s) {
+                                 double* sums16, GnState* st, HostMirror hm, hipStream_t s) {
   WeightArgs A;
   A.cv = cv;
   A.sv = sv;
   A.wp = wp;
-  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st);
+  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st, hm);
 }
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
-                         double* sums16, hipStream_t s) {
-  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate);
+                         double* sums16, HostMirror hm, hipStream_t s) {
+  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate, hm);
 }
-__global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st) {
-  if (!st->done) return;  // gated like k_outer_finish (which raised st->incomplete)
-  publish_and_rearm(sums16, st, threadIdx.x);
+__global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st, HostMirror hm) {
+  if (st->done) publish_and_rearm(sums16, st, threadIdx.x);  // gated like k_outer_finish (which raised st->incomplete)
+  mirror_to_host(st, hm, threadIdx.x, 64);
 }
-void launch_outer_publish(const double* sums16, GnState* st, hipStream_t s) {
-  hipLaunchKernelGGL(k_outer_publish, dim3(1), dim3(64), 0, s, sums16, st);
+void launch_outer_publish(const double* sums16, GnState* st, HostMirror hm, hipStream_t s) {
+  hipLaunchKernelGGL(k_outer_publish, dim3(1), dim3(64), 0, s, sums16, st, hm);
 }
 
 // PointCloud2::Transform (open3d PointCloud2.cpp:71-75): p <- (M * (p,1)).hnormalized()

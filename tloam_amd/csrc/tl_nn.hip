@@ -676,7 +676,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     // The processing ORDER only buys locality -- every query still searches its own exact 27 cells --
     // so the tile sort is done once per frame (first outer iteration, predicted pose) and reused while
     // the pose moves by centimetres.
-    (void)hipMemsetAsync(tile_cnt, 0, sizeof(unsigned long long) * (size_t)(ntiles + 1), s);
+    // (tile_cnt[0 .. ntiles] was zeroed by k_frame_init -- one launch less at the start of every frame)
     hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
     launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
     hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
