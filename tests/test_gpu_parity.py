@@ -202,3 +202,51 @@ def test_sweep_budget_top_up_is_exact(hip_module, monkeypatch, planned):
     for k in range(4):
         assert np.array_equal(H1.get_weights(k), H2.get_weights(k))
     H1.close(); H2.close()
+
+
+def _frame_fingerprint(H, T, st):
+    out = {"T": T, "stats": {k: st[k] for k in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps",
+                                                "outer_iterations", "converged_early", "kind_cost", "se3", "mu",
+                                                "solver_cost")}}
+    for k in range(4):
+        cs = H.get_correspondences(k)
+        out[f"idx{k}"], out[f"w{k}"], out[f"cost{k}"] = cs["idx"], cs["w"], cs["cost"]
+        out[f"wsrc{k}"] = H.get_weights(k)
+    return out
+
+
+def _assert_same_frame(f1, f2):
+    assert np.array_equal(f1["T"], f2["T"])
+    for k, v in f1["stats"].items():
+        assert np.array_equal(np.asarray(v), np.asarray(f2["stats"][k])), k
+    for k in f1:
+        if k not in ("T", "stats"):
+            assert np.array_equal(f1[k], f2[k]), k
+
+
+@pytest.mark.parametrize("shape", ["small", "kitti"])
+@pytest.mark.parametrize("knob", ["TLOAM_NO_HOST_MIRROR"])
+def test_host_mirror_is_exact(hip_module, monkeypatch, shape, knob):
+    """The finish kernel of an outer iteration mirrors the minimiser state into pinned host memory, which the host
+    polls instead of paying a copy + stream synchronisation.  Switching it off (development knob, read when the
+    context is created) must not change a single bit."""
+    if shape == "small":
+        sc = synth.make_scene(seed=21, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    else:   # reference caps binding (2500 / 2000 / 1200 / 200 of 3000 / 4000 / 2000 / 400 candidates)
+        sc = synth.make_scene(seed=22, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
+    H1 = hip_module.HipRegistration()
+    H1.set_frames(sc.source, sc.target)
+    frames = []
+    for rep in range(3):   # repeated frames: the sequence number advances, the results must not move
+        rc1, T1, st1 = H1.scan_match(sc.T_pred)
+        assert rc1 == 0
+        frames.append(_frame_fingerprint(H1, T1, st1))
+    _assert_same_frame(frames[0], frames[1]); _assert_same_frame(frames[0], frames[2])
+    monkeypatch.setenv(knob, "1")
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    rc2, T2, st2 = H2.scan_match(sc.T_pred)
+    assert rc2 == 0
+    _assert_same_frame(frames[0], _frame_fingerprint(H2, T2, st2))
+    assert st1["gn_sweeps"] >= 4 and st1["outer_iterations"] >= 2
+    H1.close(); H2.close()
