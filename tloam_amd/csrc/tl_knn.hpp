@@ -87,6 +87,68 @@ __device__ __forceinline__ bool topk_insert_fast(TopK<K>& tk, double d, int j) {
   }
   return tie;
 }
+// ------------------------------------------------------------------------------------------------
+// Packed-key list (the hot loops of K1): the candidate's position j in the cell-sorted records replaces the low
+// `bits` mantissa bits of its squared distance, so ONE double carries (distance, position) and a sorted
+// insertion is a v_min_f64 / v_max_f64 pair per level -- 2 VALU ops where the (distance, index) list needs 8.
+// The key orders by the distance TRUNCATED to 52 - bits mantissa bits, then by position: that is the exact
+// (distance, original index) order unless two of the kept entries (K + 1 are kept: the boundary entry too)
+// share a truncated distance -- detected afterwards on adjacent pairs, and such a query is redone with the
+// exact insertion.  +inf = empty slot / masked candidate (min/max leave it at the tail).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct KeyList {
+  double k[N];
+};
+template <int N>
+__device__ __forceinline__ void keys_clear(KeyList<N>& L) {
+#pragma unroll
+  for (int m = 0; m < N; ++m) L.k[m] = __builtin_inf();
+}
+__device__ __forceinline__ int key_bits_for(int n) {  // positions 0 .. n-1
+  return n > 1 ? 32 - __clz(n - 1) : 1;
+}
+__device__ __forceinline__ double key_pack(double d, int j, unsigned keep_mask) {  // d >= 0 or +inf (then j == 0)
+  const unsigned lo = ((unsigned)__double2loint(d) & keep_mask) | (unsigned)j;
+  return __hiloint2double(__double2hiint(d), (int)lo);
+}
+template <int N>
+__device__ __forceinline__ void key_insert(KeyList<N>& L, double key) {
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    const double lo = __builtin_fmin(L.k[m], key);
+    key = __builtin_fmax(L.k[m], key);
+    L.k[m] = lo;
+  }
+}
+// true: two kept entries share a truncated distance (or the list cannot be trusted): redo exactly
+template <int N>
+__device__ __forceinline__ bool keys_ambiguous(const KeyList<N>& L, unsigned keep_mask) {
+  bool amb = false;
+#pragma unroll
+  for (int m = 0; m + 1 < N; ++m) {
+    const bool both = L.k[m + 1] < __builtin_inf();
+    const bool same = __double2hiint(L.k[m]) == __double2hiint(L.k[m + 1]) &&
+                      (((unsigned)__double2loint(L.k[m]) ^ (unsigned)__double2loint(L.k[m + 1])) & keep_mask) == 0u;
+    amb |= both && same;
+  }
+  return amb;
+}
+// the first K entries as a (distance, position) list: the distance is recomputed from the record, exactly as
+// the scan computed it before truncation
+template <int K, int N>
+__device__ __forceinline__ void keys_unpack(const KeyList<N>& L, const PtsGlobal& pts, double qx, double qy, double qz,
+                                            unsigned keep_mask, TopK<K>& tk) {
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const bool have = L.k[m] < __builtin_inf();
+    const int j = have ? (int)((unsigned)__double2loint(L.k[m]) & ~keep_mask) : 0;
+    const double4 p = pts.p[j];
+    tk.d[m] = have ? sqdist(qx, qy, qz, p.x, p.y, p.z) : __builtin_inf();
+    tk.j[m] = have ? j : -1;
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void topk_clear(TopK<K>& tk) {
 #pragma unroll

@@ -508,14 +508,21 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
   if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
   constexpr int NR = (9 + LPQ - 1) / LPQ;  // rows per lane
   int rs[NR], re[NR];
+  // The row's two table entries (start of cell x0, end of cell x1) are at most three ints apart: ONE 16-byte
+  // request per row instead of two 4-byte ones -- K1 is bound by the number of scattered requests the CU's
+  // address unit retires (~55 per query), not by bytes.  (Reads up to 12 bytes past the last entry of the
+  // table: inside the allocation slack of DBuf.)
+  typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int span = x1 + 1 - x0;  // 1 .. 3 (<= 0: no cell in range)
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int r = sub + i * LPQ;
     const int z = cz - 1 + r / 3, y = cy - 1 + r % 3;
     const bool in = (r < 9) && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
-    const size_t base = in ? ((size_t)z * g.dim[1] + y) * g.dim[0] : 0;
-    rs[i] = in ? g.cell_start[base + x0] : 0;
-    re[i] = in ? g.cell_start[base + x1 + 1] : 0;
+    const size_t base = in ? ((size_t)z * g.dim[1] + y) * g.dim[0] + x0 : 0;
+    const int4u t = *reinterpret_cast<const int4u*>(g.cell_start + base);
+    rs[i] = in ? t.x : 0;
+    re[i] = in ? (span == 3 ? t.w : (span == 2 ? t.z : t.y)) : 0;
   }
   topk_clear<K>(tk);
   if (LPQ == 1) {
@@ -538,8 +545,10 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     int2 nx = (nr > 0) ? lds_rows[lane] : int2{0, 0};  // next row, pre-loaded
     // (ballot, not a shuffle reduction: the kinds of a wave's lanes may differ, and only a ballot is
     //  well-defined under the divergent kind branch)
-    bool tie = false;
-    const double nan = __builtin_nan("");
+    const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
+    KeyList<K + 1> L;
+    keys_clear<K + 1>(L);
+    const double inf = __builtin_inf();
     // next position of this lane's candidate stream (index 0 = a harmless in-range dummy when exhausted)
     auto next = [&](int& jx, bool& vx) {
       if (j >= e && r < nr) { j = nx.x; e = nx.y; ++r; nx = lds_rows[(r < nr ? r : 0) * 64 + lane]; }
@@ -547,24 +556,40 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
       jx = vx ? j : 0;
       j += vx ? 1 : 0;
     };
-    int ja, jb;
-    bool va, vb;
-    next(ja, va);
-    next(jb, vb);
-    double4 a = pts.p[ja], b = pts.p[jb];
-    for (int left = total; __any(left > 0); left -= 2) {
-      // software pipeline: the records of the NEXT trip are requested before this trip's two insertions
-      int ja2, jb2;
-      bool va2, vb2;
-      next(ja2, va2);
-      next(jb2, vb2);
-      const double4 a2 = pts.p[ja2], b2 = pts.p[jb2];
-      const double da = sqdist(pw.x, pw.y, pw.z, a.x, a.y, a.z), db = sqdist(pw.x, pw.y, pw.z, b.x, b.y, b.z);
-      tie |= topk_insert_fast<K>(tk, va ? da : nan, ja);
-      tie |= topk_insert_fast<K>(tk, vb ? db : nan, jb);
-      a = a2; b = b2; ja = ja2; jb = jb2; va = va2; vb = vb2;
+    // kCpt candidates per trip, and the records of the NEXT trip requested before this trip's insertions: with
+    // the two-instruction key insertion the walk is bound by the record round trips (PMC: 53 % of the wave
+    // cycles waiting on memory at two records in flight), so the trip carries as many independent loads as the
+    // register budget allows.
+#ifndef TLOAM_K1_CPT
+#define TLOAM_K1_CPT 4
+#endif
+    constexpr int kCpt = TLOAM_K1_CPT;
+    int jc[kCpt];
+    bool vc[kCpt];
+    double4 rc[kCpt];
+#pragma unroll
+    for (int u = 0; u < kCpt; ++u) next(jc[u], vc[u]);
+#pragma unroll
+    for (int u = 0; u < kCpt; ++u) rc[u] = pts.p[jc[u]];
+    for (int left = total; __any(left > 0); left -= kCpt) {
+      int jn[kCpt];
+      bool vn[kCpt];
+      double4 rn[kCpt];
+#pragma unroll
+      for (int u = 0; u < kCpt; ++u) next(jn[u], vn[u]);
+#pragma unroll
+      for (int u = 0; u < kCpt; ++u) rn[u] = pts.p[jn[u]];
+#pragma unroll
+      for (int u = 0; u < kCpt; ++u) {
+        const double du = sqdist(pw.x, pw.y, pw.z, rc[u].x, rc[u].y, rc[u].z);
+        key_insert<K + 1>(L, key_pack(vc[u] ? du : inf, jc[u], keep_mask));  // (jc == 0 when masked)
+      }
+#pragma unroll
+      for (int u = 0; u < kCpt; ++u) { jc[u] = jn[u]; vc[u] = vn[u]; rc[u] = rn[u]; }
     }
-    if (tie) {  // bit-equal distances met: redo this query with the exact (d, original index) order
+    if (!keys_ambiguous<K + 1>(L, keep_mask)) {
+      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
+    } else {  // two kept distances agree in every mantissa bit the key keeps: redo with the exact (d, original index) order
       topk_clear<K>(tk);
       for (int q = 0; q < nr; ++q) {
         const int2 v = lds_rows[q * 64 + lane];
@@ -572,6 +597,10 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
       }
     }
   } else {
+    const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
+    const double inf = __builtin_inf();
+    KeyList<K + 1> L;
+    keys_clear<K + 1>(L);
     int len = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) len = max(len, re[i] - rs[i]);
@@ -580,20 +609,44 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #pragma unroll
       for (int i = 0; i < NR; ++i) c[i] = pts.p[(rs[i] + s < re[i]) ? rs[i] + s : 0];
 #pragma unroll
-      for (int i = 0; i < NR; ++i)
-        if (rs[i] + s < re[i])
-          topk_insert<K, PtsGlobal>(tk, pts, sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z), rs[i] + s);
+      for (int i = 0; i < NR; ++i) {
+        const bool v = rs[i] + s < re[i];
+        key_insert<K + 1>(L, key_pack(v ? sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z) : inf, v ? rs[i] + s : 0,
+                                      keep_mask));
+      }
     }
-    // merge across the quad: after xor-1 and xor-2 every lane holds the exact global top-k
+    // merge across the quad: after xor-1 and xor-2 every lane holds the global list (the lanes' candidate
+    // sets are disjoint, +inf entries fall through)
 #pragma unroll
     for (int x = 1; x < LPQ; x <<= 1) {
-      double od[K];
-      int oj[K];
+      double ok[K + 1];
 #pragma unroll
-      for (int m = 0; m < K; ++m) { od[m] = __shfl_xor(tk.d[m], x, 64); oj[m] = __shfl_xor(tk.j[m], x, 64); }
+      for (int m = 0; m < K + 1; ++m) ok[m] = __shfl_xor(L.k[m], x, 64);
 #pragma unroll
-      for (int m = 0; m < K; ++m)
-        if (oj[m] >= 0) topk_insert<K, PtsGlobal>(tk, pts, od[m], oj[m]);
+      for (int m = 0; m < K + 1; ++m) key_insert<K + 1>(L, ok[m]);
+    }
+    if (!keys_ambiguous<K + 1>(L, keep_mask)) {  // (the same verdict on all lanes of the quad)
+      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
+    } else {  // redo with the exact (d, original index) order
+      for (int s = 0; s < len; ++s) {
+        double4 c[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) c[i] = pts.p[(rs[i] + s < re[i]) ? rs[i] + s : 0];
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          if (rs[i] + s < re[i])
+            topk_insert<K, PtsGlobal>(tk, pts, sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z), rs[i] + s);
+      }
+#pragma unroll
+      for (int x = 1; x < LPQ; x <<= 1) {
+        double od[K];
+        int oj[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) { od[m] = __shfl_xor(tk.d[m], x, 64); oj[m] = __shfl_xor(tk.j[m], x, 64); }
+#pragma unroll
+        for (int m = 0; m < K; ++m)
+          if (oj[m] >= 0) topk_insert<K, PtsGlobal>(tk, pts, od[m], oj[m]);
+      }
     }
   }
 }
