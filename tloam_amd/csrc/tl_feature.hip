@@ -6,7 +6,7 @@
 //   featureExtract::extractPlanarSphere  src/models/feature_extraction/feature_extract.cpp:133-197 (selection +
 //                                        ranking; the final rank/threshold loops :178-190 run on the host)
 // with the machinery of K1/K2: the uniform grid (cell >= radius), the exact (distance, index)-ordered top-K
-// list -- K = 20 here -- and the cyclic-Jacobi 3x3 eigen solve.  Compiled with -ffp-contract=off.
+// list -- K = 20 here, walked with packed keys (tl_knn.hpp) -- and the cyclic-Jacobi 3x3 eigen solve.  Compiled with -ffp-contract=off.
 #include "tl_common.hpp"
 #include "tl_knn.hpp"
 
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void k_pca_info(FeatArgs A) {
   int num = 0;
   const double qx = A.x[i], qy = A.y[i], qz = A.z[i];
   TopK<kFeatK> tk;
-  knn_grid<kFeatK>(A.g, qx, qy, qz, tk);
+  knn_grid_fast<kFeatK>(A.g, qx, qy, qz, tk);
   // SearchHybrid(cur_pt, r, K): the K nearest (K <= 20: a prefix of the sorted list), then the radius cut (:71)
   const double r2 = A.radius * A.radius;
   int cnt = 0;

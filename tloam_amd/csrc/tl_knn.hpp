@@ -199,6 +199,42 @@ __device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy
   }
 }
 
+// knn_grid with the packed-key list in the walk (2 VALU ops per list level instead of ~9: K = 20 in the PCA
+// feature extraction); a query whose kept entries are ambiguous under the truncated order is redone exactly.
+template <int K>
+__device__ __forceinline__ void knn_grid_fast(const GridView& g, double qx, double qy, double qz, TopK<K>& tk) {
+  topk_clear<K>(tk);
+  if (g.n <= 0) return;
+  const PtsGlobal pts{g.gp};
+  const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
+  const double inf = __builtin_inf();
+  KeyList<K + 1> L;
+  keys_clear<K + 1>(L);
+  const int cx = cell_coord(qx, g.org[0], g.inv_cell, g.dim[0]);
+  const int cy = cell_coord(qy, g.org[1], g.inv_cell, g.dim[1]);
+  const int cz = cell_coord(qz, g.org[2], g.inv_cell, g.dim[2]);
+  int x0 = cx - 1, x1 = cx + 1;
+  if (x0 < 0) x0 = 0;
+  if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
+  if (x0 > x1) return;
+  for (int z = cz - 1; z <= cz + 1; ++z) {
+    if (z < 0 || z >= g.dim[2]) continue;
+    for (int y = cy - 1; y <= cy + 1; ++y) {
+      if (y < 0 || y >= g.dim[1]) continue;
+      const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
+      const int s = g.cell_start[base + x0], e = g.cell_start[base + x1 + 1];
+      for (int j = s; j < e; j += 2) {  // two 32-byte records in flight
+        const bool vb = j + 1 < e;
+        const double4 a = pts.p[j], b = pts.p[vb ? j + 1 : j];
+        key_insert<K + 1>(L, key_pack(sqdist(qx, qy, qz, a.x, a.y, a.z), j, keep_mask));
+        key_insert<K + 1>(L, key_pack(vb ? sqdist(qx, qy, qz, b.x, b.y, b.z) : inf, vb ? j + 1 : 0, keep_mask));
+      }
+    }
+  }
+  if (!keys_ambiguous<K + 1>(L, keep_mask)) keys_unpack<K, K + 1>(L, pts, qx, qy, qz, keep_mask, tk);
+  else knn_grid<K>(g, qx, qy, qz, tk);
+}
+
 template <int K>
 __device__ __forceinline__ int radius_cut(const TopK<K>& tk, double radius) {
   const double r2 = radius * radius;
