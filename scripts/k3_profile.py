@@ -33,3 +33,15 @@ print("state load   :", q(ld))
 print("sweep        :", q(sw))
 print("reduce+store :", q(rd))
 print("end          :", q(end), " -> span", end.max())
+# who is slow?  by XCD (blocks are dealt round-robin to the 8 XCDs), by position in the grid, by start time
+sw_us = sw * tick_ns / 1e3
+xcd = np.arange(nb) % 8
+print("sweep us by XCD  :", " ".join("%d:%.2f/%.2f" % (x, np.median(sw_us[xcd == x]), sw_us[xcd == x].max()) for x in range(8)))
+dec = np.array_split(np.arange(nb), 10)
+print("sweep us by grid decile (p50/max):", " ".join("%.2f/%.2f" % (np.median(sw_us[i]), sw_us[i].max()) for i in dec))
+order = np.argsort(t0)
+dec = np.array_split(order, 10)
+print("sweep us by start-time decile    :", " ".join("%.2f/%.2f" % (np.median(sw_us[i]), sw_us[i].max()) for i in dec))
+print("end us by start-time decile (max):", " ".join("%.2f" % (end[i].max() * tick_ns / 1e3) for i in dec))
+slow = np.argsort(-sw_us)[:16]
+print("slowest blocks:", [(int(b), round(float(sw_us[b]), 2), round(float(t0[b] * tick_ns / 1e3), 2)) for b in slow])

@@ -9,6 +9,7 @@
 //   partials        [gridDim][32] per-block sums of H(21) g(6) cost(1)
 //   GnState         the Ceres-minimiser / dogleg state machine + pose, device resident
 #pragma once
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,14 +78,25 @@ struct SlotView {
 enum GnPhase : int { PH_ITER0 = 0, PH_CAND = 1 };
 
 struct GnState {
-  // poses
+  // ---- host-visible prefix: what the host reads after an outer iteration / a Solve.  The finish kernels
+  //      mirror exactly these kMirrorWords 8-byte words (two 64-byte PCIe writes) and then host_seq.
   double x[6];        // accepted iterate == `parameters` (registration.hpp:328)
+  double x_cost;
+  double kind_cost[kKinds];
+  int n_corr[kKinds];
+  // counters (whole scan_match)
+  int gn_evaluations, gn_iterations, accepted_steps;
+  int gn_sweeps;      // sweeps actually consumed (<= gn_evaluations, see gn_consume_wave)
+  int bad_weights;
+  int incomplete;     // set by the gated weight/finish kernels when the Solve had not terminated yet
+  unsigned long long host_seq;  // sequence number of the host mirror (see HostMirror); right after the prefix
+  // ---- device-only from here
   double x_cand[6];   // candidate evaluated by the sweep in flight
   Pose T_eval;        // exp(point being swept)
   Rt Rt_eval;         // the same as rotation matrix + translation (what K3 streams against)
   Pose T_cur;         // exp(x), used by the builders
   // minimiser
-  double x_cost, x_norm, gmax, model_cost_change;
+  double x_norm, gmax, model_cost_change;
   double g[6], H[36]; // robustified normal equations at x
   double S[6];        // Jacobi scaling (fixed at iteration 0 of each Solve)
   // dogleg
@@ -92,23 +104,15 @@ struct GnState {
   double D[6], grad[6], gn[6], U[12], sg[2], sB[4];
   int reuse, subspace_1d;
   int phase, iteration, invalid, step_successful, done;
-  // counters (whole scan_match)
-  int gn_evaluations, gn_iterations, accepted_steps;
-  int gn_sweeps;      // sweeps actually consumed (<= gn_evaluations, see gn_consume_wave)
   int no_eval_reuse;  // development knob (TLOAM_NO_EVAL_REUSE): every evaluation runs its own sweep
-  // outer-loop bookkeeping written by the finish kernel
-  int n_corr[kKinds];
-  int bad_weights;
-  int pad0;
-  int incomplete;     // set by the gated weight/finish kernels when the Solve had not terminated yet
-  int pad2;
-  double kind_cost[kKinds];
-  double dbg[8];  // phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
-  unsigned long long host_seq;  // LAST member: sequence number of the host mirror (see HostMirror)
+  double dbg[8];      // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
-// End of an outer iteration: the finish kernel copies the state into pinned host memory and then stores the
-// sequence number, so the host reads the result by polling one word instead of paying a copy kernel plus a
-// stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).  out == nullptr: off.
+constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
+static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible prefix of GnState");
+// End of an outer iteration: the finish kernel copies the host-visible prefix of the state into pinned host
+// memory and then stores the sequence number, so the host reads the result by polling one word instead of paying a
+// copy kernel plus a stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).
+// out == nullptr: off.
 struct HostMirror {
   GnState* out;
   unsigned long long seq;

@@ -1100,14 +1100,13 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 // publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
 // (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
 // Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
-// state writes are done: words first, system-scope fence, then the sequence number.
+// state writes are done: the host-visible prefix first (16 words, one coalesced store), system-scope fence, then
+// the sequence number.
 __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads) {
   if (!hm.out) return;
   __syncthreads();
-  constexpr int kWords = (int)(sizeof(GnState) / 8) - 1;  // everything but host_seq
-  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(st);
-  unsigned long long* dst = reinterpret_cast<unsigned long long*>(hm.out);
-  for (int i = tid; i < kWords; i += nthreads) dst[i] = src[i];
+  if (tid < kMirrorWords)
+    reinterpret_cast<unsigned long long*>(hm.out)[tid] = reinterpret_cast<const unsigned long long*>(st)[tid];
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(&hm.out->host_seq, hm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
