@@ -110,13 +110,17 @@ __global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict_
   if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sm[threadIdx.x][0];
 }
 // voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); an empty cloud has min bound (0, 0, 0)
-__global__ void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel, double* __restrict__ vmin) {
-  const int a = threadIdx.x;
-  if (a >= 3) return;
+__global__ __launch_bounds__(192) void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel,
+                                                       double* __restrict__ vmin) {
+  // one wave per axis, the rows spread over its lanes (min is exact in any order); a 3-thread serial loop over
+  // the 256 rows was a 26 us chain of dependent loads -- a quarter of the submap update
+  const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double m = __builtin_inf();
-  for (int b = 0; b < blocks; ++b) m = fmin(m, partial[b * 3 + a]);
+  for (int b = lane; b < blocks; b += 64) m = fmin(m, partial[b * 3 + a]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
   if (!(m < __builtin_inf())) m = 0.0;
-  vmin[a] = m - voxel * 0.5;
+  if (lane == 0) vmin[a] = m - voxel * 0.5;
 }
 
 // voxel of every in-box point -> hash slot; the counting atomic also hands out an (arbitrary) member rank
@@ -243,7 +247,7 @@ void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
   hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt);
-  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(64), 0, s, W.min_partial, kMinBlocks, J.voxel, W.vmin);
+  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(192), 0, s, W.min_partial, kMinBlocks, J.voxel, W.vmin);
   const size_t cap = (size_t)J.mask + 1;
   if (n > 0)
     hipLaunchKernelGGL(k_vox_insert, dim3(blocks_for(n)), dim3(256), 0, s, J, W.vmin, W.keys, W.cnt, W.slot_of_pt,
