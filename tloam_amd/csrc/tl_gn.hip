@@ -1105,10 +1105,10 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads) {
   if (!hm.out) return;
   __syncthreads();
+  if (tid >= 64) return;  // one wave does the hand-over (and pays the system-scope fence)
   if (tid < kMirrorWords)
     reinterpret_cast<unsigned long long*>(hm.out)[tid] = reinterpret_cast<const unsigned long long*>(st)[tid];
   __threadfence_system();
-  __syncthreads();
   if (tid == 0) __hip_atomic_store(&hm.out->host_seq, hm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t) {
@@ -1171,12 +1171,19 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
   }
   double sum[kKinds] = {0, 0, 0, 0};
   double bad = 0.0;
+  // (the side-channel costs and the index lists are only read here, the slot weights only written: say so, or the
+  //  possible aliasing serialises the thread's 6 load -> load -> store chains of a KITTI-size set)
+  double* __restrict__ w_src = A.sv.w_src;
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
     const int n = A.cv.seg_n[k];
-    const CorrSeg& seg = A.cv.k[k];
+    const double* __restrict__ cost = A.cv.k[k].cost;
+    const int* __restrict__ idx = A.cv.k[k].idx;
+    const int slot0 = A.sv.slot_off[k] - A.sv.src_lo[k];
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += 1024) {
-      const double c = seg.cost[i];
+      const double c = cost[i];
+      const int slot = slot0 + idx[i];
       sum[k] += c;
       if (!A.wp.active[k]) continue;
       if (c == 0) continue;                          // :862
@@ -1187,8 +1194,7 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
         w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
         if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
       }
-      const int slot = A.sv.slot_off[k] + (seg.idx[i] - A.sv.src_lo[k]);
-      A.sv.w_src[slot] = w;
+      w_src[slot] = w;
     }
   }
   double v[5] = {sum[0], sum[1], sum[2], sum[3], bad};
