@@ -170,6 +170,9 @@ def main():
             gn_iters_job = float(gi.item())
         k3_us, k3_n, _ = H.k3_timer()                    # working sweeps
         k3_all_us, k3_all_n = H.k3_timer_all()            # every sampled K3 launch incl. no-ops after a tolerance exit
+        # cross-check without per-launch event overhead: ONE event pair around 60 consecutive launches of the same
+        # kernel on the frame's last correspondence set (after the timed region, not part of `value`)
+        bb_us = H.time_accumulate(np.asarray(st["se3"], float), 60)
         H.close()
         D = np.linalg.inv(T) @ scene.T_true               # pose sanity (not timed)
         n_corr = st["n_corr"]
@@ -185,7 +188,12 @@ def main():
               "algorithmic_bytes_per_launch": alg_avg,
               "working_sweeps": {"launches": int(k3_n), "avg_launch_us": round(k3_avg_work_us, 3),
                                  "algorithmic_bytes_per_launch": alg, "achieved": round(ach_w, 1),
-                                 "frac": round(ach_w / HBM_PEAK_GBS, 4)}}
+                                 "frac": round(ach_w / HBM_PEAK_GBS, 4)},
+              "back_to_back": {"launches": 60, "avg_launch_us": round(bb_us, 3), "algorithmic_bytes_per_launch": alg,
+                               "achieved": round(alg / (bb_us * 1e-6) / 1e9, 1),
+                               "frac": round(alg / (bb_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "one HIP event pair around 60 consecutive launches on the last correspondence "
+                                       "set, after the timed region (no per-launch event overhead; launch gaps included)"}}
         return {"workload": W["name"], "ms_per_frame": elapsed / steps * 1e3, "gn_iters_per_sec": gn_iters_job / elapsed,
                 "gn_iters_per_frame": gn_iters / steps, "solver_evaluations_per_frame": gn_evals / steps, "n_corr": n_corr,
                 "outer_iterations": st["outer_iterations"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3])),
