@@ -76,3 +76,36 @@ def test_feature_lists_feed_the_submap(hip_module):
     H.submap_update(ss.frame_pose(1), p[pm], p[s_sub], cl[2], cl[3])
     assert len(H.get_target(0)) == len(pm) and len(H.get_target(3)) == len(pm)    # sphere submap <- planar buffer
     H.close()
+
+
+def test_near_ties_take_the_exact_path(hip_module):
+    """The neighbour walk orders candidates by a packed key -- the squared distance with its low mantissa bits
+    replaced by the candidate's position -- and must redo a query exactly when two kept distances agree in every
+    bit the key keeps.  Planted near-ties (relative difference 1e-12 .. 1e-10, far below the key's resolution),
+    exact ties (mirror points, duplicates) and ordinary points: every neighbour list in the oracle's exact
+    (distance, index) order, every PCA value bit for bit."""
+    rng = np.random.default_rng(7)
+    base = ss.feature_cloud(5, n=3000)
+    extra = []
+    for i in rng.choice(len(base), 400, replace=False):
+        q = base[i]
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+        r = rng.uniform(0.01, 0.08)
+        eps = 10.0 ** rng.uniform(-12, -10)
+        extra += [q + r * u, q + r * (1.0 + eps) * v]          # near-tie as seen from q
+        if i % 3 == 0:
+            extra += [q - r * u]                                  # exact tie with q + r*u (to rounding of q +- r*u)
+        if i % 5 == 0:
+            extra += [q + r * u]                                  # exact duplicate
+    p = np.ascontiguousarray(np.vstack([base, np.array(extra)]))
+    p = p[rng.permutation(len(p))]                                # positions in the cell-sorted records unrelated to distance
+    H = hip_module.HipRegistration()
+    for cfg in ({}, dict(K=12, min_neigh=4)):
+        g = H.pca_info(p, hip_module.default_feature_config(**cfg))
+        o = ob.pca_info(p, ob.make_feature_config(**cfg))
+        assert _same(g["neigh"], o["neigh"])
+        assert _same(g["num_sum"], o["num_sum"])
+        for k in ("flatness", "cvr", "sphericity", "normal"):
+            assert _same(g[k], o[k]), k
+    H.close()

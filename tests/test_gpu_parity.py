@@ -250,3 +250,39 @@ def test_host_mirror_is_exact(hip_module, monkeypatch, shape, knob):
     _assert_same_frame(frames[0], _frame_fingerprint(H2, T2, st2))
     assert st1["gn_sweeps"] >= 4 and st1["outer_iterations"] >= 2
     H1.close(); H2.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_quad_builder_ties_and_near_ties(hip_module, seed):
+    """Small frames run K1 with four lanes per query and the packed-key lists merged across the quad.  Targets with
+    exact duplicates and planted near-ties (relative distance difference ~1e-12 from a source point's predicted
+    position) must still give the oracle's lists index for index, and its pose."""
+    sc = synth.make_scene(seed=seed, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    rng = np.random.default_rng(seed)
+    T = sc.T_pred
+    tgt = []
+    for k in range(4):
+        t = sc.target.cloud(k)
+        src_w = sc.source.cloud(k) @ T[:3, :3].T + T[:3, 3]
+        add = [t[::6]]                                             # exact duplicates
+        for q in src_w[rng.choice(len(src_w), min(60, len(src_w)), replace=False)]:
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
+            r = rng.uniform(0.02, 0.1)
+            add.append(np.array([q + r * u, q + r * (1.0 + 1e-12) * v, q - r * u]))
+        tgt.append(np.ascontiguousarray(np.vstack([t] + add)))
+    H = hip_module.HipRegistration()
+    O = ob.Oracle(ob.make_config())
+    for k in range(4):
+        H.set_source(k, sc.source.cloud(k)); O.set_source(k, sc.source.cloud(k))
+        H.set_target(k, tgt[k]); O.set_target(k, tgt[k])
+    rh, Th, sh = H.scan_match(sc.T_pred)
+    ro, To, so = O.scan_match(sc.T_pred)
+    assert rh == ro == 0 and sh["n_corr"] == so["n_corr"]
+    for kind in range(4):
+        assert np.array_equal(H.get_correspondences(kind)["idx"], O.get_correspondences(kind)["idx"])
+    for k in ("gn_evaluations", "gn_iterations", "accepted_steps", "outer_iterations"):
+        assert sh[k] == so[k], k
+    dt, dr = pose_delta(Th, To)
+    assert dt < 1e-9 and dr < 1e-9
+    H.close()
