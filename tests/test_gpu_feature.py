@@ -81,7 +81,7 @@ def test_feature_lists_feed_the_submap(hip_module):
 def test_near_ties_take_the_exact_path(hip_module):
     """The neighbour walk orders candidates by a packed key -- the squared distance with its low mantissa bits
     replaced by the candidate's position -- and must redo a query exactly when two kept distances agree in every
-    bit the key keeps.  Planted near-ties (relative difference 1e-12 .. 1e-10, far below the key's resolution),
+    bit the key keeps.  Planted near-ties (relative difference 3e-15 .. 3e-13, below the ~1e-12 resolution of the key),
     exact ties (mirror points, duplicates) and ordinary points: every neighbour list in the oracle's exact
     (distance, index) order, every PCA value bit for bit."""
     rng = np.random.default_rng(7)
@@ -92,7 +92,7 @@ def test_near_ties_take_the_exact_path(hip_module):
         u = rng.normal(size=3); u /= np.linalg.norm(u)
         v = np.cross(u, rng.normal(size=3)); v /= np.linalg.norm(v)
         r = rng.uniform(0.01, 0.08)
-        eps = 10.0 ** rng.uniform(-12, -10)
+        eps = 10.0 ** rng.uniform(-14.5, -12.5)
         extra += [q + r * u, q + r * (1.0 + eps) * v]          # near-tie as seen from q
         if i % 3 == 0:
             extra += [q - r * u]                                  # exact tie with q + r*u (to rounding of q +- r*u)
