@@ -127,6 +127,20 @@ int reserve_seg(tloam_ctx* c, int k, size_t n) {
 }  // namespace
 
 namespace tlh {
+// Poll a word in pinned host memory that a kernel stores last (HostMirror / HostDone).  The stream is only queried
+// now and then, to notice a failed launch instead of spinning forever.  TLOAM_OK: the word arrived; 1: the stream
+// drained without it (the caller reads the result the slow way).
+int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq) {
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return TLOAM_OK;
+    if ((spins & 0x7ffu) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) return __atomic_load_n(p, __ATOMIC_ACQUIRE) == seq ? TLOAM_OK : 1;
+      if (e != hipErrorNotReady) HIPC(c, e);
+    }
+    __builtin_ia32_pause();
+  }
+}
 // The four search grids share one set of buffers (points and cell tables concatenated), so that every
 // phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
 // scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
@@ -144,15 +158,25 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     gs.tgt_off[k] = (int)tgt_total;
     tgt_total += (size_t)gs.n[k];
   }
-  HIPC(c, G.bbox.reserve((size_t)kKinds * 64 * 6));
-  launch_bbox_all(gs, G.bbox.p, c->stream);
-  HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kKinds * 64 * 6, hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
+  constexpr size_t kBoxDoubles = (size_t)kKinds * 64 * 6;
+  const double* box_rows = c->h_small;
+  if (c->h_bbox_dev) {
+    // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
+    // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
+    launch_bbox_all(gs, c->h_bbox_dev, HostDone{nullptr, nullptr, 0ull}, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    box_rows = c->h_bbox;
+  } else {
+    HIPC(c, G.bbox.reserve(kBoxDoubles));
+    launch_bbox_all(gs, G.bbox.p, HostDone{nullptr, nullptr, 0ull}, c->stream);
+    HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kBoxDoubles, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
   long long cell_total = 0;
   for (int k = 0; k < kKinds; ++k) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int b = 0; b < 64; ++b) {
-      const double* row = c->h_small + ((size_t)k * 64 + b) * 6;
+      const double* row = box_rows + ((size_t)k * 64 + b) * 6;
       for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], row[a]); hi[a] = std::max(hi[a], row[3 + a]); }
     }
     GridView& g = out[k];
@@ -188,17 +212,24 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   const size_t nc = (size_t)std::max<long long>(cell_total, 1);
   HIPC(c, G.gp.reserve(std::max<size_t>(tgt_total, 1))); HIPC(c, G.cell_of_pt.reserve(std::max<size_t>(tgt_total, 1)));
   HIPC(c, G.cell_start.reserve(nc + kKinds + 1)); HIPC(c, G.rank_of_pt.reserve(tgt_total + 1));
-  HIPC(c, G.cell_cnt.reserve(nc + 1)); HIPC(c, G.cell_scan.reserve(nc + 1));
+  {
+    // the cell histogram is all-zero between builds (k_grid_finalize_all re-zeroes what a build used): only a
+    // (re)allocation has to be cleared
+    const size_t before = G.cell_cnt.cap;
+    HIPC(c, G.cell_cnt.reserve(nc + 1));
+    if (G.cell_cnt.cap != before)
+      HIPC(c, hipMemsetAsync(G.cell_cnt.p, 0, G.cell_cnt.cap * sizeof(unsigned long long), c->stream));
+  }
+  HIPC(c, G.cell_scan.reserve(nc + 1));
   HIPC(c, G.scan_tmp.reserve(scan_tmp_elems(nc + 1)));
   for (int k = 0; k < kKinds; ++k) {
     out[k].gp = G.gp.p + gs.tgt_off[k];
     out[k].cell_start = G.cell_start.p + gs.cell_base[k] + k;
   }
   if (cell_total == 0) return TLOAM_OK;
-  HIPC(c, hipMemsetAsync(G.cell_cnt.p, 0, (nc + 1) * sizeof(unsigned long long), c->stream));
   launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream);
   launch_exclusive_scan_u64(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
-  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, c->stream);
+  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, G.cell_cnt.p, c->stream);
   launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.rank_of_pt.p, G.gp.p, c->stream);
   return TLOAM_OK;
 }
@@ -270,19 +301,8 @@ HostMirror next_mirror(tloam_ctx* c) {
 }
 int wait_state(tloam_ctx* c, const HostMirror& hm) {
   if (hm.out) {
-    const unsigned long long* p = &c->h_state->host_seq;
-    for (unsigned spins = 1;; ++spins) {
-      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == hm.seq) return TLOAM_OK;
-      if ((spins & 0x7ffu) == 0) {
-        const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipSuccess) {
-          if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == hm.seq) return TLOAM_OK;
-          break;  // drained, nothing arrived: read it the slow way
-        }
-        if (e != hipErrorNotReady) HIPC(c, e);
-      }
-      __builtin_ia32_pause();
-    }
+    const int rc = wait_word(c, &c->h_state->host_seq, hm.seq);
+    if (rc <= 0) return rc;
   }
   HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
@@ -398,6 +418,18 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     (void)hipGetLastError();
     c->h_state_dev = nullptr;  // no device view of the pinned state: fall back to copy + synchronise
   }
+  if (!c->no_host_mirror) {
+    constexpr size_t kBoxBytes = sizeof(double) * ((size_t)kKinds * 64 * 6 + 8);
+    if (hipHostMalloc((void**)&c->h_bbox, kBoxBytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(c->h_bbox, 0, kBoxBytes);
+      if (hipHostGetDevicePointer((void**)&c->h_bbox_dev, c->h_bbox, 0) != hipSuccess) c->h_bbox_dev = nullptr;
+    }
+    (void)hipGetLastError();
+  }
+  if (c->ticket.reserve(1) != hipSuccess || hipMemsetAsync(c->ticket.p, 0, sizeof(unsigned), c->stream) != hipSuccess) {
+    tloam_destroy(c);
+    return TLOAM_E_HIP;
+  }
   if (ensure_common(c) != TLOAM_OK) { tloam_destroy(c); return TLOAM_E_HIP; }
   (void)hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream);
   (void)hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream);
@@ -428,6 +460,8 @@ void tloam_destroy(tloam_ctx* c) {
   c->feat.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->h_bbox) (void)hipHostFree(c->h_bbox);
+  c->ticket.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -228,7 +228,7 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 //  grid build
 // ================================================================================================
 // per-block min/max of every kind's cloud (blockIdx.y = kind); the host finishes over 64 rows of 6
-__global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict__ out, HostDone done) {
   __shared__ double red[4][6];
   const int k = blockIdx.y;
   const double* __restrict__ x = gs.tx[k];
@@ -261,9 +261,21 @@ __global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict
     for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
     out[((size_t)k * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;
   }
+  if (!done.seq_out) return;
+  // `out` is pinned host memory: the block that takes the last ticket publishes the sequence number the host polls
+  // (no copy kernel, no stream synchronisation for the one host decision of the build: the grid dimensions)
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    if (__hip_atomic_fetch_add(done.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+      __hip_atomic_store(done.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(done.seq_out, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
-void launch_bbox_all(const GridSet& gs, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out);
+void launch_bbox_all(const GridSet& gs, double* out, HostDone done, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out, done);
 }
 
 
@@ -295,7 +307,7 @@ void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int*
 // cell_start of kind k lives at cell_start[cell_base[k] + k ...] (ncell + 1 entries per kind), relative to the
 // kind's own point block
 __global__ void k_grid_finalize_all(GridSet gs, const unsigned long long* __restrict__ cell_scan,
-                                    int* __restrict__ cell_start) {
+                                    int* __restrict__ cell_start, unsigned long long* __restrict__ cell_cnt) {
   const int k = blockIdx.y;
   const long long ncell = gs.ncell[k], base = gs.cell_base[k];
   const unsigned long long first = cell_scan[base];
@@ -303,13 +315,15 @@ __global__ void k_grid_finalize_all(GridSet gs, const unsigned long long* __rest
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i <= ncell; i += stride) {
     cell_start[base + k + i] = (i < ncell) ? (int)(cell_scan[base + i] - first) : gs.n[k];
+    cell_cnt[base + i] = 0ull;  // the histogram has been scanned: leave it empty for the next build (no memset per frame)
   }
 }
-void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start, hipStream_t s) {
+void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start,
+                              unsigned long long* cell_cnt, hipStream_t s) {
   long long m = 1;
   for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.ncell[k] + 1);
   int blocks = (int)std::min<long long>((m + 255) / 256, 2048);
-  hipLaunchKernelGGL(k_grid_finalize_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_scan, cell_start);
+  hipLaunchKernelGGL(k_grid_finalize_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_scan, cell_start, cell_cnt);
 }
 __global__ void k_grid_scatter_all(GridSet gs, const int* __restrict__ cell_of_pt,
                                    const unsigned long long* __restrict__ cell_scan,
