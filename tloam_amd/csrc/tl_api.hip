@@ -127,7 +127,7 @@ int reserve_seg(tloam_ctx* c, int k, size_t n) {
 }  // namespace
 
 namespace tlh {
-// Poll a word in pinned host memory that a kernel stores last (HostMirror / HostDone).  The stream is only queried
+// Poll a word in pinned host memory that a kernel stores last (HostMirror).  The stream is only queried
 // now and then, to notice a failed launch instead of spinning forever.  TLOAM_OK: the word arrived; 1: the stream
 // drained without it (the caller reads the result the slow way).
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq) {
@@ -163,12 +163,12 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   if (c->h_bbox_dev) {
     // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
     // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
-    launch_bbox_all(gs, c->h_bbox_dev, HostDone{nullptr, nullptr, 0ull}, c->stream);
+    launch_bbox_all(gs, c->h_bbox_dev, c->stream);
     HIPC(c, hipStreamSynchronize(c->stream));
     box_rows = c->h_bbox;
   } else {
     HIPC(c, G.bbox.reserve(kBoxDoubles));
-    launch_bbox_all(gs, G.bbox.p, HostDone{nullptr, nullptr, 0ull}, c->stream);
+    launch_bbox_all(gs, G.bbox.p, c->stream);
     HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kBoxDoubles, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
   }
@@ -426,10 +426,6 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     }
     (void)hipGetLastError();
   }
-  if (c->ticket.reserve(1) != hipSuccess || hipMemsetAsync(c->ticket.p, 0, sizeof(unsigned), c->stream) != hipSuccess) {
-    tloam_destroy(c);
-    return TLOAM_E_HIP;
-  }
   if (ensure_common(c) != TLOAM_OK) { tloam_destroy(c); return TLOAM_E_HIP; }
   (void)hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream);
   (void)hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream);
@@ -461,7 +457,6 @@ void tloam_destroy(tloam_ctx* c) {
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
-  c->ticket.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

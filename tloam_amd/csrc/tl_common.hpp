@@ -145,15 +145,7 @@ struct GridSet {
   double inv_cell[kKinds];
   int dim[kKinds][3];
 };
-// completion of a multi-block kernel whose results go straight to pinned host memory: the last block (ticket
-// counter, left at 0) stores `seq` to `seq_out` (host memory) after every block's rows are visible to the host.
-// seq_out == nullptr: off (results in device memory, the caller synchronises).
-struct HostDone {
-  unsigned* ticket;
-  unsigned long long* seq_out;
-  unsigned long long seq;
-};
-void launch_bbox_all(const GridSet& gs, double* out /*[4][64][6]*/, HostDone done, hipStream_t s);
+void launch_bbox_all(const GridSet& gs, double* out /*[4][64][6], device or pinned host*/, hipStream_t s);
 void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
                            hipStream_t s);
 void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start,

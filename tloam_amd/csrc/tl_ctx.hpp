@@ -149,9 +149,8 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
-  double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bbox rows + the completion word (index 1536)
+  double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
   double* h_bbox_dev = nullptr;
-  DBuf<unsigned> ticket;           // last-block election counter (0 between launches)
   bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
   tl::GnState* h_state_dev = nullptr;   // device address of the pinned host state (HostMirror target)
   unsigned long long mirror_seq = 0;

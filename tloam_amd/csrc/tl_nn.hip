@@ -227,8 +227,9 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 // ================================================================================================
 //  grid build
 // ================================================================================================
-// per-block min/max of every kind's cloud (blockIdx.y = kind); the host finishes over 64 rows of 6
-__global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict__ out, HostDone done) {
+// per-block min/max of every kind's cloud (blockIdx.y = kind); the host finishes over 64 rows of 6 (`out` may
+// be pinned host memory: the rows then need no copy kernel)
+__global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict__ out) {
   __shared__ double red[4][6];
   const int k = blockIdx.y;
   const double* __restrict__ x = gs.tx[k];
@@ -261,21 +262,9 @@ __global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict
     for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
     out[((size_t)k * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;
   }
-  if (!done.seq_out) return;
-  // `out` is pinned host memory: the block that takes the last ticket publishes the sequence number the host polls
-  // (no copy kernel, no stream synchronisation for the one host decision of the build: the grid dimensions)
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
-    if (__hip_atomic_fetch_add(done.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-      __hip_atomic_store(done.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(done.seq_out, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
 }
-void launch_bbox_all(const GridSet& gs, double* out, HostDone done, hipStream_t s) {
-  hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out, done);
+void launch_bbox_all(const GridSet& gs, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out);
 }
 
 
