@@ -286,3 +286,24 @@ def test_quad_builder_ties_and_near_ties(hip_module, seed):
     dt, dr = pose_delta(Th, To)
     assert dt < 1e-9 and dr < 1e-9
     H.close()
+
+
+@pytest.mark.parametrize("n_src,n_tgt", [(synth.SMALL_SRC, synth.SMALL_TGT), ((40_000, 50_000, 35_000, 8_000), (30_000, 30_000, 20_000, 5_000))])
+def test_nan_targets_are_never_neighbours(hip_module, n_src, n_tgt):
+    """A NaN coordinate gives a NaN distance, which under the reference's comparisons (nanoflann result set,
+    `<` only) is never a neighbour.  The packed-key walks (both K1 variants) must treat it the same way: targets
+    with NaN rows appended behave exactly like the clean cloud -- same lists, same pose, bit for bit."""
+    sc = synth.make_scene(seed=41, n_src=n_src, n_tgt=n_tgt)
+    H = hip_module.HipRegistration()
+    H.set_frames(sc.source, sc.target)
+    rc1, T1, st1 = H.scan_match(sc.T_pred)
+    lists1 = [H.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"] for k in range(4)]
+    bad = np.array([[np.nan, 0.0, 0.0], [1.0, np.nan, 2.0], [np.nan, np.nan, np.nan], [3.0, 4.0, np.nan]])
+    for k in range(4):
+        H.set_target(k, np.ascontiguousarray(np.vstack([sc.target.cloud(k), bad, bad])))
+    rc2, T2, st2 = H.scan_match(sc.T_pred)
+    assert rc1 == rc2 == 0
+    assert np.array_equal(T1, T2) and st1["n_corr"] == st2["n_corr"] and st1["gn_evaluations"] == st2["gn_evaluations"]
+    for k in range(4):
+        assert np.array_equal(lists1[k], H.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"])
+    H.close()

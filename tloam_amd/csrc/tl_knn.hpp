@@ -108,9 +108,12 @@ __device__ __forceinline__ void keys_clear(KeyList<N>& L) {
 __device__ __forceinline__ int key_bits_for(int n) {  // positions 0 .. n-1
   return n > 1 ? 32 - __clz(n - 1) : 1;
 }
-__device__ __forceinline__ double key_pack(double d, int j, unsigned keep_mask) {  // d >= 0 or +inf (then j == 0)
+// valid == false (masked lane), d == +inf or d == NaN (a NaN coordinate: never a neighbour, as under the exact
+// comparisons) all give the empty key
+__device__ __forceinline__ double key_pack(double d, int j, unsigned keep_mask, bool valid = true) {
   const unsigned lo = ((unsigned)__double2loint(d) & keep_mask) | (unsigned)j;
-  return __hiloint2double(__double2hiint(d), (int)lo);
+  const double key = __hiloint2double(__double2hiint(d), (int)lo);
+  return (valid && d < __builtin_inf()) ? key : __builtin_inf();
 }
 template <int N>
 __device__ __forceinline__ void key_insert(KeyList<N>& L, double key) {
@@ -207,7 +210,6 @@ __device__ __forceinline__ void knn_grid_fast(const GridView& g, double qx, doub
   if (g.n <= 0) return;
   const PtsGlobal pts{g.gp};
   const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
-  const double inf = __builtin_inf();
   KeyList<K + 1> L;
   keys_clear<K + 1>(L);
   const int cx = cell_coord(qx, g.org[0], g.inv_cell, g.dim[0]);
@@ -227,7 +229,7 @@ __device__ __forceinline__ void knn_grid_fast(const GridView& g, double qx, doub
         const bool vb = j + 1 < e;
         const double4 a = pts.p[j], b = pts.p[vb ? j + 1 : j];
         key_insert<K + 1>(L, key_pack(sqdist(qx, qy, qz, a.x, a.y, a.z), j, keep_mask));
-        key_insert<K + 1>(L, key_pack(vb ? sqdist(qx, qy, qz, b.x, b.y, b.z) : inf, vb ? j + 1 : 0, keep_mask));
+        key_insert<K + 1>(L, key_pack(sqdist(qx, qy, qz, b.x, b.y, b.z), j + 1, keep_mask, vb));
       }
     }
   }

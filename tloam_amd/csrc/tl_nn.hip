@@ -551,7 +551,6 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
     KeyList<K + 1> L;
     keys_clear<K + 1>(L);
-    const double inf = __builtin_inf();
     // next position of this lane's candidate stream (index 0 = a harmless in-range dummy when exhausted)
     auto next = [&](int& jx, bool& vx) {
       if (j >= e && r < nr) { j = nx.x; e = nx.y; ++r; nx = lds_rows[(r < nr ? r : 0) * 64 + lane]; }
@@ -585,7 +584,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #pragma unroll
       for (int u = 0; u < kCpt; ++u) {
         const double du = sqdist(pw.x, pw.y, pw.z, rc[u].x, rc[u].y, rc[u].z);
-        key_insert<K + 1>(L, key_pack(vc[u] ? du : inf, jc[u], keep_mask));  // (jc == 0 when masked)
+        key_insert<K + 1>(L, key_pack(du, jc[u], keep_mask, vc[u]));
       }
 #pragma unroll
       for (int u = 0; u < kCpt; ++u) { jc[u] = jn[u]; vc[u] = vn[u]; rc[u] = rn[u]; }
@@ -601,7 +600,6 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     }
   } else {
     const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
-    const double inf = __builtin_inf();
     KeyList<K + 1> L;
     keys_clear<K + 1>(L);
     int len = 0;
@@ -614,8 +612,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const bool v = rs[i] + s < re[i];
-        key_insert<K + 1>(L, key_pack(v ? sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z) : inf, v ? rs[i] + s : 0,
-                                      keep_mask));
+        key_insert<K + 1>(L, key_pack(sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z), rs[i] + s, keep_mask, v));
       }
     }
     // merge across the quad: after xor-1 and xor-2 every lane holds the global list (the lanes' candidate
