@@ -682,7 +682,8 @@ __device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, doubl
 #else
 #define TL_STAMP(i)
 #endif
-__device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const double* tot, int lane) {
+__device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, int lane,
+                                                const GnState* in /* state as of the start of the launch: st or a copy */) {
   TL_STAMP(1)
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
@@ -694,27 +695,27 @@ __device__ __forceinline__ void gn_consume_wave(GnState* __restrict__ st, const 
   L.mi = L.ism ? lane / 6 : 0;
   L.mj = L.ism ? lane - L.mi * 6 : 0;
   // ---- wave-uniform state
-  int phase = st->phase, iteration = st->iteration, invalid = st->invalid, step_successful = st->step_successful;
-  int reuse = st->reuse, subspace_1d = st->subspace_1d, done = 0;
-  int evals = st->gn_evaluations + 1, iters = st->gn_iterations, accepted = st->accepted_steps;
-  double x_cost = st->x_cost, x_norm = st->x_norm, gmax = st->gmax, mcc = st->model_cost_change;
-  double radius = st->radius, mu = st->mu, alpha = st->alpha, step_norm = st->step_norm;
-  double sg0 = st->sg[0], sg1 = st->sg[1], sB0 = st->sB[0], sB1 = st->sB[1], sB3 = st->sB[3];
-  Pose T_cur = st->T_cur, T_eval = st->T_eval;
+  int phase = in->phase, iteration = in->iteration, invalid = in->invalid, step_successful = in->step_successful;
+  int reuse = in->reuse, subspace_1d = in->subspace_1d, done = 0;
+  int evals = in->gn_evaluations + 1, iters = in->gn_iterations, accepted = in->accepted_steps;
+  double x_cost = in->x_cost, x_norm = in->x_norm, gmax = in->gmax, mcc = in->model_cost_change;
+  double radius = in->radius, mu = in->mu, alpha = in->alpha, step_norm = in->step_norm;
+  double sg0 = in->sg[0], sg1 = in->sg[1], sB0 = in->sB[0], sB1 = in->sB[1], sB3 = in->sB[3];
+  Pose T_cur = in->T_cur, T_eval = in->T_eval;
   // ---- lane-distributed state
   const int vk = L.isv ? lane : 0;
-  double x = L.isv ? st->x[vk] : 0.0, xc = L.isv ? st->x_cand[vk] : 0.0;
-  double S = L.isv ? st->S[vk] : 0.0, D = L.isv ? st->D[vk] : 1.0;
-  double grad = L.isv ? st->grad[vk] : 0.0, gnv = L.isv ? st->gn[vk] : 0.0;
-  double U0 = L.isv ? st->U[vk] : 0.0, U1 = L.isv ? st->U[6 + vk] : 0.0;
-  double Hc = L.ism ? st->H[lane] : 0.0, gc = L.isv ? st->g[vk] : 0.0;
+  double x = L.isv ? in->x[vk] : 0.0, xc = L.isv ? in->x_cand[vk] : 0.0;
+  double S = L.isv ? in->S[vk] : 0.0, D = L.isv ? in->D[vk] : 1.0;
+  double grad = L.isv ? in->grad[vk] : 0.0, gnv = L.isv ? in->gn[vk] : 0.0;
+  double U0 = L.isv ? in->U[vk] : 0.0, U1 = L.isv ? in->U[6 + vk] : 0.0;
+  double Hc = L.ism ? in->H[lane] : 0.0, gc = L.isv ? in->g[vk] : 0.0;
   // ---- the new sweep
   const double cost = tot[27];
   const int ui = L.mi < L.mj ? L.mi : L.mj, uj = L.mi < L.mj ? L.mj : L.mi;
   const double Hn = L.ism ? tot[ui * 6 - (ui * (ui - 1)) / 2 + (uj - ui)] : 0.0;
   const double gn_new = L.isv ? tot[21 + vk] : 0.0;
-  const int sweeps = st->gn_sweeps + 1;
-  const bool eval_reuse = st->no_eval_reuse == 0;
+  const int sweeps = in->gn_sweeps + 1;
+  const bool eval_reuse = in->no_eval_reuse == 0;
   // Evaluation reuse: when the minimiser asks for the evaluation of a point that is bit-identical to the one
   // whose totals are in `tot` -- a rejected step retried inside the halved trust region re-creates exactly the
   // same candidate (four times per Solve from the second outer iteration on) -- the answer is
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __res
   if (threadIdx.x < kReduceBuf) tot[threadIdx.x] = in48[threadIdx.x];
   __syncthreads();
   if (st->done) return;
-  gn_consume_wave(st, tot, threadIdx.x);
+  gn_consume_wave(st, tot, threadIdx.x, st);
 }
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
@@ -1020,12 +1021,21 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
                                                                  GnState* __restrict__ st) {
   __shared__ double lds[kRedGroups * 33];
   __shared__ double tot[32];
+  __shared__ GnState s_in;
   if (st->done) return;
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[0] = (double)__builtin_readcyclecounter();
 #endif
-  reduce_rows(partials, rows, lds, tot);
-  if (threadIdx.x < 64) gn_consume_wave(st, tot, threadIdx.x);
+  // the minimiser state comes in as ONE coalesced load into LDS, in flight together with the partial rows (the
+  // step's ~100 scattered field loads were a second memory round trip in front of the serial fp64 chain)
+  {
+    constexpr int kWords = (int)(sizeof(GnState) / 8);
+    static_assert(kWords <= kRedThreads, "one word per thread");
+    const unsigned long long w = threadIdx.x < kWords ? reinterpret_cast<const unsigned long long*>(st)[threadIdx.x] : 0ull;
+    if (threadIdx.x < kWords) reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = w;
+  }
+  reduce_rows(partials, rows, lds, tot);  // (its barriers also publish s_in)
+  if (threadIdx.x < 64) gn_consume_wave(st, tot, threadIdx.x, &s_in);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
