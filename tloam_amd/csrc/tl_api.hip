@@ -394,6 +394,9 @@ void tloam_default_config(tloam_tls_config* c) {
 int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   if (!cfg || !out) return TLOAM_E_INVALID;
   *out = nullptr;
+  // kernel arguments in device memory (a frame is a chain of short dependent launches); only effective if this is
+  // the process's first HIP call, never overrides the host's own setting
+  (void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return TLOAM_E_HIP;
   if (hipSetDevice(device_id) != hipSuccess) return TLOAM_E_HIP;
