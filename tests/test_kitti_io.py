@@ -49,3 +49,30 @@ def test_read_poses_rejects_other_shapes(tmp_path):
     open(p, "w").write("1 2 3\n")
     with pytest.raises(ValueError):
         kio.read_poses(p)
+
+
+def test_reference_trajectory_fixture(tmp_path):
+    """tests/golden/tloam_00_ego_motion.npz is derived from the reference's own published KITTI-00 trajectory
+    (doc/tloam_00.txt; generator: tests/golden/make_tloam00_ego_motion.py).  The first pose lines of that file,
+    kept verbatim as numbers, pin the pose reader on real reference data; the ego-motion drives bench.py's
+    KITTI-density sequence."""
+    import os
+    from tloam_amd import synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tloam_00_ego_motion.npz"))
+    se3, lines = z["se3"], z["first_pose_lines"]
+    assert se3.shape == (4540, 6) and lines.shape == (3, 12)
+    p = tmp_path / "poses.txt"
+    np.savetxt(p, lines, fmt="%.18e")
+    poses = kio.read_poses(str(p))
+    assert poses.shape == (3, 4, 4) and np.allclose(poses[0], np.eye(4), atol=1e-15)
+    for T in poses:                                   # rigid transforms (to the precision the reference wrote them with)
+        assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-4) and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-4
+    # camera -> velodyne axes: the car drives along +x (camera +z) at KITTI speeds, yaw about z
+    rel_cam = kio.relative_poses(poses)
+    assert np.allclose(se3[0][:3], [rel_cam[0][2, 3], -rel_cam[0][0, 3], -rel_cam[0][1, 3]], atol=2e-3)   # (upsilon ~ t for mrad rotations)
+    step = np.linalg.norm(se3[:, :3], axis=1)
+    assert 0.7 < step.mean() < 0.9 and step.max() < 1.5 and (se3[:, 0] > -0.05).all()
+    assert np.abs(se3[:, 5]).mean() > 3 * np.abs(se3[:, 3]).mean()
+    # exp/log used to build the constant-velocity prediction error
+    for a in se3[::500]:
+        assert np.allclose(synth.se3_log_np(synth.se3_exp_np(a)), a, atol=1e-12)

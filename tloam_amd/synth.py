@@ -46,6 +46,21 @@ def se3_exp_np(a):
     return T
 
 
+def se3_log_np(T):
+    """Inverse of se3_exp_np (input generation only): (upsilon, omega) of a rigid transform, |omega| < pi."""
+    R, t = np.asarray(T, float)[:3, :3], np.asarray(T, float)[:3, 3]
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s, c = 0.5 * float(np.linalg.norm(w)), 0.5 * (float(np.trace(R)) - 1.0)
+    th = math.atan2(s, c)
+    om = 0.5 * w if th < 1e-10 else th / (2.0 * s) * w
+    Om = _hat(om)
+    if th < 1e-10:
+        V = np.eye(3) + 0.5 * Om
+    else:
+        V = np.eye(3) + (1 - math.cos(th)) / th**2 * Om + (th - math.sin(th)) / th**3 * (Om @ Om)
+    return np.concatenate([np.linalg.solve(V, t), om])
+
+
 @dataclass
 class Frame:
     """The four feature clouds of tloam::Frame (registration_interface.hpp:19-38), (n,3) f64."""
