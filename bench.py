@@ -74,6 +74,44 @@ def pmc_traffic(world):
         return None, None
 
 
+def measured_copy_bandwidth(torch, device):
+    """On-box device-to-device copy bandwidth (read + write bytes per second) of a 512 MiB buffer: the practical
+    ceiling SURVEY 8(d) asks to see beside the 8 TB/s vendor peak."""
+    n = 512 << 20
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def prebuilt_k3(reg, synth, device):
+    """SURVEY 8(d) config 3, K3-only variant: the pre-built 760k:200k:40k set (74.88 MB algorithmic bytes per
+    evaluation, timing weights U(0,1) with 10 % exact zeros), >= 100 launches after 10 warm-ups, median of the
+    per-batch means (one HIP event pair around each batch of 20 consecutive launches)."""
+    sets, _, x_eval = synth.make_prebuilt(seed=1, weights="timing")
+    H = reg.HipRegistration(device=device)
+    for rt in range(3):
+        H.set_correspondences(rt, *sets[rt])
+    H.time_accumulate(x_eval, 10)
+    us = sorted(H.time_accumulate(x_eval, 20) for _ in range(6))
+    H.close()
+    med = 0.5 * (us[2] + us[3])
+    alg = 760_000 * 72.0 + 200_000 * 88.0 + 40_000 * 64.0
+    return {"workload": "pre-built 1 M set, plane:line:point = 760k:200k:40k (SURVEY 8(d) config 3, K3 only)",
+            "launches": 120, "avg_launch_us": round(med, 3), "algorithmic_bytes_per_launch": alg,
+            "achieved": round(alg / (med * 1e-6) / 1e9, 1), "frac": round(alg / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "contract: >= 70 % <=> <= 13.4 us"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +259,14 @@ def main():
                              "note": "the residual/Jacobian kernel on the configuration the north-star states its roofline "
                                      "target on; timed in this command over its own region of %d frames" %
                                      (args.steps if args.workload == "m1" else args.m1_steps)})
+            if not multi:
+                try:
+                    bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
+                    roofline["measured_copy_GBps"] = round(bw, 1)
+                    roofline["frac_of_measured_copy"] = round(roofline["achieved"] / bw, 4)
+                    roofline["prebuilt_k3"] = prebuilt_k3(reg, synth, local_rank)
+                except Exception as e:  # noqa: BLE001  (side measurements never take the line down)
+                    roofline["side_measurements_error"] = repr(e)[:200]
             if args.workload == "kitti":
                 hk = dict(head["k3"])
                 hk.update({"kernel": "k3_accumulate<true>", "note": "same kernel family on the headline frames: 442 KB per "
