@@ -123,8 +123,6 @@ struct ScanTemp;  // opaque
 
 // AoS double[3] -> SoA, for a sub-range
 void launch_aos_to_soa(const double* aos, size_t n, double* x, double* y, double* z, hipStream_t s);
-void launch_fill_f64(double* p, size_t n, double v, hipStream_t s);
-void launch_fill_i32(int* p, size_t n, int v, hipStream_t s);
 
 // exclusive scan of u64 values; tmp must hold scan_tmp_elems(n) u64
 size_t scan_tmp_elems(size_t n);

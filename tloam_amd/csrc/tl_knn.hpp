@@ -66,27 +66,6 @@ __device__ __forceinline__ void topk_insert(TopK<K>& tk, const P& pts, double d,
     j = before ? jm : j;
   }
 }
-// Hot-loop variant: orders by distance only and REPORTS whether the candidate tied bit-exactly with a kept
-// distance; the caller then redoes that (rare) query with the exact (d, index) insertion above.  No branch,
-// no index fetch: 8 VALU ops per level instead of ~26 instructions with two exec-mask branches.
-// A NaN distance (masked-off candidate) compares false everywhere and falls through untouched.
-template <int K>
-__device__ __forceinline__ bool topk_insert_fast(TopK<K>& tk, double d, int j) {
-  bool tie = false;
-  const double d0 = d;  // the candidate itself (d becomes the displaced element further down the list)
-#pragma unroll
-  for (int m = 0; m < K; ++m) {
-    const bool before = d < tk.d[m];
-    tie |= (d0 == tk.d[m]);
-    const double dm = tk.d[m];
-    const int jm = tk.j[m];
-    tk.d[m] = before ? d : dm;
-    tk.j[m] = before ? j : jm;
-    d = before ? dm : d;
-    j = before ? jm : j;
-  }
-  return tie;
-}
 // ------------------------------------------------------------------------------------------------
 // Packed-key list (the hot loops of K1): the candidate's position j in the cell-sorted records replaces the low
 // `bits` mantissa bits of its squared distance, so ONE double carries (distance, position) and a sorted

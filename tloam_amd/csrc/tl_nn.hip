@@ -45,29 +45,6 @@ void launch_aos_to_soa(const double* aos, size_t n, double* x, double* y, double
   hipLaunchKernelGGL(k_aos_to_soa, dim3(blocks), dim3(256), 0, s, aos, n, x, y, z);
 }
 
-__global__ void k_fill_f64(double* p, size_t n, double v) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = v;
-}
-void launch_fill_f64(double* p, size_t n, double v, hipStream_t s) {
-  if (n == 0) return;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_fill_f64, dim3(blocks), dim3(256), 0, s, p, n, v);
-}
-__global__ void k_fill_i32(int* p, size_t n, int v) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = v;
-}
-void launch_fill_i32(int* p, size_t n, int v, hipStream_t s) {
-  if (n == 0) return;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_fill_i32, dim3(blocks), dim3(256), 0, s, p, n, v);
-}
-
 // ================================================================================================
 //  exclusive scan of u64 (block-local scan + recursive scan of block totals + add)
 // ================================================================================================
