@@ -123,6 +123,9 @@ def parse():
     ap.add_argument("--m1-steps", type=int, default=10, help="timed frames of the 1 M block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kitti", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements of the roofline block (copy bandwidth, pre-built K3 set): the PMC passes "
+                         "use it so that every K3 launch they count belongs to the frame workload")
     ap.add_argument("--kitti-frames", type=int, default=200, help="length of the KITTI-density sequence block")
     ap.add_argument("--loop-frames", type=int, default=150, help="length of the device odometry-loop block")
     ap.add_argument("--seed", type=int, default=0)
@@ -259,7 +262,7 @@ def main():
                              "note": "the residual/Jacobian kernel on the configuration the north-star states its roofline "
                                      "target on; timed in this command over its own region of %d frames" %
                                      (args.steps if args.workload == "m1" else args.m1_steps)})
-            if not multi:
+            if not multi and not args.no_side:
                 try:
                     bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
                     roofline["measured_copy_GBps"] = round(bw, 1)

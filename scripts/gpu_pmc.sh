@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $O/pmc -o p -- python $R/bench.py --workload m1 --steps 2 --warmup 1 --no-cpu-baseline --no-kitti > /dev/null 2> $O/pmc.err
+timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d $O/pmc -o p -- python $R/bench.py --workload m1 --steps 2 --warmup 1 --no-cpu-baseline --no-kitti --no-side > /dev/null 2> $O/pmc.err
 cd $R && python scripts/pmc_summary.py "$KERN" $O/pmc.json $(find $O/pmc -name "*.db" | head -1) | python -c "
 import sys, json
 d = json.load(sys.stdin)

@@ -9,8 +9,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -- python $R/bench.py --workload m1 --steps 5 --warmup 1 --no-cpu-baseline --no-kitti > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -- python $R/bench.py --workload m1 --steps 5 --warmup 1 --no-cpu-baseline --no-kitti > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -- python $R/bench.py --workload m1 --steps 5 --warmup 1 --no-cpu-baseline --no-kitti --no-side > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -- python $R/bench.py --workload m1 --steps 5 --warmup 1 --no-cpu-baseline --no-kitti --no-side > $O/pmc_write.json 2> $O/pmc_write.err
 cd $R
 python scripts/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) $O/kernel_stats.csv > /dev/null
 python scripts/pmc_summary.py "k3_accumulate<false>" $O/pmc_k3.json $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) > /dev/null
