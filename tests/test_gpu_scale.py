@@ -136,3 +136,27 @@ def test_thread_per_query_builder_index_parity(hip_module, caps):
     dt, dr = pose_delta(Th, To)
     assert dt < 1e-9 and dr < 1e-9
     H.close()
+
+
+def test_quad_builder_mid_size_index_parity(hip_module):
+    """Between 16 Ki and 128 Ki source points K1 runs four lanes per query (sixteen below, one above): index-level
+    parity against the oracle at ~36 k queries."""
+    n_src = (14_000, 10_000, 9_000, 3_000)
+    n_tgt = (40_000, 30_000, 25_000, 5_000)
+    sc = synth.make_scene(seed=9, n_src=n_src, n_tgt=n_tgt, density=25.0)
+    over = dict(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+    H = hip_module.HipRegistration(hip_module.default_config(**over))
+    O = ob.Oracle(ob.make_config(**over), builder_threads=4, eval_threads=16)
+    H.set_frames(sc.source, sc.target)
+    O.set_frames(sc.source, sc.target)
+    rh, Th, sh = H.scan_match(sc.T_pred)
+    ro, To, so = O.scan_match(sc.T_pred)
+    assert rh == ro == 0 and sh["n_corr"] == so["n_corr"] and sum(so["n_corr"]) > 10_000
+    for k in ("gn_evaluations", "gn_iterations", "accepted_steps", "outer_iterations"):
+        assert sh[k] == so[k], k
+    for kind in range(4):
+        cap = len(sc.source.cloud(kind))
+        assert np.array_equal(H.get_correspondences(kind, capacity=cap)["idx"], O.get_correspondences(kind, capacity=cap)["idx"])
+    dt, dr = pose_delta(Th, To)
+    assert dt < 1e-9 and dr < 1e-9
+    H.close()

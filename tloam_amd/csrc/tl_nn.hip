@@ -413,6 +413,7 @@ __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const Ra
 // ================================================================================================
 constexpr int kTile = 4;        // cells per tile edge
 constexpr int kQuadLimit = 131072;  // at most this many queries: four lanes per query (latency-bound regime)
+constexpr int kWideLimit = 16384;   // at most this many: sixteen lanes per query (one row of the 27 cells per lane)
 
 struct TileMeta {
   int tdim[kKinds][3];
@@ -471,12 +472,12 @@ __global__ __launch_bounds__(256) void k_query_scatter(SlotView sv, const int* _
       double4{sv.sx[slot], sv.sy[slot], sv.sz[slot], __longlong_as_double((long long)slot)};
 }
 
-// One query against the HBM grid of its kind, by LPQ cooperating lanes (1 or 4).
-//   LPQ = 1: the lane resolves the nine (z,y) rows of the 27-cell neighbourhood (18 independent
-//            cell-table loads in flight) and scans them, two 32-byte candidate loads per trip.
-//   LPQ = 4: small frames are latency-bound (one wave per SIMD, a ~35-candidate dependent chain per
-//            query), so four adjacent lanes split the nine rows, walk their rows in parallel, and merge
-//            their sorted top-k lists with two xor-shuffle rounds; lane 0 of the quad finishes the fit.
+// One query against the HBM grid of its kind, by LPQ cooperating lanes (1, 4 or 16).
+//   LPQ = 1: the lane resolves the nine (z,y) rows of the 27-cell neighbourhood (one 16-byte cell-table
+//            request per row, all in flight) and walks them as one candidate stream, four records per trip.
+//   LPQ = 4 / 16: smaller frames are latency-bound (a ~35-candidate dependent chain per query), so 4 (16)
+//            adjacent lanes split the nine rows -- three (at most one) each --, walk them in parallel and merge
+//            their packed-key lists with two (four) xor-shuffle rounds; lane 0 of the group finishes the fit.
 template <int K, int LPQ>
 __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk,
                                          int2* __restrict__ lds_rows) {
@@ -715,7 +716,11 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   // every slot with a tile is in qrec[0 .. n_binned); n_binned <= n is only known on the device, so the
   // launch covers n positions and the kernel bounds itself by the scanned total
   auto grid8 = [](long long threads) { return (unsigned)(((threads + 63) / 64 + 127) / 128 * 128); };  // 8 XCDs x kXcdChunk
-  if (n <= kQuadLimit)
+  // lanes per query: the smaller the frame, the more the build is a latency chain per query and the more lanes
+  // pay (KITTI-size 9.4 k queries: 0.371-0.378 ms per frame with 4, 0.36 with 8, 0.348-0.36 with 16)
+  if (n <= kWideLimit)
+    hipLaunchKernelGGL(k_build_sorted<16>, dim3(grid8(16LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
+  else if (n <= kQuadLimit)
     hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
   else
     hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
