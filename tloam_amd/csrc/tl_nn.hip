@@ -412,8 +412,14 @@ __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const Ra
 //  Replaces the kd-tree walks of registration.cpp:444/:535/:588/:731.
 // ================================================================================================
 constexpr int kTile = 4;        // cells per tile edge
-constexpr int kQuadLimit = 131072;  // at most this many queries: four lanes per query (latency-bound regime)
-constexpr int kWideLimit = 16384;   // at most this many: sixteen lanes per query (one row of the 27 cells per lane)
+#ifndef TLOAM_K1_QUAD_LIMIT
+#define TLOAM_K1_QUAD_LIMIT 131072
+#endif
+#ifndef TLOAM_K1_WIDE_LIMIT
+#define TLOAM_K1_WIDE_LIMIT 16384
+#endif
+constexpr int kQuadLimit = TLOAM_K1_QUAD_LIMIT;  // at most this many queries: four lanes per query (latency-bound regime)
+constexpr int kWideLimit = TLOAM_K1_WIDE_LIMIT;   // at most this many: sixteen lanes per query (one row of the 27 cells per lane)
 
 struct TileMeta {
   int tdim[kKinds][3];
