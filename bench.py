@@ -198,10 +198,12 @@ def main():
         t0 = time.perf_counter()
         gn_iters = 0      # executed GN iterations: residual/Jacobian sweep + 6x6 step (tloam_stats.gn_sweeps)
         gn_evals = 0      # solver evaluations served (some from the totals of the previous sweep, see gn_sweeps)
+        host_wait = 0     # microseconds the calling thread spent waiting for the device (tloam_stats.host_wait_us)
         for _ in range(steps):
             T, st = step()
             gn_iters += st["gn_sweeps"]
             gn_evals += st["gn_evaluations"]
+            host_wait += st["host_wait_us"]
         barrier()
         elapsed = time.perf_counter() - t0
         gn_iters_job = float(gn_iters)
@@ -241,7 +243,7 @@ def main():
         return {"workload": W["name"], "ms_per_frame": elapsed / steps * 1e3, "gn_iters_per_sec": gn_iters_job / elapsed,
                 "gn_iters_per_frame": gn_iters / steps, "solver_evaluations_per_frame": gn_evals / steps, "n_corr": n_corr,
                 "outer_iterations": st["outer_iterations"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3])),
-                "k3": k3, "scene": scene, "cfg": W["cfg"]}
+                "host_wait_us_per_frame": round(host_wait / steps, 1), "k3": k3, "scene": scene, "cfg": W["cfg"]}
 
     # ---- headline: the configuration the metric is quoted on (KITTI-00 scan density); every rank its own frame pair
     head = run_frames(args.workload, args.steps, args.warmup, args.seed + rank)
@@ -284,6 +286,7 @@ def main():
                        "gn_iters_per_frame": head["gn_iters_per_frame"],
                        "solver_evaluations_per_frame": head["solver_evaluations_per_frame"], "n_corr": head["n_corr"],
                        "outer_iterations": head["outer_iterations"], "frames_per_step": world,
+                       "host_wait_us_per_frame": head["host_wait_us_per_frame"],
                        "parallelism": (f"{world} independent frame streams, one per GPU, no data-path collective (replicas, "
                                        "BASELINE.json configs[4]); the sharded single frame is reported under sharded_1m")
                        if multi else "1 GPU",

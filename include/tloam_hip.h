@@ -105,7 +105,7 @@ typedef struct tloam_stats {
                                    * work): <= gn_evaluations -- an evaluation of a point that is bit-identical
                                    * to the one just evaluated (a rejected step retried inside a halved trust
                                    * region) is served from the totals already on the device */
-  int32_t reserved1;
+  int32_t host_wait_us;        /* microseconds of this scan_match the calling thread spent waiting for the device (0 in the oracle) */
 } tloam_stats;
 
 typedef struct tloam_ctx tloam_ctx;

@@ -37,7 +37,7 @@ class Stats(C.Structure):
         ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
         ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
         ("se3", C.c_double * 6),
-        ("gn_sweeps", C.c_int32), ("reserved1", C.c_int32),
+        ("gn_sweeps", C.c_int32), ("host_wait_us", C.c_int32),
     ]
 
     def as_dict(self):

@@ -5,6 +5,8 @@
 // every per-point / per-correspondence computation is a HIP kernel (tl_nn.hip, tl_gn.hip).
 // There is no CPU fallback: without a usable device every computing entry point returns
 // TLOAM_E_HIP.
+#include <chrono>
+
 #include "tl_ctx.hpp"
 
 using namespace tl;
@@ -300,6 +302,12 @@ HostMirror next_mirror(tloam_ctx* c) {
   return hm;
 }
 int wait_state(tloam_ctx* c, const HostMirror& hm) {
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Acc {
+    tloam_ctx* c;
+    std::chrono::steady_clock::time_point t0;
+    ~Acc() { c->wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+  } acc{c, t0};
   if (hm.out) {
     const int rc = wait_word(c, &c->h_state->host_seq, hm.seq);
     if (rc <= 0) return rc;
@@ -588,6 +596,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     }
     launch_frame_init(fi, c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p, c->stream);
   }
+  c->wait_us = 0.0;
   c->mu = 1.0;  // :961
   c->noise_bound_sq = c->cfg.noise_bound * c->cfg.noise_bound;
   if (c->noise_bound_sq < 1e-16) c->noise_bound_sq = 1e-2;  // :963-964
@@ -729,6 +738,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   st.outer_iterations = iter + 1;
   st.gn_evaluations = S.gn_evaluations;
   st.gn_sweeps = S.gn_sweeps;
+  st.host_wait_us = (int32_t)c->wait_us;
   st.gn_iterations = S.gn_iterations;
   st.accepted_steps = S.accepted_steps;
   st.reserved0 = S.bad_weights;

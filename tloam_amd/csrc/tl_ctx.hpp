@@ -151,6 +151,7 @@ struct tloam_ctx {
   bool dbg_no_eval_reuse = false;
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
   double* h_bbox_dev = nullptr;
+  double wait_us = 0.0;            // time the host spent waiting for the device in the current scan_match
   bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
   tl::GnState* h_state_dev = nullptr;   // device address of the pinned host state (HostMirror target)
   unsigned long long mirror_seq = 0;

@@ -69,7 +69,7 @@ class Stats(C.Structure):
         ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
         ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
         ("se3", C.c_double * 6),
-        ("gn_sweeps", C.c_int32), ("reserved1", C.c_int32),
+        ("gn_sweeps", C.c_int32), ("host_wait_us", C.c_int32),
     ]
 
     def as_dict(self):
@@ -77,7 +77,8 @@ class Stats(C.Structure):
                     gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
                     n_corr=list(self.n_corr), converged_early=self.converged_early,
                     bad_weights=self.reserved0, kind_cost=list(self.kind_cost), mu=self.mu,
-                    solver_cost=self.solver_cost, se3=np.array(self.se3), gn_sweeps=self.gn_sweeps)
+                    solver_cost=self.solver_cost, se3=np.array(self.se3), gn_sweeps=self.gn_sweeps,
+                    host_wait_us=self.host_wait_us)
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
