@@ -134,18 +134,20 @@ class HipRegistrationCore {
  private:
   bool upload(FrameT& f, bool source) {
     if (!ctx_) return false;
-    bool all = true;
+    const double* ptr[4];
+    size_t cnt[4];
     auto put = [&](int kind, const auto& cloud_ptr) {
       using Cloud = typename std::remove_reference<decltype(*cloud_ptr)>::type;
-      const int rc = source ? tloam_set_source(ctx_, kind, PointsAccessor<Cloud>::data(*cloud_ptr), PointsAccessor<Cloud>::size(*cloud_ptr))
-                            : tloam_set_target(ctx_, kind, PointsAccessor<Cloud>::data(*cloud_ptr), PointsAccessor<Cloud>::size(*cloud_ptr));
-      all = ok(rc, source ? "tloam_set_source" : "tloam_set_target", ctx_) && all;
+      ptr[kind] = PointsAccessor<Cloud>::data(*cloud_ptr);
+      cnt[kind] = PointsAccessor<Cloud>::size(*cloud_ptr);
     };
     put(TLOAM_KIND_PLANAR, f.planar_feature);   // registration.cpp:233-236 / :242-245
     put(TLOAM_KIND_GROUND, f.ground_feature);
     put(TLOAM_KIND_EDGE, f.edge_feature);
     put(TLOAM_KIND_SPHERE, f.sphere_feature);
-    return all;
+    // the four clouds of the Frame in one call: one host synchronisation per frame
+    return source ? ok(tloam_set_source_frame(ctx_, ptr, cnt), "tloam_set_source_frame", ctx_)
+                  : ok(tloam_set_target_frame(ctx_, ptr, cnt), "tloam_set_target_frame", ctx_);
   }
 
   tloam_ctx* ctx_ = nullptr;

@@ -498,7 +498,7 @@ def odometry_loop(args, reg, torch, device):
     (front_end.cpp:278-337) on the device over a CONSISTENT synthetic street -- per frame setInputSource (the four
     scan clouds cross PCIe), scanMatching against the device-resident submap, updateSubmap with the pose just
     found.  The targets never leave HBM.  Reports ms per frame and the drift against the generator's trajectory."""
-    from tloam_amd import synth_world as sw
+    from tloam_amd import synth, synth_world as sw
     nf = args.loop_frames
     W = sw.make_world(seed=args.seed)
     Ts = sw.trajectory(nf + 1)
@@ -513,8 +513,7 @@ def odometry_loop(args, reg, torch, device):
         pred = est[-1] @ (np.linalg.inv(est[-2]) @ est[-1] if len(est) > 1 else np.eye(4))   # front_end.cpp:329-330
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(4):
-            H.set_source(k, sc[k])
+        H.set_input_source(synth.Frame(sc[0], sc[1], sc[2], sc[3]))      # setInputSource(const Frame&): one call
         rc, T, st = H.scan_match(pred)
         if rc != 0:
             raise SystemExit(f"odometry loop frame {f}: {reg.STATUS.get(rc, rc)}")
@@ -526,7 +525,7 @@ def odometry_loop(args, reg, torch, device):
     sizes = [len(H.get_target(k)) for k in range(4)]
     H.close()
     ms = np.array(ms[5:])                                                  # first frames: buffers still growing
-    return {"workload": "consistent synthetic street, %d frames, 0.8 m / frame; per frame: set_source x4 + scan_match "
+    return {"workload": "consistent synthetic street, %d frames, 0.8 m / frame; per frame: set_input_source (4 clouds) + scan_match "
                         "+ submap_update (device-resident submap)" % nf,
             "ms_per_frame": round(float(ms.mean()), 4), "ms_per_frame_p50": round(float(np.median(ms)), 4),
             "ms_per_frame_p99": round(float(np.percentile(ms, 99)), 4), "gn_iters_per_frame": round(its / nf, 2),

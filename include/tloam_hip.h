@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 2  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points */
+#define TLOAM_ABI_VERSION 3  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -125,6 +125,11 @@ const char* tloam_last_error(const tloam_ctx* ctx);
  * the FULL cloud and the context keeps its contiguous index block. */
 int tloam_set_source(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
 int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
+/* The same for the four clouds of a tloam::Frame at once (registration_interface.hpp:19-38; setInputSource /
+ * setInputTarget take a Frame, registration.cpp:232-248), indexed by TLOAM_KIND_*: one host synchronisation per
+ * frame instead of one per cloud.  xyz_aos[k] may be NULL when n[k] == 0. */
+int tloam_set_source_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
+int tloam_set_target_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
 
 /* ---- RegistrationInterface::scanMatching (registration.cpp:879-1133) -------------------
  * predict/result: 4x4 column-major.  omega_perturb3: the unit vector the reference draws

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/tloam_hip.h but not exported"
     assert set(reg.EXPORTED_SYMBOLS) == set(names)
-    assert L.tloam_abi_version() == 2
+    assert L.tloam_abi_version() == 3
 
 
 def test_struct_layout_matches_the_c_header():

@@ -486,9 +486,9 @@ void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi) {
 }
 
 // ---- setInputSource / setInputTarget (registration.cpp:232-248) --------------------------------
-int tloam_set_source(tloam_ctx* c, int kind, const double* xyz, size_t n) {
-  if (!c || kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
+namespace {
+int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   size_t lo = 0, hi = n;
   tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
@@ -498,14 +498,11 @@ int tloam_set_source(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   HIPC(c, K.src_aos.reserve(3 * std::max<size_t>(K.n_src, 1)));
   if (K.n_src > 0)
     HIPC(c, hipMemcpyAsync(K.src_aos.p, xyz + 3 * lo, sizeof(double) * 3 * K.n_src, hipMemcpyHostToDevice, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
   K.src_set = true;
   return TLOAM_OK;
 }
-
-int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
-  if (!c || kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
-  HIPC(c, hipSetDevice(c->device));
+int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   K.n_tgt = n;
   const size_t m = std::max<size_t>(n, 1);
@@ -515,9 +512,45 @@ int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
     HIPC(c, hipMemcpyAsync(K.tgt_aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     launch_aos_to_soa(K.tgt_aos.p, n, K.tx.p, K.ty.p, K.tz.p, c->stream);  // AoS -> SoA on the device
   }
-  HIPC(c, hipStreamSynchronize(c->stream));
   K.tgt_set = true;
   return TLOAM_OK;
+}
+}  // namespace
+
+int tloam_set_source(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (!c) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  const int rc = set_source_async(c, kind, xyz, n);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the call
+  return TLOAM_OK;
+}
+
+int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+  if (!c) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  const int rc = set_target_async(c, kind, xyz, n);
+  if (rc != TLOAM_OK) return rc;
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
+int tloam_set_source_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
+  if (!c || !xyz || !n) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  int rc = TLOAM_OK;
+  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_source_async(c, k, xyz[k], n[k]);
+  HIPC(c, hipStreamSynchronize(c->stream));  // the host buffers are only borrowed for the call
+  return rc;
+}
+
+int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
+  if (!c || !xyz || !n) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  int rc = TLOAM_OK;
+  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k]);
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 // ---- scanMatching, stepwise ---------------------------------------------------------------------

@@ -111,6 +111,8 @@ def load_library():
         "tloam_destroy": (None, [vp]),
         "tloam_set_source": (C.c_int, [vp, C.c_int, dp, sz]),
         "tloam_set_target": (C.c_int, [vp, C.c_int, dp, sz]),
+        "tloam_set_source_frame": (C.c_int, [vp, C.POINTER(dp), C.POINTER(sz)]),
+        "tloam_set_target_frame": (C.c_int, [vp, C.POINTER(dp), C.POINTER(sz)]),
         "tloam_scan_match": (C.c_int, [vp, dp, dp, dp, dp, sz, C.POINTER(Stats)]),
         "tloam_sm_begin": (C.c_int, [vp, dp, dp]),
         "tloam_sm_outer": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(Stats)]),
@@ -154,7 +156,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = (
     "tloam_abi_version", "tloam_status_string", "tloam_last_error", "tloam_default_config", "tloam_create",
-    "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_scan_match", "tloam_sm_begin",
+    "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_set_source_frame", "tloam_set_target_frame",
+    "tloam_scan_match", "tloam_sm_begin",
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_solve",
     "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
@@ -249,17 +252,22 @@ class HipRegistration:
             raise TloamHipError(f"{what}: {STATUS.get(rc, rc)} {msg.decode() if msg else ''}")
 
     # ---- RegistrationInterface ------------------------------------------------------------
-    def set_input_source(self, frame) -> bool:
-        """setInputSource (registration.cpp:232-239)."""
+    def _frame_call(self, fn, name, tag, frame):
+        clouds = [_aos(frame.cloud(k)) for k in range(4)]
+        ptrs = (C.POINTER(C.c_double) * 4)(*[_dp(a) for a in clouds])
+        ns = (C.c_size_t * 4)(*[len(a) for a in clouds])
         for k in range(4):
-            self.set_source(k, frame.cloud(k))
+            self._n[(tag, k)] = len(clouds[k])
+        self._check(fn(self.h, ptrs, ns), name)
         return True
+
+    def set_input_source(self, frame) -> bool:
+        """setInputSource (registration.cpp:232-239): the four clouds of the Frame in one call."""
+        return self._frame_call(self.L.tloam_set_source_frame, "tloam_set_source_frame", "s", frame)
 
     def set_input_target(self, frame) -> bool:
         """setInputTarget (registration.cpp:241-248)."""
-        for k in range(4):
-            self.set_target(k, frame.cloud(k))
-        return True
+        return self._frame_call(self.L.tloam_set_target_frame, "tloam_set_target_frame", "t", frame)
 
     def scan_matching(self, predict_pose, omega_perturb=None, scan_cloud=None):
         """scanMatching (registration.cpp:879-1133) -> (True, result_pose 4x4).  `scan_cloud`
