@@ -23,7 +23,7 @@ namespace {
 int submap_reserve_work(tloam_ctx* c, size_t n) {
   SubmapState& S = c->submap;
   const size_t m = std::max<size_t>(n, 1), cap = voxel_table_size(m);
-  HIPC(c, S.min_partial.reserve(256 * 3)); HIPC(c, S.vmin.reserve(8)); HIPC(c, S.counts.reserve(8));
+  HIPC(c, S.min_partial.reserve(256 * 6)); HIPC(c, S.vmin.reserve(8)); HIPC(c, S.counts.reserve(8));
   HIPC(c, S.overflow.reserve(8));
   HIPC(c, S.keys.reserve(cap + 1)); HIPC(c, S.cnt.reserve(cap + 1)); HIPC(c, S.off.reserve(cap + 1));
   HIPC(c, S.slot_of_pt.reserve(m)); HIPC(c, S.urank.reserve(m)); HIPC(c, S.members.reserve(m)); HIPC(c, S.sorted.reserve(m));
@@ -31,27 +31,38 @@ int submap_reserve_work(tloam_ctx* c, size_t n) {
   HIPC(c, S.scan_tmp.reserve(scan_tmp_elems(std::max(cap + 1, m + 1))));
   return TLOAM_OK;
 }
-// target[kind] <- VoxelDownSample(Crop(cloud (wx, wy, wz)[0..n), box), voxel); the output size goes to counts[slot]
-int submap_crop_voxel(tloam_ctx* c, int kind, size_t n, const double lo[3], const double hi[3], double voxel, int slot) {
+// One launch sequence for one or two clouds stored back to back in (wx, wy, wz): segment s = points
+// [s ? n0 : 0, s ? n : n0) -> target[kind[s]] = VoxelDownSample(Crop(segment, box[s]), voxel[s]); sizes to counts[s].
+// A single cloud: n0 == n, kind[1] ignored.
+struct CropVoxelSeg { int kind; size_t n; const double* lo; const double* hi; double voxel; };
+int submap_crop_voxel(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg) {
   SubmapState& S = c->submap;
-  KindData& K = c->kd[kind];
+  const size_t n0 = seg[0].n, n = n0 + (nseg > 1 ? seg[1].n : 0);
   int rc = submap_reserve_work(c, n);
   if (rc != TLOAM_OK) return rc;
-  const size_t m = std::max<size_t>(n, 1);
-  HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
   VoxelJob J;
   J.x = S.wx.p; J.y = S.wy.p; J.z = S.wz.p;
   J.n = n;
-  for (int a = 0; a < 3; ++a) { J.lo[a] = lo[a]; J.hi[a] = hi[a]; }
-  J.voxel = voxel;
-  J.mask = voxel_table_size(m) - 1;
+  J.n0 = n0;
   VoxelWork W;
+  for (int s = 0; s < 2; ++s) {
+    const CropVoxelSeg& G = seg[s < nseg ? s : 0];
+    for (int a = 0; a < 3; ++a) { J.lo[s][a] = G.lo[a]; J.hi[s][a] = G.hi[a]; }
+    J.voxel[s] = G.voxel;
+    KindData& K = c->kd[G.kind];
+    if (s < nseg) {
+      const size_t m = std::max<size_t>(G.n, 1);
+      HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
+    }
+    W.out[s][0] = K.tx.p; W.out[s][1] = K.ty.p; W.out[s][2] = K.tz.p;
+  }
+  J.mask = voxel_table_size(std::max<size_t>(n, 1)) - 1;
   W.min_partial = S.min_partial.p; W.vmin = S.vmin.p;
   W.keys = S.keys.p; W.cnt = S.cnt.p; W.off = S.off.p;
   W.slot_of_pt = S.slot_of_pt.p; W.urank = S.urank.p; W.members = S.members.p; W.sorted = S.sorted.p;
   W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
-  W.n_out = S.counts.p + slot;
-  launch_crop_voxel(J, W, K.tx.p, K.ty.p, K.tz.p, c->stream);
+  W.n_out = S.counts.p;
+  launch_crop_voxel(J, W, c->stream);
   return TLOAM_OK;
 }
 int submap_upload(tloam_ctx* c, const double* xyz, size_t n) {  // host AoS -> in_aos (device)
@@ -106,12 +117,17 @@ int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double
   if (rc != TLOAM_OK) return rc;
   HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
   HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
-  rc = submap_crop_voxel(c, TLOAM_KIND_GROUND, n_ground, kNoLo, kNoHi, S.cfg.ground_down_sample, 1);
+  {  // one cloud; its size lands in counts[0]
+    const CropVoxelSeg seg[2] = {{TLOAM_KIND_GROUND, n_ground, kNoLo, kNoHi, S.cfg.ground_down_sample},
+                                 {TLOAM_KIND_GROUND, 0, kNoLo, kNoHi, S.cfg.ground_down_sample}};
+    rc = submap_crop_voxel(c, seg, 1);
+  }
   if (rc != TLOAM_OK) return rc;
   size_t ne = 0, ng = 0;
   rc = submap_finish(c, &ne, &ng);
   if (rc != TLOAM_OK) return rc;
-  c->kd[TLOAM_KIND_GROUND].n_tgt = ng;
+  (void)ng;
+  c->kd[TLOAM_KIND_GROUND].n_tgt = ne;  // (single-cloud job: counts[0])
   c->kd[TLOAM_KIND_GROUND].tgt_set = true;
   S.inited = true;
   return TLOAM_OK;
@@ -167,29 +183,46 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
   HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
   HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
   // :246-264 edge / ground: submap += scan->Transform(pose); Crop(pose.translation() +- L)->VoxelDownSample
-  struct Acc { int kind; const double* xyz; size_t n; double L, voxel; int slot; };
-  const Acc accs[2] = {{TLOAM_KIND_EDGE, edge, n_edge, S.cfg.edge_crop_box_length, S.cfg.edge_down_sample_submap, 0},
-                       {TLOAM_KIND_GROUND, ground, n_ground, S.cfg.ground_crop_box_length, S.cfg.ground_down_sample_submap, 1}};
-  for (const Acc& A : accs) {
-    KindData& K = c->kd[A.kind];
-    const size_t n_old = K.tgt_set ? K.n_tgt : 0, n_in = n_old + A.n, m = std::max<size_t>(n_in, 1);
-    if (S.wx.cap < m || S.in_aos.cap < 3 * std::max<size_t>(A.n, 1))
-      HIPC(c, hipStreamSynchronize(c->stream));  // about to regrow a buffer the previous cloud's kernels may still read
+  // Both clouds go through ONE launch sequence (two segments of one job, tl_common.hpp VoxelJob): half the launches
+  // of two separate jobs -- the update is bound by the host's launch rate, not by the device.
+  struct Acc { int kind; const double* xyz; size_t n; double L, voxel; };
+  const Acc accs[2] = {{TLOAM_KIND_EDGE, edge, n_edge, S.cfg.edge_crop_box_length, S.cfg.edge_down_sample_submap},
+                       {TLOAM_KIND_GROUND, ground, n_ground, S.cfg.ground_crop_box_length, S.cfg.ground_down_sample_submap}};
+  size_t n_old[2], n_in[2], n_all = 0, n_up = 1;
+  for (int s = 0; s < 2; ++s) {
+    const KindData& K = c->kd[accs[s].kind];
+    n_old[s] = K.tgt_set ? K.n_tgt : 0;
+    n_in[s] = n_old[s] + accs[s].n;
+    n_all += n_in[s];
+    n_up = std::max(n_up, accs[s].n);
+  }
+  {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
+     // only then -- in steady state the capacities suffice and the update runs without a host wait
+    const size_t m = std::max<size_t>(n_all, 1);
+    bool grow = S.wx.cap < m || S.in_aos.cap < 3 * n_up || S.slot_of_pt.cap < m || S.keys.cap < voxel_table_size(m) + 1 ||
+                S.leader.cap < m + 1;
+    for (int s = 0; s < 2; ++s) grow = grow || c->kd[accs[s].kind].tx.cap < std::max<size_t>(n_in[s], 1);
+    if (grow) HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
-    launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old, S.wx.p, S.wy.p, S.wz.p, c->stream);
-    rc = submap_upload(c, A.xyz, A.n);
+    HIPC(c, S.in_aos.reserve(3 * n_up));
+  }
+  double lo[2][3], hi[2][3];
+  size_t base = 0;
+  for (int s = 0; s < 2; ++s) {
+    const Acc& A = accs[s];
+    KindData& K = c->kd[A.kind];
+    launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old[s], S.wx.p + base, S.wy.p + base, S.wz.p + base, c->stream);
+    rc = submap_upload(c, A.xyz, A.n);  // (stream-ordered after the previous segment's transform read in_aos)
     if (rc != TLOAM_OK) return rc;
-    launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + n_old, S.wy.p + n_old, S.wz.p + n_old, c->stream);
-    double lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) { lo[a] = pose[12 + a] - A.L; hi[a] = pose[12 + a] + A.L; }  // :250-254, :259-262
-    {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
-       // only then -- in steady state the capacities suffice and the update runs without a host wait
-      const size_t m_in = std::max<size_t>(n_in, 1);
-      if (K.tx.cap < m_in || S.slot_of_pt.cap < m_in || S.keys.cap < voxel_table_size(m_in) + 1 ||
-          S.leader.cap < m_in + 1)
-        HIPC(c, hipStreamSynchronize(c->stream));
-    }
-    rc = submap_crop_voxel(c, A.kind, n_in, lo, hi, A.voxel, A.slot);
+    launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + base + n_old[s], S.wy.p + base + n_old[s],
+                            S.wz.p + base + n_old[s], c->stream);
+    for (int a = 0; a < 3; ++a) { lo[s][a] = pose[12 + a] - A.L; hi[s][a] = pose[12 + a] + A.L; }  // :250-254, :259-262
+    base += n_in[s];
+  }
+  {
+    const CropVoxelSeg seg[2] = {{accs[0].kind, n_in[0], lo[0], hi[0], accs[0].voxel},
+                                 {accs[1].kind, n_in[1], lo[1], hi[1], accs[1].voxel}};
+    rc = submap_crop_voxel(c, seg, 2);
     if (rc != TLOAM_OK) return rc;
   }
   size_t ne = 0, ng = 0;

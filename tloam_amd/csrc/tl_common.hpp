@@ -186,22 +186,27 @@ void launch_fitness(const GridView& g, const double* qx, const double* qy, const
                     double radius, double* partial /*[blocks*2]*/, int blocks, hipStream_t s);
 
 // ---- device-resident submap maintenance (tl_submap.hip; front_end.cpp:201-275) ----------------
+// One Crop + VoxelDownSample launch sequence over up to TWO clouds stored back to back ("segments": the edge and
+// the ground submap of an update -- same pipeline, different box and voxel size).  Points [0, n0) are segment 0,
+// [n0, n) segment 1; the segment is part of the voxel key, so the segments never mix, and because the voxels are
+// emitted in order of first occurrence segment 0's come out first.  One cloud: n0 == n.
 struct VoxelJob {
-  const double *x, *y, *z;   // input cloud, SoA
-  size_t n;
-  double lo[3], hi[3];       // crop box, inclusive (+-inf: no crop)
-  double voxel;              // voxel size
+  const double *x, *y, *z;   // input clouds, SoA, concatenated
+  size_t n, n0;
+  double lo[2][3], hi[2][3]; // crop boxes, inclusive (+-inf: no crop)
+  double voxel[2];           // voxel sizes
   unsigned long long mask;   // hash-table capacity - 1 (power of two >= 2 n)
 };
 struct VoxelWork {           // scratch, sized by the caller (see voxel_table_size)
-  double* min_partial;       // [256][3]
-  double* vmin;              // [3] voxel_min_bound
+  double* min_partial;       // [256][6]
+  double* vmin;              // [2][3] voxel_min_bound per segment
   unsigned long long *keys, *cnt, *off;   // [cap + 1]
   int *slot_of_pt, *urank, *members, *sorted;  // [n]
   unsigned long long *leader, *leader_scan;    // [n + 1]
   unsigned long long* scan_tmp;
   int* overflow;             // set when a voxel index leaves [0, 2^21)
-  unsigned long long* n_out; // receives the size of the down-sampled cloud
+  unsigned long long* n_out; // [2] receives the sizes of the down-sampled clouds
+  double* out[2][3];         // (x, y, z) of the down-sampled cloud per segment
 };
 size_t voxel_table_size(size_t n);
 void launch_transform_to_soa(const double* aos, size_t n, const double M[16], double* ox, double* oy, double* oz,
@@ -211,7 +216,7 @@ void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], d
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s);
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);
-void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s);
+void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s);
 
 // ---- PCA feature extraction (tl_feature.hip; feature_extract.cpp:47-197) -----------------------
 struct FeatArgs {

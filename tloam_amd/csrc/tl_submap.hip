@@ -78,49 +78,56 @@ __global__ void k_soa_to_aos(const double* __restrict__ x, const double* __restr
   aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
 }
 
-__device__ __forceinline__ bool in_box(const VoxelJob& J, double x, double y, double z) {
+__device__ __forceinline__ bool in_box(const VoxelJob& J, int seg, double x, double y, double z) {
   // AxisAlignedBoundingBox::GetPointIndicesWithinBoundingBox: inclusive on both sides
-  return x >= J.lo[0] && x <= J.hi[0] && y >= J.lo[1] && y <= J.hi[1] && z >= J.lo[2] && z <= J.hi[2];
+  return x >= J.lo[seg][0] && x <= J.hi[seg][0] && y >= J.lo[seg][1] && y <= J.hi[seg][1] && z >= J.lo[seg][2] &&
+         z <= J.hi[seg][2];
 }
 
-// GetMinBound() of the cropped cloud, block partials
-__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][3]*/,
+// GetMinBound() of the cropped clouds (one per segment), block partials
+__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][6]*/,
                                                  unsigned long long* __restrict__ keys,
                                                  unsigned long long* __restrict__ cnt) {
-  __shared__ double sm[3][256];
+  __shared__ double sm[6][256];
   // the same launch empties the hash table of this job (keys = empty, cnt = 0 incl. the scan terminator)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= J.mask + 1; i += (size_t)gridDim.x * 256) {
     if (i <= J.mask) keys[i] = kEmpty;
     cnt[i] = 0ull;
   }
-  double m[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+  double m[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) m[a] = __builtin_inf();
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (size_t)gridDim.x * 256) {
     const double x = J.x[i], y = J.y[i], z = J.z[i];
-    if (in_box(J, x, y, z)) { m[0] = fmin(m[0], x); m[1] = fmin(m[1], y); m[2] = fmin(m[2], z); }
+    const int seg = i >= J.n0 ? 1 : 0;
+    if (in_box(J, seg, x, y, z)) {
+      if (seg == 0) { m[0] = fmin(m[0], x); m[1] = fmin(m[1], y); m[2] = fmin(m[2], z); }
+      else { m[3] = fmin(m[3], x); m[4] = fmin(m[4], y); m[5] = fmin(m[5], z); }
+    }
   }
 #pragma unroll
-  for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = m[a];
+  for (int a = 0; a < 6; ++a) sm[a][threadIdx.x] = m[a];
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
+      for (int a = 0; a < 6; ++a) sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sm[threadIdx.x][0];
+  if (threadIdx.x < 6) partial[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
 }
 // voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); an empty cloud has min bound (0, 0, 0)
-__global__ __launch_bounds__(192) void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel,
-                                                       double* __restrict__ vmin) {
-  // one wave per axis, the rows spread over its lanes (min is exact in any order); a 3-thread serial loop over
-  // the 256 rows was a 26 us chain of dependent loads -- a quarter of the submap update
+__global__ __launch_bounds__(384) void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel0,
+                                                       double voxel1, double* __restrict__ vmin) {
+  // one wave per (segment, axis), the rows spread over its lanes (min is exact in any order); a 3-thread serial
+  // loop over the 256 rows was a 26 us chain of dependent loads -- a quarter of the submap update
   const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double m = __builtin_inf();
-  for (int b = lane; b < blocks; b += 64) m = fmin(m, partial[b * 3 + a]);
+  for (int b = lane; b < blocks; b += 64) m = fmin(m, partial[b * 6 + a]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
   if (!(m < __builtin_inf())) m = 0.0;
-  if (lane == 0) vmin[a] = m - voxel * 0.5;
+  if (lane == 0) vmin[a] = m - (a < 3 ? voxel0 : voxel1) * 0.5;
 }
 
 // voxel of every in-box point -> hash slot; the counting atomic also hands out an (arbitrary) member rank
@@ -131,17 +138,27 @@ __global__ __launch_bounds__(256) void k_vox_insert(VoxelJob J, const double* __
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= J.n) return;
   const double x = J.x[i], y = J.y[i], z = J.z[i];
-  if (!in_box(J, x, y, z)) { slot_of_pt[i] = -1; return; }
+  const int seg = i >= J.n0 ? 1 : 0;
+  if (!in_box(J, seg, x, y, z)) { slot_of_pt[i] = -1; return; }
   // ref_coord = (p - voxel_min_bound) / voxel_size; index = int(floor(ref_coord))   (:380-383)
-  const long long ix = (long long)floor((x - vmin[0]) / J.voxel);
-  const long long iy = (long long)floor((y - vmin[1]) / J.voxel);
-  const long long iz = (long long)floor((z - vmin[2]) / J.voxel);
+  const double voxel = J.voxel[seg];
+  const long long ix = (long long)floor((x - vmin[3 * seg + 0]) / voxel);
+  const long long iy = (long long)floor((y - vmin[3 * seg + 1]) / voxel);
+  const long long iz = (long long)floor((z - vmin[3 * seg + 2]) / voxel);
   if (ix < 0 || iy < 0 || iz < 0 || ix >= (1ll << 21) || iy >= (1ll << 21) || iz >= (1ll << 21)) {
     *overflow = 1;  // "[VoxelDownSample] voxel_size is too small." (:370-372)
     slot_of_pt[i] = -1;
     return;
   }
-  const unsigned long long key = (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42);
+  // 3 x 21 bits of voxel coordinates, bit 63 = segment.  The all-ones key (segment 1, all three indices 2^21 - 1)
+  // is the empty marker: reported like an index out of range
+  const unsigned long long key = (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42) |
+                                 ((unsigned long long)seg << 63);
+  if (key == kEmpty) {
+    *overflow = 1;
+    slot_of_pt[i] = -1;
+    return;
+  }
   unsigned long long h = mix64(key) & J.mask;
   for (;;) {
     const unsigned long long prev = atomicCAS(&keys[h], kEmpty, key);
@@ -182,30 +199,31 @@ __global__ __launch_bounds__(256) void k_vox_order(size_t n, const int* __restri
   leader[i] = (r == 0) ? 1ull : 0ull;
 }
 
-// AccumulatedPoint: point_ += p in index order, GetAveragePoint = point_ / double(num) (:253-272)
-__global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, const int* __restrict__ slot_of_pt,
-                                                        const unsigned long long* __restrict__ off,
-                                                        const unsigned long long* __restrict__ cnt,
-                                                        const int* __restrict__ sorted,
-                                                        const unsigned long long* __restrict__ leader_scan,
-                                                        double* __restrict__ ox, double* __restrict__ oy,
-                                                        double* __restrict__ oz, unsigned long long* __restrict__ n_out) {
+// AccumulatedPoint: point_ += p in index order, GetAveragePoint = point_ / double(num) (:253-272); the voxels of
+// segment 0 come first in first-occurrence order, so segment 1's positions are rebased by their count
+__global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, VoxelWork W) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) *n_out = leader_scan[J.n];  // number of voxels = size of the down-sampled cloud
+  const unsigned long long base1 = W.leader_scan[J.n0];
+  if (i == 0) {  // numbers of voxels = sizes of the down-sampled clouds
+    W.n_out[0] = base1;
+    W.n_out[1] = W.leader_scan[J.n] - base1;
+  }
   if (i >= J.n) return;
-  const int h = slot_of_pt[i];
+  const int h = W.slot_of_pt[i];
   if (h < 0) return;
-  const unsigned long long pos = leader_scan[i];
-  if (leader_scan[i + 1] == pos) return;  // not a leader
-  const unsigned long long o = off[h];
-  const int m = (int)cnt[h];
+  const unsigned long long pos = W.leader_scan[i];
+  if (W.leader_scan[i + 1] == pos) return;  // not a leader
+  const int seg = i >= J.n0 ? 1 : 0;
+  const unsigned long long o = W.off[h];
+  const int m = (int)W.cnt[h];
   double sx = 0.0, sy = 0.0, sz = 0.0;
   for (int q = 0; q < m; ++q) {
-    const int j = sorted[o + q];
+    const int j = W.sorted[o + q];
     sx += J.x[j]; sy += J.y[j]; sz += J.z[j];
   }
   const double dn = (double)m;
-  ox[pos] = sx / dn; oy[pos] = sy / dn; oz[pos] = sz / dn;
+  const unsigned long long p = pos - (seg ? base1 : 0ull);
+  W.out[seg][0][p] = sx / dn; W.out[seg][1][p] = sy / dn; W.out[seg][2][p] = sz / dn;
 }
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -241,13 +259,13 @@ size_t voxel_table_size(size_t n) {
   return cap;
 }
 
-// Crop(box) -> VoxelDownSample(voxel) of the SoA cloud in J, written to (ox, oy, oz); the number of output
-// points lands in W.leader_scan[J.n] (device).  No host synchronisation.
-void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double* oy, double* oz, hipStream_t s) {
+// Crop(box) -> VoxelDownSample(voxel) of the one or two SoA clouds in J, written to W.out; the output sizes land in
+// W.n_out[0..1] (device).  No host synchronisation.
+void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s) {
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
   hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt);
-  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(192), 0, s, W.min_partial, kMinBlocks, J.voxel, W.vmin);
+  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(384), 0, s, W.min_partial, kMinBlocks, J.voxel[0], J.voxel[1], W.vmin);
   const size_t cap = (size_t)J.mask + 1;
   if (n > 0)
     hipLaunchKernelGGL(k_vox_insert, dim3(blocks_for(n)), dim3(256), 0, s, J, W.vmin, W.keys, W.cnt, W.slot_of_pt,
@@ -258,8 +276,7 @@ void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, double* ox, double
   hipLaunchKernelGGL(k_vox_order, dim3(blocks_for(n + 1)), dim3(256), 0, s, n, W.slot_of_pt, W.off, W.cnt, W.members,
                      W.sorted, W.leader);
   launch_exclusive_scan_u64(W.leader, W.leader_scan, n + 1, W.scan_tmp, s);
-  hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n + 1)), dim3(256), 0, s, J, W.slot_of_pt, W.off, W.cnt, W.sorted,
-                     W.leader_scan, ox, oy, oz, W.n_out);
+  hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n + 1)), dim3(256), 0, s, J, W);
 }
 
 }  // namespace tl
