@@ -115,8 +115,6 @@ int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double
   launch_aos_to_soa(S.in_aos.p, n_ground, S.wx.p, S.wy.p, S.wz.p, c->stream);
   rc = submap_reserve_work(c, n_ground);
   if (rc != TLOAM_OK) return rc;
-  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
   {  // one cloud; its size lands in counts[0]
     const CropVoxelSeg seg[2] = {{TLOAM_KIND_GROUND, n_ground, kNoLo, kNoHi, S.cfg.ground_down_sample},
                                  {TLOAM_KIND_GROUND, 0, kNoLo, kNoHi, S.cfg.ground_down_sample}};
@@ -171,17 +169,22 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
     if (P.tx.cap < m || Q.tx.cap < m) HIPC(c, hipStreamSynchronize(c->stream));  // regrowth: nothing may be in flight
     HIPC(c, P.tx.reserve(m)); HIPC(c, P.ty.reserve(m)); HIPC(c, P.tz.reserve(m));
     HIPC(c, Q.tx.reserve(m)); HIPC(c, Q.ty.reserve(m)); HIPC(c, Q.tz.reserve(m));
-    size_t off = 0;
-    for (auto* f : S.planar_ring) {  // one launch per buffered frame writes both submaps
-      launch_transform_to_soa2(f->aos.p, f->n, f->pose, P.tx.p + off, P.ty.p + off, P.tz.p + off, Q.tx.p + off,
-                               Q.ty.p + off, Q.tz.p + off, c->stream);
-      off += f->n;
+    if ((int)S.planar_ring.size() <= transform_ring_max()) {  // all buffered frames, both submaps: ONE launch
+      const double* aos[16]; size_t nn[16]; const double* poses[16];
+      int cnt = 0;
+      for (auto* f : S.planar_ring) { aos[cnt] = f->aos.p; nn[cnt] = f->n; poses[cnt] = f->pose; ++cnt; }
+      launch_transform_ring(cnt, aos, nn, poses, P.tx.p, P.ty.p, P.tz.p, Q.tx.p, Q.ty.p, Q.tz.p, c->stream);
+    } else {
+      size_t off = 0;
+      for (auto* f : S.planar_ring) {  // one launch per buffered frame writes both submaps
+        launch_transform_to_soa2(f->aos.p, f->n, f->pose, P.tx.p + off, P.ty.p + off, P.tz.p + off, Q.tx.p + off,
+                                 Q.ty.p + off, Q.tz.p + off, c->stream);
+        off += f->n;
+      }
     }
     P.n_tgt = Q.n_tgt = total;
     P.tgt_set = Q.tgt_set = true;
   }
-  HIPC(c, hipMemsetAsync(S.counts.p, 0, 2 * sizeof(unsigned long long), c->stream));
-  HIPC(c, hipMemsetAsync(S.overflow.p, 0, sizeof(int), c->stream));
   // :246-264 edge / ground: submap += scan->Transform(pose); Crop(pose.translation() +- L)->VoxelDownSample
   // Both clouds go through ONE launch sequence (two segments of one job, tl_common.hpp VoxelJob): half the launches
   // of two separate jobs -- the update is bound by the host's launch rate, not by the device.

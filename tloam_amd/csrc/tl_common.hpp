@@ -213,6 +213,9 @@ void launch_transform_to_soa(const double* aos, size_t n, const double M[16], do
                              hipStream_t s);
 void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], double* ax, double* ay, double* az,
                               double* bx, double* by, double* bz, hipStream_t s);
+int transform_ring_max();  // frames one launch_transform_ring call takes
+void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
+                           double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s);
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s);
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);

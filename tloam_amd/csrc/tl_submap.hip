@@ -18,6 +18,8 @@
 // Voxel membership uses an open-addressing hash table keyed by the packed voxel coordinates
 // (ix | iy << 21 | iz << 42); per-voxel member lists are ordered by index with a rank-by-counting pass so the
 // floating-point accumulation order is the reference's (ascending index).  Compiled with -ffp-contract=off.
+#include <algorithm>
+
 #include "tl_common.hpp"
 
 namespace tl {
@@ -64,6 +66,30 @@ __global__ void k_transform_to_soa2(const double* __restrict__ aos, size_t n, Ma
   bx[i] = px; by[i] = py; bz[i] = pz;
 }
 
+// the frames of the planar ring buffer (front_end.cpp:220-243) in ONE launch: blockIdx.y = frame
+constexpr int kRingMax = 8;
+struct RingArgs {
+  const double* aos[kRingMax];
+  size_t n[kRingMax], off[kRingMax];
+  Mat16 M[kRingMax];
+};
+__global__ void k_transform_ring(RingArgs R, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
+                                 double* __restrict__ bx, double* __restrict__ by, double* __restrict__ bz) {
+  const int f = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R.n[f]) return;
+  const double* __restrict__ aos = R.aos[f];
+  const Mat16& M = R.M[f];
+  const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+  double r[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) r[a] = ((M.m[a] * x + M.m[4 + a] * y) + M.m[8 + a] * z) + M.m[12 + a] * 1.0;
+  const double px = r[0] / r[3], py = r[1] / r[3], pz = r[2] / r[3];
+  const size_t o = R.off[f] + i;
+  ax[o] = px; ay[o] = py; az[o] = pz;
+  bx[o] = px; by[o] = py; bz[o] = pz;
+}
+
 __global__ void k_copy3(const double* __restrict__ ax, const double* __restrict__ ay, const double* __restrict__ az,
                         size_t n, double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,8 +113,9 @@ __device__ __forceinline__ bool in_box(const VoxelJob& J, int seg, double x, dou
 // GetMinBound() of the cropped clouds (one per segment), block partials
 __global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][6]*/,
                                                  unsigned long long* __restrict__ keys,
-                                                 unsigned long long* __restrict__ cnt) {
+                                                 unsigned long long* __restrict__ cnt, int* __restrict__ overflow) {
   __shared__ double sm[6][256];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;  // (set by k_vox_insert, the launch after the next)
   // the same launch empties the hash table of this job (keys = empty, cnt = 0 incl. the scan terminator)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= J.mask + 1; i += (size_t)gridDim.x * 256) {
     if (i <= J.mask) keys[i] = kEmpty;
@@ -243,6 +270,22 @@ void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], d
   for (int i = 0; i < 16; ++i) m.m[i] = M[i];
   hipLaunchKernelGGL(k_transform_to_soa2, dim3(blocks_for(n)), dim3(256), 0, s, aos, n, m, ax, ay, az, bx, by, bz);
 }
+int transform_ring_max() { return kRingMax; }
+void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
+                           double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s) {
+  RingArgs R;
+  size_t off = 0, nmax = 0;
+  for (int f = 0; f < count; ++f) {
+    R.aos[f] = aos[f];
+    R.n[f] = n[f];
+    R.off[f] = off;
+    for (int i = 0; i < 16; ++i) R.M[f].m[i] = poses[f][i];
+    off += n[f];
+    nmax = std::max(nmax, n[f]);
+  }
+  if (count == 0 || nmax == 0) return;
+  hipLaunchKernelGGL(k_transform_ring, dim3(blocks_for(nmax), count), dim3(256), 0, s, R, ax, ay, az, bx, by, bz);
+}
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s) {
   if (n == 0) return;
@@ -264,7 +307,7 @@ size_t voxel_table_size(size_t n) {
 void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s) {
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
-  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt);
+  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt, W.overflow);
   hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(384), 0, s, W.min_partial, kMinBlocks, J.voxel[0], J.voxel[1], W.vmin);
   const size_t cap = (size_t)J.mask + 1;
   if (n > 0)
