@@ -191,36 +191,42 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
   struct Acc { int kind; const double* xyz; size_t n; double L, voxel; };
   const Acc accs[2] = {{TLOAM_KIND_EDGE, edge, n_edge, S.cfg.edge_crop_box_length, S.cfg.edge_down_sample_submap},
                        {TLOAM_KIND_GROUND, ground, n_ground, S.cfg.ground_crop_box_length, S.cfg.ground_down_sample_submap}};
-  size_t n_old[2], n_in[2], n_all = 0, n_up = 1;
+  size_t n_old[2], n_in[2], n_all = 0;
   for (int s = 0; s < 2; ++s) {
     const KindData& K = c->kd[accs[s].kind];
     n_old[s] = K.tgt_set ? K.n_tgt : 0;
     n_in[s] = n_old[s] + accs[s].n;
     n_all += n_in[s];
-    n_up = std::max(n_up, accs[s].n);
   }
   {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
      // only then -- in steady state the capacities suffice and the update runs without a host wait
     const size_t m = std::max<size_t>(n_all, 1);
-    bool grow = S.wx.cap < m || S.in_aos.cap < 3 * n_up || S.slot_of_pt.cap < m || S.keys.cap < voxel_table_size(m) + 1 ||
-                S.leader.cap < m + 1;
+    bool grow = S.wx.cap < m || S.in_aos.cap < 3 * std::max<size_t>(accs[0].n, 1) ||
+                S.in_aos2.cap < 3 * std::max<size_t>(accs[1].n, 1) || S.slot_of_pt.cap < m ||
+                S.keys.cap < voxel_table_size(m) + 1 || S.leader.cap < m + 1;
     for (int s = 0; s < 2; ++s) grow = grow || c->kd[accs[s].kind].tx.cap < std::max<size_t>(n_in[s], 1);
     if (grow) HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
-    HIPC(c, S.in_aos.reserve(3 * n_up));
+    HIPC(c, S.in_aos.reserve(3 * std::max<size_t>(accs[0].n, 1)));
+    HIPC(c, S.in_aos2.reserve(3 * std::max<size_t>(accs[1].n, 1)));
   }
   double lo[2][3], hi[2][3];
-  size_t base = 0;
-  for (int s = 0; s < 2; ++s) {
-    const Acc& A = accs[s];
-    KindData& K = c->kd[A.kind];
-    launch_copy3(K.tx.p, K.ty.p, K.tz.p, n_old[s], S.wx.p + base, S.wy.p + base, S.wz.p + base, c->stream);
-    rc = submap_upload(c, A.xyz, A.n);  // (stream-ordered after the previous segment's transform read in_aos)
-    if (rc != TLOAM_OK) return rc;
-    launch_transform_to_soa(S.in_aos.p, A.n, pose, S.wx.p + base + n_old[s], S.wy.p + base + n_old[s],
-                            S.wz.p + base + n_old[s], c->stream);
-    for (int a = 0; a < 3; ++a) { lo[s][a] = pose[12 + a] - A.L; hi[s][a] = pose[12 + a] + A.L; }  // :250-254, :259-262
-    base += n_in[s];
+  {
+    AssembleArgs A;
+    size_t base = 0;
+    for (int s = 0; s < 2; ++s) {
+      const Acc& a = accs[s];
+      KindData& K = c->kd[a.kind];
+      double* stage = s == 0 ? S.in_aos.p : S.in_aos2.p;
+      if (a.n > 0) HIPC(c, hipMemcpyAsync(stage, a.xyz, sizeof(double) * 3 * a.n, hipMemcpyHostToDevice, c->stream));
+      A.ox[s] = K.tx.p; A.oy[s] = K.ty.p; A.oz[s] = K.tz.p;
+      A.aos[s] = stage;
+      A.n_old[s] = n_old[s]; A.n_new[s] = a.n; A.base[s] = base;
+      for (int x = 0; x < 3; ++x) { lo[s][x] = pose[12 + x] - a.L; hi[s][x] = pose[12 + x] + a.L; }  // :250-254, :259-262
+      base += n_in[s];
+    }
+    for (int i = 0; i < 16; ++i) A.M[i] = pose[i];
+    launch_assemble(A, S.wx.p, S.wy.p, S.wz.p, c->stream);  // [old | Transform(new)] of both clouds, one launch
   }
   {
     const CropVoxelSeg seg[2] = {{accs[0].kind, n_in[0], lo[0], hi[0], accs[0].voxel},

@@ -213,6 +213,13 @@ void launch_transform_to_soa(const double* aos, size_t n, const double M[16], do
                              hipStream_t s);
 void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], double* ax, double* ay, double* az,
                               double* bx, double* by, double* bz, hipStream_t s);
+struct AssembleArgs {          // per segment: old submap cloud (SoA) followed by the new scan cloud (AoS, to transform)
+  const double *ox[2], *oy[2], *oz[2];
+  const double* aos[2];
+  size_t n_old[2], n_new[2], base[2];
+  double M[16];                // column-major pose
+};
+void launch_assemble(const AssembleArgs& A, double* wx, double* wy, double* wz, hipStream_t s);
 int transform_ring_max();  // frames one launch_transform_ring call takes
 void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
                            double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s);

@@ -90,14 +90,14 @@ struct SubmapState {
   bool inited = false;
   tloam_submap_config cfg;
   std::vector<RingFrame*> planar_ring, sphere_ring;  // oldest first (std::deque in the reference)
-  DBuf<double> in_aos, wx, wy, wz, min_partial, vmin;
+  DBuf<double> in_aos, in_aos2, wx, wy, wz, min_partial, vmin;
   DBuf<unsigned long long> keys, cnt, off, leader, leader_scan, scan_tmp, counts;
   DBuf<int> slot_of_pt, urank, members, sorted, overflow;
   void release() {
     for (auto* f : planar_ring) { f->aos.release(); delete f; }
     for (auto* f : sphere_ring) { f->aos.release(); delete f; }
     planar_ring.clear(); sphere_ring.clear();
-    in_aos.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
+    in_aos.release(); in_aos2.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
     keys.release(); cnt.release(); off.release(); leader.release(); leader_scan.release(); scan_tmp.release();
     counts.release(); slot_of_pt.release(); urank.release(); members.release(); sorted.release(); overflow.release();
     inited = false;

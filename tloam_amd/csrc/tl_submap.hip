@@ -270,6 +270,31 @@ void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], d
   for (int i = 0; i < 16; ++i) m.m[i] = M[i];
   hipLaunchKernelGGL(k_transform_to_soa2, dim3(blocks_for(n)), dim3(256), 0, s, aos, n, m, ax, ay, az, bx, by, bz);
 }
+// Input assembly of the two-segment job in ONE launch (blockIdx.y = segment): [old submap | Transform(new scan)]
+// per segment, written back to back into (wx, wy, wz)
+__global__ void k_assemble(AssembleArgs A, double* __restrict__ wx, double* __restrict__ wy, double* __restrict__ wz) {
+  const int s = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n_old = A.n_old[s], n_new = A.n_new[s];
+  if (i >= n_old + n_new) return;
+  const size_t o = A.base[s] + i;
+  if (i < n_old) {  // *submap (kept as is)
+    wx[o] = A.ox[s][i]; wy[o] = A.oy[s][i]; wz[o] = A.oz[s][i];
+    return;
+  }
+  const size_t k = i - n_old;  // += scan->Transform(pose)
+  const double* __restrict__ aos = A.aos[s];
+  const double x = aos[3 * k], y = aos[3 * k + 1], z = aos[3 * k + 2];
+  double r[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) r[a] = ((A.M[a] * x + A.M[4 + a] * y) + A.M[8 + a] * z) + A.M[12 + a] * 1.0;
+  wx[o] = r[0] / r[3]; wy[o] = r[1] / r[3]; wz[o] = r[2] / r[3];
+}
+void launch_assemble(const AssembleArgs& A, double* wx, double* wy, double* wz, hipStream_t s) {
+  const size_t nmax = std::max(A.n_old[0] + A.n_new[0], A.n_old[1] + A.n_new[1]);
+  if (nmax == 0) return;
+  hipLaunchKernelGGL(k_assemble, dim3(blocks_for(nmax), 2), dim3(256), 0, s, A, wx, wy, wz);
+}
 int transform_ring_max() { return kRingMax; }
 void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
                            double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s) {
