@@ -711,9 +711,10 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   //      last three frames are enqueued (typically 2 of 5 from the second iteration on: the retried rejected steps
   //      are served by the evaluation reuse); the weight update and the finish kernel are gated on the
   //      minimiser having terminated, and raise `incomplete` otherwise -- then the Solve is topped up.
-  if ((int)c->planned_sweeps.size() < 3 * (iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), kSolveSweeps);
+  if ((int)c->planned_sweeps.size() < 3 * (iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), 0);  // 0 = no history yet
   int* hist = &c->planned_sweeps[3 * (size_t)iter];  // budget = the most this iteration needed in the last 3 frames
-  int planned = std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
+  int planned = hist[0] == 0 ? kSolveSweeps  // first frame of this context: the full budget
+                             : std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
   if (c->dbg_planned_sweeps > 0) planned = std::min(c->dbg_planned_sweeps, kSolveSweeps);
   rc = enqueue_solve(c, /*armed=*/true, planned);  // armed by sm_begin / the previous iteration's finish kernel
   if (rc != TLOAM_OK) return rc;
@@ -762,8 +763,12 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   }
   const GnState& S = *c->h_state;
   hist = &c->planned_sweeps[3 * (size_t)iter];
-  hist[2] = hist[1]; hist[1] = hist[0];
-  hist[0] = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
+  {
+    const int used = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
+    if (hist[0] == 0) hist[1] = hist[2] = used;  // the first observation stands for the whole window
+    else { hist[2] = hist[1]; hist[1] = hist[0]; }
+    hist[0] = used;
+  }
   rc = harvest_k3_events(c, S.gn_sweeps - sweeps_before);
   if (rc != TLOAM_OK) return rc;
   c->mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
