@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 3  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points */
+#define TLOAM_ABI_VERSION 3  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+                               * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
