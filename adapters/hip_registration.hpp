@@ -63,6 +63,14 @@ class HipRegistrationCore {
   tloam_ctx* context() { return ctx_; }
   const tloam_stats& lastStats() const { return stats_; }
 
+  // The unit vector the reference draws with Eigen::Vector3d::Random() when the predicted rotation is below 1e-2 rad
+  // (registration.cpp:884-886).  Default: none -> the library uses (0,0,1), deterministic.  A host that wants the
+  // reference's behaviour passes Eigen::Vector3d::Random().normalized().data() before each scanMatching.
+  void setOmegaPerturbation(const double* unit3_or_null) {
+    have_omega_ = unit3_or_null != nullptr;
+    if (have_omega_) for (int i = 0; i < 3; ++i) omega_[i] = unit3_or_null[i];
+  }
+
   bool setInputSource(FrameT& f) { return upload(f, /*source=*/true); }
   bool setInputTarget(FrameT& f) { return upload(f, /*source=*/false); }
 
@@ -71,9 +79,16 @@ class HipRegistrationCore {
     auto& scan = *out_result.scan_cloud;
     using Acc = PointsAccessor<typename std::remove_reference<decltype(scan)>::type>;
     double result[16];
-    const int rc = tloam_scan_match(ctx_, predict_pose.matrix().data(), /*omega_perturb=*/nullptr, result,
+    const int rc = tloam_scan_match(ctx_, predict_pose.matrix().data(), have_omega_ ? omega_ : nullptr, result,
                                     Acc::mutable_data(scan), Acc::size(scan), &stats_);
-    if (!ok(rc, "tloam_scan_match", ctx_)) return false;
+    if (rc == TLOAM_E_WEIGHT_RANGE) {
+      // the reference's assert at registration.cpp:871 (its build sets no NDEBUG) would have aborted the node; the
+      // solve itself ran to the end with the weights as computed and the result is written: warn and carry on
+      std::fprintf(stderr, "[tloam_hip] scanMatching: %d GNC weight(s) outside [0,1] (registration.cpp:871)\n",
+                   (int)stats_.weight_range_violations);
+    } else if (!ok(rc, "tloam_scan_match", ctx_)) {
+      return false;
+    }
     for (int i = 0; i < 16; ++i) result_pose.matrix().data()[i] = result[i];  // registration.cpp:1124
     return true;
   }
@@ -153,6 +168,8 @@ class HipRegistrationCore {
   tloam_ctx* ctx_ = nullptr;
   int status_ = TLOAM_OK;
   tloam_stats stats_{};
+  bool have_omega_ = false;
+  double omega_[3] = {0.0, 0.0, 1.0};
 };
 
 }  // namespace tloam_hip

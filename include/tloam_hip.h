@@ -37,8 +37,10 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 3  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
-                               * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us */
+#define TLOAM_ABI_VERSION 4  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+                               * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us
+                               * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
+                               *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -61,7 +63,11 @@ typedef enum tloam_status {
   TLOAM_E_HIP = -4,            /* HIP runtime error / no device                             */
   TLOAM_E_RCCL = -5,           /* RCCL error / librccl not loadable                         */
   TLOAM_E_NOT_READY = -6,      /* call sequence violated (e.g. outer step before begin)     */
-  TLOAM_E_WEIGHT_RANGE = -7    /* GNC weight left [0,1] (the reference's assert, :871)      */
+  TLOAM_E_WEIGHT_RANGE = -7    /* a GNC weight left [0,1]: the reference's assert at :871, live in its build
+                                * (CMakeLists.txt:5-6 set no NDEBUG).  Returned by tloam_sm_outer for the
+                                * iteration it happened in and by tloam_scan_match AFTER the whole solve ran:
+                                * result pose and stats are written, the weights are used as computed (what
+                                * an NDEBUG build of the reference would do); the caller decides           */
 } tloam_status;
 
 /* The 16 keys of the `TLS:` block, config/mapping/lidar_odometry.yaml:23-39, read by
@@ -97,7 +103,7 @@ typedef struct tloam_stats {
   int32_t accepted_steps;         /* ... of which accepted                                    */
   int32_t n_corr[TLOAM_NUM_KINDS];/* factors added in the LAST outer iteration, per kind      */
   int32_t converged_early;        /* 1 if the planar-cost plateau test broke the loop (:1108) */
-  int32_t reserved0;
+  int32_t weight_range_violations;/* GNC weights that left [0,1] in this scan_match (the reference asserts, :871) */
   double kind_cost[TLOAM_NUM_KINDS]; /* side-channel cost sums of the last iteration (:1091-1094) */
   double mu;                      /* GNC mu after the last update (:1089)                      */
   double solver_cost;             /* Ceres-style cost 0.5*sum(rho) at the final iterate        */
@@ -181,6 +187,10 @@ int tloam_set_correspondences(tloam_ctx* ctx, int res_type, size_t n, const doub
  * context the outputs are the all-reduced totals. */
 int tloam_accumulate(tloam_ctx* ctx, const double se3[6], double H_rowmajor[36], double g[6],
                      double* cost);
+/* Parity probe of the per-outer-iteration linear system: the robustified normal equations the minimiser
+ * held when its last Solve returned -- H = sum rho' J^T J (row-major 6x6), g = sum rho' J^T r, and the cost
+ * 0.5 sum rho, all at the ACCEPTED iterate (tloam_stats.se3).  In a sharded context: the all-reduced totals. */
+int tloam_get_normal_equations(tloam_ctx* ctx, double H_rowmajor[36], double g[6], double* cost);
 /* side-channel costs of the current set, per residual type (after tloam_accumulate/solve) */
 int tloam_get_costs(tloam_ctx* ctx, int res_type, size_t capacity, size_t* n, double* cost);
 /* One ceres::Solve as configured at registration.cpp:1036-1047 on the current set:

@@ -34,7 +34,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("outer_iterations", C.c_int32), ("gn_evaluations", C.c_int32),
         ("gn_iterations", C.c_int32), ("accepted_steps", C.c_int32),
-        ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
+        ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("weight_range_violations", C.c_int32),
         ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
         ("se3", C.c_double * 6),
         ("gn_sweeps", C.c_int32), ("host_wait_us", C.c_int32),
@@ -44,6 +44,7 @@ class Stats(C.Structure):
         return dict(outer_iterations=self.outer_iterations, gn_evaluations=self.gn_evaluations,
                     gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
                     n_corr=list(self.n_corr), converged_early=self.converged_early,
+                    bad_weights=self.weight_range_violations,
                     kind_cost=list(self.kind_cost), mu=self.mu, solver_cost=self.solver_cost,
                     se3=np.array(self.se3), gn_sweeps=self.gn_sweeps)
 
@@ -200,6 +201,13 @@ class Oracle:
         x = np.ascontiguousarray(se3, float)
         H = np.zeros(36); g = np.zeros(6); cost = C.c_double(0)
         rc = self.L.orc_accumulate(self.h, _dp(x), _dp(H), _dp(g), C.byref(cost))
+        assert rc == 0, rc
+        return H.reshape(6, 6), g, cost.value
+
+    def get_normal_equations(self):
+        H = np.zeros(36); g = np.zeros(6); cost = C.c_double(0)
+        self.L.orc_get_normal_equations.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        rc = self.L.orc_get_normal_equations(self.h, _dp(H), _dp(g), C.byref(cost))
         assert rc == 0, rc
         return H.reshape(6, 6), g, cost.value
 

@@ -512,6 +512,7 @@ struct orc_ctx {
   double prev_cost[4], cur_cost[4];
   tloam_stats stats;
   int bad_weights;
+  double last_H[36], last_g[6], last_cost; /* normal equations at the accepted iterate when the last Solve returned */
 };
 
 static void rset_reserve(orc_rset* s, int cap) {
@@ -1110,6 +1111,9 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
     }
   }
   st->solver_cost = x_cost;
+  memcpy(c->last_H, cur.H, sizeof(cur.H));
+  memcpy(c->last_g, cur.g, sizeof(cur.g));
+  c->last_cost = x_cost;
 }
 
 /* ============================================================================
@@ -1224,7 +1228,8 @@ int orc_sm_outer(orc_ctx* c, int* done, tloam_stats* stats) {
   c->stats.outer_iterations = iter + 1;
   c->stats.mu = c->mu;
   memcpy(c->stats.se3, c->x, sizeof(double) * 6);
-  c->stats.reserved0 = c->bad_weights;
+  const int weight_violation = c->bad_weights > c->stats.weight_range_violations;
+  c->stats.weight_range_violations = c->bad_weights;
   double diff = fabs(c->cur_cost[TLOAM_KIND_PLANAR] - c->prev_cost[TLOAM_KIND_PLANAR]);
   int fin = 0;
   if (diff < c->cfg.cost_threshold) { /* :1108 */
@@ -1241,7 +1246,7 @@ int orc_sm_outer(orc_ctx* c, int* done, tloam_stats* stats) {
   if (fin) c->iter = c->cfg.max_iterations;
   if (done) *done = fin;
   if (stats) *stats = c->stats;
-  return TLOAM_OK;
+  return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK; /* the reference asserts (:871; no NDEBUG in its build) */
 }
 
 int orc_sm_end(orc_ctx* c, double result[16], tloam_stats* stats) {
@@ -1258,9 +1263,10 @@ int orc_scan_match(orc_ctx* c, const double predict[16], const double* omega3, d
                    double* scan_xyz, size_t n_scan, tloam_stats* stats) {
   int rc = orc_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
-  int done = 0;
+  int done = 0, weight_violation = 0;
   while (!done) {
     rc = orc_sm_outer(c, &done, NULL);
+    if (rc == TLOAM_E_WEIGHT_RANGE) { weight_violation = 1; continue; } /* reported after the solve, like the HIP path */
     if (rc != TLOAM_OK) return rc;
   }
   rc = orc_sm_end(c, result, stats);
@@ -1274,7 +1280,7 @@ int orc_scan_match(orc_ctx* c, const double predict[16], const double* omega3, d
       p[0] = o[0] / o[3]; p[1] = o[1] / o[3]; p[2] = o[2] / o[3];
     }
   }
-  return TLOAM_OK;
+  return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;
 }
 
 /* registration.cpp:257-296 */
@@ -1387,6 +1393,16 @@ int orc_accumulate(orc_ctx* c, const double se3[6], double H[36], double g[6], d
   if (cost) *cost = nrm.cost;
   return TLOAM_OK;
 }
+/* H = sum rho' J^T J, g = sum rho' J^T r and the cost at the accepted iterate of the last Solve (what the
+ * minimiser held when it returned) -- parity probe of the per-outer-iteration linear system */
+int orc_get_normal_equations(orc_ctx* c, double H[36], double g[6], double* cost) {
+  if (!c) return TLOAM_E_INVALID;
+  if (H) memcpy(H, c->last_H, sizeof(c->last_H));
+  if (g) memcpy(g, c->last_g, sizeof(c->last_g));
+  if (cost) *cost = c->last_cost;
+  return TLOAM_OK;
+}
+
 int orc_get_costs(orc_ctx* c, int res_type, size_t capacity, size_t* n, double* cost) {
   if (!c || res_type < 0 || res_type >= 3 || !n) return TLOAM_E_INVALID;
   int kind = (res_type == TLOAM_RES_PLANE) ? TLOAM_KIND_PLANAR : (res_type == TLOAM_RES_LINE) ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE;

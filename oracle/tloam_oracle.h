@@ -72,6 +72,7 @@ int orc_set_correspondences(orc_ctx* c, int res_type, size_t n, const double* p,
 /* shard helper for the multi-rank tests: restrict the pre-built sets to [lo,hi) per type */
 int orc_accumulate(orc_ctx* c, const double se3[6], double H[36], double g[6], double* cost);
 int orc_get_costs(orc_ctx* c, int res_type, size_t capacity, size_t* n, double* cost);
+int orc_get_normal_equations(orc_ctx* c, double H[36], double g[6], double* cost);
 int orc_solve(orc_ctx* c, double se3_inout[6], tloam_stats* stats);
 
 #ifdef __cplusplus

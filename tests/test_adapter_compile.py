@@ -63,3 +63,93 @@ def test_adapter_template_compiles_and_marshals():
         out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "set=" in out.stdout
+
+
+# ---- the SUCCESS path of the C++ marshalling, on the GPU box ----------------------------------------------
+import numpy as np   # noqa: E402
+import pytest        # noqa: E402
+
+SRC_GPU = r'''
+#include <array>
+#include <cstdio>
+#include <memory>
+#include <vector>
+#include "adapters/hip_registration.hpp"
+struct Cloud { std::vector<std::array<double, 3>> points_; };
+struct Frame {
+  std::shared_ptr<Cloud> scan_cloud = std::make_shared<Cloud>(), edge_feature = std::make_shared<Cloud>(),
+      sphere_feature = std::make_shared<Cloud>(), planar_feature = std::make_shared<Cloud>(),
+      ground_feature = std::make_shared<Cloud>();
+};
+struct Mat { double m[16]; double* data() { return m; } };
+struct Pose { Mat mat; Mat& matrix() { return mat; } };
+static bool read_cloud(FILE* f, Cloud& c) {
+  long long n = 0;
+  if (std::fread(&n, sizeof(n), 1, f) != 1) return false;
+  c.points_.resize((size_t)n);
+  return n == 0 || std::fread(c.points_.data(), 24, (size_t)n, f) == (size_t)n;
+}
+int main(int argc, char** argv) {
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  Frame src, tgt, out;
+  // file order: planar, ground, edge, sphere (TLOAM_KIND_*), source then target, then the scan cloud, then the pose
+  Cloud* order_s[4] = {src.planar_feature.get(), src.ground_feature.get(), src.edge_feature.get(), src.sphere_feature.get()};
+  Cloud* order_t[4] = {tgt.planar_feature.get(), tgt.ground_feature.get(), tgt.edge_feature.get(), tgt.sphere_feature.get()};
+  for (auto* c : order_s) if (!read_cloud(f, *c)) return 3;
+  for (auto* c : order_t) if (!read_cloud(f, *c)) return 3;
+  if (!read_cloud(f, *out.scan_cloud)) return 3;
+  Pose pred{}, res{};
+  if (std::fread(pred.mat.m, 8, 16, f) != 16) return 3;
+  std::fclose(f);
+  tloam_tls_config cfg; tloam_default_config(&cfg);
+  tloam_hip::HipRegistrationCore<Frame, Pose> reg(cfg, 0);
+  if (!reg.valid()) return 4;
+  if (!reg.setInputSource(src) || !reg.setInputTarget(tgt)) return 5;
+  if (!reg.scanMatching(out, pred, res)) return 6;
+  auto fit = reg.getFitnessScore();
+  for (int i = 0; i < 16; ++i) std::printf("%.17g ", res.mat.m[i]);
+  std::printf("\n%d %d %d %d %d\n", reg.lastStats().n_corr[0], reg.lastStats().n_corr[1], reg.lastStats().n_corr[2],
+              reg.lastStats().n_corr[3], reg.lastStats().gn_evaluations);
+  const auto& p = out.scan_cloud->points_;
+  std::printf("%.17g %.17g %.17g\n", p[0][0], p[0][1], p[0][2]);
+  std::printf("%.17g %.17g\n", fit.first, fit.second);
+  return 0;
+}
+'''
+
+
+@pytest.mark.gpu
+def test_adapter_success_path_on_the_gpu(hip_module):
+    """adapters/hip_registration.hpp compiled on the box and run on a real scene: setInputSource / setInputTarget /
+    scanMatching / getFitnessScore all succeed, and the pose, the in-place transformed scan cloud and the statistics
+    equal what the C ABI returns when called directly (the Python binding) -- bit for bit."""
+    from tloam_amd import synth
+    sc = synth.make_scene(seed=21)
+    scan = np.ascontiguousarray(sc.source.planar[:50].copy())
+    lib_dir = os.path.join(ROOT, "tloam_amd")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp"); exe = os.path.join(d, "t"); dat = os.path.join(d, "scene.bin")
+        open(src, "w").write(SRC_GPU)
+        with open(dat, "wb") as f:
+            for fr in (sc.source, sc.target):
+                for k in range(4):
+                    a = np.ascontiguousarray(fr.cloud(k), np.float64)
+                    f.write(np.int64(len(a)).tobytes()); f.write(a.tobytes())
+            f.write(np.int64(len(scan)).tobytes()); f.write(scan.tobytes())
+            f.write(np.ascontiguousarray(sc.T_pred.T, np.float64).tobytes())     # column-major
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", ROOT, src, "-o", exe, "-L", lib_dir,
+                               "-l:libtloam_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+        out = subprocess.run([exe, dat], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    lines = out.stdout.strip().splitlines()
+    T_cpp = np.array(lines[0].split(), float).reshape(4, 4).T
+    H = hip_module.HipRegistration(); H.set_frames(sc.source, sc.target)
+    scan_py = scan.copy()
+    rc, T, st = H.scan_match(sc.T_pred, scan=scan_py)
+    assert rc == 0
+    assert np.array_equal(T_cpp, T)
+    assert [int(v) for v in lines[1].split()] == st["n_corr"] + [st["gn_evaluations"]]
+    assert np.array_equal(np.array(lines[2].split(), float), scan_py[0])
+    rcf, fit, rmse = H.fitness()
+    assert rcf == 0 and np.array_equal(np.array(lines[3].split(), float), [fit, rmse])

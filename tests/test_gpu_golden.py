@@ -77,6 +77,31 @@ def test_fitness_parity(hip_module):
     assert H.get_fitness_score() == (f, r)
 
 
+def test_fitness_threshold_above_the_search_cell_and_call_order(hip_module):
+    """getFitnessScore accepts any positive fitness_thres (registration.cpp:257-296): larger than the builders'
+    radius the walk widens; between sm_begin and sm_end the context belongs to the solve (NOT_READY), and a fitness
+    call never disturbs the slot arrays of the following scan_match."""
+    sc = synth.make_scene(seed=13, noise=0.01)
+    for thres in (0.6, 1.7):
+        H = hip_module.HipRegistration(hip_module.default_config(fitness_thres=thres))
+        O = ob.Oracle(ob.make_config(fitness_thres=thres))
+        H.set_frames(sc.source, sc.target); O.set_frames(sc.source, sc.target)
+        rc, T0, st0 = H.scan_match(sc.T_pred); O.scan_match(sc.T_pred)
+        rc, f, r = H.fitness(); rco, fo, ro = O.fitness()
+        assert rc == 0 and rco == 0 and fo > 0
+        assert abs(f - fo) < 1e-12 * max(1.0, fo) and abs(r - ro) < 1e-12 * max(1.0, ro), (thres, f, fo, r, ro)
+        assert H.sm_begin(sc.T_pred) == 0
+        assert H.fitness()[0] == -6                      # TLOAM_E_NOT_READY while the solve is active
+        while True:
+            rc, done, _ = H.sm_outer()
+            assert rc == 0
+            if done:
+                break
+        rc, T1, st1 = H.sm_end()
+        assert rc == 0 and np.array_equal(T0, T1)        # the fitness call in between changed nothing
+        H.close()
+
+
 def test_repeated_scan_match_is_bit_reproducible(hip_module):
     """Fixed-order reductions, no atomics on the value path: identical inputs -> identical bits."""
     sc = synth.make_scene(seed=13)

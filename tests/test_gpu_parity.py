@@ -75,6 +75,9 @@ def test_scan_match_stepwise_parity(hip_module, seed):
             ch, co = H.get_correspondences(kind), O.get_correspondences(kind)
             assert np.array_equal(ch["idx"], co["idx"]), (it, kind)
             np.testing.assert_allclose(ch["a"], co["a"], rtol=0, atol=1e-9)
+            if kind == 2:   # the edge line's second endpoint (registration.cpp:484)
+                assert len(ch["b"]) == len(co["b"]) > 0
+                np.testing.assert_allclose(ch["b"], co["b"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(ch["d"], co["d"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(ch["w"], co["w"], rtol=1e-9, atol=1e-15)
             np.testing.assert_allclose(ch["cost"], co["cost"], rtol=1e-7, atol=1e-14)
@@ -83,6 +86,12 @@ def test_scan_match_stepwise_parity(hip_module, seed):
                (st_o["gn_iterations"], st_o["accepted_steps"], st_o["gn_evaluations"]), (it, st_h, st_o)
         np.testing.assert_allclose(st_h["se3"], st_o["se3"], rtol=0, atol=1e-9)
         np.testing.assert_allclose(st_h["kind_cost"], st_o["kind_cost"], rtol=1e-7, atol=1e-14)
+        # the linear system itself, per outer iteration: H, g and the cost at the accepted iterate of this Solve
+        Hh, gh, ch_ = H.get_normal_equations()
+        Ho, go, co_ = O.get_normal_equations()
+        np.testing.assert_allclose(Hh, Ho, rtol=1e-9, atol=1e-9 * np.abs(Ho).max())
+        np.testing.assert_allclose(gh, go, rtol=1e-7, atol=1e-9 * max(np.abs(go).max(), np.abs(Ho).max() * 1e-6))
+        assert abs(ch_ - co_) <= 1e-9 * abs(co_) and abs(ch_ - st_h["solver_cost"]) == 0.0
         assert done_h == done_o
         if done_h:
             break

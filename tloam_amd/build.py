@@ -45,6 +45,33 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def build_variant(name, flags, units=("tl_gn.hip",), verbose=False):
+    """Tuning builds (never the product library): tloam_amd/_variants/lib_<name>.so = the shipped objects with
+    `units` recompiled under extra -D flags.  Selected at run time with TLOAM_HIP_LIB=<path>."""
+    build(force=False, verbose=verbose)
+    hipcc = _hipcc()
+    vdir = os.path.join(HERE, "_variants")
+    odir = os.path.join(vdir, "obj_" + name)
+    os.makedirs(odir, exist_ok=True)
+    objs, procs = [], []
+    for src, extra in UNITS:
+        if src in units:
+            obj = os.path.join(odir, src.replace(".hip", ".o"))
+            cmd = [hipcc, *COMMON, *extra, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        else:
+            obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    out = os.path.join(vdir, f"lib_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
@@ -74,4 +101,12 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m tloam_amd.build --variant NAME [--units a.hip,b.hip] -- -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        units = ("tl_gn.hip",)
+        if "--units" in sys.argv:
+            units = tuple(sys.argv[sys.argv.index("--units") + 1].split(","))
+        flags = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
+        print(build_variant(sys.argv[i + 1], flags, units, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -343,7 +343,7 @@ int ensure_common(tloam_ctx* c) {
   HIPC(c, c->red48.reserve(kReduceBuf));
   HIPC(c, c->sums16.reserve(16));
   HIPC(c, c->wpart.reserve(256 * 8));
-  HIPC(c, c->rank_counts.reserve(64 * kKinds));
+  HIPC(c, c->rank_counts.reserve((size_t)kMaxRanks * kKinds));
   HIPC(c, c->se3_dev.reserve(8));
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;
@@ -459,6 +459,7 @@ void tloam_destroy(tloam_ctx* c) {
     K.c_d.release(); K.c_w.release(); K.c_cost.release();
   }
   c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
+  c->fit_x.release(); c->fit_y.release(); c->fit_z.release();
   c->raw.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
   c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qrec.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
@@ -779,7 +780,8 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   st.host_wait_us = (int32_t)c->wait_us;
   st.gn_iterations = S.gn_iterations;
   st.accepted_steps = S.accepted_steps;
-  st.reserved0 = S.bad_weights;
+  const bool weight_violation = S.bad_weights > st.weight_range_violations;
+  st.weight_range_violations = S.bad_weights;
   st.mu = c->mu;
   st.solver_cost = S.x_cost;
   memcpy(st.se3, S.x, sizeof(double) * 6);
@@ -805,7 +807,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   if (fin) c->iter = c->cfg.max_iterations;
   if (done) *done = fin;
   if (stats) *stats = st;
-  return TLOAM_OK;
+  return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;  // the iteration is complete either way (:871)
 }
 
 int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
@@ -822,8 +824,10 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
   int done = 0;
+  bool weight_violation = false;
   while (!done) {
     rc = tloam_sm_outer(c, &done, nullptr);
+    if (rc == TLOAM_E_WEIGHT_RANGE) { weight_violation = true; continue; }  // reported after the solve
     if (rc != TLOAM_OK) return rc;
   }
   rc = tloam_sm_end(c, result, stats);
@@ -835,7 +839,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     HIPC(c, hipMemcpyAsync(scan_xyz, c->misc.p, sizeof(double) * 3 * n_scan, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
   }
-  return TLOAM_OK;
+  return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;
 }
 
 // ---- getFitnessScore (registration.cpp:257-296) -------------------------------------------------
@@ -844,6 +848,7 @@ int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
   *fitness = 0.0;
   *rmse = 0.0;
   if (c->cfg.fitness_thres <= 0.0) return TLOAM_OK;  // :258-261
+  if (c->active) return TLOAM_E_NOT_READY;  // between sm_begin and sm_end the context belongs to the solve
   HIPC(c, hipSetDevice(c->device));
   const int blocks = 64;
   HIPC(c, c->misc.reserve(4096));
@@ -854,11 +859,11 @@ int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
     KindData& K = c->kd[k];
     // the kd-trees are the ones built by the last scanMatching (:889-915); none yet -> no hits
     if (!K.grid_valid || K.n_src == 0) continue;
-    if (c->cfg.fitness_thres > K.gv.cell) { c->last_error = "fitness_thres larger than the search cell"; return TLOAM_E_INVALID; }
-    // raw scan-frame source points (:271): convert this kind's AoS block to SoA scratch
-    HIPC(c, c->sx.reserve(K.n_src)); HIPC(c, c->sy.reserve(K.n_src)); HIPC(c, c->sz.reserve(K.n_src));
-    launch_aos_to_soa(K.src_aos.p, K.n_src, c->sx.p, c->sy.p, c->sz.p, c->stream);
-    launch_fitness(K.gv, c->sx.p, c->sy.p, c->sz.p, (int)K.n_src, c->cfg.fitness_thres, c->misc.p, blocks, c->stream);
+    // raw scan-frame source points (:271): this kind's AoS block as SoA, in scratch of its own (the slot arrays
+    // sx/sy/sz belong to scan_match: SlotView holds their addresses)
+    HIPC(c, c->fit_x.reserve(K.n_src)); HIPC(c, c->fit_y.reserve(K.n_src)); HIPC(c, c->fit_z.reserve(K.n_src));
+    launch_aos_to_soa(K.src_aos.p, K.n_src, c->fit_x.p, c->fit_y.p, c->fit_z.p, c->stream);
+    launch_fitness(K.gv, c->fit_x.p, c->fit_y.p, c->fit_z.p, (int)K.n_src, c->cfg.fitness_thres, c->misc.p, blocks, c->stream);
     HIPC(c, hipMemcpyAsync(c->h_small, c->misc.p, sizeof(double) * blocks * 2, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < blocks; ++b) { err_local[k] += c->h_small[2 * b]; fit_local[k] += c->h_small[2 * b + 1]; }
@@ -1066,6 +1071,23 @@ int tloam_accumulate(tloam_ctx* c, const double se3[6], double H[36], double g[6
   return TLOAM_OK;
 }
 
+int tloam_get_normal_equations(tloam_ctx* c, double H[36], double g[6], double* cost) {
+  if (!c) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  GnState* S = (GnState*)malloc(sizeof(GnState));
+  if (!S) return TLOAM_E_INVALID;
+  const hipError_t e = hipMemcpy(S, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) {
+    if (H) memcpy(H, S->H, sizeof(double) * 36);
+    if (g) memcpy(g, S->g, sizeof(double) * 6);
+    if (cost) *cost = S->x_cost;
+  }
+  free(S);
+  HIPC(c, e);
+  return TLOAM_OK;
+}
+
 int tloam_get_costs(tloam_ctx* c, int res_type, size_t capacity, size_t* n, double* cost) {
   if (!c || res_type < 0 || res_type >= TLOAM_NUM_RES || !n) return TLOAM_E_INVALID;
   const int kind = res_type == TLOAM_RES_PLANE ? TLOAM_KIND_PLANAR : (res_type == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE);
@@ -1179,7 +1201,7 @@ int tloam_rccl_unique_id(void* out128) {
 }
 
 int tloam_comm_init_rccl(tloam_ctx* c, int rank, int nranks, const void* unique_id128) {
-  if (!c || !unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
+  if (!c || !unique_id128 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   if (!load_rccl(&c->last_error)) return TLOAM_E_RCCL;
   Uid128 id;
@@ -1198,7 +1220,7 @@ int tloam_comm_init_rccl(tloam_ctx* c, int rank, int nranks, const void* unique_
 }
 
 int tloam_comm_init_callback(tloam_ctx* c, int rank, int nranks, tloam_allreduce_fn fn, void* user) {
-  if (!c || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return TLOAM_E_INVALID;
+  if (!c || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return TLOAM_E_INVALID;
   c->rank = rank;
   c->nranks = nranks;
   c->cb = fn;

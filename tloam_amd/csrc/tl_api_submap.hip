@@ -131,16 +131,31 @@ int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double
   return TLOAM_OK;
 }
 
+static int submap_update_body(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
+                              const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
+                              const double* ground, size_t n_ground);
+
 int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
                         const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
                         const double* ground, size_t n_ground) {
   if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
     return TLOAM_E_INVALID;
-  SubmapState& S = c->submap;
-  if (!S.inited) return TLOAM_E_NOT_READY;
+  if (!c->submap.inited) return TLOAM_E_NOT_READY;
   HIPC(c, hipSetDevice(c->device));
+  const int rc = submap_update_body(c, pose, planar, n_planar, sphere, n_sphere, edge, n_edge, ground, n_ground);
+  // The host clouds are borrowed for the call only and are copied asynchronously; the success path ends in the one
+  // synchronisation of submap_finish -- every error path must drain the stream before the buffers go back.
+  if (rc != TLOAM_OK) (void)hipStreamSynchronize(c->stream);
+  return rc;
+}
+
+static int submap_update_body(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
+                              const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
+                              const double* ground, size_t n_ground) {
+  SubmapState& S = c->submap;
+  (void)sphere;
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
-  auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep) -> int {
+  auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep, bool upload) -> int {
     RingFrame* f = nullptr;
     if ((int)ring.size() >= keep) {  // recycle the frame that falls out
       f = ring.front();
@@ -152,12 +167,15 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
     ring.push_back(f);
     f->n = n;
     memcpy(f->pose, pose, sizeof(double) * 16);
+    if (!upload) return TLOAM_OK;
     HIPC(c, f->aos.reserve(3 * std::max<size_t>(n, 1)));
     if (n > 0) HIPC(c, hipMemcpyAsync(f->aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     return TLOAM_OK;
   };
-  int rc = push(S.sphere_ring, sphere, n_sphere, S.cfg.sphere_frame_size);
-  if (rc == TLOAM_OK) rc = push(S.planar_ring, planar, n_planar, S.cfg.planar_frame_size);
+  // The sphere buffer is kept for its bookkeeping only (sizes, poses, frame count): nothing ever reads its points --
+  // the sphere submap is rebuilt from the PLANAR buffer (front_end.cpp:221) -- so they are not uploaded.
+  int rc = push(S.sphere_ring, nullptr, n_sphere, S.cfg.sphere_frame_size, /*upload=*/false);
+  if (rc == TLOAM_OK) rc = push(S.planar_ring, planar, n_planar, S.cfg.planar_frame_size, /*upload=*/true);
   if (rc != TLOAM_OK) return rc;
   // :220-243 both submaps are rebuilt from submap_planar_buffer (the sphere loop iterates the PLANAR buffer)
   size_t total = 0;

@@ -25,6 +25,7 @@ constexpr int kAccStride = 32;   // padded row of the partials buffer
 constexpr int kReduceBuf = 48;   // the all-reduced buffer: 28 used + per-kind tail
 constexpr int kChunk = 128;      // correspondences per wave-chunk in K3 (64 lanes x 2)
 constexpr int kMaxK = 8;         // max neighbours of tloam_knn
+constexpr int kMaxRanks = 16;    // ranks one frame can be sharded over (rank_counts rows, mailbox slots); a node has 8 GPUs
 
 // residual type of a kind (registration.cpp:981-992 builder -> cost functor)
 __host__ __device__ inline int res_type_of_kind(int kind) {

@@ -133,6 +133,7 @@ struct tloam_ctx {
   KindData kd[kKinds];
   // concatenated per-source-slot arrays of the current scan_match
   DBuf<double> sx, sy, sz, w_src, raw;
+  DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)

@@ -234,7 +234,8 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
   if (DEPTH == 1) {
     for (int t = 0; t < m; ++t) {
       ChunkBuf<RES> b;
-      fetch<RES>(seg, TL_J(t), b);
+      if (t == 0 && use_pre) b = pre;  // requested before the state's scalar loads came back
+      else fetch<RES>(seg, TL_J(t), b);
       consume<RES>(T, seg, TL_J(t), n, b, a);
     }
   } else if (DEPTH == 2) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
   const unsigned long long wc0 = wall_clock64();  // 100 MHz, one base for the whole device
 #endif
   ChunkBuf<TLOAM_RES_PLANE> pre;
-  const bool spec = (TLOAM_K3_PLANE_DEPTH == 2) && (gw + 1) * kChunk <= cv.k[0].cap;
+  const bool spec = (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cv.k[0].cap;
   if (spec) fetch<TLOAM_RES_PLANE>(cv.k[0], gw * kChunk + lane * 2, pre);
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)

@@ -181,6 +181,26 @@ __device__ __forceinline__ void knn_grid(const GridView& g, double qx, double qy
   }
 }
 
+// the same search over the (2 reach + 1)^3 cells around the query: any radius, not only radius <= cell
+// (getFitnessScore takes whatever fitness_thres the configuration holds).  The (distance, original index) order
+// of the list is total, so the result does not depend on the walk order.
+template <int K>
+__device__ __forceinline__ void knn_grid_reach(const GridView& g, double qx, double qy, double qz, int reach, TopK<K>& tk) {
+  topk_clear<K>(tk);
+  if (g.n <= 0) return;
+  const PtsGlobal pts{g.gp};
+  const int cx = cell_coord(qx, g.org[0], g.inv_cell, g.dim[0]);
+  const int cy = cell_coord(qy, g.org[1], g.inv_cell, g.dim[1]);
+  const int cz = cell_coord(qz, g.org[2], g.inv_cell, g.dim[2]);
+  const int x0 = max(cx - reach, 0), x1 = min(cx + reach, g.dim[0] - 1);
+  if (x0 > x1) return;
+  for (int z = max(cz - reach, 0); z <= min(cz + reach, g.dim[2] - 1); ++z)
+    for (int y = max(cy - reach, 0); y <= min(cy + reach, g.dim[1] - 1); ++y) {
+      const size_t base = ((size_t)z * g.dim[1] + y) * g.dim[0];
+      scan_range<K>(pts, g.cell_start[base + x0], g.cell_start[base + x1 + 1], qx, qy, qz, tk);
+    }
+}
+
 // knn_grid with the packed-key list in the walk (2 VALU ops per list level instead of ~9: K = 20 in the PCA
 // feature extraction); a query whose kept entries are ambiguous under the truncated order is redone exactly.
 template <int K>

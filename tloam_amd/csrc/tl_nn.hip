@@ -896,12 +896,15 @@ void launch_knn(const GridView& g, const double* qx, const double* qy, const dou
 // fitness: per block (sum of squared distances of hits, number of hits); fixed grid, fixed tree
 __global__ __launch_bounds__(256) void k_fitness(GridView g, const double* __restrict__ qx,
                                                  const double* __restrict__ qy, const double* __restrict__ qz,
-                                                 int nq, double radius, double* __restrict__ partial) {
+                                                 int nq, double radius, int reach, double* __restrict__ partial) {
   __shared__ double red[4][2];
   double err = 0.0, hits = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
     TopK<1> tk;
-    knn_grid<1>(g, qx[i], qy[i], qz[i], tk);  // :271-272 raw scan-frame point, k = 1
+    // :271-272 raw scan-frame point, k = 1; the structure was built for the builders' radius, a larger
+    // fitness_thres widens the walk
+    if (reach <= 1) knn_grid<1>(g, qx[i], qy[i], qz[i], tk);
+    else knn_grid_reach<1>(g, qx[i], qy[i], qz[i], reach, tk);
     if (tk.d[0] < radius * radius) { err += tk.d[0]; hits += 1.0; }  // :273 adds the SQUARED distance
   }
 #pragma unroll
@@ -920,7 +923,11 @@ __global__ __launch_bounds__(256) void k_fitness(GridView g, const double* __res
 }
 void launch_fitness(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
                     double radius, double* partial, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_fitness, dim3(blocks), dim3(256), 0, s, g, qx, qy, qz, nq, radius, partial);
+  // every target within `radius` of a query lies within `reach` cells of the query's cell in each direction
+  // (clamped: beyond 2^20 cells the walk covers the whole grid anyway)
+  const double cells = radius * g.inv_cell;
+  const int reach = cells < 1.0 ? 1 : (cells > 1048576.0 ? 1048576 : (int)cells + 1);
+  hipLaunchKernelGGL(k_fitness, dim3(blocks), dim3(256), 0, s, g, qx, qy, qz, nq, radius, reach, partial);
 }
 
 }  // namespace tl

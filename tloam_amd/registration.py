@@ -66,7 +66,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("outer_iterations", C.c_int32), ("gn_evaluations", C.c_int32),
         ("gn_iterations", C.c_int32), ("accepted_steps", C.c_int32),
-        ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("reserved0", C.c_int32),
+        ("n_corr", C.c_int32 * 4), ("converged_early", C.c_int32), ("weight_range_violations", C.c_int32),
         ("kind_cost", C.c_double * 4), ("mu", C.c_double), ("solver_cost", C.c_double),
         ("se3", C.c_double * 6),
         ("gn_sweeps", C.c_int32), ("host_wait_us", C.c_int32),
@@ -76,7 +76,7 @@ class Stats(C.Structure):
         return dict(outer_iterations=self.outer_iterations, gn_evaluations=self.gn_evaluations,
                     gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
                     n_corr=list(self.n_corr), converged_early=self.converged_early,
-                    bad_weights=self.reserved0, kind_cost=list(self.kind_cost), mu=self.mu,
+                    bad_weights=self.weight_range_violations, kind_cost=list(self.kind_cost), mu=self.mu,
                     solver_cost=self.solver_cost, se3=np.array(self.se3), gn_sweeps=self.gn_sweeps,
                     host_wait_us=self.host_wait_us)
 
@@ -124,6 +124,7 @@ def load_library():
         "tloam_set_correspondences": (C.c_int, [vp, C.c_int, sz, dp, dp, dp, dp, dp]),
         "tloam_accumulate": (C.c_int, [vp, dp, dp, dp, dp]),
         "tloam_get_costs": (C.c_int, [vp, C.c_int, sz, C.POINTER(sz), dp]),
+        "tloam_get_normal_equations": (C.c_int, [vp, dp, dp, dp]),
         "tloam_solve": (C.c_int, [vp, dp, C.POINTER(Stats)]),
         "tloam_time_accumulate": (C.c_int, [vp, dp, C.c_int, dp]),
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
@@ -159,7 +160,8 @@ EXPORTED_SYMBOLS = (
     "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_set_source_frame", "tloam_set_target_frame",
     "tloam_scan_match", "tloam_sm_begin",
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
-    "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_solve",
+    "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
+    "tloam_solve",
     "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
@@ -430,6 +432,12 @@ class HipRegistration:
         x = np.ascontiguousarray(se3, float)
         H = np.zeros(36); g = np.zeros(6); cost = C.c_double(0)
         self._check(self.L.tloam_accumulate(self.h, _dp(x), _dp(H), _dp(g), C.byref(cost)), "tloam_accumulate")
+        return H.reshape(6, 6), g, cost.value
+
+    def get_normal_equations(self):
+        """(H 6x6, g, cost) the minimiser held at the accepted iterate when its last Solve returned."""
+        H = np.zeros(36); g = np.zeros(6); cost = C.c_double(0)
+        self._check(self.L.tloam_get_normal_equations(self.h, _dp(H), _dp(g), C.byref(cost)), "tloam_get_normal_equations")
         return H.reshape(6, 6), g, cost.value
 
     def get_costs(self, res_type):
