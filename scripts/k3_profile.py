@@ -13,11 +13,20 @@ for rt in range(3):
     H.set_correspondences(rt, p, a, b, d, w)
 us = [H.time_accumulate(x_eval, 50) for _ in range(3)]
 print("K3 us/launch", us)
-H.time_accumulate(x_eval, 1)
+reps = int(os.environ.get("K3_PROFILE_REPS", "1"))
 L = H.L
+allrows = []
+for _ in range(reps):
+    H.time_accumulate(x_eval, 1)
+    b_ = np.zeros(4096 * 32)
+    nb_ = L.tloam_debug_partials(H.h, b_.ctypes.data_as(C.POINTER(C.c_double)), b_.size)
+    allrows.append(b_[: nb_ * 32].reshape(nb_, 32)[:, 28:32].copy())
+if os.environ.get("K3_PROFILE_DUMP"):
+    np.save(os.environ["K3_PROFILE_DUMP"], np.stack(allrows))
 buf = np.zeros(4096 * 32)
 nb = L.tloam_debug_partials(H.h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size)
 rows = buf[: nb * 32].reshape(nb, 32)
+
 wc = rows[:, 28]                                # wall clock (10 ns ticks, low 32 bits) at entry
 wdur = np.floor(rows[:, 31] / 65536.0)          # wall-clock ticks entry -> end of block
 rows[:, 31] -= wdur * 65536.0

@@ -22,7 +22,9 @@ UNITS = [
     ("tl_nn.hip", ["-ffp-contract=off"]),
     ("tl_submap.hip", ["-ffp-contract=off"]),   # voxel indices / means in the oracle's operation order
     ("tl_feature.hip", ["-ffp-contract=off"]),  # PCA gates (flatness / cvr thresholds) like the oracle
-    ("tl_gn.hip", []),
+    # kernel arguments: the first 12 dwords of every kernel of this unit arrive preloaded in SGPRs (gfx950 command
+    # processor) -- the K3 / minimiser kernels put what their first loads need there (tl_gn.hip, k3_accumulate)
+    ("tl_gn.hip", ["-mllvm", "-amdgpu-kernarg-preload-count=12"]),
     ("tl_api.hip", []),
     ("tl_api_submap.hip", []),
     ("tl_api_feature.hip", []),
@@ -57,6 +59,8 @@ def build_variant(name, flags, units=("tl_gn.hip",), verbose=False):
     for src, extra in UNITS:
         if src in units:
             obj = os.path.join(odir, src.replace(".hip", ".o"))
+            if "-DNO_PRELOAD" in flags:   # A/B of the kernel-argument preload
+                extra = [f for f in extra if f not in ("-mllvm", "-amdgpu-kernarg-preload-count=12")]
             cmd = [hipcc, *COMMON, *extra, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         else:

@@ -106,23 +106,26 @@ int reserve_seg(tloam_ctx* c, int k, size_t n) {
   KindData& K = c->kd[k];
   const size_t cap = round_up(std::max<size_t>(n, 1), kChunk) + kChunk;  // + one chunk: double2 tail reads
   HIPC(c, K.c_idx.reserve(cap));
-  HIPC(c, K.c_px.reserve(cap)); HIPC(c, K.c_py.reserve(cap)); HIPC(c, K.c_pz.reserve(cap));
-  HIPC(c, K.c_ax.reserve(cap)); HIPC(c, K.c_ay.reserve(cap)); HIPC(c, K.c_az.reserve(cap));
-  if (k == TLOAM_KIND_EDGE) { HIPC(c, K.c_bx.reserve(cap)); HIPC(c, K.c_by.reserve(cap)); HIPC(c, K.c_bz.reserve(cap)); }
-  if (k <= TLOAM_KIND_GROUND) HIPC(c, K.c_d.reserve(cap));
-  HIPC(c, K.c_w.reserve(cap));
-  HIPC(c, K.c_cost.reserve(cap));
+  if (cap > K.c_stride) {  // (grow-only, like every DBuf; the contents are rewritten by the caller)
+    const size_t stride = std::max(cap, K.c_stride + K.c_stride / 2);
+    HIPC(c, K.c_buf.reserve(stride * kSegStreams));
+    K.c_stride = stride;
+  }
   K.c_cap = cap - kChunk;
   CorrSeg& s = c->cv.k[k];
+  double* b = K.c_buf.p;
+  const size_t st = K.c_stride;
   s.idx = K.c_idx.p;
-  s.px = K.c_px.p; s.py = K.c_py.p; s.pz = K.c_pz.p;
-  s.ax = K.c_ax.p; s.ay = K.c_ay.p; s.az = K.c_az.p;
-  s.bx = K.c_bx.p; s.by = K.c_by.p; s.bz = K.c_bz.p;
-  s.d = K.c_d.p;
-  s.w = K.c_w.p;
-  s.cost = K.c_cost.p;
+  s.px = b + SS_PX * st; s.py = b + SS_PY * st; s.pz = b + SS_PZ * st;
+  s.ax = b + SS_AX * st; s.ay = b + SS_AY * st; s.az = b + SS_AZ * st;
+  s.bx = (k == TLOAM_KIND_EDGE) ? b + SS_BX * st : nullptr;
+  s.by = (k == TLOAM_KIND_EDGE) ? b + SS_BY * st : nullptr;
+  s.bz = (k == TLOAM_KIND_EDGE) ? b + SS_BZ * st : nullptr;
+  s.d = (k <= TLOAM_KIND_GROUND) ? b + SS_D * st : nullptr;
+  s.w = b + SS_W * st;
+  s.cost = b + SS_COST * st;
   s.cap = (int)K.c_cap;
-  s.pad = 0;
+  s.stride = (int)st;
   return TLOAM_OK;
 }
 
@@ -454,9 +457,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
     K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
-    K.c_idx.release(); K.c_px.release(); K.c_py.release(); K.c_pz.release(); K.c_ax.release();
-    K.c_ay.release(); K.c_az.release(); K.c_bx.release(); K.c_by.release(); K.c_bz.release();
-    K.c_d.release(); K.c_w.release(); K.c_cost.release();
+    K.c_idx.release(); K.c_buf.release();
   }
   c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
   c->fit_x.release(); c->fit_y.release(); c->fit_z.release();

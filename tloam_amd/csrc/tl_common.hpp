@@ -45,6 +45,8 @@ struct GridView {
 };
 
 // ---- compact correspondence set: one SoA segment per kind ------------------------------------
+// stream order inside a kind's buffer (stream s starts at base + s * stride doubles)
+enum SegStream : int { SS_PX = 0, SS_PY, SS_PZ, SS_AX, SS_AY, SS_AZ, SS_W, SS_D, SS_BX, SS_BY, SS_BZ, SS_COST, kSegStreams };
 struct CorrSeg {
   int* idx;                 // global source index of each correspondence
   double *px, *py, *pz;     // source point (sensor frame)
@@ -54,7 +56,7 @@ struct CorrSeg {
   double* w;                // TLS weight captured at build time
   double* cost;             // side channel (`mutable double* cost`, registration.hpp:51,76,96)
   int cap;                  // capacity (multiple of kChunk)
-  int pad;
+  int stride;               // doubles between consecutive streams of the kind's buffer (SegStream order)
 };
 struct CorrView {
   CorrSeg k[kKinds];

@@ -60,9 +60,12 @@ struct KindData {
   GridView gv{};
   bool grid_valid = false;
   // compact correspondence segment
+  // ONE allocation per kind: kSegStreams arrays of `c_stride` doubles each, in the order of tl::SegStream -- K3 gets
+  // the planar segment as (base, stride) in its first kernel arguments, which the command processor preloads into
+  // SGPRs, so a wave can request its first chunk before any scalar load has returned
   DBuf<int> c_idx;
-  DBuf<double> c_px, c_py, c_pz, c_ax, c_ay, c_az, c_bx, c_by, c_bz, c_d, c_w, c_cost;
-  size_t c_cap = 0;
+  DBuf<double> c_buf;
+  size_t c_cap = 0, c_stride = 0;
   size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
 };
 

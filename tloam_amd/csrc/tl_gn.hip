@@ -186,8 +186,13 @@ __device__ __forceinline__ double2 ld2o_t(const double* base, unsigned byte_off)
   const v2d v = NT ? __builtin_nontemporal_load(p) : *p;
   return double2{v.x, v.y};
 }
+// Cache policy of the streams (measured on the 74.88 MB set, scripts/k3_stats.py, same box, p50 of 40 batches of 20
+// launches): default loads + default stores 14.1-14.2 us; streaming (nt) stores only 14.6; nt loads only 13.0-13.4;
+// nt loads AND nt stores 12.7-13.0 (0.72-0.74 of 8 TB/s).  Every byte is used exactly once per launch, so the
+// lines should not displace each other in L2 on their way through; the set itself (and the cost slots the weight
+// kernel reads afterwards) still lives in the 256 MB Infinity Cache across the launches of a Solve.
 #ifndef TLOAM_K3_NT
-#define TLOAM_K3_NT false
+#define TLOAM_K3_NT true
 #endif
 __device__ __forceinline__ double2 ld2o(const double* base, unsigned byte_off) { return ld2o_t<TLOAM_K3_NT>(base, byte_off); }
 template <int RES>
@@ -198,6 +203,15 @@ __device__ __forceinline__ void fetch(const CorrSeg& seg, int j, ChunkBuf<RES>& 
   b.w = ld2o(seg.w, o);
   if (RES == TLOAM_RES_PLANE) b.d = ld2o(seg.d, o);
   if (RES == TLOAM_RES_LINE) { b.bx = ld2o(seg.bx, o); b.by = ld2o(seg.by, o); b.bz = ld2o(seg.bz, o); }
+}
+// the planar segment's chunk straight from (base, stride): the kernel's first arguments, preloaded into SGPRs
+__device__ __forceinline__ void fetch_spec(const double* base, int stride, int j, ChunkBuf<TLOAM_RES_PLANE>& b) {
+  const unsigned o = (unsigned)j * 8u;
+  const size_t st = (size_t)stride;
+  b.px = ld2o(base + SS_PX * st, o); b.py = ld2o(base + SS_PY * st, o); b.pz = ld2o(base + SS_PZ * st, o);
+  b.ax = ld2o(base + SS_AX * st, o); b.ay = ld2o(base + SS_AY * st, o); b.az = ld2o(base + SS_AZ * st, o);
+  b.w = ld2o(base + SS_W * st, o);
+  b.d = ld2o(base + SS_D * st, o);
 }
 template <int RES>
 __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a) {
@@ -216,8 +230,16 @@ __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, 
     if (rem > 1) c1 = eval_point(T, Vec3{b.px.y, b.py.y, b.pz.y}, Vec3{b.ax.y, b.ay.y, b.az.y}, b.w.y, a);
   }
   // the `mutable double* cost` side channel (registration.hpp:51,76,96): written on EVERY sweep
+#ifndef TLOAM_K3_NO_NT_STORE
+  // streaming store: the slots are not read again before the weight kernel, keep them out of the way of the loads
+  // and out of the end-of-kernel write-back
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  if (rem > 1) __builtin_nontemporal_store(v2d{c0, c1}, reinterpret_cast<v2d*>(seg.cost + j));
+  else __builtin_nontemporal_store(c0, seg.cost + j);
+#else
   if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
   else seg.cost[j] = c0;
+#endif
 }
 
 // All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment.  DEPTH 2: software-pipelined, the loads of
@@ -250,38 +272,22 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
       fetch<RES>(seg, TL_J(t + 1), b0);
       consume<RES>(T, seg, TL_J(t), n, b1, a);
     }
-  } else {  // DEPTH 3: two chunks of loads in flight behind the one being evaluated
-    ChunkBuf<RES> b0, b1, b2;
-    fetch<RES>(seg, TL_J(0), b0);
-    if (m > 1) fetch<RES>(seg, TL_J(1), b1);
-    for (int t = 0;; t += 3) {
-      // invariant: chunks t (b0) and t+1 (b1, if < m) are loaded or in flight
-      if (t + 2 < m) fetch<RES>(seg, TL_J(t + 2), b2);
-      consume<RES>(T, seg, TL_J(t), n, b0, a);
-      if (t + 1 >= m) break;
-      if (t + 3 < m) fetch<RES>(seg, TL_J(t + 3), b0);
-      consume<RES>(T, seg, TL_J(t + 1), n, b1, a);
-      if (t + 2 >= m) break;
-      if (t + 4 < m) fetch<RES>(seg, TL_J(t + 4), b1);
-      consume<RES>(T, seg, TL_J(t + 2), n, b2, a);
-      if (t + 3 >= m) break;
-    }
   }
 #undef TL_J
 }
 
 #ifndef TLOAM_K3_WAVES
-#define TLOAM_K3_WAVES 2  // 3+ waves/SIMD spills (measured 31-41 us vs 15.4 us)
+#define TLOAM_K3_WAVES 4  // register budget of 128: the one-chunk-deep sweep needs 118
 #endif
 #ifndef TLOAM_K3_PLANE_DEPTH
-#define TLOAM_K3_PLANE_DEPTH 2
+#define TLOAM_K3_PLANE_DEPTH 1
 #endif
 #ifndef TLOAM_K3_LINE_DEPTH
-#define TLOAM_K3_LINE_DEPTH 2
+#define TLOAM_K3_LINE_DEPTH 1
 #endif
 // one full sweep of this wave's share of the four segments
-__device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int gw, int W, int lane, Acc& a,
-                                          const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
+__device__ __forceinline__ void sweep_all(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, int gw, int W,
+                                          int lane, Acc& a, const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
   const ChunkBuf<TLOAM_RES_LINE> no_line{};
   const ChunkBuf<TLOAM_RES_POINT> no_point{};
 #pragma unroll
@@ -293,7 +299,7 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int g
   int first = 0;
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
-    const int n = cv.seg_n[k];
+    const int n = seg_n[k];
     const int nchunks = (n + kChunk - 1) / kChunk;
     int i0 = (gw - first) % W;
     if (i0 < 0) i0 += W;
@@ -307,8 +313,8 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const Rt& T, int g
 // Small correspondence sets (KITTI caps: <= 5.9 k factors): the grid has one wave per chunk of the
 // concatenated (planar | ground | edge | sphere) list, so wave gw owns exactly chunk gw -- one fetch, one
 // evaluation, no chunk loop and no modulo distribution.  Same per-wave arithmetic as sweep_all.
-__device__ __forceinline__ void sweep_single(const CorrView& cv, const Rt& T, int gw, int lane, Acc& a,
-                                             const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
+__device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, int gw, int lane,
+                                             Acc& a, const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
@@ -316,7 +322,7 @@ __device__ __forceinline__ void sweep_single(const CorrView& cv, const Rt& T, in
   int g = gw;
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
-    const int n = cv.seg_n[k];
+    const int n = seg_n[k];
     const int nchunks = (n + kChunk - 1) / kChunk;
     if (g >= 0 && g < nchunks) {
       const int j = g * kChunk + lane * 2;
@@ -355,32 +361,38 @@ __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
 
 // SINGLE = false: the streaming variant (grid = the resident chip, every wave loops over its chunks with
 // software-pipelined loads).  SINGLE = true: small sets, one wave per chunk (sweep_single).
+// Argument order: the first twelve dwords -- the planar segment as (base, stride, capacity), the flag, the state,
+// the segment sizes and the output rows -- are preloaded into SGPRs by the command processor
+// (-mllvm -amdgpu-kernarg-preload-count=12, see build.py), so the wave's first chunk AND the state's scalar loads
+// are requested in the first instructions, before the kernel-argument segment itself has been read.
 template <bool SINGLE>
-__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv, GnState* __restrict__ st,
-                                                        double* __restrict__ partials, int force) {
+__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const double* __restrict__ seg0, int stride0, int cap0,
+                                                        int force, GnState* __restrict__ st,
+                                                        const int* __restrict__ seg_n, double* __restrict__ partials,
+                                                        CorrView cv) {
   __shared__ double red[4][32];
   // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
   // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
   // Speculative first fetch: the wave's first chunk of the planar segment is requested straight from the
-  // kernel arguments, BEFORE the dependent scalar loads of the state (done flag, pose, segment sizes)
+  // preloaded arguments, BEFORE the dependent scalar loads of the state (done flag, pose, segment sizes)
   // come back -- their latency overlaps the first HBM round trip.  The capacity bound keeps it in range.
 #ifdef TLOAM_K3_PROFILE
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
   const unsigned long long wc0 = wall_clock64();  // 100 MHz, one base for the whole device
 #endif
   ChunkBuf<TLOAM_RES_PLANE> pre;
-  const bool spec = (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cv.k[0].cap;
-  if (spec) fetch<TLOAM_RES_PLANE>(cv.k[0], gw * kChunk + lane * 2, pre);
+  const bool spec = (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cap0;
+  if (spec) fetch_spec(seg0, stride0, gw * kChunk + lane * 2, pre);
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
 #ifdef TLOAM_K3_PROFILE
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-  if (SINGLE) sweep_single(cv, T, gw, lane, a, pre, spec);
-  else sweep_all(cv, T, gw, gridDim.x * 4, lane, a, pre, spec);
+  if (SINGLE) sweep_single(cv, seg_n, T, gw, lane, a, pre, spec);
+  else sweep_all(cv, seg_n, T, gw, gridDim.x * 4, lane, a, pre, spec);
 #ifdef TLOAM_K3_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
@@ -401,6 +413,7 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(CorrView cv
 #endif
 }
 
+
 int k3_grid_for(int total_cap) {
   if (const char* e = getenv("TLOAM_K3_BLOCKS")) {  // tuning aid
     const int b = atoi(e);
@@ -410,7 +423,8 @@ int k3_grid_for(int total_cap) {
   int waves = (total_cap + kChunk - 1) / kChunk;
   int blocks = (waves + 3) / 4;
   if (blocks < 1) blocks = 1;
-  const int resident = 256 * TLOAM_K3_WAVES;  // blocks of 4 waves that fit the chip at once
+
+  const int resident = 256 * 2;  // two blocks of 4 waves per CU (2 waves per SIMD): more resident waves only lengthen the dispatch ramp
   if (blocks > resident) {
     // balance: every wave gets the same number of chunks
     const int per_wave = (waves + resident * 4 - 1) / (resident * 4);
@@ -427,9 +441,11 @@ void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool
   if (ev_start && ev_stop) {
     // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
     // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, cv, st, partials, force ? 1 : 0);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
+                          cv.k[0].cap, force ? 1 : 0, st, cv.seg_n, partials, cv);
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, cv, st, partials, force ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, force ? 1 : 0, st,
+                       cv.seg_n, partials, cv);
   }
 }
 
