@@ -149,12 +149,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # TLOAM_BENCH_ONE_DEVICE=1 (development): all ranks on cuda:0, launcher collectives over gloo -- RCCL refuses two
+    # ranks on one device; the library's own peer mailbox does not, so the N > 1 code path can be driven on a 1-GPU box
+    one_dev = os.environ.get("TLOAM_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    cdev = "cpu" if one_dev else "cuda"   # where the launcher's own collective tensors live
     dist = None
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if multi:
@@ -208,10 +217,10 @@ def main():
         elapsed = time.perf_counter() - t0
         gn_iters_job = float(gn_iters)
         if multi:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-            gi = torch.tensor([float(gn_iters)], dtype=torch.float64, device="cuda")
+            gi = torch.tensor([float(gn_iters)], dtype=torch.float64, device=cdev)
             dist.all_reduce(gi, op=dist.ReduceOp.SUM)     # whole-job GN iterations
             gn_iters_job = float(gi.item())
         k3_us, k3_n, _ = H.k3_timer()                    # working sweeps
@@ -302,7 +311,7 @@ def main():
     # ---------------- N > 1: ONE frame sharded over the ranks (strong scaling, RCCL all-reduce per sweep) ----------------
     if multi and side is not None:
         sharded = sharded_frame(args, reg, synth, torch, dist, m1["cfg"], m1["n_src"], m1["n_tgt"], rank, world, local_rank,
-                                barrier)
+                                barrier, cdev)
         if rank == 0:
             sharded["replica_ms_per_frame"] = round(side["ms_per_frame"], 4)
             if "ms_per_frame" in sharded:
@@ -326,57 +335,96 @@ def main():
         dist.destroy_process_group()
 
 
-def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier):
-    """BASELINE.json configs[3]: the SAME frame on every rank, source points sharded in contiguous index
-    blocks, targets replicated, one RCCL all-reduce of 48 doubles per GN sweep (native librccl on the
-    compute stream).  Any failure is reported in the block instead of taking the headline down."""
-    res = {"workload": "one 1M-correspondence frame, source points sharded x%d, targets replicated, "
-                       "1 RCCL all-reduce (48 f64) per GN sweep" % world, "scaling": "strong", "n_gpus": world}
+def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier, cdev="cuda"):
+    """BASELINE.json configs[3]: the SAME frame on every rank, source points sharded in contiguous index blocks,
+    targets replicated, the 48 doubles of the normal equations exchanged once per GN sweep -- by the library's own
+    one-shot peer mailbox over xGMI (every rank stores its row into every rank's buffer; HIP IPC handles all-gathered
+    here) or, if that cannot be set up on every rank, by one RCCL all-reduce on the compute stream.  Besides the whole
+    frame the block times the sweep alone and the sweep + exchange: their difference is the
+    latency the exchange adds to a GN iteration.  Any failure is reported in the block instead of taking the headline down."""
+    res = {"workload": "one 1M-correspondence frame, source points sharded x%d, targets replicated, one exchange of "
+                       "48 f64 per GN sweep" % world, "scaling": "strong", "n_gpus": world}
+
+    def agreed(err):
+        """every rank learns whether ALL ranks succeeded before anyone enqueues a collective"""
+        flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return float(flag.item()) == 0.0
+
     H = None
     try:
         scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
-        H = reg.HipRegistration(cfg, device=local_rank)
-        uid = [None]
-        if rank == 0:
+        mode, err = None, None
+        if os.environ.get("TLOAM_BENCH_NO_MAILBOX") != "1":
+            H = reg.HipRegistration(cfg, device=local_rank)
             try:
-                uid = [reg.rccl_unique_id()]
+                handles = [None] * world
+                dist.all_gather_object(handles, H.comm_mailbox_export())
+                H.comm_init_mailbox(rank, world, handles)
             except Exception as e:  # noqa: BLE001
-                uid = [e]
-        dist.broadcast_object_list(uid, src=0)
-        init_err = None
-        try:
-            if isinstance(uid[0], Exception):
-                raise uid[0]
-            H.comm_init_rccl(rank, world, uid[0])
-            H.set_frames(scene.source, scene.target)
-        except Exception as e:  # noqa: BLE001
-            init_err = e
-        # every rank learns whether ALL ranks initialised before anyone enqueues a collective
-        flag = torch.tensor([0.0 if init_err is None else 1.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if float(flag.item()) != 0.0:
-            raise RuntimeError(f"sharded-path initialisation failed on some rank ({init_err})")
+                err = e
+            if agreed(err):
+                mode = "mailbox"
+            else:
+                res["mailbox_error"] = repr(err)[:200] if err is not None else "failed on another rank"
+                H.close()
+                H = None
+        if mode is None:
+            H = reg.HipRegistration(cfg, device=local_rank)
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [reg.rccl_unique_id()]
+                except Exception as e:  # noqa: BLE001
+                    uid = [e]
+            dist.broadcast_object_list(uid, src=0)
+            err = None
+            try:
+                if isinstance(uid[0], Exception):
+                    raise uid[0]
+                H.comm_init_rccl(rank, world, uid[0])
+            except Exception as e:  # noqa: BLE001
+                err = e
+            if not agreed(err):
+                raise RuntimeError(f"sharded-path initialisation failed on some rank ({err})")
+            mode = "rccl"
+        res["exchange"] = ("one-shot peer mailbox over xGMI (no collective library on the data path)" if mode == "mailbox"
+                           else "ncclAllReduce (RCCL) of 48 f64 on the compute stream")
+        H.set_frames(scene.source, scene.target)
         ok = 1.0
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(max(min(args.warmup, 3), 1)):
             rc, T, st = H.scan_match(scene.T_pred)
             ok = ok if rc == 0 else 0.0
         barrier()
         t0 = time.perf_counter()
         it = 0
-        for _ in range(args.steps):
+        steps = args.m1_steps
+        for _ in range(steps):
             rc, T, st = H.scan_match(scene.T_pred)
             ok = ok if rc == 0 else 0.0
             it += st["gn_sweeps"]
         barrier()
         dt = time.perf_counter() - t0
-        tt = torch.tensor([dt, -ok], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, -ok], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0].item())
         if float(tt[1].item()) != -1.0:
             raise RuntimeError("scan_match failed on at least one rank")
         D = np.linalg.inv(T) @ scene.T_true
-        res.update({"ms_per_frame": round(dt / args.steps * 1e3, 4), "gn_iters_per_sec": round(it / dt, 2),
-                    "n_corr": st["n_corr"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3]))})
+        res.update({"frames": steps, "ms_per_frame": round(dt / steps * 1e3, 4), "gn_iters_per_sec": round(it / dt, 2),
+                    "gn_iters_per_frame": it / steps, "n_corr": st["n_corr"],
+                    "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3]))})
+        # the sweep alone / sweep + exchange on this frame's set (collective calls; max over ranks)
+        x = np.asarray(st["se3"], float)
+        H.time_sharded_sweep(x, 10, True)
+        t_ex = sorted(H.time_sharded_sweep(x, 40, True) for _ in range(3))[1]
+        t_no = sorted(H.time_sharded_sweep(x, 40, False) for _ in range(3))[1]
+        tt = torch.tensor([t_ex, t_no], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res["per_sweep_us"] = {"sweep_plus_exchange": round(float(tt[0].item()), 3), "sweep_alone": round(float(tt[1].item()), 3),
+                               "exchange_adds": round(float(tt[0].item() - tt[1].item()), 3),
+                               "note": "40 back-to-back launches per HIP event pair, median of 3, max over ranks; the sweep "
+                                       "covers this rank's 1/%d of the set, its last block folds the rows" % world}
     except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
         res["error"] = f"{type(e).__name__}: {e}"
     finally:

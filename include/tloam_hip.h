@@ -199,6 +199,11 @@ int tloam_solve(tloam_ctx* ctx, double se3_inout[6], tloam_stats* stats);
 /* Timing helper for the bench: `launches` back-to-back K3 sweeps at se3 on the context's
  * stream bracketed by HIP events; returns the mean kernel-pair time in microseconds. */
 int tloam_time_accumulate(tloam_ctx* ctx, const double se3[6], int launches, double* mean_us);
+/* Sharded contexts, collective (every rank calls it with the same arguments): `launches` sweeps over this rank's
+ * block of the current set, each followed -- with_exchange != 0 -- by the exchange of the 48 doubles exactly as a GN
+ * iteration performs it (mailbox: posted by the sweep's last block and gathered by a one-wave kernel; RCCL / callback:
+ * all-reduce), one HIP event pair around the lot.  The difference with / without is the latency the exchange adds. */
+int tloam_time_sharded_sweep(tloam_ctx* ctx, const double se3[6], int launches, int with_exchange, double* mean_us);
 /* accumulated HIP-event time (us) and launch count of the K3 sweeps since the last reset; the first
  * call arms the timer: each K3 dispatch then carries a HIP start/stop event pair bound to the
  * dispatch packet (hipExtLaunchKernelGGL), i.e. the elapsed time is the kernel duration itself */
@@ -290,6 +295,15 @@ int tloam_comm_init_rccl(tloam_ctx* ctx, int rank, int nranks, const void* uniqu
 typedef int (*tloam_allreduce_fn)(void* user, double* device_buf, int count, void* hip_stream);
 int tloam_comm_init_callback(tloam_ctx* ctx, int rank, int nranks, tloam_allreduce_fn fn,
                              void* user);
+/* (c) one-shot peer exchange ("mailbox") over xGMI, no collective library on the data path.  Every rank calls
+ *     tloam_comm_mailbox_export (64 bytes = a hipIpcMemHandle_t of its small fine-grained buffer), the launcher
+ *     all-gathers the handles (rank order), every rank calls tloam_comm_init_mailbox with all of them.  A sharded
+ *     GN iteration is then TWO launches: the sweep, whose last block stores the 48 doubles into every rank's
+ *     buffer, and the step, which adds the ranks' rows in rank order (bit-identical on all ranks).  A peer that
+ *     never posts makes the waiting kernel give up after ~2 s: TLOAM_E_RCCL from the scan_match in progress.
+ *     One process per rank (HIP IPC does not open a handle in the process that made it). */
+int tloam_comm_mailbox_export(tloam_ctx* ctx, void* handle64_out);
+int tloam_comm_init_mailbox(tloam_ctx* ctx, int rank, int nranks, const void* handles64_by_rank);
 /* contiguous index block [*lo,*hi) of n items owned by `rank` of `nranks` (pure function) */
 void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi);
 

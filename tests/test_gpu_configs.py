@@ -3,7 +3,7 @@
 configs[3]  "Synthetic 1 M-correspondence frame sharded across 2/4/8 GPUs" -- here two ranks (two processes, two
             contexts) on cuda:0, the 1 M frame (synth.M1_SRC / M1_TGT, caps lifted): contiguous source blocks,
             replicated targets, the all-reduce of the 48-double normal-equation buffer carried by gloo through
-            tloam_comm_init_callback.  Pose, minimiser counters and the merged correspondence index lists must
+            tloam_comm_init_callback, or exchanged by the library's own peer mailbox (tloam_comm_init_mailbox).  Pose, minimiser counters and the merged correspondence index lists must
             equal the single-rank solve of the same frame.
 configs[4]  "8 independent KITTI scan-pairs, one per GPU" -- here >= 4 live contexts in one process on cuda:0, each
             with its own KITTI-density pair, their outer iterations interleaved and their scan_match calls
@@ -33,15 +33,15 @@ def _m1_cfg(reg):
     return reg.default_config(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
 
 
-def _worker_1m(rank, world, port, q):
+def _worker_1m(rank, world, port, q, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from test_gpu_multirank import _make_allreduce
+        from test_gpu_multirank import init_comm
         from tloam_amd import registration as reg
         sc = synth.make_scene(seed=0, n_src=synth.M1_SRC, n_tgt=synth.M1_TGT)
         H = reg.HipRegistration(_m1_cfg(reg))
-        H.comm_init_callback(rank, world, _make_allreduce())
+        init_comm(H, mode, rank, world)
         H.set_frames(sc.source, sc.target)
         rc, T, st = H.scan_match(sc.T_pred)
         assert rc == 0, rc
@@ -55,12 +55,13 @@ def _worker_1m(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_config3_two_ranks_1m_frame_on_one_gpu(hip_module):
+@pytest.mark.parametrize("mode", ["callback", "mailbox"])
+def test_config3_two_ranks_1m_frame_on_one_gpu(hip_module, mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_1m, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_1m, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs: p.start()
     res = q.get(timeout=600)
     for p in procs:

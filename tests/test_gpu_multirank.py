@@ -1,6 +1,8 @@
 """-m gpu: the sharded (multi-rank) path on ONE GPU.  Two processes each own a context on cuda:0 with a
 contiguous block of the source points; the sum all-reduce of the 48-double normal-equation buffer (and of
-the cap / cost-sum side buffers) is supplied through tloam_comm_init_callback and carried by gloo.  The
+the cap / cost-sum side buffers) is supplied through tloam_comm_init_callback and carried by gloo, or done by
+the library's own one-shot peer exchange (tloam_comm_init_mailbox: buffers shared through HIP IPC, every rank
+stores its 48 doubles into every rank's buffer, the step kernel adds them in rank order).  The
 pose, the per-iteration bookkeeping and the correspondence counts must equal the single-rank solve.
 (RCCL refuses two ranks on one device, so the native ncclAllReduce path is exercised with nranks = 1.)"""
 import ctypes as C
@@ -39,21 +41,32 @@ def _make_allreduce():
     return allreduce
 
 
-def _worker(rank, world, port, q, caps):
+def init_comm(H, mode, rank, world):
+    """callback: sum all-reduce through host memory + gloo.  mailbox: the one-shot peer exchange -- every rank exports
+    its buffer (HIP IPC), the handles are all-gathered (here through gloo), every rank maps its peers."""
+    if mode == "mailbox":
+        handles = [None] * world
+        dist.all_gather_object(handles, H.comm_mailbox_export())
+        H.comm_init_mailbox(rank, world, handles)
+    else:
+        H.comm_init_callback(rank, world, _make_allreduce())
+
+
+def _worker(rank, world, port, q, caps, mode="callback"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tloam_amd import registration as reg
         sc = synth.make_scene(seed=31)
         H = reg.HipRegistration(reg.default_config(**caps))
-        H.comm_init_callback(rank, world, _make_allreduce())
+        init_comm(H, mode, rank, world)
         H.set_frames(sc.source, sc.target)
         rc, T, st = H.scan_match(sc.T_pred)
         assert rc == 0
         idx = [H.get_correspondences(k)["idx"].tolist() for k in range(4)]
         # pre-built sets, sharded
         sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=3001, n_line=777, n_point=130)
-        P = reg.HipRegistration(); P.comm_init_callback(rank, world, _make_allreduce())
+        P = reg.HipRegistration(); init_comm(P, mode, rank, world)
         for rt in range(3):
             P.set_correspondences(rt, *sets[rt])
         Hm, g, cost = P.accumulate(x_eval)
@@ -67,14 +80,15 @@ def _worker(rank, world, port, q, caps):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["callback", "mailbox"])
 @pytest.mark.parametrize("caps", [{}, dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)],
                          ids=["default_caps", "caps_bind_across_ranks"])
-def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps):
+def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps, mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, caps)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, caps, mode)) for r in range(world)]
     for p in procs: p.start()
     res = q.get(timeout=300)
     for p in procs:

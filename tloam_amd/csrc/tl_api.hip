@@ -89,6 +89,11 @@ int sync_stream(tloam_ctx* c) {
 // sum all-reduce of a small device buffer of doubles across the ranks of this context
 int allreduce(tloam_ctx* c, double* dev, int count) {
   if (c->nranks <= 1 || c->comm == COMM_NONE) return TLOAM_OK;
+  if (c->comm == COMM_MAILBOX) {
+    if (count > 64) { c->last_error = "mailbox exchange: more than 64 values"; return TLOAM_E_INVALID; }
+    launch_mbox_allreduce(dev, count, c->mbox, c->stream);
+    return TLOAM_OK;
+  }
   if (c->comm == COMM_CALLBACK) {
     const int rc = c->cb(c->cb_user, dev, count, (void*)c->stream);
     if (rc != 0) { c->last_error = "allreduce callback failed"; return TLOAM_E_RCCL; }
@@ -326,14 +331,27 @@ constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evalua
 int enqueue_solve(tloam_ctx* c, bool armed, int sweeps) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   for (int sweep = 0; sweep < sweeps; ++sweep) {
-    int rc = launch_k3_timed(c, false);
-    if (rc != TLOAM_OK) return rc;
     if (c->nranks > 1) {
-      launch_reduce(c->partials.p, c->k3_grid, c->state.p, c->red48.p, c->stream);
-      rc = allreduce(c, c->red48.p, kReduceBuf);  // the 42 normal-equation scalars + cost
-      if (rc != TLOAM_OK) return rc;
-      launch_gn_step(c->state.p, c->red48.p, c->stream);
+      // sharded GN iteration = 2 launches (+ the collective): the sweep, whose last block folds the rows into the
+      // 48-double buffer (the 42 normal-equation scalars + cost) and -- with the mailbox -- stores it straight into
+      // every rank's buffer over xGMI; then the step, which (mailbox) adds the ranks' rows in rank order itself
+      K3Fuse fuse;
+      memset(&fuse, 0, sizeof(fuse));
+      fuse.ticket = c->k3_ticket.p;
+      fuse.out48 = c->red48.p;
+      if (c->comm == COMM_MAILBOX) fuse.mb = c->mbox;
+      launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, false, fuse, c->stream);
+      c->batch_launches++;
+      if (c->comm == COMM_MAILBOX) {
+        launch_gn_step_mbox(c->state.p, c->mbox, c->stream);
+      } else {
+        const int rc = allreduce(c, c->red48.p, kReduceBuf);
+        if (rc != TLOAM_OK) return rc;
+        launch_gn_step(c->state.p, c->red48.p, c->stream);
+      }
     } else {
+      const int rc = launch_k3_timed(c, false);
+      if (rc != TLOAM_OK) return rc;
       launch_reduce_and_step(c->partials.p, c->k3_grid, c->state.p, c->stream);
     }
   }
@@ -348,6 +366,10 @@ int ensure_common(tloam_ctx* c) {
   HIPC(c, c->wpart.reserve(256 * 8));
   HIPC(c, c->rank_counts.reserve((size_t)kMaxRanks * kKinds));
   HIPC(c, c->se3_dev.reserve(8));
+  if (!c->k3_ticket.p) {
+    HIPC(c, c->k3_ticket.reserve(4));
+    HIPC(c, hipMemsetAsync(c->k3_ticket.p, 0, 4 * sizeof(int), c->stream));
+  }
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;
 }
@@ -453,6 +475,10 @@ void tloam_destroy(tloam_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl_comm);
+  for (int r = 0; r < kMaxRanks; ++r)
+    if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
+  if (c->mbox_local) (void)hipFree(c->mbox_local);
+  c->mbox_ctr.release(); c->k3_ticket.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
@@ -748,7 +774,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
       launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, hm, c->stream);
       rc = allreduce(c, c->sums16.p, 16);
       if (rc != TLOAM_OK) return rc;
-      launch_outer_publish(c->sums16.p, c->state.p, hm, c->stream);
+      launch_outer_publish(c->sums16.p, c->state.p, hm, c->comm == COMM_MAILBOX ? c->mbox.ctr + 1 : nullptr, c->stream);
     } else {
       launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, hm, c->stream);  // + publish + re-arm
     }
@@ -756,6 +782,10 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     rc = wait_state(c, hm);
     if (rc != TLOAM_OK) return rc;
     if (!c->h_state->incomplete) break;
+    if (c->h_state->incomplete == 3) {
+      c->last_error = "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)";
+      return TLOAM_E_RCCL;
+    }
     if (attempt > 0 || planned >= kSolveSweeps) {
       c->last_error = "the minimiser did not terminate within its evaluation budget";
       return TLOAM_E_INVALID;
@@ -1148,6 +1178,44 @@ int tloam_time_accumulate(tloam_ctx* c, const double se3[6], int launches, doubl
   return TLOAM_OK;
 }
 
+// Sharded contexts (collective call: every rank, same arguments): `launches` sweeps of this rank's block of the
+// current set at se3, each followed (with_exchange != 0) by the exchange of the 48 doubles exactly as a GN iteration
+// does it -- mailbox: posted by the sweep's last block, gathered by a one-wave kernel; RCCL / callback: all-reduce of
+// the folded buffer -- bracketed by one HIP event pair.  with_exchange == 0: the sweeps alone (the last block
+// still folds the rows).  The difference of the two is the latency the exchange adds to a GN iteration.
+int tloam_time_sharded_sweep(tloam_ctx* c, const double se3[6], int launches, int with_exchange, double* mean_us) {
+  if (!c || !se3 || launches < 1 || !mean_us) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!c->partials.p) return TLOAM_E_NOT_READY;
+  memcpy(c->h_small, se3, sizeof(double) * 6);
+  HIPC(c, hipMemcpyAsync(c->se3_dev.p, c->h_small, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+  launch_set_eval(c->state.p, c->se3_dev.p, c->stream);
+  K3Fuse fuse;
+  memset(&fuse, 0, sizeof(fuse));
+  fuse.ticket = c->k3_ticket.p;
+  fuse.out48 = c->red48.p;
+  const bool mbox = with_exchange && c->comm == COMM_MAILBOX && c->nranks > 1;
+  if (mbox) fuse.mb = c->mbox;
+  hipEvent_t e0, e1;
+  HIPC(c, hipEventCreate(&e0));
+  HIPC(c, hipEventCreate(&e1));
+  HIPC(c, hipEventRecord(e0, c->stream));
+  int rc = TLOAM_OK;
+  for (int i = 0; i < launches && rc == TLOAM_OK; ++i) {
+    launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, true, fuse, c->stream);
+    if (mbox) launch_mbox_gather_only(c->red48.p, c->mbox, c->stream);
+    else if (with_exchange) rc = allreduce(c, c->red48.p, kReduceBuf);
+  }
+  HIPC(c, hipEventRecord(e1, c->stream));
+  HIPC(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_us = (double)ms * 1e3 / launches;
+  return rc;
+}
+
 int tloam_k3_timer(tloam_ctx* c, int reset, double* total_us, int64_t* launches, double* algorithmic_bytes) {
   if (!c) return TLOAM_E_INVALID;
   if (total_us) *total_us = c->k3_total_us;
@@ -1227,6 +1295,62 @@ int tloam_comm_init_callback(tloam_ctx* c, int rank, int nranks, tloam_allreduce
   c->cb = fn;
   c->cb_user = user;
   c->comm = COMM_CALLBACK;
+  return TLOAM_OK;
+}
+
+// (c) one-shot peer exchange over xGMI, no collective library on the data path: every rank exports a small
+//     fine-grained buffer through HIP IPC, maps its peers', and from then on a sharded GN iteration is the sweep
+//     (its last block stores the 48 doubles into every rank's buffer) and the step (adds them in rank order).
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "tloam_comm_mailbox_export hands out 64 bytes");
+int tloam_comm_mailbox_export(tloam_ctx* c, void* handle64) {
+  if (!c || !handle64) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (!c->mbox_local) {
+    const size_t bytes = sizeof(double) * kMboxDoubles;
+    void* p = nullptr;
+    // uncached fine-grained device memory: peers' stores land in memory, local polls read memory
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    }
+    HIPC(c, e);
+    HIPC(c, hipMemset(p, 0, bytes));
+    c->mbox_local = (double*)p;
+  }
+  hipIpcMemHandle_t h;
+  HIPC(c, hipIpcGetMemHandle(&h, c->mbox_local));
+  memcpy(handle64, &h, sizeof(h));
+  return TLOAM_OK;
+}
+
+int tloam_comm_init_mailbox(tloam_ctx* c, int rank, int nranks, const void* handles64) {
+  if (!c || !handles64 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
+  if (!c->mbox_local) return TLOAM_E_NOT_READY;  // export first
+  HIPC(c, hipSetDevice(c->device));
+  memset(&c->mbox, 0, sizeof(c->mbox));
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { c->mbox.peer[r] = c->mbox_local; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles64 + 64 * (size_t)r, sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      c->last_error = std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e);
+      (void)hipGetLastError();
+      return TLOAM_E_RCCL;
+    }
+    c->mbox_opened[r] = p;
+    c->mbox.peer[r] = (double*)p;
+  }
+  HIPC(c, c->mbox_ctr.reserve(4));
+  HIPC(c, hipMemset(c->mbox_ctr.p, 0, 4 * sizeof(unsigned long long)));
+  c->mbox.ctr = c->mbox_ctr.p;
+  c->mbox.rank = rank;
+  c->mbox.nranks = nranks;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->comm = COMM_MAILBOX;
   return TLOAM_OK;
 }
 

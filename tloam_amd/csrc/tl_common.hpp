@@ -108,6 +108,7 @@ struct GnState {
   int reuse, subspace_1d;
   int phase, iteration, invalid, step_successful, done;
   int no_eval_reuse;  // development knob (TLOAM_NO_EVAL_REUSE): every evaluation runs its own sweep
+  int comm_error;     // a mailbox exchange timed out (sharded contexts): published to the host as incomplete = 3
   double dbg[8];      // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
@@ -120,6 +121,22 @@ struct HostMirror {
   GnState* out;
   unsigned long long seq;
 };
+
+// ---- one-shot peer exchange of a sharded context ("mailbox") -------------
+// Every rank owns a small buffer in fine-grained (uncached) device memory that its peers map through HIP IPC:
+//   [2 parities][kMaxRanks writers][kMboxSlot doubles]   (<= 64 values ... , word kMboxSlot-1 = the exchange id)
+// Exchange number id (1, 2, ...; counted on the device, identically on every rank): rank r stores its values
+// into slot [id & 1][r] of EVERY rank's buffer over xGMI, fences at system scope, stores the id; a reader waits for
+// the id in all nranks slots of its OWN buffer and adds the rows in rank order (deterministic, identical on all
+// ranks).  Two parities suffice: a rank can only post id + 2 after it has gathered id + 1, which every rank posts
+// only after it has finished gathering id.
+constexpr int kMboxSlot = 80;   // up to 64 values + padding; the last word carries the exchange id
+struct MboxView {
+  double* peer[kMaxRanks];        // device-visible address of every rank's buffer (peer[rank] = the local one)
+  unsigned long long* ctr;        // [0] exchanges completed so far (device-resident, survives frames); [1] error flag
+  int rank, nranks;
+};
+constexpr size_t kMboxDoubles = (size_t)2 * kMaxRanks * kMboxSlot;
 
 // ---- host-callable launchers (defined in tl_nn.hip / tl_gn.hip) ------------------------------
 struct ScanTemp;  // opaque
@@ -252,6 +269,18 @@ int k3_grid_for(int total_cap);
 bool k3_single_pass(int total_cap, int grid);  // one wave per chunk (small sets) vs the streaming variant
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// sharded contexts: the sweep whose LAST block (ticket counter) also folds the block rows into out48 and, with a
+// mailbox, posts them to every rank -- the sweep of a sharded GN iteration is then 2 launches (+ the collective)
+struct K3Fuse {
+  int* ticket;       // zero between launches
+  double* out48;     // this rank's totals (all-reduced by RCCL / the callback when there is no mailbox)
+  MboxView mb;       // mb.nranks == 0: no mailbox
+};
+void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
+                     const K3Fuse& fuse, hipStream_t s);
+void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s);   // gather (rank order) + consume
+void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream_t s);  // buf <- sum over ranks
+void launch_mbox_gather_only(double* out48, const MboxView& mb, hipStream_t s);
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
 void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);
@@ -267,7 +296,8 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
                     int blocks, const GnState* st, hipStream_t s);
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
                          double* sums8, HostMirror hm, hipStream_t s);
-void launch_outer_publish(const double* sums8, GnState* st, HostMirror hm, hipStream_t s);
+void launch_outer_publish(const double* sums8, GnState* st, HostMirror hm, const unsigned long long* comm_err_or_null,
+                          hipStream_t s);
 // weights + finish in one launch for small single-rank sets
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
                                  double* sums16, GnState* st, HostMirror hm, hipStream_t s);

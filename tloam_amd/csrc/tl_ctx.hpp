@@ -81,7 +81,7 @@ struct GridBuffers {
 };
 
 
-enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2 };
+enum CommMode { COMM_NONE = 0, COMM_CALLBACK = 1, COMM_RCCL = 2, COMM_MAILBOX = 3 };
 
 // ---- device-resident submap (front_end.cpp:201-275): frame buffers + scratch of the crop/voxel pipeline ----
 struct RingFrame {
@@ -168,6 +168,13 @@ struct tloam_ctx {
   tloam_allreduce_fn cb = nullptr;
   void* cb_user = nullptr;
   void* nccl_comm = nullptr;
+  // one-shot peer exchange (tl_common.hpp MboxView): the local buffer (fine-grained device memory, exported through
+  // HIP IPC), the peers' buffers as mapped here, the device-resident exchange counter, the ticket of the fused sweep
+  double* mbox_local = nullptr;
+  void* mbox_opened[tl::kMaxRanks] = {};   // hipIpcOpenMemHandle results (closed at destroy)
+  tl::MboxView mbox{};
+  DBuf<unsigned long long> mbox_ctr;
+  DBuf<int> k3_ticket;
   // scanMatching host state
   bool active = false;
   bool have_build = false;   // the compact set matches build_x

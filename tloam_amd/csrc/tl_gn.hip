@@ -17,6 +17,7 @@
 // wave reduction by cross-lane shuffles, 4-wave LDS combine, one 32-double partial row per block,
 // then a fixed-order tree over the rows: bit-reproducible run to run (no atomics).
 #include <stdlib.h>
+#include <string.h>
 
 #include <hip/hip_ext.h>
 
@@ -194,26 +195,32 @@ __device__ __forceinline__ double2 ld2o_t(const double* base, unsigned byte_off)
 #ifndef TLOAM_K3_NT
 #define TLOAM_K3_NT true
 #endif
-__device__ __forceinline__ double2 ld2o(const double* base, unsigned byte_off) { return ld2o_t<TLOAM_K3_NT>(base, byte_off); }
-template <int RES>
+// NT: streaming policy (the 1 M-class sets); false for the KITTI-size sets, which live in L2 across the launches of
+// a frame (442 KB: with streaming loads/stores the weight kernel and the next sweep fetch them from further away)
+template <int RES, bool NT>
 __device__ __forceinline__ void fetch(const CorrSeg& seg, int j, ChunkBuf<RES>& b) {
+#define ld2o ld2o_t<NT>
   const unsigned o = (unsigned)j * 8u;
   b.px = ld2o(seg.px, o); b.py = ld2o(seg.py, o); b.pz = ld2o(seg.pz, o);
   b.ax = ld2o(seg.ax, o); b.ay = ld2o(seg.ay, o); b.az = ld2o(seg.az, o);
   b.w = ld2o(seg.w, o);
   if (RES == TLOAM_RES_PLANE) b.d = ld2o(seg.d, o);
   if (RES == TLOAM_RES_LINE) { b.bx = ld2o(seg.bx, o); b.by = ld2o(seg.by, o); b.bz = ld2o(seg.bz, o); }
+#undef ld2o
 }
 // the planar segment's chunk straight from (base, stride): the kernel's first arguments, preloaded into SGPRs
+template <bool NT>
 __device__ __forceinline__ void fetch_spec(const double* base, int stride, int j, ChunkBuf<TLOAM_RES_PLANE>& b) {
+#define ld2o ld2o_t<NT>
   const unsigned o = (unsigned)j * 8u;
   const size_t st = (size_t)stride;
   b.px = ld2o(base + SS_PX * st, o); b.py = ld2o(base + SS_PY * st, o); b.pz = ld2o(base + SS_PZ * st, o);
   b.ax = ld2o(base + SS_AX * st, o); b.ay = ld2o(base + SS_AY * st, o); b.az = ld2o(base + SS_AZ * st, o);
   b.w = ld2o(base + SS_W * st, o);
   b.d = ld2o(base + SS_D * st, o);
+#undef ld2o
 }
-template <int RES>
+template <int RES, bool NT>
 __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a) {
   const int rem = n - j;  // >= 2: both correspondences of this lane, 1: the first only, <= 0: none
   if (rem <= 0) return;
@@ -230,23 +237,23 @@ __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, 
     if (rem > 1) c1 = eval_point(T, Vec3{b.px.y, b.py.y, b.pz.y}, Vec3{b.ax.y, b.ay.y, b.az.y}, b.w.y, a);
   }
   // the `mutable double* cost` side channel (registration.hpp:51,76,96): written on EVERY sweep
-#ifndef TLOAM_K3_NO_NT_STORE
-  // streaming store: the slots are not read again before the weight kernel, keep them out of the way of the loads
-  // and out of the end-of-kernel write-back
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  if (rem > 1) __builtin_nontemporal_store(v2d{c0, c1}, reinterpret_cast<v2d*>(seg.cost + j));
-  else __builtin_nontemporal_store(c0, seg.cost + j);
-#else
-  if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
-  else seg.cost[j] = c0;
-#endif
+  if (NT) {
+    // streaming store: the slots are not read again before the weight kernel, keep them out of the way of the loads
+    // and out of the end-of-kernel write-back
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    if (rem > 1) __builtin_nontemporal_store(v2d{c0, c1}, reinterpret_cast<v2d*>(seg.cost + j));
+    else __builtin_nontemporal_store(c0, seg.cost + j);
+  } else {
+    if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
+    else seg.cost[j] = c0;
+  }
 }
 
 // All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment.  DEPTH 2: software-pipelined, the loads of
 // the next chunk are in flight while the current one is evaluated (planes: 76 % of the bytes).  DEPTH 1:
 // plain load-then-evaluate (lines/points: keeps the register budget at 3 waves/SIMD).  Control flow is
 // wave-uniform.
-template <int RES, int DEPTH>
+template <int RES, int DEPTH, bool NT>
 __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, int n, int nchunks, int i0, int W,
                                               int lane, Acc& a, const ChunkBuf<RES>& pre, bool use_pre) {
   if (i0 >= nchunks) return;
@@ -257,20 +264,20 @@ __device__ __forceinline__ void sweep_segment(const Rt& T, const CorrSeg& seg, i
     for (int t = 0; t < m; ++t) {
       ChunkBuf<RES> b;
       if (t == 0 && use_pre) b = pre;  // requested before the state's scalar loads came back
-      else fetch<RES>(seg, TL_J(t), b);
-      consume<RES>(T, seg, TL_J(t), n, b, a);
+      else fetch<RES, NT>(seg, TL_J(t), b);
+      consume<RES, NT>(T, seg, TL_J(t), n, b, a);
     }
   } else if (DEPTH == 2) {
     ChunkBuf<RES> b0, b1;
     if (use_pre) b0 = pre;  // chunk i0 was requested before the kernel even knew the segment sizes
-    else fetch<RES>(seg, TL_J(0), b0);
+    else fetch<RES, NT>(seg, TL_J(0), b0);
     for (int t = 1;; t += 2) {
-      if (t >= m) { consume<RES>(T, seg, TL_J(t - 1), n, b0, a); break; }
-      fetch<RES>(seg, TL_J(t), b1);
-      consume<RES>(T, seg, TL_J(t - 1), n, b0, a);
-      if (t + 1 >= m) { consume<RES>(T, seg, TL_J(t), n, b1, a); break; }
-      fetch<RES>(seg, TL_J(t + 1), b0);
-      consume<RES>(T, seg, TL_J(t), n, b1, a);
+      if (t >= m) { consume<RES, NT>(T, seg, TL_J(t - 1), n, b0, a); break; }
+      fetch<RES, NT>(seg, TL_J(t), b1);
+      consume<RES, NT>(T, seg, TL_J(t - 1), n, b0, a);
+      if (t + 1 >= m) { consume<RES, NT>(T, seg, TL_J(t), n, b1, a); break; }
+      fetch<RES, NT>(seg, TL_J(t + 1), b0);
+      consume<RES, NT>(T, seg, TL_J(t), n, b1, a);
     }
   }
 #undef TL_J
@@ -304,9 +311,9 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const int* __restr
     int i0 = (gw - first) % W;
     if (i0 < 0) i0 += W;
     if (k <= TLOAM_KIND_GROUND)
-      sweep_segment<TLOAM_RES_PLANE, TLOAM_K3_PLANE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, pre0, use_pre0 && k == 0);
-    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_line, false);
-    else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_point, false);
+      sweep_segment<TLOAM_RES_PLANE, TLOAM_K3_PLANE_DEPTH, TLOAM_K3_NT>(T, cv.k[k], n, nchunks, i0, W, lane, a, pre0, use_pre0 && k == 0);
+    else if (k == TLOAM_KIND_EDGE) sweep_segment<TLOAM_RES_LINE, TLOAM_K3_LINE_DEPTH, TLOAM_K3_NT>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_line, false);
+    else sweep_segment<TLOAM_RES_POINT, TLOAM_K3_LINE_DEPTH, TLOAM_K3_NT>(T, cv.k[k], n, nchunks, i0, W, lane, a, no_point, false);
     first = (first + nchunks) % W;
   }
 }
@@ -329,16 +336,16 @@ __device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __re
       if (k <= TLOAM_KIND_GROUND) {
         ChunkBuf<TLOAM_RES_PLANE> b;
         if (use_pre0 && k == 0) b = pre0;
-        else fetch<TLOAM_RES_PLANE>(cv.k[k], j, b);
-        consume<TLOAM_RES_PLANE>(T, cv.k[k], j, n, b, a);
+        else fetch<TLOAM_RES_PLANE, false>(cv.k[k], j, b);
+        consume<TLOAM_RES_PLANE, false>(T, cv.k[k], j, n, b, a);
       } else if (k == TLOAM_KIND_EDGE) {
         ChunkBuf<TLOAM_RES_LINE> b;
-        fetch<TLOAM_RES_LINE>(cv.k[k], j, b);
-        consume<TLOAM_RES_LINE>(T, cv.k[k], j, n, b, a);
+        fetch<TLOAM_RES_LINE, false>(cv.k[k], j, b);
+        consume<TLOAM_RES_LINE, false>(T, cv.k[k], j, n, b, a);
       } else {
         ChunkBuf<TLOAM_RES_POINT> b;
-        fetch<TLOAM_RES_POINT>(cv.k[k], j, b);
-        consume<TLOAM_RES_POINT>(T, cv.k[k], j, n, b, a);
+        fetch<TLOAM_RES_POINT, false>(cv.k[k], j, b);
+        consume<TLOAM_RES_POINT, false>(T, cv.k[k], j, n, b, a);
       }
     }
     g -= nchunks;
@@ -361,15 +368,100 @@ __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
 
 // SINGLE = false: the streaming variant (grid = the resident chip, every wave loops over its chunks with
 // software-pipelined loads).  SINGLE = true: small sets, one wave per chunk (sweep_single).
+
+// ---- sharded contexts: the last block of the sweep folds the rows and hands the totals on -------------------
+// system-scope accesses to the (uncached, fine-grained) mailbox memory
+__device__ __forceinline__ void mbox_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double mbox_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// rank `mb.rank` posts vals[0 .. count) (count <= kMboxSlot - 1) as exchange `id` into every rank's buffer.
+// Called by (at least) the first 64 threads of a block; `vals` in LDS or registers of lane c.
+__device__ __forceinline__ void mbox_post(const MboxView& mb, unsigned long long id, const double* vals, int count, int tid) {
+  const size_t slot = ((size_t)(id & 1ull) * kMaxRanks + (size_t)mb.rank) * kMboxSlot;
+  if (tid < 64) {
+    for (int r = 0; r < mb.nranks; ++r)
+      if (tid < count) mbox_store(mb.peer[r] + slot + tid, vals[tid]);
+    __threadfence_system();  // the values before the id, on every link
+    if (tid < mb.nranks)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.peer[tid] + slot + (kMboxSlot - 1)), id, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// waits (bounded: ~2 s of the 100 MHz wall clock) for exchange `id` from every rank, then out[c] = sum over ranks
+// in rank order for c < count.  One wave; returns false on time-out (a peer died / never posted).
+__device__ __forceinline__ bool mbox_gather(const MboxView& mb, unsigned long long id, double* out /* LDS */, int count, int lane) {
+  const double* mine = mb.peer[mb.rank] + (size_t)(id & 1ull) * kMaxRanks * kMboxSlot;
+  const unsigned long long t0 = wall_clock64();
+  bool ok = true;
+  if (lane < mb.nranks) {
+    const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(mine + (size_t)lane * kMboxSlot + (kMboxSlot - 1));
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != id) {
+      if (wall_clock64() - t0 > 200000000ull) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  ok = __all(ok ? 1 : 0) != 0;
+  __threadfence_system();
+  if (lane < count) {
+    double t = 0.0;
+    for (int r = 0; r < mb.nranks; ++r) t += mbox_load(mine + (size_t)r * kMboxSlot + lane);
+    out[lane] = t;
+  }
+  return ok;
+}
+
+__device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const K3Fuse& fuse) {
+  __shared__ int s_last;
+  __shared__ double s_grp[8 * 33];
+  __shared__ double s_tot[kReduceBuf];
+  __threadfence();  // this block's row is visible device-wide before the ticket is taken
+  if (threadIdx.x == 0) s_last = (atomicAdd(fuse.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other blocks' rows
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 row groups x 32 columns, fixed order
+  const int rows = (int)gridDim.x;
+  double v[4] = {0, 0, 0, 0};
+  for (int b0 = grp; b0 < rows; b0 += 4 * 8) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = b0 + u * 8;
+      // (device-scope load: the rows were written by other XCDs, whose L2 this one does not snoop)
+      const double x = __hip_atomic_load(partials + (size_t)min(r, rows - 1) * kAccStride + comp, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+      v[u] += (r < rows) ? x : 0.0;
+    }
+  }
+  s_grp[grp * 33 + comp] = (v[0] + v[1]) + (v[2] + v[3]);
+  __syncthreads();
+  if (threadIdx.x < kReduceBuf) {
+    double t = 0.0;
+    if (threadIdx.x < kAccN)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += s_grp[g * 33 + threadIdx.x];
+    s_tot[threadIdx.x] = t;
+    fuse.out48[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0) *fuse.ticket = 0;  // re-armed for the next launch (stream order)
+  __syncthreads();
+  if (fuse.mb.nranks > 0) {
+    const unsigned long long id = __hip_atomic_load(fuse.mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    mbox_post(fuse.mb, id, s_tot, kReduceBuf, threadIdx.x);
+  }
+}
+
 // Argument order: the first twelve dwords -- the planar segment as (base, stride, capacity), the flag, the state,
 // the segment sizes and the output rows -- are preloaded into SGPRs by the command processor
 // (-mllvm -amdgpu-kernarg-preload-count=12, see build.py), so the wave's first chunk AND the state's scalar loads
 // are requested in the first instructions, before the kernel-argument segment itself has been read.
-template <bool SINGLE>
+template <bool SINGLE, bool FUSE>
 __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const double* __restrict__ seg0, int stride0, int cap0,
                                                         int force, GnState* __restrict__ st,
                                                         const int* __restrict__ seg_n, double* __restrict__ partials,
-                                                        CorrView cv) {
+                                                        CorrView cv, K3Fuse fuse) {
   __shared__ double red[4][32];
   // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
   // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
@@ -384,7 +476,7 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
 #endif
   ChunkBuf<TLOAM_RES_PLANE> pre;
   const bool spec = (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cap0;
-  if (spec) fetch_spec(seg0, stride0, gw * kChunk + lane * 2, pre);
+  if (spec) fetch_spec<!SINGLE && TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
@@ -403,6 +495,7 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   if (threadIdx.x < kAccStride)
     partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (FUSE) k3_last_block_reduce(partials, fuse);
 #ifdef TLOAM_K3_PROFILE
   if (threadIdx.x == 0) {  // development aid (scripts/k3_profile.py): wave 0's timeline in the spare columns
     const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -437,16 +530,24 @@ int k3_grid_for(int total_cap) {
 bool k3_single_pass(int total_cap, int grid) { return (total_cap + kChunk - 1) / kChunk <= grid * 4; }
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop) {
-  auto kern = single ? k3_accumulate<true> : k3_accumulate<false>;
+  auto kern = single ? k3_accumulate<true, false> : k3_accumulate<false, false>;
+  K3Fuse none;
+  memset(&none, 0, sizeof(none));
   if (ev_start && ev_stop) {
     // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
     // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
-                          cv.k[0].cap, force ? 1 : 0, st, cv.seg_n, partials, cv);
+                          cv.k[0].cap, force ? 1 : 0, st, cv.seg_n, partials, cv, none);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, force ? 1 : 0, st,
-                       cv.seg_n, partials, cv);
+                       cv.seg_n, partials, cv, none);
   }
+}
+void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
+                     const K3Fuse& fuse, hipStream_t s) {
+  auto kern = single ? k3_accumulate<true, true> : k3_accumulate<false, true>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, force ? 1 : 0, st,
+                     cv.seg_n, partials, cv, fuse);
 }
 
 // ================================================================================================
@@ -1032,6 +1133,60 @@ __global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __res
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
 }
+// mailbox contexts: wait for every rank's totals of this sweep (posted by the last block of its K3), add them in
+// rank order and advance the minimiser -- identically on every rank
+__global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
+  __shared__ double tot[kMboxSlot];
+  if (st->done) return;  // (the sweep of this launch was a no-op on every rank: nothing was posted)
+  const unsigned long long id = __hip_atomic_load(mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  const bool ok = mbox_gather(mb, id, tot, kReduceBuf, threadIdx.x);
+  if (threadIdx.x == 0) {
+    mb.ctr[0] = id;
+    if (!ok) mb.ctr[1] = 1ull;
+  }
+  __syncthreads();
+  if (!ok) {  // a peer never posted: stop the minimiser, the host reports TLOAM_E_RCCL
+    if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
+    return;
+  }
+  gn_consume_wave(st, tot, threadIdx.x, st);
+}
+void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s) {
+  hipLaunchKernelGGL(k_gn_step_mbox, dim3(1), dim3(64), 0, s, st, mb);
+}
+// timing aid (tloam_time_sharded_sweep): the gather half of the step without the minimiser
+__global__ __launch_bounds__(64) void k_mbox_gather_only(double* out48, MboxView mb) {
+  __shared__ double tot[kMboxSlot];
+  const unsigned long long id = __hip_atomic_load(mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  const bool ok = mbox_gather(mb, id, tot, kReduceBuf, threadIdx.x);
+  if (threadIdx.x < kReduceBuf) out48[threadIdx.x] = tot[threadIdx.x];
+  if (threadIdx.x == 0) {
+    mb.ctr[0] = id;
+    if (!ok) mb.ctr[1] = 1ull;
+  }
+}
+void launch_mbox_gather_only(double* out48, const MboxView& mb, hipStream_t s) {
+  hipLaunchKernelGGL(k_mbox_gather_only, dim3(1), dim3(64), 0, s, out48, mb);
+}
+// the small side exchanges of a sharded frame (cap prefix counts, cost sums) through the same mailbox: one launch
+__global__ __launch_bounds__(64) void k_mbox_allreduce(double* buf, int count, MboxView mb) {
+  __shared__ double vals[kMboxSlot];
+  const int t = threadIdx.x;
+  if (t < count) vals[t] = buf[t];
+  __syncthreads();
+  const unsigned long long id = __hip_atomic_load(mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  mbox_post(mb, id, vals, count, t);
+  const bool ok = mbox_gather(mb, id, vals, count, t);
+  __syncthreads();
+  if (t < count) buf[t] = vals[t];
+  if (t == 0) {
+    mb.ctr[0] = id;
+    if (!ok) mb.ctr[1] = 1ull;
+  }
+}
+void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream_t s) {
+  hipLaunchKernelGGL(k_mbox_allreduce, dim3(1), dim3(64), 0, s, buf, count, mb);
+}
 
 // single-GPU fast path: reduce the block rows and advance the minimiser in ONE launch
 __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* __restrict__ partials, int rows,
@@ -1257,12 +1412,15 @@ void launch_outer_finish(const double* partial, int blocks, const int* seg_n, Gn
                          double* sums16, HostMirror hm, hipStream_t s) {
   hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate, hm);
 }
-__global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st, HostMirror hm) {
+__global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st, HostMirror hm,
+                                const unsigned long long* __restrict__ comm_err) {
   if (st->done) publish_and_rearm(sums16, st, threadIdx.x);  // gated like k_outer_finish (which raised st->incomplete)
+  if (threadIdx.x == 0 && (st->comm_error || (comm_err && *comm_err))) st->incomplete = 3;  // exchange timed out
   mirror_to_host(st, hm, threadIdx.x, 64);
 }
-void launch_outer_publish(const double* sums16, GnState* st, HostMirror hm, hipStream_t s) {
-  hipLaunchKernelGGL(k_outer_publish, dim3(1), dim3(64), 0, s, sums16, st, hm);
+void launch_outer_publish(const double* sums16, GnState* st, HostMirror hm, const unsigned long long* comm_err,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_outer_publish, dim3(1), dim3(64), 0, s, sums16, st, hm, comm_err);
 }
 
 // PointCloud2::Transform (open3d PointCloud2.cpp:71-75): p <- (M * (p,1)).hnormalized()

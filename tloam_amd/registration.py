@@ -125,8 +125,11 @@ def load_library():
         "tloam_accumulate": (C.c_int, [vp, dp, dp, dp, dp]),
         "tloam_get_costs": (C.c_int, [vp, C.c_int, sz, C.POINTER(sz), dp]),
         "tloam_get_normal_equations": (C.c_int, [vp, dp, dp, dp]),
+        "tloam_comm_mailbox_export": (C.c_int, [vp, vp]),
+        "tloam_comm_init_mailbox": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "tloam_solve": (C.c_int, [vp, dp, C.POINTER(Stats)]),
         "tloam_time_accumulate": (C.c_int, [vp, dp, C.c_int, dp]),
+        "tloam_time_sharded_sweep": (C.c_int, [vp, dp, C.c_int, C.c_int, dp]),
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
@@ -162,9 +165,10 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
-    "tloam_time_accumulate", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
+    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
+    "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
     "tloam_comm_init_callback", "tloam_shard_range", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
 )
 
@@ -460,6 +464,14 @@ class HipRegistration:
         self._check(self.L.tloam_time_accumulate(self.h, _dp(x), int(launches), C.byref(us)), "tloam_time_accumulate")
         return us.value
 
+    def time_sharded_sweep(self, se3, launches=50, with_exchange=True):
+        """collective: every rank calls it with the same arguments (tloam_time_sharded_sweep)."""
+        x = np.ascontiguousarray(se3, float)
+        us = C.c_double(0)
+        self._check(self.L.tloam_time_sharded_sweep(self.h, _dp(x), int(launches), int(bool(with_exchange)), C.byref(us)),
+                    "tloam_time_sharded_sweep")
+        return us.value
+
     def k3_timer(self, reset=False):
         us = C.c_double(0); n = C.c_int64(0); b = C.c_double(0)
         self._check(self.L.tloam_k3_timer(self.h, int(bool(reset)), C.byref(us), C.byref(n), C.byref(b)), "tloam_k3_timer")
@@ -475,6 +487,20 @@ class HipRegistration:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.L.tloam_comm_init_rccl(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)),
                     "tloam_comm_init_rccl")
+
+    def comm_mailbox_export(self) -> bytes:
+        """64 bytes (hipIpcMemHandle_t) of this context's exchange buffer; all-gather them in rank order."""
+        buf = C.create_string_buffer(64)
+        self._check(self.L.tloam_comm_mailbox_export(self.h, C.cast(buf, C.c_void_p)), "tloam_comm_mailbox_export")
+        return bytes(buf.raw)
+
+    def comm_init_mailbox(self, rank, nranks, handles):
+        """handles: the nranks 64-byte handles in rank order (this rank's own entry is ignored)."""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == 64 * int(nranks)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self.L.tloam_comm_init_mailbox(self.h, int(rank), int(nranks), C.cast(buf, C.c_void_p)),
+                    "tloam_comm_init_mailbox")
 
     def comm_init_callback(self, rank, nranks, fn):
         """fn(device_ptr:int, count:int, stream:int) -> 0 ; must sum-all-reduce `count` doubles in place."""
