@@ -316,3 +316,37 @@ def test_nan_targets_are_never_neighbours(hip_module, n_src, n_tgt):
     for k in range(4):
         assert np.array_equal(lists1[k], H.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"])
     H.close()
+
+
+@pytest.mark.parametrize("shape", ["small", "kitti", "caps", "noise_free", "m1"])
+def test_device_driven_loop_equals_host_driven_loop(hip_module, monkeypatch, shape):
+    """tloam_scan_match enqueues every outer GNC iteration at once -- builders / refresh gated on device flags, the
+    plateau break and the loop end decided by the finish kernel -- and waits once.  The stepwise machinery
+    (TLOAM_NO_DEVICE_LOOP: the host decides between iterations, as tloam_sm_outer does) must give the same frame, bit
+    for bit: pose, counters, index lists, captured weights, side-channel costs, GNC weights -- over three frames, so
+    that the learned sweep budgets are in play as well."""
+    over = {}
+    if shape == "small":
+        sc = synth.make_scene(seed=14, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)
+    elif shape == "kitti":
+        sc = synth.make_scene(seed=15, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
+    elif shape == "caps":
+        sc = synth.make_scene(seed=16)
+        over = dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)
+    elif shape == "noise_free":
+        sc = synth.make_scene(seed=17, noise=0.0)
+    else:
+        big = 1 << 30
+        sc = synth.make_scene(seed=1, n_src=(50000, 26000, 20000, 4000), n_tgt=(50000, 26000, 20000, 4000))
+        over = dict(planar_maxnum=big, ground_maxnum=big, edge_maxnum=big, sphere_maxnum=big)
+    H1 = hip_module.HipRegistration(hip_module.default_config(**over))
+    H1.set_frames(sc.source, sc.target)
+    monkeypatch.setenv("TLOAM_NO_DEVICE_LOOP", "1")      # read once, when the context is created
+    H2 = hip_module.HipRegistration(hip_module.default_config(**over))
+    H2.set_frames(sc.source, sc.target)
+    for frame in range(3):
+        rc1, T1, st1 = H1.scan_match(sc.T_pred)
+        rc2, T2, st2 = H2.scan_match(sc.T_pred)
+        assert rc1 == rc2 == 0
+        _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
+    H1.close(); H2.close()

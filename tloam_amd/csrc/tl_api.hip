@@ -11,7 +11,8 @@
 
 using namespace tl;
 
-struct Uid128 { char bytes[128]; };  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
+struct Uid128 { char bytes[128]; };
+constexpr int kMirrorSlots = 8;  // pinned result slots: one per outer iteration of a device-driven frame (slot 0: stepwise API)  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
 
 namespace {
 // ---- RCCL, loaded at run time so the library also loads where librccl is absent ----------------
@@ -156,8 +157,21 @@ int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq)
 // scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
 // temporary one.
 // radius[k] <= 0: kind not rebuilt (its view is left empty).  One host synchronisation (bounding boxes).
+// rows of launch_bbox_all ([kind][64][6]) -> (lo[3], hi[3]) per kind
+static void reduce_box_rows(const double* box_rows, double boxes[kKinds][6]) {
+  for (int k = 0; k < kKinds; ++k) {
+    double* b = boxes[k];
+    b[0] = b[1] = b[2] = 1e300;
+    b[3] = b[4] = b[5] = -1e300;
+    for (int r = 0; r < 64; ++r) {
+      const double* row = box_rows + ((size_t)k * 64 + r) * 6;
+      for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], row[a]); b[3 + a] = std::max(b[3 + a], row[3 + a]); }
+    }
+  }
+}
+// known_boxes: the clouds' bounds are already on the host (targets: taken at set_target) -- no launch, no wait
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], const CloudRef clouds[kKinds],
-                     GridView out[kKinds]) {
+                     GridView out[kKinds], const double (*known_boxes)[6]) {
   GridSet gs;
   memset(&gs, 0, sizeof(gs));
   size_t tgt_total = 0;
@@ -169,26 +183,29 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     tgt_total += (size_t)gs.n[k];
   }
   constexpr size_t kBoxDoubles = (size_t)kKinds * 64 * 6;
-  const double* box_rows = c->h_small;
-  if (c->h_bbox_dev) {
-    // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
-    // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
-    launch_bbox_all(gs, c->h_bbox_dev, c->stream);
-    HIPC(c, hipStreamSynchronize(c->stream));
-    box_rows = c->h_bbox;
+  double boxes[kKinds][6];
+  if (known_boxes) {
+    memcpy(boxes, known_boxes, sizeof(boxes));
   } else {
-    HIPC(c, G.bbox.reserve(kBoxDoubles));
-    launch_bbox_all(gs, G.bbox.p, c->stream);
-    HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kBoxDoubles, hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipStreamSynchronize(c->stream));
+    const double* box_rows = c->h_small;
+    if (c->h_bbox_dev) {
+      // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
+      // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
+      launch_bbox_all(gs, c->h_bbox_dev, c->stream);
+      HIPC(c, hipStreamSynchronize(c->stream));
+      box_rows = c->h_bbox;
+    } else {
+      HIPC(c, G.bbox.reserve(kBoxDoubles));
+      launch_bbox_all(gs, G.bbox.p, c->stream);
+      HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kBoxDoubles, hipMemcpyDeviceToHost, c->stream));
+      HIPC(c, hipStreamSynchronize(c->stream));
+    }
+    reduce_box_rows(box_rows, boxes);
   }
   long long cell_total = 0;
   for (int k = 0; k < kKinds; ++k) {
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int b = 0; b < 64; ++b) {
-      const double* row = box_rows + ((size_t)k * 64 + b) * 6;
-      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], row[a]); hi[a] = std::max(hi[a], row[3 + a]); }
-    }
+    const double* lo = boxes[k];
+    const double* hi = boxes[k] + 3;
     GridView& g = out[k];
     memset(&g, 0, sizeof(g));
     gs.cell_base[k] = cell_total;
@@ -245,11 +262,31 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
 }
 int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridView out[kKinds]) {
   CloudRef clouds[kKinds];
+  bool known = true;
   for (int k = 0; k < kKinds; ++k) {
     const KindData& K = c->kd[k];
     clouds[k] = CloudRef{K.tx.p, K.ty.p, K.tz.p, K.tgt_set ? K.n_tgt : 0};
+    if (radius[k] > 0.0 && clouds[k].n > 0 && !c->tgt_box_valid[k]) known = false;
   }
-  return build_grids_over(c, G, radius, clouds, out);
+  return build_grids_over(c, G, radius, clouds, out, known ? c->tgt_box : nullptr);
+}
+// bounds of the target clouds registered so far, taken while the hand-over call is synchronising anyway
+int enqueue_target_bounds(tloam_ctx* c) {
+  if (!c->h_bbox_dev) return TLOAM_OK;  // no pinned rows: scanMatching computes them itself
+  GridSet gs;
+  memset(&gs, 0, sizeof(gs));
+  for (int k = 0; k < kKinds; ++k) {
+    const KindData& K = c->kd[k];
+    gs.tx[k] = K.tx.p; gs.ty[k] = K.ty.p; gs.tz[k] = K.tz.p;
+    gs.n[k] = K.tgt_set ? (int)K.n_tgt : 0;
+  }
+  launch_bbox_all(gs, c->h_bbox_dev, c->stream);
+  return TLOAM_OK;
+}
+void finish_target_bounds(tloam_ctx* c) {  // after the stream has been synchronised
+  if (!c->h_bbox_dev) return;
+  reduce_box_rows(c->h_bbox, c->tgt_box);
+  for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = c->kd[k].tgt_set && c->kd[k].n_tgt > 0;
 }
 }  // namespace tlh
 
@@ -278,9 +315,10 @@ int launch_k3_timed(tloam_ctx* c, bool force) {
   }
   return TLOAM_OK;
 }
-// fold the recorded event pairs into the accumulated timers (stream must be idle).  The first
-// `working` launches of the batch did a sweep; later ones were no-op launches after `done`.
-int harvest_k3_events(tloam_ctx* c, int working) {
+// fold the recorded event pairs into the accumulated timers (stream must be idle).  The launches of the batch belong
+// to `nsolve` Solves starting at batch positions start[i]; of each, the first working[i] launches did a sweep, the
+// later ones were no-op launches after `done`.
+int harvest_k3_events_multi(tloam_ctx* c, int nsolve, const int* start, const int* working) {
   c->batch_launches = 0;
   if (!c->k3_timing) { c->ev_used = 0; c->ev_batch_idx.clear(); return TLOAM_OK; }
   const size_t pairs = c->ev_used / 2;
@@ -289,7 +327,10 @@ int harvest_k3_events(tloam_ctx* c, int working) {
     HIPC(c, hipEventElapsedTime(&ms, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
     c->k3_all_us += (double)ms * 1e3;
     c->k3_all_launches += 1;
-    if (c->ev_batch_idx[i] < working) {
+    const int b = c->ev_batch_idx[i];
+    int sv = 0;
+    while (sv + 1 < nsolve && start[sv + 1] <= b) ++sv;
+    if (b - start[sv] < working[sv]) {
       c->k3_total_us += (double)ms * 1e3;
       c->k3_launches += 1;
     }
@@ -298,18 +339,22 @@ int harvest_k3_events(tloam_ctx* c, int working) {
   c->ev_batch_idx.clear();
   return TLOAM_OK;
 }
+int harvest_k3_events(tloam_ctx* c, int working) {
+  const int zero = 0;
+  return harvest_k3_events_multi(c, 1, &zero, &working);
+}
 
 // Result of an outer iteration on the host.  With the mirror the finish kernel has been handed
 // {pinned state, sequence number}: poll the number (a word in host memory the device writes last); the stream
 // is only queried now and then, to notice a failed launch instead of spinning forever.  Otherwise, or if the
 // stream drained without the number arriving, copy the state and synchronise.
-HostMirror next_mirror(tloam_ctx* c) {
+HostMirror next_mirror(tloam_ctx* c, int slot = 0) {
   HostMirror hm;
-  hm.out = c->h_state_dev;
+  hm.out = c->h_state_dev ? c->h_state_dev + slot : nullptr;
   hm.seq = hm.out ? ++c->mirror_seq : 0ull;
   return hm;
 }
-int wait_state(tloam_ctx* c, const HostMirror& hm) {
+int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
   const auto t0 = std::chrono::steady_clock::now();
   struct Acc {
     tloam_ctx* c;
@@ -317,10 +362,10 @@ int wait_state(tloam_ctx* c, const HostMirror& hm) {
     ~Acc() { c->wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
   } acc{c, t0};
   if (hm.out) {
-    const int rc = wait_word(c, &c->h_state->host_seq, hm.seq);
+    const int rc = wait_word(c, &c->h_state[slot].host_seq, hm.seq);
     if (rc <= 0) return rc;
   }
-  HIPC(c, hipMemcpyAsync(c->h_state, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipMemcpyAsync(c->h_state + slot, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
   return TLOAM_OK;
 }
@@ -440,15 +485,16 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   if (const char* e = getenv("TLOAM_DEBUG_MAX_SWEEPS")) c->dbg_max_sweeps = atoi(e);
   c->dbg_no_build_reuse = getenv("TLOAM_NO_BUILD_REUSE") != nullptr;
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
+  c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_state, sizeof(GnState), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_state, sizeof(GnState) * kMirrorSlots, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostMalloc((void**)&c->h_small, sizeof(double) * 4096, hipHostMallocDefault) != hipSuccess) {
     delete c;
     return TLOAM_E_HIP;
   }
-  memset(c->h_state, 0, sizeof(GnState));
+  memset(c->h_state, 0, sizeof(GnState) * kMirrorSlots);
   c->no_host_mirror = getenv("TLOAM_NO_HOST_MIRROR") != nullptr;
   if (!c->no_host_mirror && hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) {
     (void)hipGetLastError();
@@ -533,6 +579,7 @@ int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   K.n_tgt = n;
+  c->tgt_box_valid[kind] = false;
   const size_t m = std::max<size_t>(n, 1);
   HIPC(c, K.tgt_aos.reserve(3 * m));
   HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
@@ -557,9 +604,11 @@ int tloam_set_source(tloam_ctx* c, int kind, const double* xyz, size_t n) {
 int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   if (!c) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
-  const int rc = set_target_async(c, kind, xyz, n);
+  int rc = set_target_async(c, kind, xyz, n);
+  if (rc == TLOAM_OK) rc = enqueue_target_bounds(c);
   if (rc != TLOAM_OK) return rc;
   HIPC(c, hipStreamSynchronize(c->stream));
+  finish_target_bounds(c);
   return TLOAM_OK;
 }
 
@@ -577,7 +626,9 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   HIPC(c, hipSetDevice(c->device));
   int rc = TLOAM_OK;
   for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k]);
+  if (rc == TLOAM_OK) rc = enqueue_target_bounds(c);
   HIPC(c, hipStreamSynchronize(c->stream));
+  if (rc == TLOAM_OK) finish_target_bounds(c);
   return rc;
 }
 
@@ -673,6 +724,142 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   return TLOAM_OK;
 }
 
+// ---- pieces of one outer GNC iteration, shared by the stepwise API (the host decides between iterations) and by
+//      tloam_scan_match's device-driven loop (every iteration enqueued at once, one host wait per frame) -----------
+namespace {
+constexpr int kMaxOuterFast = kMirrorSlots;   // outer iterations the device-driven loop plans for
+
+void outer_params(const tloam_ctx* c, BuildParams* bp, GridView grids[kKinds]) {
+  for (int k = 0; k < kKinds; ++k) {
+    bp->radius[k] = kind_radius(c->cfg, k);
+    bp->maxnum[k] = kind_maxnum(c->cfg, k);
+    bp->active[k] = kind_active(c->cfg, k);
+    grids[k] = c->kd[k].gv;
+  }
+  bp->edge_dir_thres = c->cfg.edge_dir_thres;
+}
+int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
+  const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
+  const size_t ntiles = (size_t)build_tile_count(grids);
+  HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
+  HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)ntiles, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
+  HIPC(c, c->qrec.reserve(n_slots + 1));
+  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
+  return TLOAM_OK;
+}
+// :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps
+int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate) {
+  const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
+  launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
+               c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+  launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
+  const double* rank_counts = nullptr;
+  if (c->nranks > 1) {
+    launch_rank_counts(c->sv, c->rank_counts.p, c->rank, c->nranks, c->stream);
+    const int rc = allreduce(c, c->rank_counts.p, c->nranks * kKinds);
+    if (rc != TLOAM_OK) return rc;
+    rank_counts = c->rank_counts.p;
+  }
+  // seg_n: every kind with slots and a positive cap is rewritten by the compaction, the others keep the 0 of
+  // k_frame_init; only a sharded rank can find its cap already filled by the lower ranks and write nothing
+  if (c->nranks > 1) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
+  launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->state.p, c->stream, gate);
+  return TLOAM_OK;
+}
+// budget of K3 sweeps of outer iteration `iter`: the most it needed in the last three frames
+int planned_sweeps_for(tloam_ctx* c, int iter) {
+  if ((int)c->planned_sweeps.size() < 3 * (iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), 0);  // 0 = no history yet
+  const int* hist = &c->planned_sweeps[3 * (size_t)iter];
+  int planned = hist[0] == 0 ? kSolveSweeps  // first frame of this context: the full budget
+                             : std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
+  if (c->dbg_planned_sweeps > 0) planned = std::min(c->dbg_planned_sweeps, kSolveSweeps);
+  return planned;
+}
+WeightParams weight_params(const tloam_ctx* c, double mu, const BuildParams& bp) {
+  WeightParams wp;
+  wp.th1 = (mu + 1) / mu * c->noise_bound_sq;   // :1049
+  wp.th2 = mu / (mu + 1) * c->noise_bound_sq;   // :1050
+  wp.mu = mu;
+  wp.noise_bound_sq = c->noise_bound_sq;
+  for (int k = 0; k < kKinds; ++k) wp.active[k] = bp.active[k];
+  return wp;
+}
+// :1049-1086 thresholds + weight update, :1091-1094 cost sums, publish (+ device-side loop control when ctl.fast)
+int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl) {
+  // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
+  size_t cap = 0;
+  for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
+  const int wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
+  const bool small_set = cap <= 16384;  // one 1024-thread block does weights + sums + publish in a single launch
+  if (c->nranks == 1 && small_set) {
+    launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, hm, ctl, c->stream);
+    return TLOAM_OK;
+  }
+  launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
+  if (c->nranks > 1) {
+    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, hm, ctl, c->stream);
+    const int rc = allreduce(c, c->sums16.p, 16);
+    if (rc != TLOAM_OK) return rc;
+    launch_outer_publish(c->sums16.p, c->state.p, hm, c->comm == COMM_MAILBOX ? c->mbox.ctr + 1 : nullptr, c->stream);
+  } else {
+    launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, hm, ctl, c->stream);  // + publish + re-arm
+  }
+  return TLOAM_OK;
+}
+// host bookkeeping of a finished outer iteration from the mirrored state S (:1089-1121); returns whether the loop ends.
+// *weight_violation: the reference's assert (:871) would have fired in this iteration.
+bool account_outer(tloam_ctx* c, int iter, const GnState& S, double mu, int sweeps_before, bool* weight_violation) {
+  int* hist = &c->planned_sweeps[3 * (size_t)iter];
+  {
+    const int used = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
+    if (hist[0] == 0) hist[1] = hist[2] = used;  // the first observation stands for the whole window
+    else { hist[2] = hist[1]; hist[1] = hist[0]; }
+    hist[0] = used;
+  }
+  c->mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
+  tloam_stats& st = c->stats;
+  st.outer_iterations = iter + 1;
+  st.gn_evaluations = S.gn_evaluations;
+  st.gn_sweeps = S.gn_sweeps;
+  st.host_wait_us = (int32_t)c->wait_us;
+  st.gn_iterations = S.gn_iterations;
+  st.accepted_steps = S.accepted_steps;
+  *weight_violation = S.bad_weights > st.weight_range_violations;
+  st.weight_range_violations = S.bad_weights;
+  st.mu = c->mu;
+  st.solver_cost = S.x_cost;
+  memcpy(st.se3, S.x, sizeof(double) * 6);
+  int nn[kKinds];
+  for (int k = 0; k < kKinds; ++k) {
+    c->cur_cost[k] = S.kind_cost[k];
+    st.kind_cost[k] = S.kind_cost[k];
+    st.n_corr[k] = S.n_corr[k];
+    nn[k] = S.n_corr[k];
+  }
+  c->k3_alg_bytes = alg_bytes_of(nn);
+  bool fin = false;
+  if (fabs(c->cur_cost[TLOAM_KIND_PLANAR] - c->prev_cost[TLOAM_KIND_PLANAR]) < c->cfg.cost_threshold) {  // :1108
+    st.converged_early = 1;
+    fin = true;
+  } else {
+    for (int k = 0; k < kKinds; ++k) c->prev_cost[k] = c->cur_cost[k];  // :1113-1116 (slots re-zeroed by the next compaction)
+    c->iter = iter + 1;
+    if (c->iter >= c->cfg.max_iterations) fin = true;
+  }
+  if (fin) c->iter = c->cfg.max_iterations;
+  return fin;
+}
+// :1027-1033.  When iteration 0 reaches this point no Evaluate() has run yet, so every residual slot the
+// reference takes maxCoeff() over is still the 0 it was initialised with (:931-949); the literal formula
+// then gives mu = 1/(0 - 1) = -1 -> 1e-10.
+double initial_mu(const tloam_ctx* c) {
+  const double max_residual = 0.0;
+  double mu = 1 / (2 * max_residual / c->noise_bound_sq - 1.0);
+  if (mu <= 0) mu = 1e-10;
+  return mu;
+}
+}  // namespace
+
 int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   if (!c || !c->active) return TLOAM_E_NOT_READY;
   HIPC(c, hipSetDevice(c->device));
@@ -683,24 +870,11 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     return TLOAM_OK;
   }
   int rc;
-  // ---- :976-1020 the four builders (K1 + K2), then the index-order caps
   BuildParams bp;
-  for (int k = 0; k < kKinds; ++k) {
-    bp.radius[k] = kind_radius(c->cfg, k);
-    bp.maxnum[k] = kind_maxnum(c->cfg, k);
-    bp.active[k] = kind_active(c->cfg, k);
-  }
-  bp.edge_dir_thres = c->cfg.edge_dir_thres;
   GridView grids[kKinds];
-  for (int k = 0; k < kKinds; ++k) grids[k] = c->kd[k].gv;
-  const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
-  {
-    const size_t ntiles = (size_t)build_tile_count(grids);
-    HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
-    HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)ntiles, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
-    HIPC(c, c->qrec.reserve(n_slots + 1));
-    HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
-  }
+  outer_params(c, &bp, grids);
+  rc = outer_reserve(c, grids);
+  if (rc != TLOAM_OK) return rc;
   // The correspondence search is a pure function of (pose, clouds).  In the reference's GNC dynamics the
   // outer iterations after the first usually reject every step, so the pose -- hence every
   // neighbour list, fit and gate -- is bit-identical to the previous outer iteration: then only the
@@ -708,81 +882,33 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   const bool same_pose = iter > 0 && c->have_build && memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) == 0 &&
                          !c->dbg_no_build_reuse;
   if (!same_pose) {
-    launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-                 c->qrec.p, c->scan_tmp.p, /*rebin=*/iter == 0, c->stream);
-    launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream);
-    const double* rank_counts = nullptr;
-    if (c->nranks > 1) {
-      launch_rank_counts(c->sv, c->rank_counts.p, c->rank, c->nranks, c->stream);
-      rc = allreduce(c, c->rank_counts.p, c->nranks * kKinds);
-      if (rc != TLOAM_OK) return rc;
-      rank_counts = c->rank_counts.p;
-    }
-    // seg_n: every kind with slots and a positive cap is rewritten by the compaction, the others keep the 0 of
-    // k_frame_init; only a sharded rank can find its cap already filled by the lower ranks and write nothing
-    if (c->nranks > 1) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
-    launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->stream);
+    rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, nullptr);
+    if (rc != TLOAM_OK) return rc;
     memcpy(c->build_x, c->stats.se3, sizeof(c->build_x));
     c->have_build = true;
   } else {
     launch_refresh(c->sv, c->cv, c->stream);
   }
-  if (iter == 0) {
-    // :1027-1033.  At this point no Evaluate() has run in iteration 0, so every residual slot the
-    // reference takes maxCoeff() over is still the 0 it was initialised with (:931-949); the
-    // literal formula then gives mu = 1/(0 - 1) = -1 -> 1e-10.
-    const double max_residual = 0.0;
-    c->mu = 1 / (2 * max_residual / c->noise_bound_sq - 1.0);
-    if (c->mu <= 0) c->mu = 1e-10;
-  }
+  if (iter == 0) c->mu = initial_mu(c);
   // ---- :1036-1047 ceres::Solve, device resident.  Only as many sweeps as this outer iteration needed in the
   //      last three frames are enqueued (typically 2 of 5 from the second iteration on: the retried rejected steps
   //      are served by the evaluation reuse); the weight update and the finish kernel are gated on the
   //      minimiser having terminated, and raise `incomplete` otherwise -- then the Solve is topped up.
-  if ((int)c->planned_sweeps.size() < 3 * (iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), 0);  // 0 = no history yet
-  int* hist = &c->planned_sweeps[3 * (size_t)iter];  // budget = the most this iteration needed in the last 3 frames
-  int planned = hist[0] == 0 ? kSolveSweeps  // first frame of this context: the full budget
-                             : std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
-  if (c->dbg_planned_sweeps > 0) planned = std::min(c->dbg_planned_sweeps, kSolveSweeps);
+  const int planned = planned_sweeps_for(c, iter);
   rc = enqueue_solve(c, /*armed=*/true, planned);  // armed by sm_begin / the previous iteration's finish kernel
   if (rc != TLOAM_OK) return rc;
-  // ---- :1049-1086 thresholds + weight update, :1091-1094 cost sums
   const double mu = c->mu;
-  WeightParams wp;
-  wp.th1 = (mu + 1) / mu * c->noise_bound_sq;
-  wp.th2 = mu / (mu + 1) * c->noise_bound_sq;
-  wp.mu = mu;
-  wp.noise_bound_sq = c->noise_bound_sq;
-  for (int k = 0; k < kKinds; ++k) wp.active[k] = bp.active[k];
-  // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
-  int wblocks = 64;
-  bool small_set = false;
-  {
-    size_t cap = 0;
-    for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
-    wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
-    small_set = cap <= 16384;  // one 1024-thread block does weights + sums + publish in a single launch
-  }
+  const WeightParams wp = weight_params(c, mu, bp);
+  const OuterCtl host_decides{c->cfg.cost_threshold, 0, 0};
   const int sweeps_before = c->stats.gn_sweeps;
   for (int attempt = 0;; ++attempt) {
     const HostMirror hm = next_mirror(c);
-    if (c->nranks == 1 && small_set) {
-      launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, hm, c->stream);
-    } else {
-    launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
-    if (c->nranks > 1) {
-      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, hm, c->stream);
-      rc = allreduce(c, c->sums16.p, 16);
-      if (rc != TLOAM_OK) return rc;
-      launch_outer_publish(c->sums16.p, c->state.p, hm, c->comm == COMM_MAILBOX ? c->mbox.ctr + 1 : nullptr, c->stream);
-    } else {
-      launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, c->state.p, c->state.p, c->sums16.p, hm, c->stream);  // + publish + re-arm
-    }
-    }
+    rc = enqueue_finish(c, wp, hm, host_decides);
+    if (rc != TLOAM_OK) return rc;
     rc = wait_state(c, hm);
     if (rc != TLOAM_OK) return rc;
     if (!c->h_state->incomplete) break;
-    if (c->h_state->incomplete == 3) {
+    if (c->h_state->incomplete == OS_COMM_ERROR) {
       c->last_error = "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)";
       return TLOAM_E_RCCL;
     }
@@ -794,52 +920,106 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     if (rc != TLOAM_OK) return rc;
   }
   const GnState& S = *c->h_state;
-  hist = &c->planned_sweeps[3 * (size_t)iter];
-  {
-    const int used = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
-    if (hist[0] == 0) hist[1] = hist[2] = used;  // the first observation stands for the whole window
-    else { hist[2] = hist[1]; hist[1] = hist[0]; }
-    hist[0] = used;
-  }
   rc = harvest_k3_events(c, S.gn_sweeps - sweeps_before);
   if (rc != TLOAM_OK) return rc;
-  c->mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
-  tloam_stats& st = c->stats;
-  st.outer_iterations = iter + 1;
-  st.gn_evaluations = S.gn_evaluations;
-  st.gn_sweeps = S.gn_sweeps;
-  st.host_wait_us = (int32_t)c->wait_us;
-  st.gn_iterations = S.gn_iterations;
-  st.accepted_steps = S.accepted_steps;
-  const bool weight_violation = S.bad_weights > st.weight_range_violations;
-  st.weight_range_violations = S.bad_weights;
-  st.mu = c->mu;
-  st.solver_cost = S.x_cost;
-  memcpy(st.se3, S.x, sizeof(double) * 6);
-  for (int k = 0; k < kKinds; ++k) {
-    c->cur_cost[k] = S.kind_cost[k];
-    st.kind_cost[k] = S.kind_cost[k];
-    st.n_corr[k] = S.n_corr[k];
-  }
-  {
-    int nn[kKinds];
-    for (int k = 0; k < kKinds; ++k) nn[k] = S.n_corr[k];
-    c->k3_alg_bytes = alg_bytes_of(nn);
-  }
-  int fin = 0;
-  if (fabs(c->cur_cost[TLOAM_KIND_PLANAR] - c->prev_cost[TLOAM_KIND_PLANAR]) < c->cfg.cost_threshold) {  // :1108
-    st.converged_early = 1;
-    fin = 1;
-  } else {
-    for (int k = 0; k < kKinds; ++k) c->prev_cost[k] = c->cur_cost[k];  // :1113-1116 (slots re-zeroed by the next compaction)
-    c->iter = iter + 1;
-    if (c->iter >= c->cfg.max_iterations) fin = 1;
-  }
-  if (fin) c->iter = c->cfg.max_iterations;
-  if (done) *done = fin;
-  if (stats) *stats = st;
+  bool weight_violation = false;
+  const bool fin = account_outer(c, iter, S, mu, sweeps_before, &weight_violation);
+  if (done) *done = fin ? 1 : 0;
+  if (stats) *stats = c->stats;
   return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;  // the iteration is complete either way (:871)
 }
+
+// ---- scanMatching with the outer GNC loop driven from the device ------------------------------------------------
+// Every outer iteration of the frame is enqueued up front -- builders + scan + compaction gated on "the pose moved",
+// the refresh gated on "it did not", the planned sweeps, the finish kernel, which makes the loop decisions of
+// registration.cpp:1108-1121 itself (plateau break, max_iterations, the next iteration's gates) and mirrors the
+// iteration's result into its own pinned slot -- and the host waits ONCE, for the last slot.  (The stepwise API keeps
+// the host in the loop: one round trip of ~12 us plus ~4 us of launch catch-up per following kernel and per outer
+// iteration on an otherwise idle GPU.)  Returns 1 when the frame has to be finished by the stepwise path (a Solve
+// ran out of its planned budget): the context is then positioned at that outer iteration.
+namespace {
+int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
+  const int M = c->cfg.max_iterations;
+  BuildParams bp;
+  GridView grids[kKinds];
+  outer_params(c, &bp, grids);
+  int rc = outer_reserve(c, grids);
+  if (rc != TLOAM_OK) return rc;
+  GnState* st = c->state.p;
+  const int* run_build = &st->run_build;
+  const int* run_refresh = &st->run_refresh;
+  int planned[kMaxOuterFast], solve_start[kMaxOuterFast], used[kMaxOuterFast];
+  double mus[kMaxOuterFast];
+  HostMirror hms[kMaxOuterFast];
+  double mu = initial_mu(c);
+  for (int iter = 0; iter < M; ++iter) {
+    if (iter == 0) {
+      rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
+    } else {
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build);
+      launch_refresh(c->sv, c->cv, c->stream, run_refresh);
+    }
+    if (rc != TLOAM_OK) return rc;
+    planned[iter] = planned_sweeps_for(c, iter);
+    solve_start[iter] = c->batch_launches;
+    rc = enqueue_solve(c, /*armed=*/true, planned[iter]);
+    if (rc != TLOAM_OK) return rc;
+    mus[iter] = mu;
+    hms[iter] = next_mirror(c, iter);
+    const OuterCtl ctl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0};
+    rc = enqueue_finish(c, weight_params(c, mu, bp), hms[iter], ctl);
+    if (rc != TLOAM_OK) return rc;
+    mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
+  }
+  rc = wait_state(c, hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did
+  if (rc != TLOAM_OK) return rc;
+  // ---- the frame's bookkeeping, iteration by iteration, from the mirrored slots
+  int resume = 0;
+  for (int iter = 0; iter < M; ++iter) {
+    const GnState* S = &c->h_state[iter];
+    used[iter] = 0;
+    if (S->host_seq != hms[iter].seq) {
+      c->last_error = "device-driven loop: the result slot of an outer iteration was not written";
+      return TLOAM_E_HIP;
+    }
+    if (S->incomplete == OS_SKIPPED) break;   // the loop had ended before this iteration
+    if (S->incomplete == OS_INCOMPLETE) {
+      // The Solve of this iteration ran out of its planned budget: the device stopped the loop there (the sweeps of
+      // the later iterations, gated only on `done`, have meanwhile continued this same Solve; their builds, refreshes
+      // and finish kernels were gated off).  Top the Solve up to its full budget and finish the iteration with the
+      // host deciding; the rest of the frame then goes through the stepwise path.
+      HIPC(c, hipMemsetAsync(&st->stop, 0, sizeof(int), c->stream));
+      rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps);
+      if (rc != TLOAM_OK) return rc;
+      const HostMirror hm = next_mirror(c, 0);
+      rc = enqueue_finish(c, weight_params(c, mus[iter], bp), hm, OuterCtl{c->cfg.cost_threshold, 0, 0});
+      if (rc != TLOAM_OK) return rc;
+      rc = wait_state(c, hm, 0);
+      if (rc != TLOAM_OK) return rc;
+      S = &c->h_state[0];
+      if (S->incomplete) {
+        c->last_error = "the minimiser did not terminate within its evaluation budget";
+        return TLOAM_E_INVALID;
+      }
+      resume = 1;
+    }
+    const int sweeps_before = c->stats.gn_sweeps;
+    // the compact set of this iteration was (re)built iff the pose had moved since the last build
+    if (iter == 0 || memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) != 0) memcpy(c->build_x, c->stats.se3, sizeof(c->build_x));
+    c->have_build = true;
+    c->mu = mus[iter];
+    bool wv = false;
+    const bool fin = account_outer(c, iter, *S, mus[iter], sweeps_before, &wv);
+    used[iter] = std::min(S->gn_sweeps - sweeps_before, planned[iter]);
+    if (wv) *weight_violation = true;
+    if (fin) { resume = 0; break; }
+    if (resume) break;
+  }
+  rc = harvest_k3_events_multi(c, M, solve_start, used);
+  if (rc != TLOAM_OK) return rc;
+  return resume;  // 1: the caller continues stepwise from c->iter
+}
+}  // namespace
 
 int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
   if (!c || !c->active || !result) return TLOAM_E_NOT_READY;
@@ -856,6 +1036,14 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   if (rc != TLOAM_OK) return rc;
   int done = 0;
   bool weight_violation = false;
+  // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
+  // iterations fit the result slots, no development knob that needs the host between iterations
+  if (c->nranks == 1 && c->h_state_dev && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
+      !c->dbg_no_build_reuse && !c->no_device_loop) {
+    rc = scan_match_device_loop(c, &weight_violation);
+    if (rc < 0) return rc;
+    done = rc == 0 ? 1 : 0;
+  }
   while (!done) {
     rc = tloam_sm_outer(c, &done, nullptr);
     if (rc == TLOAM_E_WEIGHT_RANGE) { weight_violation = true; continue; }  // reported after the solve

@@ -127,6 +127,7 @@ int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double
   (void)ng;
   c->kd[TLOAM_KIND_GROUND].n_tgt = ne;  // (single-cloud job: counts[0])
   c->kd[TLOAM_KIND_GROUND].tgt_set = true;
+  c->tgt_box_valid[TLOAM_KIND_GROUND] = false;
   S.inited = true;
   return TLOAM_OK;
 }
@@ -154,6 +155,7 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
                               const double* ground, size_t n_ground) {
   SubmapState& S = c->submap;
   (void)sphere;
+  for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = false;  // the targets are about to be rebuilt on the device
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
   auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep, bool upload) -> int {
     RingFrame* f = nullptr;

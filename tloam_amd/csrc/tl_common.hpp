@@ -109,6 +109,13 @@ struct GnState {
   int phase, iteration, invalid, step_successful, done;
   int no_eval_reuse;  // development knob (TLOAM_NO_EVAL_REUSE): every evaluation runs its own sweep
   int comm_error;     // a mailbox exchange timed out (sharded contexts): published to the host as incomplete = 3
+  // ---- outer GNC loop driven from the device (tloam_scan_match enqueues ALL outer iterations at once and waits once)
+  double x_build[6];  // `parameters` the compact set was built at (written by the compaction)
+  double prev_planar; // planar side-channel cost sum of the previous outer iteration (registration.cpp:1108), +inf at start
+  int stop;           // 0 running | 1 the loop has ended (plateau break :1108 or max_iterations) | 2 Solve out of budget
+  int run_build;      // gates of the NEXT outer iteration's launches: builders + scan + compaction run iff the pose moved,
+  int run_refresh;    // the refresh iff it did not (see k_refresh); both 0 once the loop has ended
+  int pad_loop;
   double dbg[8];      // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
@@ -120,6 +127,14 @@ static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible pre
 struct HostMirror {
   GnState* out;
   unsigned long long seq;
+};
+// status of an outer iteration as the host reads it in GnState.incomplete
+enum OuterStatus : int { OS_OK = 0, OS_INCOMPLETE = 1, OS_COMM_ERROR = 3, OS_PLATEAU = 4, OS_SKIPPED = 8 };
+// device-driven loop control handed to the finish kernels (fast == 0: the host decides, as in the stepwise API)
+struct OuterCtl {
+  double cost_threshold;  // registration.cpp:1108
+  int fast;               // 1: evaluate the plateau test / pose comparison on the device and set the gates
+  int last;               // this is outer iteration max_iterations - 1
 };
 
 // ---- one-shot peer exchange of a sharded context ("mailbox") -------------
@@ -146,8 +161,9 @@ void launch_aos_to_soa(const double* aos, size_t n, double* x, double* y, double
 
 // exclusive scan of u64 values; tmp must hold scan_tmp_elems(n) u64
 size_t scan_tmp_elems(size_t n);
+// gate != nullptr: a device flag; the launches do nothing where it reads 0
 void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n,
-                               unsigned long long* tmp, hipStream_t s);
+                               unsigned long long* tmp, hipStream_t s, const int* gate = nullptr);
 
 // grid build for all four kinds at once (one launch per phase, blockIdx.y = kind): bbox (finished on the
 // host), histogram over the CONCATENATED cell tables, one exclusive scan, finalize, scatter
@@ -191,14 +207,14 @@ void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, 
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s);
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr);
 int build_tile_count(const GridView grids[kKinds]);  // size of the concatenated tile index space
 // cap + compaction (after the flag scan)
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
-                    const double* rank_counts, int rank, int nranks, hipStream_t s);
+                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate = nullptr);
 void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s);
 // same correspondences, new outer iteration: re-capture the weights, zero the side-channel slots
-void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s);
+void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s, const int* gate = nullptr);
 // generic hybrid search (tloam_knn / fitness)
 void launch_knn(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
                 double radius, int k, int* out_idx, double* out_d2, int* out_cnt, hipStream_t s);
@@ -295,12 +311,12 @@ struct WeightParams {
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
                     int blocks, const GnState* st, hipStream_t s);
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
-                         double* sums8, HostMirror hm, hipStream_t s);
+                         double* sums8, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_outer_publish(const double* sums8, GnState* st, HostMirror hm, const unsigned long long* comm_err_or_null,
                           hipStream_t s);
 // weights + finish in one launch for small single-rank sets
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
-                                 double* sums16, GnState* st, HostMirror hm, hipStream_t s);
+                                 double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
 
 }  // namespace tl

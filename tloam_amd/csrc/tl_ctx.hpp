@@ -153,8 +153,13 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
+  bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
   double* h_bbox_dev = nullptr;
+  // bounds of the registered target clouds, taken at hand-over (set_target*: the call synchronises anyway), so that
+  // scanMatching can size its search grids without a host round trip of its own
+  double tgt_box[tl::kKinds][6];
+  bool tgt_box_valid[tl::kKinds] = {false, false, false, false};
   double wait_us = 0.0;            // time the host spent waiting for the device in the current scan_match
   bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
   tl::GnState* h_state_dev = nullptr;   // device address of the pinned host state (HostMirror target)
@@ -208,6 +213,8 @@ struct tloam_ctx {
 namespace tlh {
 // tl_api.hip
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
-                     tl::GridView out[tl::kKinds]);
+                     tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr);
 int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], tl::GridView out[tl::kKinds]);
+int enqueue_target_bounds(tloam_ctx* c);
+void finish_target_bounds(tloam_ctx* c);
 }  // namespace tlh

@@ -553,8 +553,8 @@ void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid
 // ================================================================================================
 //  fixed-order reduction of the per-block rows (one block of 256 threads: 8 row groups x 32 columns)
 // ================================================================================================
-constexpr int kRedThreads = 512;
-constexpr int kRedGroups = kRedThreads / 32;  // 16 row groups x 32 columns
+constexpr int kRedThreads = 256;  // one wave per SIMD: the step's wave may use the whole register file (no scratch)
+constexpr int kRedGroups = kRedThreads / 32;  // 8 row groups x 32 columns
 __device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[16][33]*/,
                                             double* out32 /* LDS [32] */) {
   const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -590,125 +590,10 @@ void launch_reduce(const double* partials, int grid, GnState* st, double* out48,
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st, out48);
 }
 
-// ================================================================================================
-//  K5: Ceres TrustRegionMinimizer + DoglegStrategy on the 6x6 system -- ONE WAVE AS A 6x6 MATRIX.
-//  Lane l < 36 owns matrix element (l/6, l%6); lane k < 6 owns element k of every 6-vector; scalars
-//  are wave-uniform.  Hs = S H S, the Cholesky factorisation, the two triangular solves, quadratic
-//  forms and norms are a handful of cross-lane shuffles each, so the whole trust-region step is a
-//  few hundred wave instructions with no scratch and no serial 36-element loops.  The two SE(3)
-//  "Plus" evaluations a step needs (candidate point on lane 0, Ceres' projected-gradient point on
-//  lane 1) run in lockstep and cost one.
-// ================================================================================================
-// Wave-wide sum / max in the VALU data-parallel-primitive network (row_shr 1,2,4,8, row_bcast 15, 31):
-// ~20 instructions and no LDS round trips, against six dependent ds_bpermute hops for a shuffle
-// butterfly (the step kernel does ~10 of these on its critical path).  Result broadcast from lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double v) {  // lanes without a source read 0
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double rdlane(double v, int lane_const) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
   return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wsum(double v) {
-  v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row holds the row sum
-  v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-  return rdlane(v, 63);
-}
-__device__ __forceinline__ double wmax(double v) {  // for non-negative values (0 is the identity)
-  v = fmax(v, dpp_fetch<0x111, 0xf>(v));
-  v = fmax(v, dpp_fetch<0x112, 0xf>(v));
-  v = fmax(v, dpp_fetch<0x114, 0xf>(v));
-  v = fmax(v, dpp_fetch<0x118, 0xf>(v));
-  v = fmax(v, dpp_fetch<0x142, 0xa>(v));
-  v = fmax(v, dpp_fetch<0x143, 0xc>(v));
-  return rdlane(v, 63);
-}
-__device__ __forceinline__ double lget(double v, int src) { return __shfl(v, src, 64); }
-
-// SE(3) exp / log / product for the step kernel: the same maps as tl_se3.hpp (sophus se3.hpp:761-785,
-// :223-256, :304-309) with the trigonometry folded -- one sincos of the half angle for exp
-// (cos t = 1 - 2 sin^2(t/2), sin t = 2 sin(t/2) cos(t/2)), none for log (for a unit quaternion
-// cot(theta/2) = w/|v|) -- equal to the literal forms to rounding (~1e-16), a third of the instructions.
-__device__ __forceinline__ Pose exp_fast(const double a[6]) {
-  const double ox = a[3], oy = a[4], oz = a[5];
-  const double theta_sq = ox * ox + oy * oy + oz * oz;
-  Pose T;
-  const Vec3 om{ox, oy, oz}, u{a[0], a[1], a[2]};
-  if (theta_sq < kSophusEps * kSophusEps) {
-    const double theta_po4 = theta_sq * theta_sq;
-    const double imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
-    T.qw = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
-    T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
-    const Vec3 t = rotate(T, u);
-    T.tx = t.x; T.ty = t.y; T.tz = t.z;
-    return T;
-  }
-  const double theta = sqrt(theta_sq);
-  double sh, ch;
-  sincos(0.5 * theta, &sh, &ch);
-  const double inv_theta = 1.0 / theta;
-  const double imag = sh * inv_theta;
-  T.qw = ch; T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
-  Vec3 t;
-  if (theta < kSophusEps) {
-    t = rotate(T, u);
-  } else {
-    const double c1 = 2.0 * imag * imag;                                       // (1 - cos t) / t^2
-    const double c2 = (theta - 2.0 * sh * ch) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
-    const Vec3 w1 = cross(om, u);
-    const Vec3 w2 = cross(om, w1);
-    t = u + c1 * w1 + c2 * w2;
-  }
-  T.tx = t.x; T.ty = t.y; T.tz = t.z;
-  return T;
-}
-__device__ __forceinline__ Pose compose_fast(const Pose& A, const Pose& B) {
-  Pose C;
-  C.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
-  C.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
-  C.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
-  C.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
-  const double il = 1.0 / sqrt(C.qw * C.qw + C.qx * C.qx + C.qy * C.qy + C.qz * C.qz);
-  C.qw *= il; C.qx *= il; C.qy *= il; C.qz *= il;
-  const Vec3 rt = rotate(A, Vec3{B.tx, B.ty, B.tz});
-  C.tx = A.tx + rt.x; C.ty = A.ty + rt.y; C.tz = A.tz + rt.z;
-  return C;
-}
-__device__ __forceinline__ void log_fast(const Pose& T, double a[6]) {
-  const double squared_n = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
-  const double w = T.qw;
-  double f, theta, c2;
-  if (squared_n < kSophusEps * kSophusEps) {
-    f = 2.0 / w - (2.0 / 3.0) * squared_n / (w * w * w);
-    theta = 2.0 * squared_n / w;
-    c2 = 1.0 / 12.0;
-  } else {
-    const double n = sqrt(squared_n);
-    if (fabs(w) < kSophusEps) {
-      f = (w > 0.0) ? kPi / n : -kPi / n;
-      theta = f * n;
-      c2 = 1.0 / (theta * theta);  // cos(theta/2) -> 0
-    } else {
-      f = 2.0 * atan(n / w) / n;
-      theta = f * n;
-      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : (1.0 - 0.5 * theta * w / n) / (theta * theta);
-    }
-  }
-  const Vec3 om{f * T.qx, f * T.qy, f * T.qz};
-  const Vec3 t{T.tx, T.ty, T.tz};
-  const Vec3 w1 = cross(om, t);
-  const Vec3 w2 = cross(om, w1);
-  const Vec3 ups = t + (-0.5) * w1 + c2 * w2;
-  a[0] = ups.x; a[1] = ups.y; a[2] = ups.z;
-  a[3] = om.x;  a[4] = om.y;  a[5] = om.z;
 }
 
 struct Vec2 { double x, y; };
@@ -716,7 +601,7 @@ struct Vec2 { double x, y; };
 // Ceres roots a quartic -- the global minimiser is unique, here bracketed by sampling the angle
 // and polished by bisection on the tangential derivative).  Rare branch: only when the
 // Gauss-Newton step leaves the trust region.
-__device__ __noinline__ Vec2 min_on_circle(double B0, double B1, double B2, double B3, double g0, double g1, double r) {
+__device__ __forceinline__ Vec2 min_on_circle(double B0, double B1, double B2, double B3, double g0, double g1, double r) {
   const int NS = 720;
   double best = 1e300, bth = 0.0;
   const double b01 = 0.5 * (B1 + B2);
@@ -740,134 +625,230 @@ __device__ __noinline__ Vec2 min_on_circle(double B0, double B1, double B2, doub
   return Vec2{r * cos(th), r * sin(th)};
 }
 
-// lane-distributed helpers.  M: element (mi,mj) on lane mi*6+mj (lanes >= 36 hold 0);
-// v: element k on lane k (lanes >= 6 hold 0).
-struct LaneIx {
-  int lane, mi, mj;   // mi/mj clamped to 0 for lanes >= 36 (their values are masked anyway)
-  bool ism, isv;
-};
-__device__ __forceinline__ double quad_form(const LaneIx& L, double a, double M, double b) {  // a^T M b
-  const double ai = lget(a, L.mi), bj = lget(b, L.mj);  // all lanes active for the shuffles
-  return wsum(L.ism ? ai * M * bj : 0.0);
-}
-__device__ __forceinline__ double vdot(double a, double b) { return wsum(a * b); }  // lanes >= 6 hold 0
-
-// Solve (A) y = b with A symmetric positive definite, lane-distributed right-looking Cholesky.
-// Returns false where a pivot is not positive / the result not finite (Ceres: LINEAR_SOLVER_FAILURE).
-__device__ __forceinline__ bool chol_solve_wave(const LaneIx& L, double a, double b, double* y_out) {
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double pivot = rdlane(a, k * 7);
-    if (!(pivot > 0.0) || !isfinite(pivot)) ok = false;
-    const double lkk = sqrt(pivot);
-    if (L.ism && L.mj == k && L.mi >= k) a = (L.mi == k) ? lkk : a / lkk;
-    const double lik = lget(a, L.mi * 6 + k);
-    const double ljk = lget(a, L.mj * 6 + k);
-    if (L.ism && L.mi > k && L.mj > k) a -= lik * ljk;
-  }
-  // forward: L z = b
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double zk = rdlane(b, k) / rdlane(a, k * 7);
-    const double lik = lget(a, (L.isv ? L.lane : 0) * 6 + k);
-    if (L.lane == k) b = zk;
-    if (L.isv && L.lane > k) b -= lik * zk;
-  }
-  // backward: L^T y = z
-#pragma unroll
-  for (int k = 5; k >= 0; --k) {
-    const double yk = rdlane(b, k) / rdlane(a, k * 7);
-    const double lki = lget(a, k * 6 + (L.isv ? L.lane : 0));
-    if (L.lane == k) b = yk;
-    if (L.isv && L.lane < k) b -= lki * yk;
-  }
-  if (__any((L.isv && !isfinite(b)) ? 1 : 0)) ok = false;
-  *y_out = L.isv ? b : 0.0;
-  return ok;
-}
-
-// Consume one reduced sweep (tot: H upper triangle 0..20, g 21..26, cost 27 -- in LDS) and run the
-// minimiser until the next sweep is needed or it is done.  Mirrors trust_region_minimizer.cc
-// Minimize(): IterationZero, then per iteration ComputeTrustRegionStep -> candidate -> tolerances
-// -> IsStepSuccessful -> Handle(Un)SuccessfulStep, with DoglegStrategy (SUBSPACE_DOGLEG) inlined.
-// The candidate sweep is fused (cost + Jacobian in one pass): Ceres evaluates the candidate
-// cost-only and re-evaluates an accepted point with Jacobians -- same numbers, half the traffic.
-// The gradient-tolerance test of a freshly accepted point is evaluated together with the next
-// candidate and, if it fires, the speculative iteration is rolled back.
 #ifdef TLOAM_STEP_PROFILE
 #define TL_STAMP(i) if (lane == 0) st->dbg[i] = (double)__builtin_readcyclecounter();
 #else
 #define TL_STAMP(i)
 #endif
-__device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, int lane,
-                                                const GnState* in /* state as of the start of the launch: st or a copy */) {
+
+// ================================================================================================
+//  K5: Ceres TrustRegionMinimizer + DoglegStrategy on the 6x6 system, ONE WAVE, WAVE-UNIFORM: every lane carries the
+//  system in registers and executes the same instruction stream, so the Cholesky factorisation, the solves and the
+//  quadratic forms are plain register arithmetic with no cross-lane exchange on the critical path (round 1's
+//  lane-as-matrix-element form spent ~18 dependent LDS-crossbar round trips on them: 5.1-5.6 k cycles for the dogleg
+//  part against 1.7-2.2 k here), and the IEEE divisions / square roots of the chain (39 and 18 of them, 12-35
+//  dependent instructions each) are v_rcp_f64 / v_rsq_f64 + one Newton step (<= 1-2 ulp).  The two SE(3) "Plus"
+//  evaluations a step needs run in lockstep: even lanes the candidate, odd lanes Ceres' projected-gradient point.
+//  What is left is issue-bound: ~4 k wave instructions at >= 4 cycles each (a 64-wide fp64 instruction occupies the
+//  16-lane pipe for four cycles whether or not the lanes differ).
+//
+//  Consume one reduced sweep (tot: H upper triangle 0..20, g 21..26, cost 27 -- in LDS) and run the minimiser until
+//  the next sweep is needed or it is done.  Mirrors trust_region_minimizer.cc Minimize(): IterationZero, then per
+//  iteration ComputeTrustRegionStep -> candidate -> tolerances -> IsStepSuccessful -> Handle(Un)SuccessfulStep, with
+//  DoglegStrategy (SUBSPACE_DOGLEG) inlined.  The candidate sweep is fused (cost + Jacobian in one pass): Ceres
+//  evaluates the candidate cost-only and re-evaluates an accepted point with Jacobians -- same numbers, half the
+//  traffic.  The gradient-tolerance test of a freshly accepted point is evaluated together with the next candidate
+//  and, if it fires, the speculative iteration is rolled back.
+//  Evaluation reuse: when the minimiser asks for the evaluation of a point that is bit-identical to the one whose
+//  totals are in `tot` -- a rejected step retried inside the halved trust region re-creates exactly the same candidate
+//  (four times per Solve from the second outer iteration on) -- the answer is already here: count the
+//  evaluation and go round again instead of waiting for another sweep.  Residuals, Jacobians and side-channel costs
+//  are pure functions of the point, so nothing observable changes.
+// ================================================================================================
+__device__ __forceinline__ double fsqrt(double x) {  // x >= 0
+  const double r = fast_rsqrt(x);
+  return x > 0.0 ? x * r : x;
+}
+__device__ __forceinline__ double dot6(const double a[6], const double b[6]) {
+  return ((a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3])) + (a[4] * b[4] + a[5] * b[5]);
+}
+// a^T M b with M symmetric, stored as its upper triangle (ut)
+__device__ __forceinline__ double quad6(const double a[6], const double M[21], const double b[6]) {
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double row = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) row = __builtin_fma(M[i <= j ? ut(i, j) : ut(j, i)], b[j], row);
+    acc = __builtin_fma(a[i], row, acc);
+  }
+  return acc;
+}
+// (A) y = b, A symmetric positive definite (upper triangle in Au, destroyed).  false: a pivot is not positive /
+// finite or the result is not finite (Ceres: LINEAR_SOLVER_FAILURE).
+__device__ __forceinline__ bool chol6_uniform(double Au[21], const double b[6], double y[6]) {
+  bool ok = true;
+  double inv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double pivot = Au[ut(k, k)];
+    if (!(pivot > 0.0) || !isfinite(pivot)) ok = false;
+    inv[k] = fast_rsqrt(pivot);                      // 1 / l_kk
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) Au[ut(k, j)] *= inv[k];   // row k of L^T
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) Au[ut(i, j)] = __builtin_fma(-Au[ut(k, i)], Au[ut(k, j)], Au[ut(i, j)]);
+  }
+  double z[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) z[k] = b[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {   // L z = b
+    z[k] *= inv[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) z[i] = __builtin_fma(-Au[ut(k, i)], z[k], z[i]);
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {  // L^T y = z
+    double t = z[k];
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) t = __builtin_fma(-Au[ut(k, j)], y[j], t);
+    y[k] = t * inv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (!isfinite(y[k])) ok = false;
+  return ok;
+}
+
+// exp / product / log with the reciprocals and square roots of the chain on v_rcp / v_rsq (+ Newton)
+__device__ __forceinline__ Pose exp_fast2(const double a[6]) {
+  const double ox = a[3], oy = a[4], oz = a[5];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  Pose T;
+  const Vec3 om{ox, oy, oz}, u{a[0], a[1], a[2]};
+  if (theta_sq < kSophusEps * kSophusEps) {
+    const double theta_po4 = theta_sq * theta_sq;
+    const double imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+    T.qw = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
+    const Vec3 t = rotate(T, u);
+    T.tx = t.x; T.ty = t.y; T.tz = t.z;
+    return T;
+  }
+  const double inv_theta = fast_rsqrt(theta_sq);
+  const double theta = theta_sq * inv_theta;
+  double sh, ch;
+  sincos(0.5 * theta, &sh, &ch);
+  const double imag = sh * inv_theta;
+  T.qw = ch; T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
+  Vec3 t;
+  if (theta < kSophusEps) {
+    t = rotate(T, u);
+  } else {
+    const double c1 = 2.0 * imag * imag;                                            // (1 - cos t) / t^2
+    const double c2 = (theta - 2.0 * sh * ch) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
+    const Vec3 w1 = cross(om, u);
+    const Vec3 w2 = cross(om, w1);
+    t = u + c1 * w1 + c2 * w2;
+  }
+  T.tx = t.x; T.ty = t.y; T.tz = t.z;
+  return T;
+}
+__device__ __forceinline__ Pose compose_fast2(const Pose& A, const Pose& B) {
+  Pose C;
+  C.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
+  C.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
+  C.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
+  C.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
+  const double il = fast_rsqrt(C.qw * C.qw + C.qx * C.qx + C.qy * C.qy + C.qz * C.qz);
+  C.qw *= il; C.qx *= il; C.qy *= il; C.qz *= il;
+  const Vec3 rt = rotate(A, Vec3{B.tx, B.ty, B.tz});
+  C.tx = A.tx + rt.x; C.ty = A.ty + rt.y; C.tz = A.tz + rt.z;
+  return C;
+}
+__device__ __forceinline__ void log_fast2(const Pose& T, double a[6]) {
+  const double squared_n = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
+  const double w = T.qw;
+  double f, theta, c2;
+  if (squared_n < kSophusEps * kSophusEps) {
+    const double iw = fast_rcp(w);
+    f = 2.0 * iw - (2.0 / 3.0) * squared_n * (iw * iw * iw);
+    theta = 2.0 * squared_n * iw;
+    c2 = 1.0 / 12.0;
+  } else {
+    const double in_ = fast_rsqrt(squared_n);   // 1 / n
+    const double n = squared_n * in_;
+    if (fabs(w) < kSophusEps) {
+      f = (w > 0.0) ? kPi * in_ : -kPi * in_;
+      theta = f * n;
+      c2 = fast_rcp(theta * theta);  // cos(theta/2) -> 0
+    } else {
+      f = 2.0 * atan(n * fast_rcp(w)) * in_;
+      theta = f * n;
+      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : (1.0 - 0.5 * theta * w * in_) * fast_rcp(theta * theta);
+    }
+  }
+  const Vec3 om{f * T.qx, f * T.qy, f * T.qz};
+  const Vec3 t{T.tx, T.ty, T.tz};
+  const Vec3 w1 = cross(om, t);
+  const Vec3 w2 = cross(om, w1);
+  const Vec3 ups = t + (-0.5) * w1 + c2 * w2;
+  a[0] = ups.x; a[1] = ups.y; a[2] = ups.z;
+  a[3] = om.x;  a[4] = om.y;  a[5] = om.z;
+}
+
+// `sm`: the state as of the start of the launch, in LDS (one coalesced copy, see k_reduce_and_step); the cold part
+// of the state (H, g of the accepted point, the subspace basis) stays THERE and is read when needed -- the wave's
+// registers hold only what the chain works on.
+__device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* tot /* LDS */, int lane, GnState* sm /* LDS */) {
   TL_STAMP(1)
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
   const int max_num_iterations = 4, max_consecutive_invalid = 5;
-  LaneIx L;
-  L.lane = lane;
-  L.ism = lane < 36;
-  L.isv = lane < 6;
-  L.mi = L.ism ? lane / 6 : 0;
-  L.mj = L.ism ? lane - L.mi * 6 : 0;
-  // ---- wave-uniform state
-  int phase = in->phase, iteration = in->iteration, invalid = in->invalid, step_successful = in->step_successful;
-  int reuse = in->reuse, subspace_1d = in->subspace_1d, done = 0;
-  int evals = in->gn_evaluations + 1, iters = in->gn_iterations, accepted = in->accepted_steps;
-  double x_cost = in->x_cost, x_norm = in->x_norm, gmax = in->gmax, mcc = in->model_cost_change;
-  double radius = in->radius, mu = in->mu, alpha = in->alpha, step_norm = in->step_norm;
-  double sg0 = in->sg[0], sg1 = in->sg[1], sB0 = in->sB[0], sB1 = in->sB[1], sB3 = in->sB[3];
-  Pose T_cur = in->T_cur, T_eval = in->T_eval;
-  // ---- lane-distributed state
-  const int vk = L.isv ? lane : 0;
-  double x = L.isv ? in->x[vk] : 0.0, xc = L.isv ? in->x_cand[vk] : 0.0;
-  double S = L.isv ? in->S[vk] : 0.0, D = L.isv ? in->D[vk] : 1.0;
-  double grad = L.isv ? in->grad[vk] : 0.0, gnv = L.isv ? in->gn[vk] : 0.0;
-  double U0 = L.isv ? in->U[vk] : 0.0, U1 = L.isv ? in->U[6 + vk] : 0.0;
-  double Hc = L.ism ? in->H[lane] : 0.0, gc = L.isv ? in->g[vk] : 0.0;
+  // ---- state (all wave-uniform)
+  int phase = sm->phase, iteration = sm->iteration, invalid = sm->invalid, step_successful = sm->step_successful;
+  int reuse = sm->reuse, subspace_1d = sm->subspace_1d, done = 0;
+  int evals = sm->gn_evaluations + 1, iters = sm->gn_iterations, accepted = sm->accepted_steps;
+  double x_cost = sm->x_cost, x_norm = sm->x_norm, gmax = sm->gmax, mcc = sm->model_cost_change;
+  double radius = sm->radius, mu = sm->mu, step_norm = sm->step_norm;
+  Pose T_cur = sm->T_cur, T_eval = sm->T_eval;
+  double x[6], xc[6], S[6], D[6], grad[6], gnv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    x[i] = sm->x[i]; xc[i] = sm->x_cand[i]; S[i] = sm->S[i]; D[i] = sm->D[i]; grad[i] = sm->grad[i]; gnv[i] = sm->gn[i];
+  }
   // ---- the new sweep
   const double cost = tot[27];
-  const int ui = L.mi < L.mj ? L.mi : L.mj, uj = L.mi < L.mj ? L.mj : L.mi;
-  const double Hn = L.ism ? tot[ui * 6 - (ui * (ui - 1)) / 2 + (uj - ui)] : 0.0;
-  const double gn_new = L.isv ? tot[21 + vk] : 0.0;
-  const int sweeps = in->gn_sweeps + 1;
-  const bool eval_reuse = in->no_eval_reuse == 0;
-  // Evaluation reuse: when the minimiser asks for the evaluation of a point that is bit-identical to the one
-  // whose totals are in `tot` -- a rejected step retried inside the halved trust region re-creates exactly the
-  // same candidate (four times per Solve from the second outer iteration on) -- the answer is
-  // already here: count the evaluation and go round again instead of waiting for another sweep.  Residuals,
-  // Jacobians and side-channel costs are pure functions of the point, so nothing observable changes.
-  bool gn_inside = false;  // this launch already produced the candidate of the current (reused) Gauss-Newton step
+  const int sweeps = sm->gn_sweeps + 1;
+  const bool eval_reuse = sm->no_eval_reuse == 0;
+  bool dirty_S = false, dirty_dl = false, dirty_x = false;
+  bool gn_inside = false;
   for (;;) {
-  const double xc_held = xc;        // the point `tot` was evaluated at (PH_CAND)
+  double xc_held[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xc_held[i] = xc[i];
   const Pose T_held = T_eval;
   const int phase_in = phase;
   bool need_gmax = false;
+  bool take_sweep = false;   // the totals of this sweep become the system of the accepted point
   if (phase == PH_ITER0) {
     x_cost = cost;
-    Hc = Hn;
-    gc = gn_new;
-    const double hkk = lget(Hn, vk * 7);
-    S = L.isv ? 1.0 / (1.0 + sqrt(hkk)) : 0.0;  // jacobi_scaling, fixed at iteration 0 of the Solve
-    x_norm = sqrt(vdot(x, x));
+    take_sweep = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = fast_rcp(1.0 + fsqrt(tot[ut(i, i)]));  // jacobi_scaling, fixed at iteration 0 of the Solve
+    x_norm = fsqrt(dot6(x, x));
     step_successful = 1;
     need_gmax = true;
+    dirty_S = true;
   } else {
     const double candidate_cost = cost;
-    const double dx = x - xc;
-    if (sqrt(vdot(dx, dx)) <= parameter_tolerance * (x_norm + parameter_tolerance)) done = 1;   // ParameterToleranceReached
+    double dx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dx[i] = x[i] - xc[i];
+    if (fsqrt(dot6(dx, dx)) <= parameter_tolerance * (x_norm + parameter_tolerance)) done = 1;   // ParameterToleranceReached
     else if (fabs(x_cost - candidate_cost) <= function_tolerance * x_cost) done = 1;             // FunctionToleranceReached
     else {
-      const double rel = (x_cost - candidate_cost) / mcc;   // TrustRegionStepEvaluator::StepQuality
+      const double rel = (x_cost - candidate_cost) / mcc;   // TrustRegionStepEvaluator::StepQuality (a decision: exact division)
       if (rel > min_relative_decrease) {                    // HandleSuccessfulStep
-        x = xc;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x[i] = xc[i];
         T_cur = T_eval;
-        x_norm = sqrt(vdot(x, x));
+        x_norm = fsqrt(dot6(x, x));
         x_cost = candidate_cost;
-        Hc = Hn;
-        gc = gn_new;
+        take_sweep = true;
         step_successful = 1;
         accepted++;
         need_gmax = true;
@@ -875,12 +856,22 @@ __device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, 
         if (rel > 0.75) radius = fmax(radius, 3.0 * step_norm);
         mu = fmax(1e-8, 2.0 * mu / 10.0);
         reuse = 0;
+        dirty_x = true;
       } else {                                              // HandleUnsuccessfulStep / StepRejected
         step_successful = 0;
         radius *= 0.5;
         reuse = 1;
       }
     }
+  }
+  if (take_sweep) {
+    // H (full 6x6) and g of the accepted point: LDS copy and device state, one element per lane
+    const int mi = lane < 36 ? lane / 6 : 0, mj = lane < 36 ? lane - mi * 6 : 0;
+    const int lo = mi < mj ? mi : mj, hi = mi < mj ? mj : mi;
+    const double h = tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+    const double gg = tot[21 + (lane < 6 ? lane : 0)];
+    if (lane < 36) { sm->H[lane] = h; st->H[lane] = h; }
+    if (lane < 6) { sm->g[lane] = gg; st->g[lane] = gg; }
   }
   while (!done) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient test deferred while need_gmax)
@@ -900,103 +891,120 @@ __device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, 
     gn_inside = false;
     TL_STAMP(2)
     // ---- Jacobi-scaled system
-    const double s_i = lget(S, L.mi), s_j = lget(S, L.mj);
-    const double Hs = L.ism ? s_i * Hc * s_j : 0.0;
-    const double gs = S * gc;
+    double Hs[21], gs[6], gc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      gc[i] = sm->g[i];
+      gs[i] = S[i] * gc[i];
+#pragma unroll
+      for (int j = i; j < 6; ++j) Hs[ut(i, j)] = S[i] * sm->H[i * 6 + j] * S[j];
+    }
     bool lin_ok = true;
     if (!reuse) {  // DoglegStrategy::ComputeStep, fresh
       reuse = 1;
-      const double hkk = lget(Hs, vk * 7);
-      D = L.isv ? sqrt(fmin(fmax(hkk, 1e-6), 1e32)) : 1.0;  // min_diagonal_ / max_diagonal_
-      grad = gs / D;                                         // ComputeGradient
-      // (ComputeCauchyPoint: alpha is only consumed by TRADITIONAL_DOGLEG; not needed for SUBSPACE_DOGLEG)
+      dirty_dl = true;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        D[i] = fsqrt(fmin(fmax(Hs[ut(i, i)], 1e-6), 1e32));  // min_diagonal_ / max_diagonal_
+        grad[i] = gs[i] * fast_rcp(D[i]);                      // ComputeGradient
+      }
       // ComputeGaussNewtonStep: (Hs + mu D^2) y = gs ; on failure mu *= 10 while mu < max_mu (1.0)
       bool ok = false;
-      double y = 0.0;
+      double y[6] = {0, 0, 0, 0, 0, 0};
       while (mu < 1.0) {
-        const double dd = lget(D, L.mi);
-        const double A = Hs + ((L.ism && L.mi == L.mj) ? mu * dd * dd : 0.0);
-        if (chol_solve_wave(L, A, gs, &y)) { ok = true; break; }
+        double A[21];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) A[i] = Hs[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[ut(i, i)] = __builtin_fma(mu * D[i], D[i], A[ut(i, i)]);
+        if (chol6_uniform(A, gs, y)) { ok = true; break; }
         mu *= 10.0;
       }
       if (!ok) lin_ok = false;
-      else gnv = -D * y;
+      else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gnv[i] = -D[i] * y[i];
+      }
       subspace_1d = -1;  // ComputeSubspaceModel is deferred until a step actually leaves the trust region
     }
     TL_STAMP(3)
-    double step = 0.0;
+    double step[6] = {0, 0, 0, 0, 0, 0};
     bool valid = false;
-    const double gn2 = vdot(gnv, gnv);
-    if (lin_ok && gn2 == 0.0 && vdot(grad, grad) == 0.0) lin_ok = false;  // rank-0 subspace (Ceres: failure)
+    const double gn2 = dot6(gnv, gnv);
+    if (lin_ok && gn2 == 0.0 && dot6(grad, grad) == 0.0) lin_ok = false;  // rank-0 subspace (Ceres: failure)
     if (lin_ok) {  // ComputeSubspaceDoglegStep
-      const double gnn = sqrt(gn2);
+      const double gnn = fsqrt(gn2);
+      double iD[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) iD[i] = fast_rcp(D[i]);
       if (gnn <= radius) {
-        step = gnv / D;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) step[i] = gnv[i] * iD[i];
         step_norm = gnn;
         gn_inside = true;
       } else {
+        // the Gauss-Newton step leaves the trust region (rare): the 2-D subspace model lives in the LDS copy
         if (subspace_1d < 0) {
-          // ComputeSubspaceModel (first time this Gauss-Newton step is outside the region): orthonormal
-          // basis of span{grad, gn}, larger column first; g and B of the 2-D model
-          const double n0 = sqrt(vdot(grad, grad));
+          // ComputeSubspaceModel: orthonormal basis of span{grad, gn}, larger column first; g and B of the 2-D model
+          const double n0 = fsqrt(dot6(grad, grad));
           const bool gfirst = n0 >= gnn;
           const double nf = gfirst ? n0 : gnn, ns = gfirst ? gnn : n0;
-          const double first = gfirst ? grad : gnv, second = gfirst ? gnv : grad;
-          const double u0 = first / nf;
-          const double proj = vdot(u0, second);
-          double u1 = second - proj * u0;
-          const double nr = sqrt(vdot(u1, u1));
+          const double inf_ = fast_rcp(nf);
+          double u0[6], u1[6], second[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { u0[i] = (gfirst ? grad[i] : gnv[i]) * inf_; second[i] = gfirst ? gnv[i] : grad[i]; }
+          const double proj = dot6(u0, second);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) u1[i] = second[i] - proj * u0[i];
+          const double nr = fsqrt(dot6(u1, u1));
           if (ns == 0.0 || nr <= 1e-14 * nf) {
             subspace_1d = 1;
           } else {
             subspace_1d = 0;
-            u1 /= nr;
-            U0 = u0;
-            U1 = u1;
-            sg0 = vdot(u0, grad);
-            sg1 = vdot(u1, grad);
-            const double v0 = u0 / D, v1 = u1 / D;
-            sB0 = quad_form(L, v0, Hs, v0);
-            sB1 = quad_form(L, v0, Hs, v1);
-            sB3 = quad_form(L, v1, Hs, v1);
+            const double inr = fast_rcp(nr);
+            double v0[6], v1[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { u1[i] *= inr; v0[i] = u0[i] * iD[i]; v1[i] = u1[i] * iD[i]; }
+            const double b0 = quad6(v0, Hs, v0), b1 = quad6(v0, Hs, v1), b3 = quad6(v1, Hs, v1);
+            const double g0 = dot6(u0, grad), g1 = dot6(u1, grad);
+            if (lane == 0) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) { sm->U[i] = u0[i]; sm->U[6 + i] = u1[i]; st->U[i] = u0[i]; st->U[6 + i] = u1[i]; }
+              sm->sg[0] = g0; sm->sg[1] = g1; sm->sB[0] = b0; sm->sB[1] = b1; sm->sB[2] = b1; sm->sB[3] = b3;
+              st->sg[0] = g0; st->sg[1] = g1; st->sB[0] = b0; st->sB[1] = b1; st->sB[2] = b1; st->sB[3] = b3;
+            }
           }
         }
         if (subspace_1d) {
-          const double gnorm = sqrt(vdot(grad, grad));
-          step = -(radius / gnorm) * grad / D;
+          const double k = -radius * fast_rsqrt(dot6(grad, grad));
+#pragma unroll
+          for (int i = 0; i < 6; ++i) step[i] = k * grad[i] * iD[i];
         } else {
-          const Vec2 m2 = min_on_circle(sB0, sB1, sB1, sB3, sg0, sg1, radius);
-          step = (U0 * m2.x + U1 * m2.y) / D;
+          const Vec2 m2 = min_on_circle(sm->sB[0], sm->sB[1], sm->sB[1], sm->sB[3], sm->sg[0], sm->sg[1], radius);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) step[i] = (sm->U[i] * m2.x + sm->U[6 + i] * m2.y) * iD[i];
         }
         step_norm = radius;
       }
-      if (!L.isv) step = 0.0;
-      mcc = -vdot(step, gs) - 0.5 * quad_form(L, step, Hs, step);  // model_cost_change_
+      mcc = -dot6(step, gs) - 0.5 * quad6(step, Hs, step);  // model_cost_change_
       valid = mcc > 0.0;
     }
     TL_STAMP(4)
-    // ---- candidate Plus(x, delta) on lane 0 and projected-gradient point Plus(x, -g) on lane 1
-    const double delta = valid ? step * S : 0.0;
+    // ---- candidate Plus(x, delta) on the even lanes and projected-gradient point Plus(x, -g) on the odd lanes
     if (valid || need_gmax) {
-      double in[6];
+      double din[6];
+      const bool odd = (lane & 1) != 0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        // shuffles must run with all lanes active: hoisted out of the per-lane select
-        const double gi = lget(gc, i), di = lget(delta, i);
-        in[i] = (lane == 1) ? -gi : di;
-      }
-      const Pose C = compose_fast(exp_fast(in), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
+      for (int i = 0; i < 6; ++i) din[i] = odd ? -gc[i] : (valid ? step[i] * S[i] : 0.0);
+      const Pose C = compose_fast2(exp_fast2(din), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
       double out[6];
-      log_fast(C, out);
-      double xc_new = 0.0, diff = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double c0 = lget(out[i], 0), c1 = lget(out[i], 1);
-        if (lane == i) { xc_new = c0; diff = fabs(x - c1); }
-      }
+      log_fast2(C, out);
       if (need_gmax) {
         need_gmax = false;
-        gmax = wmax(L.isv ? diff : 0.0);  // || x - Plus(x, -g) ||_inf
+        double m = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m = fmax(m, fabs(x[i] - rdlane(out[i], 1)));
+        gmax = m;  // || x - Plus(x, -g) ||_inf
         if (gmax <= gradient_tolerance) {  // the accepted point was already converged: roll back
           iteration--;
           iters--;
@@ -1005,9 +1013,11 @@ __device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, 
         }
       }
       if (valid) {
-        xc = xc_new;
-        T_eval.qw = lget(C.qw, 0); T_eval.qx = lget(C.qx, 0); T_eval.qy = lget(C.qy, 0); T_eval.qz = lget(C.qz, 0);
-        T_eval.tx = lget(C.tx, 0); T_eval.ty = lget(C.ty, 0); T_eval.tz = lget(C.tz, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xc[i] = rdlane(out[i], 0);
+        T_eval.qw = rdlane(C.qw, 0); T_eval.qx = rdlane(C.qx, 0); T_eval.qy = rdlane(C.qy, 0); T_eval.qz = rdlane(C.qz, 0);
+        T_eval.tx = rdlane(C.tx, 0); T_eval.ty = rdlane(C.ty, 0); T_eval.tz = rdlane(C.tz, 0);
+        dirty_x = true;
       }
     }
     if (!valid) {  // HandleInvalidStep -> DoglegStrategy::StepIsInvalid
@@ -1023,32 +1033,39 @@ __device__ __forceinline__ void gn_consume_wave(GnState* st, const double* tot, 
     break;  // the next K3 sweep evaluates x_cand
   }
   if (done || !eval_reuse || phase_in != PH_CAND || phase != PH_CAND) break;
-  const bool same_pose = T_eval.qw == T_held.qw && T_eval.qx == T_held.qx && T_eval.qy == T_held.qy &&
-                         T_eval.qz == T_held.qz && T_eval.tx == T_held.tx && T_eval.ty == T_held.ty &&
-                         T_eval.tz == T_held.tz;
-  if (!same_pose || !__all((!L.isv || xc == xc_held) ? 1 : 0)) break;
+  bool same = T_eval.qw == T_held.qw && T_eval.qx == T_held.qx && T_eval.qy == T_held.qy && T_eval.qz == T_held.qz &&
+              T_eval.tx == T_held.tx && T_eval.ty == T_held.ty && T_eval.tz == T_held.tz;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) same = same && (xc[i] == xc_held[i]);
+  if (!same) break;
   evals++;  // served from the totals in hand
   }
   TL_STAMP(5)
-  // ---- write back
-  if (L.isv) {
-    st->x[vk] = x; st->x_cand[vk] = xc; st->S[vk] = S; st->D[vk] = D; st->grad[vk] = grad; st->gn[vk] = gnv;
-    st->U[vk] = U0; st->U[6 + vk] = U1; st->g[vk] = gc;
-  }
-  if (L.ism) st->H[lane] = Hc;
+  // ---- write back (lane 0; only what this launch changed)
   if (lane == 0) {
+    if (dirty_x) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { st->x[i] = x[i]; st->x_cand[i] = xc[i]; }
+      st->T_cur = T_cur; st->T_eval = T_eval;
+      st->Rt_eval = to_rt(T_eval);
+    }
+    if (dirty_S) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) st->S[i] = S[i];
+    }
+    if (dirty_dl) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { st->D[i] = D[i]; st->grad[i] = grad[i]; st->gn[i] = gnv[i]; }
+    }
     st->phase = phase; st->iteration = iteration; st->invalid = invalid; st->step_successful = step_successful;
     st->reuse = reuse; st->subspace_1d = subspace_1d; st->done = done;
     st->gn_evaluations = evals; st->gn_iterations = iters; st->accepted_steps = accepted;
     st->gn_sweeps = sweeps;
     st->x_cost = x_cost; st->x_norm = x_norm; st->gmax = gmax; st->model_cost_change = mcc;
-    st->radius = radius; st->mu = mu; st->alpha = alpha; st->step_norm = step_norm;
-    st->sg[0] = sg0; st->sg[1] = sg1; st->sB[0] = sB0; st->sB[1] = sB1; st->sB[2] = sB1; st->sB[3] = sB3;
-    st->T_cur = T_cur; st->T_eval = T_eval;
-    st->Rt_eval = to_rt(T_eval);
+    st->radius = radius; st->mu = mu; st->step_norm = step_norm;
   }
 }
-
+#define TL_GN_CONSUME gn_consume_uniform
 // start-of-Solve values of the minimiser (Ceres defaults: initial_trust_region_radius 1e4, min_mu 1e-8);
 // the sweep point is the current pose
 __device__ __forceinline__ void arm_solver(GnState& s) {
@@ -1100,6 +1117,8 @@ __global__ __launch_bounds__(256) void k_frame_init(FrameInit fi, double* __rest
       for (int i = 0; i < 6; ++i) st->x[i] = fi.x[i];
       st->T_cur = se3_exp(st->x);
       st->no_eval_reuse = fi.no_eval_reuse;
+      st->prev_planar = __builtin_inf();   // registration.cpp:952-959
+      st->run_build = 1;                   // the first outer iteration always builds
       arm_solver(*st);
     }
   }
@@ -1123,12 +1142,20 @@ void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_set_eval, dim3(1), dim3(64), 0, s, st, se3_dev);
 }
 
+// one wave: the state into LDS (three coalesced rounds)
+__device__ __forceinline__ void load_state_lds(const GnState* st, GnState* sm, int lane) {
+  constexpr int kWords = (int)(sizeof(GnState) / 8);
+  for (int i = lane; i < kWords; i += 64)
+    reinterpret_cast<unsigned long long*>(sm)[i] = reinterpret_cast<const unsigned long long*>(st)[i];
+}
 __global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __restrict__ in48) {
   __shared__ double tot[kReduceBuf];
+  __shared__ GnState s_in;
   if (threadIdx.x < kReduceBuf) tot[threadIdx.x] = in48[threadIdx.x];
+  load_state_lds(st, &s_in, threadIdx.x);
   __syncthreads();
-  if (st->done) return;
-  gn_consume_wave(st, tot, threadIdx.x, st);
+  if (s_in.done) return;
+  TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
 }
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
@@ -1137,7 +1164,10 @@ void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
 // rank order and advance the minimiser -- identically on every rank
 __global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
   __shared__ double tot[kMboxSlot];
-  if (st->done) return;  // (the sweep of this launch was a no-op on every rank: nothing was posted)
+  __shared__ GnState s_in;
+  load_state_lds(st, &s_in, threadIdx.x);
+  __syncthreads();
+  if (s_in.done) return;  // (the sweep of this launch was a no-op on every rank: nothing was posted)
   const unsigned long long id = __hip_atomic_load(mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
   const bool ok = mbox_gather(mb, id, tot, kReduceBuf, threadIdx.x);
   if (threadIdx.x == 0) {
@@ -1149,7 +1179,7 @@ __global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
     if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
     return;
   }
-  gn_consume_wave(st, tot, threadIdx.x, st);
+  TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
 }
 void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step_mbox, dim3(1), dim3(64), 0, s, st, mb);
@@ -1194,12 +1224,12 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
   __shared__ double lds[kRedGroups * 33];
   __shared__ double tot[32];
   __shared__ GnState s_in;
-  if (st->done) return;
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[0] = (double)__builtin_readcyclecounter();
 #endif
   // the minimiser state comes in as ONE coalesced load into LDS, in flight together with the partial rows (the
-  // step's ~100 scattered field loads were a second memory round trip in front of the serial fp64 chain)
+  // step's ~100 scattered field loads were a second memory round trip in front of the serial fp64 chain); the
+  // `done` flag of a finished Solve is read from that copy -- no round trip of its own in front of the loads
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
     static_assert(kWords <= kRedThreads, "one word per thread");
@@ -1207,7 +1237,8 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
     if (threadIdx.x < kWords) reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = w;
   }
   reduce_rows(partials, rows, lds, tot);  // (its barriers also publish s_in)
-  if (threadIdx.x < 64) gn_consume_wave(st, tot, threadIdx.x, &s_in);
+  if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
+  if (threadIdx.x < 64) TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
@@ -1229,7 +1260,7 @@ struct WeightArgs {
 // st->incomplete, and the host tops the Solve up and runs them again.
 __global__ __launch_bounds__(256) void k_weights(WeightArgs A, double* __restrict__ partial, const GnState* __restrict__ st) {
   __shared__ double red[4][8];
-  if (!st->done) return;
+  if (!st->done || st->stop) return;  // (stop: the device-driven loop has ended, the set's weights are final)
   double sum[kKinds] = {0, 0, 0, 0};
   double bad = 0.0;
   const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
@@ -1284,35 +1315,84 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 // Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
 // state writes are done: the host-visible prefix first (16 words, one coalesced store), system-scope fence, then
 // the sequence number.
-__device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads) {
+// status >= 0 replaces the `incomplete` word of the copy (a launch that was gated off reports OS_SKIPPED without
+// touching the state itself).
+__device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
   if (!hm.out) return;
   __syncthreads();
   if (tid >= 64) return;  // one wave does the hand-over (and pays the system-scope fence)
-  if (tid < kMirrorWords)
-    reinterpret_cast<unsigned long long*>(hm.out)[tid] = reinterpret_cast<const unsigned long long*>(st)[tid];
+  if (tid < kMirrorWords) {
+    unsigned long long w = reinterpret_cast<const unsigned long long*>(st)[tid];
+    constexpr int kStatusWord = (int)(offsetof(GnState, incomplete) / 8);
+    static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
+    if (status >= 0 && tid == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
+    reinterpret_cast<unsigned long long*>(hm.out)[tid] = w;
+  }
   __threadfence_system();
   if (tid == 0) __hip_atomic_store(&hm.out->host_seq, hm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t) {
+// ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the
+// plateau test of registration.cpp:1108 and the "did the pose move" comparison that selects build or refresh are made
+// here, and the gates of the next iteration's launches are set accordingly; once the loop has ended `done` stays 1
+// (sweeps and steps are no-ops) and both gates are 0.
+__device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t, const OuterCtl& ctl) {
   if (t < 4) {
     st->kind_cost[t] = sums16[t];
     st->n_corr[t] = (int)sums16[4 + t];
   }
   if (t == 0) {
     st->bad_weights += (int)sums16[8];
-    st->incomplete = 0;
-    arm_solver(*st);
+    st->incomplete = OS_OK;
+    if (!ctl.fast) {
+      arm_solver(*st);
+    } else {
+      const double cur = sums16[TLOAM_KIND_PLANAR];
+      if (fabs(cur - st->prev_planar) < ctl.cost_threshold) {   // :1108 (prev = +inf in the first iteration)
+        st->incomplete = OS_PLATEAU;
+        st->stop = 1;
+        st->run_build = st->run_refresh = 0;
+      } else {
+        st->prev_planar = cur;                                   // :1113-1116
+        if (ctl.last) {
+          st->stop = 1;
+          st->run_build = st->run_refresh = 0;
+        } else {
+          bool moved = false;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) moved = moved || (st->x[i] != st->x_build[i]);
+          st->run_build = moved ? 1 : 0;
+          st->run_refresh = moved ? 0 : 1;
+          arm_solver(*st);
+        }
+      }
+    }
   }
+}
+// entry of a finish kernel: 0 go on | 1 gated off (loop ended earlier) | 2 the Solve has not terminated
+__device__ __forceinline__ int finish_gate(GnState* gate, const OuterCtl& ctl, int t) {
+  const int stop0 = ctl.fast ? gate->stop : 0, done0 = gate->done;
+  __syncthreads();  // every thread has read the flags before thread 0 changes them
+  if (stop0) return 1;
+  if (!done0) {
+    if (t == 0) {
+      gate->incomplete = OS_INCOMPLETE;
+      if (ctl.fast) { gate->stop = 2; gate->run_build = gate->run_refresh = 0; }
+    }
+    return 2;
+  }
+  return 0;
 }
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
                                                      const int* __restrict__ seg_n, double* __restrict__ sums16,
-                                                     GnState* st_or_null, GnState* gate, HostMirror hm) {
+                                                     GnState* st_or_null, GnState* gate, HostMirror hm, OuterCtl ctl) {
   __shared__ double sh[16];
   const int t = threadIdx.x;
-  if (!gate->done) {  // the Solve is still running: nothing to finish yet (see k_weights)
-    if (t == 0) gate->incomplete = 1;
-    if (st_or_null) mirror_to_host(gate, hm, t, 64);
-    return;
+  {
+    const int g = finish_gate(gate, ctl, t);  // 2: the Solve is still running, nothing to finish yet (see k_weights)
+    if (g != 0) {
+      if (st_or_null) mirror_to_host(gate, hm, t, 64, g == 1 ? (int)OS_SKIPPED : -1);
+      return;
+    }
   }
   double v[5] = {0, 0, 0, 0, 0};
   for (int b = t; b < blocks; b += 64) {  // blocks <= 256: at most 4 rows per lane, fixed order
@@ -1334,7 +1414,7 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
   __syncthreads();
   if (t < 16) sums16[t] = sh[t];
   if (st_or_null) {  // single rank: no exchange in between
-    publish_and_rearm(sh, st_or_null, t);
+    publish_and_rearm(sh, st_or_null, t, ctl);
     mirror_to_host(st_or_null, hm, t, 64);
   }
 }
@@ -1343,13 +1423,16 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
 // removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
 // folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
 __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, const int* __restrict__ seg_n,
-                                                               double* __restrict__ sums16, GnState* st, HostMirror hm) {
+                                                               double* __restrict__ sums16, GnState* st, HostMirror hm,
+                                                               OuterCtl ctl) {
   __shared__ double red[16][8];
   __shared__ double sh[16];
-  if (!st->done) {  // gate, see k_weights
-    if (threadIdx.x == 0) st->incomplete = 1;
-    mirror_to_host(st, hm, threadIdx.x, 1024);
-    return;
+  {
+    const int g = finish_gate(st, ctl, threadIdx.x);  // gate, see k_weights
+    if (g != 0) {
+      mirror_to_host(st, hm, threadIdx.x, 1024, g == 1 ? (int)OS_SKIPPED : -1);
+      return;
+    }
   }
   double sum[kKinds] = {0, 0, 0, 0};
   double bad = 0.0;
@@ -1397,24 +1480,24 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
   if (threadIdx.x >= 64 && threadIdx.x < 68) sh[threadIdx.x - 60] = (double)seg_n[threadIdx.x - 64];
   __syncthreads();
   if (threadIdx.x < 16) sums16[threadIdx.x] = sh[threadIdx.x];
-  if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x);
+  if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x, ctl);
   mirror_to_host(st, hm, threadIdx.x, 1024);
 }
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
-                                 double* sums16, GnState* st, HostMirror hm, hipStream_t s) {
+                                 double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s) {
   WeightArgs A;
   A.cv = cv;
   A.sv = sv;
   A.wp = wp;
-  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st, hm);
+  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st, hm, ctl);
 }
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
-                         double* sums16, HostMirror hm, hipStream_t s) {
-  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate, hm);
+                         double* sums16, HostMirror hm, OuterCtl ctl, hipStream_t s) {
+  hipLaunchKernelGGL(k_outer_finish, dim3(1), dim3(64), 0, s, partial, blocks, seg_n, sums16, st_or_null, gate, hm, ctl);
 }
 __global__ void k_outer_publish(const double* __restrict__ sums16, GnState* st, HostMirror hm,
                                 const unsigned long long* __restrict__ comm_err) {
-  if (st->done) publish_and_rearm(sums16, st, threadIdx.x);  // gated like k_outer_finish (which raised st->incomplete)
+  if (st->done) publish_and_rearm(sums16, st, threadIdx.x, OuterCtl{0.0, 0, 0});  // gated like k_outer_finish (which raised st->incomplete)
   if (threadIdx.x == 0 && (st->comm_error || (comm_err && *comm_err))) st->incomplete = 3;  // exchange timed out
   mirror_to_host(st, hm, threadIdx.x, 64);
 }

@@ -107,8 +107,10 @@ __device__ __forceinline__ void wave_store_rows(unsigned long long* __restrict__
 
 __global__ __launch_bounds__(kScanThreads) void k_scan_tile(const unsigned long long* __restrict__ in,
                                                             unsigned long long* __restrict__ out, size_t n,
-                                                            unsigned long long* __restrict__ tile_total) {
+                                                            unsigned long long* __restrict__ tile_total,
+                                                            const int* __restrict__ gate) {
   __shared__ unsigned long long wave_tot[kScanThreads / 64];
+  if (gate && *gate == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t wbase = (size_t)blockIdx.x * kScanTile + (size_t)wave * (kScanRows * kScanRowElems);
   unsigned long long ex[kScanRows], a[kScanRows][kScanPer];
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tile(const unsigned long 
   if (threadIdx.x == kScanThreads - 1) tile_total[blockIdx.x] = wave_off + tot;
 }
 __global__ __launch_bounds__(kScanThreads) void k_scan_add(unsigned long long* __restrict__ out, size_t n,
-                                                           const unsigned long long* __restrict__ tile_off) {
+                                                           const unsigned long long* __restrict__ tile_off,
+                                                           const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const unsigned long long add = tile_off[blockIdx.x];
   const size_t base = (size_t)blockIdx.x * kScanTile + threadIdx.x;
 #pragma unroll
@@ -134,9 +138,11 @@ constexpr int kSmallThreads = 1024;
 constexpr int kSmallRows = 4;                                   // 1024 elements per wave
 constexpr int kSmallTile = (kSmallThreads / 64) * kSmallRows * kScanRowElems;  // 16384
 __global__ __launch_bounds__(kSmallThreads) void k_scan_small(const unsigned long long* __restrict__ in,
-                                                              unsigned long long* __restrict__ out, size_t n) {
+                                                              unsigned long long* __restrict__ out, size_t n,
+                                                              const int* __restrict__ gate) {
   __shared__ unsigned long long wave_tot[kSmallThreads / 64];
   __shared__ unsigned long long carry_s;
+  if (gate && *gate == 0) return;
   if (threadIdx.x == 0) carry_s = 0ull;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,8 +163,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_scan_small(const unsigned lon
 // medium inputs: every block sums the totals of the tiles before it itself (<= 1024 loads) -- two
 // launches instead of three
 __global__ __launch_bounds__(kScanThreads) void k_scan_add_direct(unsigned long long* __restrict__ out, size_t n,
-                                                                  const unsigned long long* __restrict__ tile_total) {
+                                                                  const unsigned long long* __restrict__ tile_total,
+                                                                  const int* __restrict__ gate) {
   __shared__ unsigned long long red[kScanThreads / 64];
+  if (gate && *gate == 0) return;
   unsigned long long acc = 0;
   for (int t = threadIdx.x; t < (int)blockIdx.x; t += kScanThreads) acc += tile_total[t];
 #pragma unroll
@@ -183,21 +191,21 @@ size_t scan_tmp_elems(size_t n) {
   return total + 16;
 }
 void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n,
-                               unsigned long long* tmp, hipStream_t s) {
+                               unsigned long long* tmp, hipStream_t s, const int* gate) {
   if (n == 0) return;
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
   if (n <= (size_t)kSmallTile) {
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kSmallThreads), 0, s, in, out, n);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kSmallThreads), 0, s, in, out, n, gate);
     return;
   }
   unsigned long long* totals = tmp;
   unsigned long long* totals_scan = tmp + tiles;
-  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals);
+  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals, gate);
   if (tiles <= 1024) {
-    hipLaunchKernelGGL(k_scan_add_direct, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals);
+    hipLaunchKernelGGL(k_scan_add_direct, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals, gate);
   } else {
-    launch_exclusive_scan_u64(totals, totals_scan, tiles, tmp + 2 * tiles, s);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals_scan);
+    launch_exclusive_scan_u64(totals, totals_scan, tiles, tmp + 2 * tiles, s, gate);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, out, n, totals_scan, gate);
   }
 }
 
@@ -663,7 +671,8 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
 template <int LPQ>
 __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
                                                      const unsigned long long* __restrict__ n_sorted,
-                                                     const double4* __restrict__ qrec) {
+                                                     const double4* __restrict__ qrec, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;  // device-driven outer loop: the pose did not move, the set is only refreshed
   // XCD-aware order: the dispatcher deals blocks round-robin to the 8 XCDs (each with a private L2), so
   // physical block b is given logical position (b % 8) * (blocks / 8) + b / 8 -- every XCD then walks one
   // CONTIGUOUS eighth of the tile-sorted queries and neighbouring tiles share target records in its L2
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s) {
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -725,11 +734,11 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   // lanes per query: the smaller the frame, the more the build is a latency chain per query and the more lanes
   // pay (KITTI-size 9.4 k queries: 0.371-0.378 ms per frame with 4, 0.36 with 8, 0.348-0.36 with 16)
   if (n <= kWideLimit)
-    hipLaunchKernelGGL(k_build_sorted<16>, dim3(grid8(16LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
+    hipLaunchKernelGGL(k_build_sorted<16>, dim3(grid8(16LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
   else if (n <= kQuadLimit)
-    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
+    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
   else
-    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec);
+    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
 }
 int build_tile_count(const GridView grids[kKinds]) {
   int base = 0;
@@ -755,8 +764,12 @@ struct CompactArgs {
   int* seg_n;
   const double* rank_counts;  // [nranks*4] counted totals per rank (all-reduced), or null
   int rank, nranks;
+  GnState* st;                // receives the pose the set was built at (x_build)
+  const int* gate;
 };
 __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
+  if (A.gate && *A.gate == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x < 6 && A.st) A.st->x_build[threadIdx.x] = A.st->x[threadIdx.x];
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int n_slots = A.sv.slot_off[kKinds];
   if (slot >= n_slots) return;
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
   seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
 }
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
-                    const double* rank_counts, int rank, int nranks, hipStream_t s) {
+                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   CompactArgs A;
@@ -813,12 +826,15 @@ void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& b
   A.rank_counts = rank_counts;
   A.rank = rank;
   A.nranks = nranks;
+  A.st = st;
+  A.gate = gate;
   hipLaunchKernelGGL(k_compact, dim3((n + 255) / 256), dim3(256), 0, s, A);
 }
 // Outer iteration with an unchanged pose: the factor list is the previous one.  What a fresh
 // AddResidualBlock pass would change is only the weight captured by value (registration.hpp:51,76,96) and
 // the zeroed residual slot (registration.cpp:1118-1121).
-__global__ __launch_bounds__(256) void k_refresh(SlotView sv, CorrView cv) {
+__global__ __launch_bounds__(256) void k_refresh(SlotView sv, CorrView cv, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
@@ -830,12 +846,12 @@ __global__ __launch_bounds__(256) void k_refresh(SlotView sv, CorrView cv) {
     }
   }
 }
-void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s) {
+void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s, const int* gate) {
   int cap = 0;
   for (int k = 0; k < kKinds; ++k) cap += cv.k[k].cap;
   int blocks = (cap + 255) / 256;
   blocks = std::max(1, std::min(blocks, 2048));
-  hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(256), 0, s, sv, cv);
+  hipLaunchKernelGGL(k_refresh, dim3(blocks), dim3(256), 0, s, sv, cv, gate);
 }
 
 // per-rank `counted` totals -> row `rank` of a zeroed [nranks*4] buffer (summed by the all-reduce)
