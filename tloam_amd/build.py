@@ -16,15 +16,16 @@ OUT = os.path.join(HERE, "libtloam_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# kernel arguments: the first 12 dwords of every kernel arrive preloaded in SGPRs (gfx950 command processor) instead of
+# behind a scalar-load round trip -- the K3 / minimiser / finish kernels order their arguments for it (tl_gn.hip)
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=12"]
 COMMON += os.environ.get("TLOAM_EXTRA_HIPCC_FLAGS", "").split()  # development aid (-DTLOAM_K3_PROFILE ...)
 UNITS = [
     # K1/K2: un-fused fp64 so the discontinuous gates see the oracle's operation order
-    ("tl_nn.hip", ["-ffp-contract=off"]),
+    ("tl_nn.hip", ["-ffp-contract=off", *PRELOAD]),
     ("tl_submap.hip", ["-ffp-contract=off"]),   # voxel indices / means in the oracle's operation order
     ("tl_feature.hip", ["-ffp-contract=off"]),  # PCA gates (flatness / cvr thresholds) like the oracle
-    # kernel arguments: the first 12 dwords of every kernel of this unit arrive preloaded in SGPRs (gfx950 command
-    # processor) -- the K3 / minimiser kernels put what their first loads need there (tl_gn.hip, k3_accumulate)
-    ("tl_gn.hip", ["-mllvm", "-amdgpu-kernarg-preload-count=12"]),
+    ("tl_gn.hip", [*PRELOAD]),
     ("tl_api.hip", []),
     ("tl_api_submap.hip", []),
     ("tl_api_feature.hip", []),
@@ -60,7 +61,7 @@ def build_variant(name, flags, units=("tl_gn.hip",), verbose=False):
         if src in units:
             obj = os.path.join(odir, src.replace(".hip", ".o"))
             if "-DNO_PRELOAD" in flags:   # A/B of the kernel-argument preload
-                extra = [f for f in extra if f not in ("-mllvm", "-amdgpu-kernarg-preload-count=12")]
+                extra = [f for f in extra if f not in PRELOAD]
             cmd = [hipcc, *COMMON, *extra, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         else:

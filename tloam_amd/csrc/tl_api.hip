@@ -350,7 +350,7 @@ int harvest_k3_events(tloam_ctx* c, int working) {
 // stream drained without the number arriving, copy the state and synchronise.
 HostMirror next_mirror(tloam_ctx* c, int slot = 0) {
   HostMirror hm;
-  hm.out = c->h_state_dev ? c->h_state_dev + slot : nullptr;
+  hm.out = c->h_mirror_dev ? c->h_mirror_dev + slot : nullptr;
   hm.seq = hm.out ? ++c->mirror_seq : 0ull;
   return hm;
 }
@@ -362,8 +362,17 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
     ~Acc() { c->wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
   } acc{c, t0};
   if (hm.out) {
-    const int rc = wait_word(c, &c->h_state[slot].host_seq, hm.seq);
-    if (rc <= 0) return rc;
+    // the number in all three segments of the slot (MirrorSlot), then the prefix out of them
+    const MirrorSlot* ms = c->h_mirror + slot;
+    int rc = TLOAM_OK;
+    for (int sgm = 0; sgm < 3 && rc == TLOAM_OK; ++sgm) rc = wait_word(c, &ms->w[sgm * 8 + 7], hm.seq);
+    if (rc < 0) return rc;
+    if (rc == TLOAM_OK) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(c->h_state + slot);
+      for (int w = 0; w < kMirrorWords; ++w) dst[w] = ms->w[(w / 7) * 8 + (w % 7)];
+      c->h_state[slot].host_seq = hm.seq;
+      return TLOAM_OK;
+    }
   }
   HIPC(c, hipMemcpyAsync(c->h_state + slot, c->state.p, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
@@ -496,9 +505,14 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   }
   memset(c->h_state, 0, sizeof(GnState) * kMirrorSlots);
   c->no_host_mirror = getenv("TLOAM_NO_HOST_MIRROR") != nullptr;
-  if (!c->no_host_mirror && hipHostGetDevicePointer((void**)&c->h_state_dev, c->h_state, 0) != hipSuccess) {
+  if (!c->no_host_mirror) {
+    if (hipHostMalloc((void**)&c->h_mirror, sizeof(MirrorSlot) * kMirrorSlots, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(c->h_mirror, 0, sizeof(MirrorSlot) * kMirrorSlots);
+      if (((uintptr_t)c->h_mirror & 63u) != 0 ||
+          hipHostGetDevicePointer((void**)&c->h_mirror_dev, c->h_mirror, 0) != hipSuccess)
+        c->h_mirror_dev = nullptr;  // no (aligned) device view of the slots: fall back to copy + synchronise
+    }
     (void)hipGetLastError();
-    c->h_state_dev = nullptr;  // no device view of the pinned state: fall back to copy + synchronise
   }
   if (!c->no_host_mirror) {
     constexpr size_t kBoxBytes = sizeof(double) * ((size_t)kKinds * 64 * 6 + 8);
@@ -540,6 +554,7 @@ void tloam_destroy(tloam_ctx* c) {
   c->submap.release();
   c->feat.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->h_mirror) (void)hipHostFree(c->h_mirror);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -976,8 +991,12 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   // ---- the frame's bookkeeping, iteration by iteration, from the mirrored slots
   int resume = 0;
   for (int iter = 0; iter < M; ++iter) {
-    const GnState* S = &c->h_state[iter];
     used[iter] = 0;
+    if (iter < M - 1) {   // (written before the last slot: already there -- this only unpacks it)
+      rc = wait_state(c, hms[iter], iter);
+      if (rc != TLOAM_OK) return rc;
+    }
+    const GnState* S = &c->h_state[iter];
     if (S->host_seq != hms[iter].seq) {
       c->last_error = "device-driven loop: the result slot of an outer iteration was not written";
       return TLOAM_E_HIP;
@@ -1038,7 +1057,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
   // iterations fit the result slots, no development knob that needs the host between iterations
-  if (c->nranks == 1 && c->h_state_dev && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
+  if (c->nranks == 1 && c->h_mirror_dev && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
       !c->dbg_no_build_reuse && !c->no_device_loop) {
     rc = scan_match_device_loop(c, &weight_violation);
     if (rc < 0) return rc;

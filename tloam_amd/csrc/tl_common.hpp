@@ -124,8 +124,17 @@ static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible pre
 // memory and then stores the sequence number, so the host reads the result by polling one word instead of paying a
 // copy kernel plus a stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).
 // out == nullptr: off.
+// The slot is written WITHOUT any fence: it is three 64-byte segments, each carrying seven words of the prefix and,
+// last, the sequence number; one wave stores all 24 words with one instruction, every segment leaves the GPU as one
+// aligned 64-byte write (a full cache line for the host), so a segment whose number has arrived has arrived whole,
+// and the host waits for the number in all three.  (A system-scope release would first write back every dirty L2
+// line of the kernel, ~2 us; writing the number behind the words with only a wave-level wait is NOT safe: the two
+// cache lines travel through different L2 channels.)
+struct MirrorSlot {
+  unsigned long long w[24];
+};
 struct HostMirror {
-  GnState* out;
+  MirrorSlot* out;
   unsigned long long seq;
 };
 // status of an outer iteration as the host reads it in GnState.incomplete

@@ -162,7 +162,8 @@ struct tloam_ctx {
   bool tgt_box_valid[tl::kKinds] = {false, false, false, false};
   double wait_us = 0.0;            // time the host spent waiting for the device in the current scan_match
   bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
-  tl::GnState* h_state_dev = nullptr;   // device address of the pinned host state (HostMirror target)
+  tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
+  tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;
   int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
   std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames

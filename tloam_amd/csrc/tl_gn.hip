@@ -1320,16 +1320,16 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
 __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
   if (!hm.out) return;
   __syncthreads();
-  if (tid >= 64) return;  // one wave does the hand-over (and pays the system-scope fence)
-  if (tid < kMirrorWords) {
-    unsigned long long w = reinterpret_cast<const unsigned long long*>(st)[tid];
+  if (tid >= 24) return;  // one store instruction of one wave: 3 segments x (7 words + sequence number), see MirrorSlot
+  const int seg = tid >> 3, pos = tid & 7, word = seg * 7 + pos;
+  unsigned long long w = hm.seq;
+  if (pos < 7) {
+    w = word < kMirrorWords ? reinterpret_cast<const unsigned long long*>(st)[word] : 0ull;
     constexpr int kStatusWord = (int)(offsetof(GnState, incomplete) / 8);
     static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
-    if (status >= 0 && tid == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
-    reinterpret_cast<unsigned long long*>(hm.out)[tid] = w;
+    if (status >= 0 && word == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
   }
-  __threadfence_system();
-  if (tid == 0) __hip_atomic_store(&hm.out->host_seq, hm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&hm.out->w[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the
 // plateau test of registration.cpp:1108 and the "did the pose move" comparison that selects build or refresh are made
@@ -1422,11 +1422,31 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
 // launch of one 1024-thread block -- the frame is a chain of launch-latency-bound kernels, every boundary
 // removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
 // folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
-__global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, const int* __restrict__ seg_n,
-                                                               double* __restrict__ sums16, GnState* st, HostMirror hm,
-                                                               OuterCtl ctl) {
+// Argument order: state, sizes, output and mirror first (preloaded SGPRs, see k3_accumulate).  The kernel is one
+// dependent chain of memory round trips on an otherwise idle GPU, so everything it will need is REQUESTED in its
+// first instructions: the loop flags (done / stop), the segment sizes and -- speculatively, bounded by the segment
+// capacities from the kernel arguments -- the first three (cost, index) pairs of every kind per thread (a KITTI-cap
+// set is 2500 / 2000 / 1200 / 200: all of it); the gate is evaluated when they are all back.
+__global__ __launch_bounds__(1024) void k_weights_finish_small(GnState* st, const int* __restrict__ seg_n,
+                                                               double* __restrict__ sums16, HostMirror hm, OuterCtl ctl,
+                                                               WeightArgs A) {
   __shared__ double red[16][8];
   __shared__ double sh[16];
+  constexpr int kPre = 3;
+  double pc[kKinds][kPre];
+  int pi[kKinds][kPre];
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k)
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int i = threadIdx.x + u * 1024;
+      const bool in = i < A.cv.k[k].cap;
+      pc[k][u] = in ? A.cv.k[k].cost[i] : 0.0;
+      pi[k][u] = in ? A.cv.k[k].idx[i] : 0;
+    }
+  int nseg[kKinds];
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
   {
     const int g = finish_gate(st, ctl, threadIdx.x);  // gate, see k_weights
     if (g != 0) {
@@ -1437,30 +1457,30 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
   double sum[kKinds] = {0, 0, 0, 0};
   double bad = 0.0;
   // (the side-channel costs and the index lists are only read here, the slot weights only written: say so, or the
-  //  possible aliasing serialises the thread's 6 load -> load -> store chains of a KITTI-size set)
+  //  possible aliasing serialises the thread's load -> load -> store chains)
   double* __restrict__ w_src = A.sv.w_src;
+  auto one = [&](int k, double c, int id) {
+    sum[k] += c;
+    if (!A.wp.active[k]) return;
+    if (c == 0) return;                            // :862
+    double w;
+    if (c >= A.wp.th1) w = 0.0;                    // :865
+    else if (c <= A.wp.th2) w = 1.0;               // :867
+    else {
+      w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+      if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+    }
+    w_src[A.sv.slot_off[k] - A.sv.src_lo[k] + id] = w;
+  };
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
-    const int n = A.cv.seg_n[k];
+    const int n = nseg[k];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)   // same element order per thread as a plain strided loop
+      if ((int)threadIdx.x + u * 1024 < n) one(k, pc[k][u], pi[k][u]);
     const double* __restrict__ cost = A.cv.k[k].cost;
     const int* __restrict__ idx = A.cv.k[k].idx;
-    const int slot0 = A.sv.slot_off[k] - A.sv.src_lo[k];
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      const double c = cost[i];
-      const int slot = slot0 + idx[i];
-      sum[k] += c;
-      if (!A.wp.active[k]) continue;
-      if (c == 0) continue;                          // :862
-      double w;
-      if (c >= A.wp.th1) w = 0.0;                    // :865
-      else if (c <= A.wp.th2) w = 1.0;               // :867
-      else {
-        w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
-        if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
-      }
-      w_src[slot] = w;
-    }
+    for (int i = threadIdx.x + kPre * 1024; i < n; i += 1024) one(k, cost[i], idx[i]);
   }
   double v[5] = {sum[0], sum[1], sum[2], sum[3], bad};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1477,7 +1497,7 @@ __global__ __launch_bounds__(1024) void k_weights_finish_small(WeightArgs A, con
     for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
     sh[threadIdx.x < 4 ? threadIdx.x : 8] = t;
   }
-  if (threadIdx.x >= 64 && threadIdx.x < 68) sh[threadIdx.x - 60] = (double)seg_n[threadIdx.x - 64];
+  if (threadIdx.x >= 64 && threadIdx.x < 68) sh[threadIdx.x - 60] = (double)nseg[threadIdx.x - 64];
   __syncthreads();
   if (threadIdx.x < 16) sums16[threadIdx.x] = sh[threadIdx.x];
   if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x, ctl);
@@ -1489,7 +1509,7 @@ void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const W
   A.cv = cv;
   A.sv = sv;
   A.wp = wp;
-  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, A, seg_n, sums16, st, hm, ctl);
+  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, st, seg_n, sums16, hm, ctl, A);
 }
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
                          double* sums16, HostMirror hm, OuterCtl ctl, hipStream_t s) {
