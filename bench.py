@@ -57,7 +57,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
 # THIS command, summarised by scripts/pmc_summary.py with the gfx950 x2 FETCH_SIZE correction).  PMC counters
 # cannot be read from inside the process, so the line quotes the committed summary and says so.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_k3_bench_m1.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r02_pmc_k3_bench_m1.json"),
+                                os.path.join(ROOT, "profiles", "r01_pmc_k3_bench_m1.json")) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r02_pmc_k3_bench_m1.json"))
 
 
 def pmc_traffic(world):
@@ -66,7 +68,8 @@ def pmc_traffic(world):
     try:
         d = json.load(open(PMC_SUMMARY))
         return float(d["traffic_bytes_per_launch_all"]), {
-            "source": "profiles/r01_pmc_k3_bench_m1.json (separate rocprofv3 --pmc passes of this command)",
+            "source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a committed "
+                      "summary quoted here, not a counter read by this run)" % os.path.basename(PMC_SUMMARY),
             "fetch_bytes_per_launch": d["fetch_bytes_per_launch_all"],
             "write_bytes_per_launch": d["write_bytes_per_launch_all"],
             "working_sweeps_traffic": d["traffic_bytes_per_launch_working"]}
@@ -107,9 +110,27 @@ def prebuilt_k3(reg, synth, device):
     med = 0.5 * (us[2] + us[3])
     alg = 760_000 * 72.0 + 200_000 * 88.0 + 40_000 * 64.0
     return {"workload": "pre-built 1 M set, plane:line:point = 760k:200k:40k (SURVEY 8(d) config 3, K3 only)",
-            "launches": 120, "avg_launch_us": round(med, 3), "algorithmic_bytes_per_launch": alg,
+            "launches": 120, "avg_launch_us": round(med, 3), "algorithmic_bytes_per_launch": alg, "bound": "hbm",
             "achieved": round(alg / (med * 1e-6) / 1e9, 1), "frac": round(alg / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "note": "contract: >= 70 % <=> <= 13.4 us"}
+
+
+def k1_roofline(H, world):
+    """roofline_k1: the correspondence-search kernel (K1 + K2) on the state the 1 M frame left behind, 20 back-to-back
+    launches between one HIP event pair (tloam_time_build).  ALGORITHMIC bytes per query: the 32-byte
+    query record in, the k nearest 32-byte target records kept (5, sphere kind 1), the 64-byte raw record + 8-byte flag out."""
+    try:
+        H.time_build(3)
+        us, nq = H.time_build(20)
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:160]}
+    per_kind = [H._n.get(("s", k), 0) for k in range(4)]
+    alg = sum(per_kind[k] * (32.0 + 5 * 32.0 + 72.0) for k in (0, 1, 2)) + per_kind[3] * (32.0 + 32.0 + 72.0)
+    return {"kernel": "k_build_sorted<1>", "bound": "hbm", "launches": 20, "avg_launch_us": round(us, 2), "queries_per_launch": int(nq),
+            "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "exact k-NN over the 27-cell neighbourhood: ~70 candidate records examined per query (2-3 points per "
+                    "cell), ~34 VALU instructions each -- issue-bound, not bandwidth-bound (DESIGN.md section 5)"}
 
 
 def parse():
@@ -129,6 +150,12 @@ def parse():
     ap.add_argument("--kitti-frames", type=int, default=200, help="length of the KITTI-density sequence block")
     ap.add_argument("--loop-frames", type=int, default=150, help="length of the device odometry-loop block")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--kitti-dir", default=None,
+                    help="a KITTI odometry sequence directory (<dir>/velodyne/*.bin or <dir>/*.bin): replay it through "
+                         "reader -> labeller -> device feature extraction -> scan matching -> device submap and write the "
+                         "trajectory (--kitti-out); reported as \"kitti_replay\".  Skipped when the directory is absent.")
+    ap.add_argument("--kitti-out", default=None, help="trajectory file of the replay (KITTI pose format; default <dir>/tloam_hip_poses.txt)")
+    ap.add_argument("--kitti-max-frames", type=int, default=0)
     return ap.parse_args()
 
 
@@ -228,6 +255,7 @@ def main():
         # cross-check without per-launch event overhead: ONE event pair around 60 consecutive launches of the same
         # kernel on the frame's last correspondence set (after the timed region, not part of `value`)
         bb_us = H.time_accumulate(np.asarray(st["se3"], float), 60)
+        k1 = k1_roofline(H, world) if (wl == "m1" and rank == 0 and not args.no_side) else None
         H.close()
         D = np.linalg.inv(T) @ scene.T_true               # pose sanity (not timed)
         n_corr = st["n_corr"]
@@ -252,7 +280,7 @@ def main():
         return {"workload": W["name"], "ms_per_frame": elapsed / steps * 1e3, "gn_iters_per_sec": gn_iters_job / elapsed,
                 "gn_iters_per_frame": gn_iters / steps, "solver_evaluations_per_frame": gn_evals / steps, "n_corr": n_corr,
                 "outer_iterations": st["outer_iterations"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3])),
-                "host_wait_us_per_frame": round(host_wait / steps, 1), "k3": k3, "scene": scene, "cfg": W["cfg"]}
+                "host_wait_us_per_frame": round(host_wait / steps, 1), "k3": k3, "k1": k1, "scene": scene, "cfg": W["cfg"]}
 
     # ---- headline: the configuration the metric is quoted on (KITTI-00 scan density); every rank its own frame pair
     head = run_frames(args.workload, args.steps, args.warmup, args.seed + rank)
@@ -267,20 +295,38 @@ def main():
         traffic, traffic_detail = pmc_traffic(world)
         roofline = None
         if side is not None:
-            roofline = dict(side["k3"])
-            roofline.update({"kernel": "k3_accumulate<false>", "traffic": traffic, "traffic_detail": traffic_detail,
-                             "workload": side["workload"],
-                             "note": "the residual/Jacobian kernel on the configuration the north-star states its roofline "
-                                     "target on; timed in this command over its own region of %d frames" %
+            in_frame = dict(side["k3"])
+            in_frame.update({"workload": side["workload"],
+                             "note": "the same kernel inside the timed 1 M frames (%d frames): every launch follows the one-block "
+                                     "minimiser step, i.e. starts on an idle chip; per-launch HIP event pairs read 1.2-2.5 us "
+                                     "more than the dispatch timestamps (DESIGN.md section 7)" %
                                      (args.steps if args.workload == "m1" else args.m1_steps)})
+            roofline = None
             if not multi and not args.no_side:
                 try:
+                    # SURVEY 8(d) config 3, the roofline-characterisation run proper: K3 alone on the pre-built
+                    # 760k:200k:40k set, >= 100 launches after 10 warm-ups, HIP events around batches of 20, median
+                    pk = prebuilt_k3(reg, synth, local_rank)
+                    roofline = {"bound": "hbm", "achieved": pk["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pk["frac"],
+                                "traffic": traffic, "traffic_detail": traffic_detail, "kernel": "k3_accumulate<false, false>",
+                                "avg_launch_us": pk["avg_launch_us"], "launches": pk["launches"],
+                                "algorithmic_bytes_per_launch": pk["algorithmic_bytes_per_launch"], "workload": pk["workload"],
+                                "launch_timing": "one HIP event pair per batch of 20 consecutive launches on the context's stream, "
+                                                 "median of the 6 batch means (120 launches after 10 warm-ups)",
+                                "note": pk["note"]}
                     bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
                     roofline["measured_copy_GBps"] = round(bw, 1)
                     roofline["frac_of_measured_copy"] = round(roofline["achieved"] / bw, 4)
-                    roofline["prebuilt_k3"] = prebuilt_k3(reg, synth, local_rank)
                 except Exception as e:  # noqa: BLE001  (side measurements never take the line down)
-                    roofline["side_measurements_error"] = repr(e)[:200]
+                    roofline = None
+                    in_frame["side_measurements_error"] = repr(e)[:200]
+            if roofline is None:   # N > 1 / --no-side: the in-frame figure stands in
+                roofline = dict(in_frame)
+                roofline.update({"kernel": "k3_accumulate<false, false>", "traffic": traffic, "traffic_detail": traffic_detail})
+            else:
+                roofline["in_frame"] = in_frame
+            if side.get("k1"):
+                roofline["roofline_k1"] = side["k1"]
             if args.workload == "kitti":
                 hk = dict(head["k3"])
                 hk.update({"kernel": "k3_accumulate<true>", "note": "same kernel family on the headline frames: 442 KB per "
@@ -328,6 +374,14 @@ def main():
             out["odometry_loop"] = odometry_loop(args, reg, torch, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head, side, args, kitti_seq)
+        if kitti_seq is not None:   # the honest per-frame cost of the plug-in as wired in INTEGRATION.md section 1
+            out["config"]["ms_per_frame_incl_pcie_upload"] = kitti_seq["report"]["ms_per_frame_incl_pcie_upload"]
+            out["config"]["pcie_note"] = ("value / ms_per_step time scan_match with the eight clouds resident in HBM (the reference's "
+                                          "own bracket, front_end.cpp:320-322); handing the clouds over through "
+                                          "setInputSource/setInputTarget every frame costs ms_per_frame_incl_pcie_upload, with "
+                                          "the device-resident submap odometry_loop.ms_per_frame")
+        if args.kitti_dir:
+            out["kitti_replay"] = kitti_replay(args, reg, torch, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:
@@ -582,20 +636,23 @@ def odometry_loop(args, reg, torch, device):
 
 
 def cpu_baseline(head, side, args, kitti_seq=None):
-    """The oracle (a dependency-free port of the reference's Ceres-configured solve, NOT Ceres) on the host cores,
-    threaded in the reference's shape: 4 builder threads (registration.cpp:976-1020), evaluation on
-    hardware_concurrency()/2 threads (:184, :1044).  Bounded sample: ONE scan_match of the headline frame pair
-    (repeated a few times when it is the KITTI-density pair), one of the 1 M frame, and the first 8 frames of the
-    KITTI-density sequence, where the pose the GPU returned is checked against the port's."""
+    """The CPU path timed beside the GPU's in the same run: the oracle -- a dependency-free port of the
+    reference's Ceres-configured solve, NOT Ceres -- compiled for this host as the survey specifies for the timed path
+    (-O3 -march=native, its own `fast` build; the -ffp-contract=off parity build is not what is timed), swept over the
+    evaluator thread counts {1,2,4,8,16,32} with min(4, threads) builder threads (the reference runs its four builders as
+    four async tasks, registration.cpp:976-1020, and Ceres on hardware_concurrency()/2 threads, :184,:1044).  `value` is
+    the BEST of the sweep with its thread count in `cores`; the single-thread figure and the reference's own thread shape
+    are reported beside it.  Bounded sample: the headline frame pair x10 per thread count, one 1 M frame, and the first 8
+    frames of the KITTI-density sequence, where the pose the GPU returned is checked against the port's."""
     from oracle import binding as ob
     cores = os.cpu_count() or 1
-    eval_threads = max(1, cores // 2)
 
-    def port(block, reps, bt=4, et=None):
+    def port(block, reps, bt, et):
         cfg = block["cfg"]
         oc = ob.make_config(**{f: getattr(cfg, f) for f, _ in cfg._fields_ if f != "reserved0"})
-        O = ob.Oracle(oc, builder_threads=bt, eval_threads=et or eval_threads)
+        O = ob.Oracle(oc, builder_threads=bt, eval_threads=et, fast=True)
         O.set_frames(block["scene"].source, block["scene"].target)
+        O.scan_match(block["scene"].T_pred)          # warm (thread pool, caches)
         t0 = time.perf_counter()
         it = 0
         for _ in range(reps):
@@ -604,50 +661,76 @@ def cpu_baseline(head, side, args, kitti_seq=None):
         dt = time.perf_counter() - t0
         return it / dt, dt / reps * 1e3
 
-    v, ms = port(head, 20 if head["ms_per_frame"] < 1.0 else 1)
-    res = {"value": round(v, 3), "unit": "GN iter/s", "cores": max(4, eval_threads), "host_cores": cores, "kind": "port",
-           "ms_per_frame": round(ms, 3), "workload": head["workload"],
-           "sample": "scan_match of the headline frame pair x20 + one 1M frame + the first 8 frames of the KITTI-density "
-                     "sequence (C oracle, -O3, OpenMP: 4 builder threads, eval on cores/2)"}
-    if head["ms_per_frame"] < 1.0:   # small frames: the 128-thread shape is dominated by OpenMP overhead -- also single-threaded
-        vs, mss = port(head, 20, bt=1, et=1)
-        res["single_thread"] = {"value": round(vs, 3), "ms_per_frame": round(mss, 3)}
-        if vs > v:   # quote the FASTER CPU shape as the baseline; keep the other beside it
-            res["reference_thread_shape"] = {"value": res["value"], "ms_per_frame": res["ms_per_frame"], "cores": res["cores"]}
-            res.update(value=round(vs, 3), ms_per_frame=round(mss, 3), cores=1)
+    small = head["ms_per_frame"] < 1.0
+    sweep = {}
+    for et in [t for t in (1, 2, 4, 8, 16, 32) if t <= cores]:
+        v, ms = port(head, 10 if small else 1, min(4, et), et)
+        sweep[et] = {"value": round(v, 3), "ms_per_frame": round(ms, 3)}
+    best = max(sweep, key=lambda t: sweep[t]["value"])
+    res = {"value": sweep[best]["value"], "unit": "GN iter/s", "cores": best, "host_cores": cores, "kind": "port",
+           "build": "oracle/tloam_oracle.c, gcc -O3 -march=native -fopenmp (the cpu_baseline build; parity uses -ffp-contract=off)",
+           "ms_per_frame": sweep[best]["ms_per_frame"], "workload": head["workload"],
+           "single_thread": sweep[1], "thread_sweep": {str(t): sweep[t] for t in sweep},
+           "sample": "scan_match of the headline frame pair x10 per thread count (1..32 evaluator threads, min(4, t) builder "
+                     "threads) + one 1M frame + the first 8 frames of the KITTI-density sequence"}
+    ref_et = max(1, cores // 2)
+    if ref_et not in sweep:   # the reference's own shape: 4 builder tasks, Ceres on hardware_concurrency()/2 threads
+        v, ms = port(head, 3 if small else 1, 4, ref_et)
+        res["reference_thread_shape"] = {"value": round(v, 3), "ms_per_frame": round(ms, 3), "cores": ref_et}
     if side is not None and side is not head:
-        v1, ms1 = port(side, 1)
-        res["m1_frame"] = {"value": round(v1, 3), "ms_per_frame": round(ms1, 2)}
+        v1, ms1 = port(side, 1, 4, min(32, max(1, cores // 2)))
+        res["m1_frame"] = {"value": round(v1, 3), "ms_per_frame": round(ms1, 2), "cores": min(32, max(1, cores // 2))}
     if kitti_seq is not None:
-        # the same port on the first frames of the KITTI-density sequence: CPU ms/frame beside the GPU's, and
-        # the pose the GPU returned for those frames checked against it (the oracle as the checker)
+        # the port on the first frames of the KITTI-density sequence: CPU ms/frame beside the GPU's, and the pose the
+        # GPU returned for those frames checked against the PARITY build of the port (the oracle as the checker)
         from tloam_amd import registration as reg
         from tloam_amd import synth
         kc = reg.default_config()
         ko = ob.make_config(**{f: getattr(kc, f) for f, _ in kc._fields_ if f != "reserved0"})
-        K = ob.Oracle(ko, builder_threads=4, eval_threads=eval_threads)
-        K1 = ob.Oracle(ko, builder_threads=1, eval_threads=1)   # and single-threaded (both shapes)
+        K = ob.Oracle(ko, builder_threads=min(4, best), eval_threads=best, fast=True)
+        K1 = ob.Oracle(ko, builder_threads=1, eval_threads=1)   # parity build, single thread: the checker
         tms, tms1, dts, drs, its = [], [], [], [], 0
         for f, T_gpu in sorted(kitti_seq["poses"].items()):
             sc = kitti_frame(synth, args.seed, f)
             K1.set_frames(sc.source, sc.target)
             t0 = time.perf_counter()
-            K1.scan_match(sc.T_pred)
+            rc, T_cpu, stc = K1.scan_match(sc.T_pred)
             tms1.append((time.perf_counter() - t0) * 1e3)
             K.set_frames(sc.source, sc.target)
             t0 = time.perf_counter()
-            rc, T_cpu, stc = K.scan_match(sc.T_pred)
+            K.scan_match(sc.T_pred)
             tms.append((time.perf_counter() - t0) * 1e3)
             its += stc["gn_evaluations"]
             D = np.linalg.inv(T_cpu) @ T_gpu
             dts.append(float(np.linalg.norm(D[:3, 3])))
             drs.append(float(np.arccos(np.clip((np.trace(D[:3, :3]) - 1.0) / 2.0, -1.0, 1.0))))
         if tms:
-            res["kitti_sequence"] = {"frames": len(tms), "ms_per_frame": round(float(np.mean(tms)), 3),
-                                    "ms_per_frame_1_thread": round(float(np.mean(tms1)), 3),
+            res["kitti_sequence"] = {"frames": len(tms), "ms_per_frame": round(float(np.mean(tms)), 3), "cores": best,
+                                    "ms_per_frame_parity_build_1_thread": round(float(np.mean(tms1)), 3),
                                     "gn_iters_per_sec": round(its / (sum(tms) * 1e-3), 1),
                                     "gpu_vs_port_pose_delta": {"max_dt_m": max(dts), "max_dR_rad": max(drs)}}
     return res
+
+
+def kitti_replay(args, reg, torch, device):
+    """--kitti-dir: BASELINE.json configs[0]/[1] in their literal wording -- a KITTI sequence directory replayed through
+    tloam_amd/replay.py (reader, stand-in labeller, device PCA feature extraction, scan matching, device submap) with the
+    trajectory written in the reference's savePose format.  Absent directory: reported, nothing run."""
+    from tloam_amd import replay
+    files = replay.list_scans(args.kitti_dir)
+    if not files:
+        return {"kitti_dir": args.kitti_dir, "skipped": "no .bin scans found (KITTI data is not part of this image)"}
+    outp = args.kitti_out or os.path.join(args.kitti_dir, "tloam_hip_poses.txt")
+    H = reg.HipRegistration(reg.default_config(), device=device)
+    try:
+        poses, rep = replay.replay(H, files, out_poses=outp, max_frames=args.kitti_max_frames or None,
+                                   sync=torch.cuda.synchronize)
+    finally:
+        H.close()
+    rep.update({"kitti_dir": args.kitti_dir, "trajectory_file": outp,
+                "path_length_m": round(float(sum(np.linalg.norm(poses[i][:3, 3] - poses[i - 1][:3, 3]) for i in range(1, len(poses)))), 2),
+                "note": "labels from the stand-in labeller of tloam_amd/replay.py, not the reference's DCVC segmentation"})
+    return rep
 
 
 if __name__ == "__main__":

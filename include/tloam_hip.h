@@ -199,6 +199,10 @@ int tloam_solve(tloam_ctx* ctx, double se3_inout[6], tloam_stats* stats);
 /* Timing helper for the bench: `launches` back-to-back K3 sweeps at se3 on the context's
  * stream bracketed by HIP events; returns the mean kernel-pair time in microseconds. */
 int tloam_time_accumulate(tloam_ctx* ctx, const double se3[6], int launches, double* mean_us);
+/* Timing helper for the bench: `launches` back-to-back runs of the correspondence-search kernel (K1 + K2:
+ * SearchHybrid + the four builders, registration.cpp:427-635, :714-778) over the source points of the last
+ * scan_match -- same pose, grids and query order -- between one HIP event pair; *queries = points searched. */
+int tloam_time_build(tloam_ctx* ctx, int launches, double* mean_us, int64_t* queries);
 /* Sharded contexts, collective (every rank calls it with the same arguments): `launches` sweeps over this rank's
  * block of the current set, each followed -- with_exchange != 0 -- by the exchange of the 48 doubles exactly as a GN
  * iteration performs it (mailbox: posted by the sweep's last block and gathered by a one-wave kernel; RCCL / callback:

@@ -71,7 +71,34 @@ def build(force=False):
     return _LIB_PATH
 
 
+def build_fast():
+    """cpu_baseline build: -O3 -march=native for THIS machine's CPU (file name tagged with it)."""
+    import hashlib
+    try:
+        info = open("/proc/cpuinfo").read()
+        key = "".join(l for l in info.splitlines() if l.startswith(("model name", "flags")))[:4096]
+    except OSError:
+        key = "unknown"
+    tag = hashlib.sha1(key.encode()).hexdigest()[:10]
+    out = os.path.join(_HERE, "_build", f"liboracle_fast_{tag}.so")
+    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "tloam_oracle.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "fast", f"FAST_OUT=_build/liboracle_fast_{tag}.so"], stdout=subprocess.DEVNULL)
+    return out
+
+
 _lib = None
+_lib_fast = None
+
+
+def lib_fast():
+    global _lib_fast
+    if _lib_fast is None:
+        _lib_fast = C.CDLL(build_fast())
+        _lib_fast.orc_create.argtypes = [C.POINTER(TlsConfig), C.POINTER(C.c_void_p)]
+        _lib_fast.orc_destroy.argtypes = [C.c_void_p]
+        _lib_fast.orc_destroy.restype = None
+    return _lib_fast
 
 
 def lib():
@@ -99,8 +126,8 @@ def _aos(x):
 class Oracle:
     """Same call surface as tloam_amd.HipRegistration, backed by the C restatement."""
 
-    def __init__(self, cfg: TlsConfig | None = None, builder_threads=1, eval_threads=1):
-        self.L = lib()
+    def __init__(self, cfg: TlsConfig | None = None, builder_threads=1, eval_threads=1, fast=False):
+        self.L = lib_fast() if fast else lib()   # fast: the cpu_baseline build (never the parity checker)
         self.cfg = cfg or make_config()
         self.h = C.c_void_p()
         rc = self.L.orc_create(C.byref(self.cfg), C.byref(self.h))

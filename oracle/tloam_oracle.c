@@ -512,7 +512,9 @@ struct orc_ctx {
   double prev_cost[4], cur_cost[4];
   tloam_stats stats;
   int bad_weights;
-  double last_H[36], last_g[6], last_cost; /* normal equations at the accepted iterate when the last Solve returned */
+  double last_H[36], last_g[6], last_cost;
+  void* eval_part; /* orc_normal[eval_part_n]: per-thread partial sums of the threaded evaluator */
+  int eval_part_n; /* normal equations at the accepted iterate when the last Solve returned */
 };
 
 static void rset_reserve(orc_rset* s, int cap) {
@@ -547,6 +549,7 @@ void orc_destroy(orc_ctx* c) {
     grid_free(&c->grid[k]);
     rset_free(&c->set[k]);
   }
+  free(c->eval_part);
   free(c);
 }
 void orc_set_threads(orc_ctx* c, int builder_threads, int eval_threads) {
@@ -795,36 +798,46 @@ static void evaluate(orc_ctx* c, const double x[6], int want_J, orc_normal* out)
   double q[4], t[3];
   orc_se3_exp(x, q, t); /* the reference does this once per block (:22,:58,:98); hoisted */
   memset(out, 0, sizeof(*out));
-  for (int kind = 0; kind < 4; ++kind) {
-    orc_rset* s = &c->set[kind];
-    int rt = kind_res_type(kind);
-    int n = s->n;
-    if (n == 0) continue;
 #ifdef _OPENMP
-    if (c->eval_threads > 1) {
-      int nt = c->eval_threads;
-      orc_normal* part = (orc_normal*)calloc((size_t)nt, sizeof(orc_normal));
+  if (c->eval_threads > 1) {
+    /* Ceres' evaluator threads (num_threads, registration.cpp:1044): ONE parallel region per evaluation over all
+     * four kinds, per-thread partial sums kept in the context (no allocation per call), folded in thread order */
+    const int nt = c->eval_threads;
+    if (c->eval_part_n < nt) {
+      free(c->eval_part);
+      c->eval_part = calloc((size_t)nt, sizeof(orc_normal));
+      c->eval_part_n = nt;
+    }
+    orc_normal* part = (orc_normal*)c->eval_part;
 #pragma omp parallel num_threads(nt)
-      {
-        int tid = omp_get_thread_num();
-#pragma omp for schedule(static)
+    {
+      const int tid = omp_get_thread_num();
+      memset(&part[tid], 0, sizeof(orc_normal));
+      for (int kind = 0; kind < 4; ++kind) {
+        orc_rset* s = &c->set[kind];
+        const int rt = kind_res_type(kind);
+        const int n = s->n;
+#pragma omp for schedule(static) nowait
         for (int j = 0; j < n; ++j) {
           double sc;
-          eval_block(rt, q, t, s->p + 3 * j, s->a + 3 * j, s->b + 3 * j, s->d[j], s->w[j], &sc, want_J,
-                     &part[tid]);
+          eval_block(rt, q, t, s->p + 3 * j, s->a + 3 * j, s->b + 3 * j, s->d[j], s->w[j], &sc, want_J, &part[tid]);
           s->cost[j] = sc;
           if (!c->prebuilt) c->resid[kind][s->idx[j]] = sc;
         }
       }
-      for (int th = 0; th < nt; ++th) {
-        out->cost += part[th].cost;
-        for (int m = 0; m < 6; ++m) out->g[m] += part[th].g[m];
-        for (int m = 0; m < 36; ++m) out->H[m] += part[th].H[m];
-      }
-      free(part);
-      continue;
     }
+    for (int th = 0; th < nt; ++th) {
+      out->cost += part[th].cost;
+      for (int m = 0; m < 6; ++m) out->g[m] += part[th].g[m];
+      for (int m = 0; m < 36; ++m) out->H[m] += part[th].H[m];
+    }
+    return;
+  }
 #endif
+  for (int kind = 0; kind < 4; ++kind) {
+    orc_rset* s = &c->set[kind];
+    int rt = kind_res_type(kind);
+    int n = s->n;
     for (int j = 0; j < n; ++j) {
       double sc;
       eval_block(rt, q, t, s->p + 3 * j, s->a + 3 * j, s->b + 3 * j, s->d[j], s->w[j], &sc, want_J, out);

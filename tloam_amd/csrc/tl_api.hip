@@ -716,7 +716,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     {
       GridView gviews[kKinds];
       for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
-      const size_t ntiles = (size_t)build_tile_count(gviews);
+      const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off[kKinds]);
       HIPC(c, c->tile_cnt.reserve(ntiles + 1));
       fi.tile_cnt = c->tile_cnt.p;
       fi.n_tile_cnt = (int)ntiles + 1;
@@ -755,7 +755,7 @@ void outer_params(const tloam_ctx* c, BuildParams* bp, GridView grids[kKinds]) {
 }
 int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
-  const size_t ntiles = (size_t)build_tile_count(grids);
+  const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off[kKinds]);
   HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
   HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)ntiles, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
   HIPC(c, c->qrec.reserve(n_slots + 1));
@@ -1421,6 +1421,35 @@ int tloam_time_sharded_sweep(tloam_ctx* c, const double se3[6], int launches, in
   (void)hipEventDestroy(e1);
   *mean_us = (double)ms * 1e3 / launches;
   return rc;
+}
+
+// Timing helper for the bench (roofline_k1): `launches` back-to-back runs of the correspondence-search kernel
+// (K1 + K2: SearchHybrid + the four builders) over the source slots of the last scan_match -- same pose, same grids,
+// same query order; the kernel only rewrites the raw records and flags it wrote before -- bracketed by one HIP event
+// pair.  *queries = source points searched per launch.
+int tloam_time_build(tloam_ctx* c, int launches, double* mean_us, int64_t* queries) {
+  if (!c || launches < 1 || !mean_us) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  if (c->active || !c->have_build || !c->qrec.p) return TLOAM_E_NOT_READY;
+  BuildParams bp;
+  GridView grids[kKinds];
+  outer_params(c, &bp, grids);
+  hipEvent_t e0, e1;
+  HIPC(c, hipEventCreate(&e0));
+  HIPC(c, hipEventCreate(&e1));
+  HIPC(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; ++i)
+    launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p, c->qrec.p,
+                 c->scan_tmp.p, /*rebin=*/false, c->stream, nullptr);
+  HIPC(c, hipEventRecord(e1, c->stream));
+  HIPC(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPC(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *mean_us = (double)ms * 1e3 / launches;
+  if (queries) *queries = (int64_t)c->sv.slot_off[kKinds];
+  return TLOAM_OK;
 }
 
 int tloam_k3_timer(tloam_ctx* c, int reset, double* total_us, int64_t* launches, double* algorithmic_bytes) {

@@ -217,7 +217,7 @@ void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, 
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr);
-int build_tile_count(const GridView grids[kKinds]);  // size of the concatenated tile index space
+int build_tile_count(const GridView grids[kKinds], int n_slots);  // bins of the query counting sort (tiles, or cells of tiles)
 // cap + compaction (after the flag scan)
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
                     const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate = nullptr);

@@ -432,7 +432,14 @@ constexpr int kWideLimit = TLOAM_K1_WIDE_LIMIT;   // at most this many: sixteen 
 struct TileMeta {
   int tdim[kKinds][3];
   int tile_base[kKinds + 1];  // concatenated tile index space over the 4 kinds
+  int sub;                    // bins per tile: 1 (queries grouped by tile) or 64 (by cell inside the tile, see bin_sub)
 };
+// Thread-per-query frames (> kQuadLimit queries) sort their queries by CELL, tile-major: the 64 lanes of a wave then
+// cover ~25 neighbouring cells instead of 64 scattered ones of a tile, lanes of one cell walk the same nine rows in
+// the same order, and a gather instruction touches 2-3x fewer distinct cache lines -- the walk is bound by the
+// lines the CU's address unit retires, not by bytes.  Smaller frames (several lanes per query) keep the coarse sort:
+// their scan over the bins would cost more than it saves.
+static int bin_sub(int n_slots) { return n_slots > kQuadLimit ? kTile * kTile * kTile : 1; }
 struct BuildArgs {
   SlotView sv;
   GridView grid[kKinds];
@@ -467,8 +474,9 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   const int cx = clampi(cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
   const int cy = clampi(cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
   const int cz = clampi(cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
-  const int t = A.tm.tile_base[kind] +
-                ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
+  int t = A.tm.tile_base[kind] +
+          ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
+  if (A.tm.sub > 1) t = t * A.tm.sub + ((cz % kTile) * kTile + (cy % kTile)) * kTile + (cx % kTile);
   tile_of_slot[slot] = t;
   rank_in_tile[slot] = (int)atomicAdd(&tile_cnt[t], 1ull);  // the one atomic of the sort: count AND rank
 }
@@ -717,7 +725,8 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     base += A.tm.tdim[k][0] * A.tm.tdim[k][1] * A.tm.tdim[k][2];
   }
   A.tm.tile_base[kKinds] = base;
-  const int ntiles = base;
+  A.tm.sub = bin_sub(n);
+  const int ntiles = base * A.tm.sub;   // bins of the counting sort
   if (rebin) {
     // The processing ORDER only buys locality -- every query still searches its own exact 27 cells --
     // so the tile sort is done once per frame (first outer iteration, predicted pose) and reused while
@@ -740,14 +749,14 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   else
     hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
 }
-int build_tile_count(const GridView grids[kKinds]) {
+int build_tile_count(const GridView grids[kKinds], int n_slots) {
   int base = 0;
   for (int k = 0; k < kKinds; ++k) {
     int t = 1;
     for (int a = 0; a < 3; ++a) t *= (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
     base += t;
   }
-  return base;
+  return base * bin_sub(n_slots);
 }
 
 // ================================================================================================

@@ -130,6 +130,7 @@ def load_library():
         "tloam_solve": (C.c_int, [vp, dp, C.POINTER(Stats)]),
         "tloam_time_accumulate": (C.c_int, [vp, dp, C.c_int, dp]),
         "tloam_time_sharded_sweep": (C.c_int, [vp, dp, C.c_int, C.c_int, dp]),
+        "tloam_time_build": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64)]),
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
@@ -165,7 +166,7 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
-    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
+    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
@@ -463,6 +464,12 @@ class HipRegistration:
         us = C.c_double(0)
         self._check(self.L.tloam_time_accumulate(self.h, _dp(x), int(launches), C.byref(us)), "tloam_time_accumulate")
         return us.value
+
+    def time_build(self, launches=20):
+        """(mean us per launch, queries per launch) of the correspondence-search kernel on the last frame's state."""
+        us = C.c_double(0); n = C.c_int64(0)
+        self._check(self.L.tloam_time_build(self.h, int(launches), C.byref(us), C.byref(n)), "tloam_time_build")
+        return us.value, n.value
 
     def time_sharded_sweep(self, se3, launches=50, with_exchange=True):
         """collective: every rank calls it with the same arguments (tloam_time_sharded_sweep)."""
