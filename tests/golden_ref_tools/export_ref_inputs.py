@@ -1,0 +1,48 @@
+"""tests/golden/case_*.npz -> oracle/_ref/in/case_*.bin + cases.txt: the inputs of the committed golden cases in the
+flat binary form oracle/ref_harness/ref_dump.cpp reads (layout documented there).  Cases the reference would perturb
+with Eigen::Vector3d::Random() (predicted |omega| < 1e-2, registration.cpp:884-886) are left out: their result
+depends on a draw the caller cannot control."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+CFG_ORDER = ["k_corr", "factor_num", "edge_dist_thres", "edge_dir_thres", "edge_maxnum", "sphere_maxnum", "sphere_dist_thres",
+             "planar_dist_thres", "planar_maxnum", "ground_maxnum", "ground_dist_thres", "max_iterations", "cost_threshold",
+             "gnc_factor", "noise_bound", "fitness_thres"]
+
+
+def main(out_dir=None):
+    from oracle import binding as ob
+    from oracle import oracle_np as onp
+    out_dir = out_dir or os.path.join(ROOT, "oracle", "_ref", "in")
+    os.makedirs(out_dir, exist_ok=True)
+    names = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "case_*.npz"))):
+        z = np.load(path, allow_pickle=False)
+        cfg = dict(ob.DEFAULTS)
+        cfg.update(json.loads(str(z["cfg_json"])))
+        x = onp.se3_log(z["T_pred"]) if hasattr(onp, "se3_log") else None
+        if x is not None and np.linalg.norm(x[3:]) < 1e-2:
+            continue
+        name = os.path.basename(path)[:-4]
+        with open(os.path.join(out_dir, name + ".bin"), "wb") as f:
+            f.write(np.int32(int(z["n_outer"])).tobytes())
+            f.write(np.array([float(cfg[k]) for k in CFG_ORDER], np.float64).tobytes())
+            f.write(np.ascontiguousarray(z["T_pred"], np.float64).tobytes())            # row-major
+            for side in ("src", "tgt"):
+                for k in range(4):
+                    a = np.ascontiguousarray(z[f"{side}{k}"], np.float64)
+                    f.write(np.int64(len(a)).tobytes())
+                    f.write(a.tobytes())
+        names.append(name)
+    open(os.path.join(out_dir, "cases.txt"), "w").write("\n".join(names) + "\n")
+    return names
+
+
+if __name__ == "__main__":
+    print("\n".join(main(sys.argv[1] if len(sys.argv) > 1 else None)))

@@ -1,0 +1,85 @@
+"""The pin, when it exists.  tests/golden_ref/case_*.ref.txt are the result poses of the REFERENCE's own
+LocalRegistration::scanMatching (built against real Eigen / Ceres 2.0 / Open3D 0.12 by oracle/ref_harness, run with
+max_iterations = 1..n_outer on the inputs of the committed golden cases).  They cannot be produced in the round's image
+-- none of those packages exists here -- so this module skips until someone with the toolchain drops the files in; then
+the C oracle and the golden vectors are held against the real thing: pose after every outer GNC iteration within the
+north-star tolerance (|dt| < 1e-6 m, |dR| < 1e-6 rad).
+
+CPU (always): the exporter writes the harness's inputs, the harness sources reference the reference, and the CMake
+recipe refuses to configure without the real packages (no stand-ins)."""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = sorted(glob.glob(os.path.join(ROOT, "tests", "golden_ref", "case_*.ref.txt")))
+
+
+def _read_ref(path):
+    out = {}
+    for line in open(path):
+        if line.startswith("k "):
+            v = line.split()
+            out[int(v[1])] = np.array(v[2:18], float).reshape(4, 4)
+    return out
+
+
+@pytest.mark.skipif(not REF, reason="tests/golden_ref/ is empty: the reference cannot be built in this image "
+                                    "(oracle/ref_harness/CMakeLists.txt needs Eigen3, Ceres 2.0, Open3D 0.12, yaml-cpp, ROS)")
+@pytest.mark.parametrize("path", REF or ["-"], ids=[os.path.basename(p)[5:-8] for p in REF] or ["none"])
+def test_oracle_and_golden_match_the_reference(path):
+    import json
+    from oracle import binding as ob
+    from tloam_amd import synth
+    z = np.load(os.path.join(ROOT, "tests", "golden", os.path.basename(path)[:-8] + ".npz"), allow_pickle=False)
+    ref = _read_ref(path)
+    cfg = json.loads(str(z["cfg_json"]))
+    for k, T_ref in sorted(ref.items()):
+        # golden vector: the pose after outer iteration k
+        dt, dr = pose_delta(synth.se3_exp_np(z[f"it{k - 1}_x"]), T_ref)
+        assert dt < 1e-6 and dr < 1e-6, ("golden", k, dt, dr)
+        # the C oracle run the way the harness ran the reference
+        O = ob.Oracle(ob.make_config(**dict(cfg, max_iterations=k)))
+        for kind in range(4):
+            O.set_source(kind, z[f"src{kind}"]); O.set_target(kind, z[f"tgt{kind}"])
+        rc, T, st = O.scan_match(z["T_pred"])
+        assert rc == 0
+        dt, dr = pose_delta(T, T_ref)
+        assert dt < 1e-6 and dr < 1e-6, ("oracle", k, dt, dr)
+
+
+def test_exporter_writes_the_harness_inputs(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden_ref_tools"))
+    import export_ref_inputs as ex
+    names = ex.main(str(tmp_path))
+    assert len(names) >= 5 and "case_small_rotation_perturbed" not in names   # the Random() case cannot be pinned
+    raw = open(tmp_path / (names[0] + ".bin"), "rb").read()
+    z = np.load(os.path.join(ROOT, "tests", "golden", names[0] + ".npz"), allow_pickle=False)
+    assert np.frombuffer(raw[:4], np.int32)[0] == int(z["n_outer"])
+    assert np.array_equal(np.frombuffer(raw[4 + 128: 4 + 256], np.float64).reshape(4, 4), z["T_pred"])
+    n0 = np.frombuffer(raw[4 + 256: 4 + 264], np.int64)[0]
+    assert n0 == len(z["src0"])
+
+
+def test_harness_compiles_the_reference_itself_and_needs_the_real_packages(tmp_path):
+    src = open(os.path.join(ROOT, "oracle", "ref_harness", "ref_dump.cpp")).read()
+    cm = open(os.path.join(ROOT, "oracle", "ref_harness", "CMakeLists.txt")).read()
+    assert '#include "tloam/models/registration/registration.hpp"' in src and "tloam::LocalRegistration reg(" in src
+    assert "${TLOAM_REFERENCE_DIR}/src/models/registration/registration.cpp" in cm
+    for pkg in ("Eigen3", "Ceres", "Open3D", "yaml-cpp"):
+        assert f"find_package({pkg}" in cm
+    cmake = shutil.which("cmake")
+    if not cmake or not os.path.isdir("/root/reference"):
+        pytest.skip("cmake / the reference checkout are not on this machine")
+    r = subprocess.run([cmake, "-S", os.path.join(ROOT, "oracle", "ref_harness"), "-B", str(tmp_path / "b"),
+                        "-DTLOAM_REFERENCE_DIR=/root/reference"], capture_output=True, text=True)
+    if r.returncode == 0:
+        pytest.skip("this machine HAS the reference's toolchain: build oracle/_ref and generate tests/golden_ref/")
+    assert any(p in (r.stderr + r.stdout) for p in ("Eigen3", "Ceres", "Open3D", "yaml-cpp", "roscpp")), r.stderr[-400:]
