@@ -57,9 +57,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
 # THIS command, summarised by scripts/pmc_summary.py with the gfx950 x2 FETCH_SIZE correction).  PMC counters
 # cannot be read from inside the process, so the line quotes the committed summary and says so.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r02_pmc_k3_bench_m1.json"),
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json"),
                                 os.path.join(ROOT, "profiles", "r01_pmc_k3_bench_m1.json")) if os.path.exists(p)),
-                   os.path.join(ROOT, "profiles", "r02_pmc_k3_bench_m1.json"))
+                   os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json"))
 
 
 def pmc_traffic(world):
