@@ -605,15 +605,22 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     int len = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i) len = max(len, re[i] - rs[i]);
-    for (int s = 0; s < len; ++s) {  // step s: candidate s of each of this lane's rows, loads in flight together
-      double4 c[NR];
+    // kU steps per trip: candidates s .. s + kU - 1 of each of this lane's rows are requested together (the walk of a
+    // small frame is a latency chain: one record round trip per trip, so the trip carries as many as the rows allow)
+    constexpr int kU = (NR == 1) ? 4 : 2;
+    for (int s = 0; s < len; s += kU) {
+      double4 c[kU][NR];
 #pragma unroll
-      for (int i = 0; i < NR; ++i) c[i] = pts.p[(rs[i] + s < re[i]) ? rs[i] + s : 0];
+      for (int u = 0; u < kU; ++u)
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        const bool v = rs[i] + s < re[i];
-        key_insert<K + 1>(L, key_pack(sqdist(pw.x, pw.y, pw.z, c[i].x, c[i].y, c[i].z), rs[i] + s, keep_mask, v));
-      }
+        for (int i = 0; i < NR; ++i) c[u][i] = pts.p[(rs[i] + s + u < re[i]) ? rs[i] + s + u : 0];
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const bool v = rs[i] + s + u < re[i];
+          key_insert<K + 1>(L, key_pack(sqdist(pw.x, pw.y, pw.z, c[u][i].x, c[u][i].y, c[u][i].z), rs[i] + s + u, keep_mask, v));
+        }
     }
     // merge across the quad: after xor-1 and xor-2 every lane holds the global list (the lanes' candidate
     // sets are disjoint, +inf entries fall through)
