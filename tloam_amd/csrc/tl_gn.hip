@@ -805,22 +805,21 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
   double x_cost = sm->x_cost, x_norm = sm->x_norm, gmax = sm->gmax, mcc = sm->model_cost_change;
   double radius = sm->radius, mu = sm->mu, step_norm = sm->step_norm;
   Pose T_cur = sm->T_cur, T_eval = sm->T_eval;
-  double x[6], xc[6], S[6], D[6], grad[6], gnv[6];
+  // The LDS copy is the home of the state; registers hold only what the chain is working on (the dogleg vectors D,
+  // grad, gn are read from / written to the copy where they are used: short live ranges keep the wave inside the
+  // 256 architectural VGPRs -- the first version shuttled 650 values per launch through accumulator registers).
+  double x[6], xc[6], S[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    x[i] = sm->x[i]; xc[i] = sm->x_cand[i]; S[i] = sm->S[i]; D[i] = sm->D[i]; grad[i] = sm->grad[i]; gnv[i] = sm->gn[i];
-  }
+  for (int i = 0; i < 6; ++i) { x[i] = sm->x[i]; xc[i] = sm->x_cand[i]; S[i] = sm->S[i]; }
   // ---- the new sweep
   const double cost = tot[27];
   const int sweeps = sm->gn_sweeps + 1;
   const bool eval_reuse = sm->no_eval_reuse == 0;
-  bool dirty_S = false, dirty_dl = false, dirty_x = false;
+  bool dirty_S = false, dirty_x = false;
   bool gn_inside = false;
   for (;;) {
-  double xc_held[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) xc_held[i] = xc[i];
-  const Pose T_held = T_eval;
+  // (the point `tot` was evaluated at is the candidate of the state as it came in -- sm->x_cand / sm->T_eval -- in
+  //  every pass of this loop: a further pass only happens when the new candidate is bit-identical to it)
   const int phase_in = phase;
   bool need_gmax = false;
   bool take_sweep = false;   // the totals of this sweep become the system of the accepted point
@@ -902,7 +901,7 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
     bool lin_ok = true;
     if (!reuse) {  // DoglegStrategy::ComputeStep, fresh
       reuse = 1;
-      dirty_dl = true;
+      double D[6], grad[6], gnv[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         D[i] = fsqrt(fmin(fmax(Hs[ut(i, i)], 1e-6), 1e32));  // min_diagonal_ / max_diagonal_
@@ -921,12 +920,20 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
         mu *= 10.0;
       }
       if (!ok) lin_ok = false;
-      else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) gnv[i] = -D[i] * y[i];
+      for (int i = 0; i < 6; ++i) gnv[i] = ok ? -D[i] * y[i] : sm->gn[i];
+      {  // the dogleg data of this point: LDS copy + device state, one element per lane
+        const int k6 = lane < 6 ? lane : 0;
+        double dv = D[0], gv = grad[0], nv = gnv[0];
+#pragma unroll
+        for (int i = 1; i < 6; ++i) { dv = (k6 == i) ? D[i] : dv; gv = (k6 == i) ? grad[i] : gv; nv = (k6 == i) ? gnv[i] : nv; }
+        if (lane < 6) { sm->D[lane] = dv; sm->grad[lane] = gv; sm->gn[lane] = nv; st->D[lane] = dv; st->grad[lane] = gv; st->gn[lane] = nv; }
       }
       subspace_1d = -1;  // ComputeSubspaceModel is deferred until a step actually leaves the trust region
     }
+    double D[6], grad[6], gnv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { D[i] = sm->D[i]; grad[i] = sm->grad[i]; gnv[i] = sm->gn[i]; }
     TL_STAMP(3)
     double step[6] = {0, 0, 0, 0, 0, 0};
     bool valid = false;
@@ -1033,10 +1040,11 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
     break;  // the next K3 sweep evaluates x_cand
   }
   if (done || !eval_reuse || phase_in != PH_CAND || phase != PH_CAND) break;
-  bool same = T_eval.qw == T_held.qw && T_eval.qx == T_held.qx && T_eval.qy == T_held.qy && T_eval.qz == T_held.qz &&
-              T_eval.tx == T_held.tx && T_eval.ty == T_held.ty && T_eval.tz == T_held.tz;
+  const Pose& Th = sm->T_eval;
+  bool same = T_eval.qw == Th.qw && T_eval.qx == Th.qx && T_eval.qy == Th.qy && T_eval.qz == Th.qz &&
+              T_eval.tx == Th.tx && T_eval.ty == Th.ty && T_eval.tz == Th.tz;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) same = same && (xc[i] == xc_held[i]);
+  for (int i = 0; i < 6; ++i) same = same && (xc[i] == sm->x_cand[i]);
   if (!same) break;
   evals++;  // served from the totals in hand
   }
@@ -1052,10 +1060,6 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
     if (dirty_S) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) st->S[i] = S[i];
-    }
-    if (dirty_dl) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { st->D[i] = D[i]; st->grad[i] = grad[i]; st->gn[i] = gnv[i]; }
     }
     st->phase = phase; st->iteration = iteration; st->invalid = invalid; st->step_successful = step_successful;
     st->reuse = reuse; st->subspace_1d = subspace_1d; st->done = done;
