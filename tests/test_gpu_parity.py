@@ -350,3 +350,22 @@ def test_device_driven_loop_equals_host_driven_loop(hip_module, monkeypatch, sha
         assert rc1 == rc2 == 0
         _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
     H1.close(); H2.close()
+
+
+@pytest.mark.parametrize("shape", ["small", "kitti"])
+def test_fused_sweep_step_is_exact(hip_module, monkeypatch, shape):
+    """KITTI-size sets run a GN iteration as ONE launch (the sweep's last block folds the rows and runs the minimiser
+    step); with TLOAM_NO_FUSED_SMALL the sweep and the step are two launches.  Same row fold, same step: same bits."""
+    sc = (synth.make_scene(seed=23, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT) if shape == "small"
+          else synth.make_scene(seed=24, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT))
+    H1 = hip_module.HipRegistration()
+    H1.set_frames(sc.source, sc.target)
+    monkeypatch.setenv("TLOAM_NO_FUSED_SMALL", "1")      # read once, when the context is created
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    for frame in range(2):
+        rc1, T1, st1 = H1.scan_match(sc.T_pred)
+        rc2, T2, st2 = H2.scan_match(sc.T_pred)
+        assert rc1 == rc2 == 0
+        _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
+    H1.close(); H2.close()

@@ -403,6 +403,10 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps) {
         if (rc != TLOAM_OK) return rc;
         launch_gn_step(c->state.p, c->red48.p, c->stream);
       }
+    } else if (c->k3_single && !c->no_fused_small) {
+      // KITTI-size set: one launch per GN iteration (k_sweep_step_small)
+      launch_sweep_step_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, c->stream);
+      c->batch_launches++;
     } else {
       const int rc = launch_k3_timed(c, false);
       if (rc != TLOAM_OK) return rc;
@@ -495,6 +499,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->dbg_no_build_reuse = getenv("TLOAM_NO_BUILD_REUSE") != nullptr;
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
+  c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||

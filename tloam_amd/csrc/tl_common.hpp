@@ -311,6 +311,8 @@ void launch_solve_init(GnState* st, hipStream_t s);                   // begin o
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s);  // consume a reduced sweep
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s);
+// small sets on one rank: sweep + step in ONE launch (ticket: zero between launches)
+void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s);
 // K4
 struct WeightParams {
   double th1, th2, mu, noise_bound_sq;

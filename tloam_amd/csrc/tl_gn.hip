@@ -413,29 +413,49 @@ __device__ __forceinline__ bool mbox_gather(const MboxView& mb, unsigned long lo
   return ok;
 }
 
-__device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const K3Fuse& fuse) {
+// The block's row is handed over with DEVICE-scope stores (written through to memory: the eight XCDs' L2s do not snoop
+// each other) followed by a wait for their completion and the ticket; the last block reads the rows with device-scope
+// loads.  No cache-wide release / acquire (a `__threadfence()` here writes back and invalidates the whole L2 of the
+// XCD: that is what made round 1's fused sweep + step cost what the launch boundary it removed did).
+__device__ __forceinline__ bool k3_take_ticket(double* __restrict__ partials, const double (*red)[32], int* ticket) {
   __shared__ int s_last;
-  __shared__ double s_grp[8 * 33];
-  __shared__ double s_tot[kReduceBuf];
-  __threadfence();  // this block's row is visible device-wide before the ticket is taken
-  if (threadIdx.x == 0) s_last = (atomicAdd(fuse.ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  if (threadIdx.x < kAccStride)
+    __hip_atomic_store(partials + (size_t)blockIdx.x * kAccStride + threadIdx.x,
+                       ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the wave's stores have completed (vmcnt) ...
+  __syncthreads();                                          // ... in every wave of the block
+  if (threadIdx.x == 0)
+    s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
   __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // acquire: the other blocks' rows
-  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;  // 8 row groups x 32 columns, fixed order
-  const int rows = (int)gridDim.x;
-  double v[4] = {0, 0, 0, 0};
-  for (int b0 = grp; b0 < rows; b0 += 4 * 8) {
+  return s_last != 0;
+}
+// Fixed-order fold of the per-block rows by 256 threads -> tot[0 .. kReduceBuf) in LDS: 8 row groups x 32 columns,
+// sixteen independent loads in flight per thread (a 489-row fold is four rounds), one tree -- the SAME tree whether the
+// rows are folded by the last block of the sweep (AGENT: device-scope loads, the rows come from other XCDs), by the
+// separate reduce kernel or by the step kernel, so the paths agree bit for bit.
+template <bool AGENT>
+__device__ __forceinline__ void fold_rows(const double* __restrict__ partials, int rows, double* s_grp /*[8*33]*/, double* s_tot) {
+  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  constexpr int kU = 16;
+  double v[kU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = b0 + u * 8;
-      // (device-scope load: the rows were written by other XCDs, whose L2 this one does not snoop)
-      const double x = __hip_atomic_load(partials + (size_t)min(r, rows - 1) * kAccStride + comp, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-      v[u] += (r < rows) ? x : 0.0;
+  for (int u = 0; u < kU; ++u) v[u] = 0.0;
+  for (int b0 = grp; b0 < rows; b0 += kU * 8) {
+    double x[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const double* p = partials + (size_t)min(b0 + u * 8, rows - 1) * kAccStride + comp;
+      x[u] = AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
     }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) v[u] += (b0 + u * 8 < rows) ? x[u] : 0.0;
   }
-  s_grp[grp * 33 + comp] = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+  for (int w = kU / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) v[u] += v[u + w];
+  s_grp[grp * 33 + comp] = v[0];
   __syncthreads();
   if (threadIdx.x < kReduceBuf) {
     double t = 0.0;
@@ -443,10 +463,16 @@ __device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partia
 #pragma unroll
       for (int g = 0; g < 8; ++g) t += s_grp[g * 33 + threadIdx.x];
     s_tot[threadIdx.x] = t;
-    fuse.out48[threadIdx.x] = t;
   }
-  if (threadIdx.x == 0) *fuse.ticket = 0;  // re-armed for the next launch (stream order)
   __syncthreads();
+}
+__device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const double (*red)[32], const K3Fuse& fuse) {
+  __shared__ double s_grp[8 * 33];
+  __shared__ double s_tot[kReduceBuf];
+  if (!k3_take_ticket(partials, red, fuse.ticket)) return;
+  fold_rows<true>(partials, (int)gridDim.x, s_grp, s_tot);
+  if (threadIdx.x < kReduceBuf) fuse.out48[threadIdx.x] = s_tot[threadIdx.x];
+  if (threadIdx.x == 0) __hip_atomic_store(fuse.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
   if (fuse.mb.nranks > 0) {
     const unsigned long long id = __hip_atomic_load(fuse.mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
     mbox_post(fuse.mb, id, s_tot, kReduceBuf, threadIdx.x);
@@ -492,10 +518,12 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   const double tot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
-  if (threadIdx.x < kAccStride)
+  if (FUSE) {
+    k3_last_block_reduce(partials, red, fuse);
+  } else if (threadIdx.x < kAccStride) {
     partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-  if (FUSE) k3_last_block_reduce(partials, fuse);
+  }
 #ifdef TLOAM_K3_PROFILE
   if (threadIdx.x == 0) {  // development aid (scripts/k3_profile.py): wave 0's timeline in the spare columns
     const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
@@ -554,36 +582,12 @@ void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid
 //  fixed-order reduction of the per-block rows (one block of 256 threads: 8 row groups x 32 columns)
 // ================================================================================================
 constexpr int kRedThreads = 256;  // one wave per SIMD: the step's wave may use the whole register file (no scratch)
-constexpr int kRedGroups = kRedThreads / 32;  // 8 row groups x 32 columns
-__device__ __forceinline__ void reduce_rows(const double* __restrict__ partials, int rows, double* lds /*[16][33]*/,
-                                            double* out32 /* LDS [32] */) {
-  const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight independent chains: eight loads in flight per lane
-  for (int b0 = grp; b0 < rows; b0 += 8 * kRedGroups) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {  // predicated, so the tail also keeps eight loads in flight
-      const int r = b0 + u * kRedGroups;
-      const double x = partials[(size_t)min(r, rows - 1) * kAccStride + comp];
-      v[u] += (r < rows) ? x : 0.0;
-    }
-  }
-  lds[grp * 33 + comp] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < kRedGroups; ++g) t += lds[g * 33 + threadIdx.x];
-    out32[threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
 __global__ __launch_bounds__(kRedThreads) void k_reduce(const double* __restrict__ partials, int rows,
                                                         const GnState* __restrict__ st, double* __restrict__ out48) {
-  __shared__ double lds[kRedGroups * 33];
-  __shared__ double tot[32];
+  __shared__ double lds[8 * 33];
+  __shared__ double tot[kReduceBuf];
   (void)st;
-  reduce_rows(partials, rows, lds, tot);
+  fold_rows<false>(partials, rows, lds, tot);
   if (threadIdx.x < kReduceBuf) out48[threadIdx.x] = (threadIdx.x < kAccN) ? tot[threadIdx.x] : 0.0;
 }
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s) {
@@ -1225,8 +1229,8 @@ void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream
 // single-GPU fast path: reduce the block rows and advance the minimiser in ONE launch
 __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* __restrict__ partials, int rows,
                                                                  GnState* __restrict__ st) {
-  __shared__ double lds[kRedGroups * 33];
-  __shared__ double tot[32];
+  __shared__ double lds[8 * 33];
+  __shared__ double tot[kReduceBuf];
   __shared__ GnState s_in;
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[0] = (double)__builtin_readcyclecounter();
@@ -1240,12 +1244,55 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
     const unsigned long long w = threadIdx.x < kWords ? reinterpret_cast<const unsigned long long*>(st)[threadIdx.x] : 0ull;
     if (threadIdx.x < kWords) reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = w;
   }
-  reduce_rows(partials, rows, lds, tot);  // (its barriers also publish s_in)
+  fold_rows<false>(partials, rows, lds, tot);  // (its barriers also publish s_in)
   if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
   if (threadIdx.x < 64) TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
+}
+// ---- one GN iteration of a KITTI-size set in ONE launch ----------------------------------------------------------
+// The sweep (one wave per chunk, as k3_accumulate<true, *>) and the minimiser step: every block hands its row over
+// with device-scope stores and takes a ticket (k3_take_ticket: no cache-wide fence), the LAST block folds the rows
+// and runs the step on its first wave.  Every block requests the minimiser state into LDS in its first instructions
+// (which block will be last is not known), so the step starts without a memory round trip of its own.  Against
+// sweep + step as two launches this removes a kernel boundary, the step's dispatch and its row / state loads from the
+// dependent chain of every GN iteration (measured: the hand-over adds 1.8 us to the 3.65 us sweep of a KITTI-cap set).
+__global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __restrict__ seg0, int stride0, int cap0, int pad_,
+                                                             GnState* __restrict__ st, const int* __restrict__ seg_n,
+                                                             double* __restrict__ partials, int* __restrict__ ticket,
+                                                             CorrView cv) {
+  __shared__ double red[4][32];
+  __shared__ double s_grp[8 * 33];
+  __shared__ double tot[kReduceBuf];
+  __shared__ GnState s_in;
+  (void)pad_;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  ChunkBuf<TLOAM_RES_PLANE> pre;
+  const bool spec = (gw + 1) * kChunk <= cap0;
+  if (spec) fetch_spec<false>(seg0, stride0, gw * kChunk + lane * 2, pre);
+  {
+    constexpr int kWords = (int)(sizeof(GnState) / 8);
+    static_assert(kWords <= 256, "one word per thread");
+    if (threadIdx.x < kWords)
+      reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
+  }
+  if (st->done) return;            // after a tolerance exit the remaining launches are no-ops (uniform over the grid)
+  const Rt T = st->Rt_eval;
+  Acc a;
+  sweep_single(cv, seg_n, T, gw, lane, a, pre, spec);
+  const double wtot = wave_reduce_acc(a, lane);
+  if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
+  __syncthreads();
+  if (!k3_take_ticket(partials, red, ticket)) return;
+  fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (threadIdx.x < 64) gn_consume_uniform(st, tot, threadIdx.x, &s_in);
+}
+void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, 0, st,
+                     cv.seg_n, partials, ticket, cv);
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
