@@ -767,11 +767,19 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
   return TLOAM_OK;
 }
-// :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps
-int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate) {
+// :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
+// caps, the compaction AND the alternative (refresh) are one launch (k_prepare_small) -- `also_refresh` says whether this
+// call stands for both alternatives of a device-gated iteration.
+bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv) && !c->no_fused_small; }
+int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate,
+                  const int* refresh_gate = nullptr) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
   launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
                c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+  if (prepare_small_path(c)) {
+    launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
+    return TLOAM_OK;
+  }
   launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
   const double* rank_counts = nullptr;
   if (c->nranks > 1) {
@@ -784,6 +792,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
   // k_frame_init; only a sharded rank can find its cap already filled by the lower ranks and write nothing
   if (c->nranks > 1) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
   launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->state.p, c->stream, gate);
+  if (refresh_gate) launch_refresh(c->sv, c->cv, c->stream, refresh_gate);
   return TLOAM_OK;
 }
 // budget of K3 sweeps of outer iteration `iter`: the most it needed in the last three frames
@@ -976,8 +985,7 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     if (iter == 0) {
       rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
     } else {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build);
-      launch_refresh(c->sv, c->cv, c->stream, run_refresh);
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh);   // both alternatives, device-gated
     }
     if (rc != TLOAM_OK) return rc;
     planned[iter] = planned_sweeps_for(c, iter);

@@ -224,6 +224,10 @@ void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& b
 void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s);
 // same correspondences, new outer iteration: re-capture the weights, zero the side-channel slots
 void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s, const int* gate = nullptr);
+// small single-rank frames: flag scan + caps + compaction (run_build, or always if null) or refresh (run_refresh) in ONE launch
+bool prepare_small_fits(const SlotView& sv);
+void launch_prepare_small(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n, GnState* st,
+                          const int* run_build, const int* run_refresh, hipStream_t s);
 // generic hybrid search (tloam_knn / fitness)
 void launch_knn(const GridView& g, const double* qx, const double* qy, const double* qz, int nq,
                 double radius, int k, int* out_idx, double* out_d2, int* out_cnt, hipStream_t s);

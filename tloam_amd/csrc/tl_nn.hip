@@ -830,6 +830,120 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
   seg.w[pos] = A.sv.w_src[slot];  // weight captured by value at construction (registration.hpp:51,76,96)
   seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
 }
+// ---- small single-rank frames: ONE launch prepares the factor set of an outer iteration --------------------------
+// A KITTI-size frame is a chain of launches that each cost more to start than to run, and the device-driven outer loop
+// enqueues BOTH alternatives of every iteration behind device flags: builders + flag scan + compaction if the pose
+// moved, refresh if it did not -- three launches that exit at once for every one that works.  Here the flag scan is
+// folded into the compaction (every block belongs to one kind and sums that kind's flags in front of it itself: at most
+// ~16 loads per thread, all in flight) and the refresh shares the launch: `run_build` -> scan + caps + compaction,
+// else `run_refresh` -> refresh, else nothing.  Same factor lists, same records (the prefix sums are integers).
+struct PrepareArgs {
+  SlotView sv;
+  CorrView cv;
+  int maxnum[kKinds];
+  int blk_off[kKinds + 1];   // first block of every kind (blocks of 256 slots, per kind)
+  int* seg_n;
+  GnState* st;
+  const int* run_build;      // null: always compact
+  const int* run_refresh;
+};
+__global__ __launch_bounds__(256) void k_prepare_small(PrepareArgs A) {
+  __shared__ unsigned long long wsum[4];
+  __shared__ unsigned long long wpre[4];
+  const bool build = !A.run_build || *A.run_build != 0;
+  if (!build) {
+    if (A.run_refresh && *A.run_refresh != 0) {   // the set of the previous iteration, new captured weights, zeroed slots
+      const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) {
+        const int n = A.cv.seg_n[k];
+        const CorrSeg& seg = A.cv.k[k];
+        for (int i = tid; i < n; i += stride) {
+          seg.w[i] = A.sv.w_src[A.sv.slot_off[k] + (seg.idx[i] - A.sv.src_lo[k])];
+          seg.cost[i] = 0.0;
+        }
+      }
+    }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 6 && A.st) A.st->x_build[threadIdx.x] = A.st->x[threadIdx.x];
+  int kind = 0;
+#pragma unroll
+  for (int k = 1; k < kKinds; ++k) kind += ((int)blockIdx.x >= A.blk_off[k]) ? 1 : 0;
+  const int chunk = (int)blockIdx.x - A.blk_off[kind];
+  const int base = A.sv.slot_off[kind], nk = A.sv.slot_off[kind + 1] - base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // packed (counted | valid << 32) flags: own slot + this thread's column of every earlier chunk of the kind
+  const int local = chunk * 256 + (int)threadIdx.x;
+  const unsigned long long f = local < nk ? A.sv.flags[base + local] : 0ull;
+  unsigned long long before = 0ull;
+  for (int c0 = 0; c0 < chunk; c0 += 8) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (c0 + u < chunk) ? A.sv.flags[base + (c0 + u) * 256 + (int)threadIdx.x] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) before += v[u];
+  }
+  // block totals of `before` (the kind's flags in front of this block) and the exclusive scan of the block's own flags
+  unsigned long long incl = f;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+  if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wpre[wave] = before;
+  __syncthreads();
+  unsigned long long pre = (wpre[0] + wpre[1]) + (wpre[2] + wpre[3]);
+  for (int w = 0; w < wave; ++w) pre += wsum[w];
+  const unsigned long long sc = pre + incl - f, sn = pre + incl;
+  if (local >= nk) return;
+  const long long C = (long long)(sc & 0xffffffffull), Cn = (long long)(sn & 0xffffffffull);
+  const int V = (int)(sc >> 32), Vn = (int)(sn >> 32);
+  const long long maxnum = (long long)A.maxnum[kind];
+  // number of factors of this kind = V just past the LAST slot whose C is still below the cap (see k_compact)
+  const bool last_slot = (local + 1 == nk);
+  if (C < maxnum && (last_slot || Cn >= maxnum)) A.seg_n[kind] = Vn;
+  if ((f >> 32) == 0ull) return;  // not valid
+  if (C >= maxnum) return;
+  const CorrSeg& seg = A.cv.k[kind];
+  if (V >= seg.cap) return;
+  const int slot = base + local, pos = V;
+  seg.idx[pos] = local + A.sv.src_lo[kind];
+  seg.px[pos] = A.sv.sx[slot]; seg.py[pos] = A.sv.sy[slot]; seg.pz[pos] = A.sv.sz[slot];
+  const double2* q = reinterpret_cast<const double2*>(A.sv.raw + (size_t)slot * 8);
+  const double2 q0 = q[0], q1 = q[1];
+  seg.ax[pos] = q0.x; seg.ay[pos] = q0.y; seg.az[pos] = q1.x;
+  if (kind == TLOAM_KIND_EDGE) {
+    const double2 q2 = q[2];
+    seg.bx[pos] = q1.y; seg.by[pos] = q2.x; seg.bz[pos] = q2.y;
+  }
+  if (kind <= TLOAM_KIND_GROUND) seg.d[pos] = q[3].x;
+  seg.w[pos] = A.sv.w_src[slot];  // weight captured by value at construction (registration.hpp:51,76,96)
+  seg.cost[pos] = 0.0;            // fresh side-channel slot (registration.cpp:1118-1121)
+}
+bool prepare_small_fits(const SlotView& sv) { return sv.slot_off[kKinds] <= 16384; }
+void launch_prepare_small(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n, GnState* st,
+                          const int* run_build, const int* run_refresh, hipStream_t s) {
+  PrepareArgs A;
+  A.sv = sv;
+  A.cv = cv;
+  int blocks = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    A.maxnum[k] = bp.maxnum[k];
+    A.blk_off[k] = blocks;
+    blocks += (sv.slot_off[k + 1] - sv.slot_off[k] + 255) / 256;
+  }
+  A.blk_off[kKinds] = blocks;
+  A.seg_n = seg_n;
+  A.st = st;
+  A.run_build = run_build;
+  A.run_refresh = run_refresh;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_prepare_small, dim3(blocks), dim3(256), 0, s, A);
+}
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
                     const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate) {
   const int n = sv.slot_off[kKinds];
