@@ -255,9 +255,15 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   }
   if (cell_total == 0) return TLOAM_OK;
   launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream);
-  launch_exclusive_scan_u64(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
-  launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, G.cell_cnt.p, c->stream);
-  launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.rank_of_pt.p, G.gp.p, c->stream);
+  const int tiles = scan_tiles_only(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
+  if (tiles > 0) {
+    launch_grid_finalize_scatter_all(gs, G.cell_scan.p, G.scan_tmp.p, tiles, G.cell_start.p, G.cell_cnt.p, G.cell_of_pt.p,
+                                     G.rank_of_pt.p, G.gp.p, c->stream);
+  } else {
+    launch_exclusive_scan_u64(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
+    launch_grid_finalize_all(gs, G.cell_scan.p, G.cell_start.p, G.cell_cnt.p, c->stream);
+    launch_grid_scatter_all(gs, G.cell_of_pt.p, G.cell_scan.p, G.rank_of_pt.p, G.gp.p, c->stream);
+  }
   return TLOAM_OK;
 }
 int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridView out[kKinds]) {

@@ -193,6 +193,12 @@ void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int*
                            hipStream_t s);
 void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start,
                               unsigned long long* cell_cnt /* re-zeroed */, hipStream_t s);
+// medium-size builds: tile-local scan only (returns the tile count, 0 = not applicable), then finalize + scatter in ONE
+// launch that adds the tiles' offsets itself -- three launches per build instead of five
+int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s);
+void launch_grid_finalize_scatter_all(const GridSet& gs, const unsigned long long* cell_scan, const unsigned long long* totals,
+                                      int tiles, int* cell_start, unsigned long long* cell_cnt, const int* cell_of_pt,
+                                      const int* rank_of_pt, double4* gp, hipStream_t s);
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
                              const int* rank_of_pt, double4* gp, hipStream_t s);
 

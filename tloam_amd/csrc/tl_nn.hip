@@ -209,6 +209,15 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
   }
 }
 
+// first half of the medium-size scan only: tile-local exclusive scans + per-tile totals (the consumer adds the tiles'
+// offsets itself, see k_grid_finalize_scatter_all).  Returns the number of tiles; 0 = not applicable (use the full scan).
+int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s) {
+  const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  if (n <= (size_t)kSmallTile || tiles > 1024) return 0;
+  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals, (const int*)nullptr);
+  return (int)tiles;
+}
+
 // ================================================================================================
 //  grid build
 // ================================================================================================
@@ -312,6 +321,68 @@ __global__ void k_grid_scatter_all(GridSet gs, const int* __restrict__ cell_of_p
     gp[gs.tgt_off[k] + pos] =
         double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
   }
+}
+// finalize + scatter in ONE launch, straight from the TILE-LOCAL scan: every block first turns the (<= 1024) tile totals
+// into tile offsets in LDS (what k_scan_add_direct would add in place in a launch of its own), then blocks
+// [0, fin_blocks) of every kind write the cell table and re-zero the histogram, the others scatter the points.
+__global__ __launch_bounds__(256) void k_grid_finalize_scatter_all(GridSet gs, const unsigned long long* __restrict__ cell_scan,
+                                                                   const unsigned long long* __restrict__ totals, int tiles,
+                                                                   int fin_blocks, int* __restrict__ cell_start,
+                                                                   unsigned long long* __restrict__ cell_cnt,
+                                                                   const int* __restrict__ cell_of_pt,
+                                                                   const int* __restrict__ rank_of_pt, double4* __restrict__ gp) {
+  __shared__ unsigned long long toff[1024];
+  __shared__ unsigned long long wtot[4];
+  {  // exclusive prefix of the tile totals: 4 consecutive tiles per thread
+    const int t0 = threadIdx.x * 4;
+    unsigned long long v[4], run = 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = (t0 + u < tiles) ? totals[t0 + u] : 0ull; run += v[u]; }
+    unsigned long long incl = run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long pre = incl - run;
+    for (int w = 0; w < wave; ++w) pre += wtot[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { toff[t0 + u] = pre; pre += v[u]; }
+    __syncthreads();
+  }
+  const int k = blockIdx.y;
+  const long long ncell = gs.ncell[k], base = gs.cell_base[k];
+  const unsigned long long first = cell_scan[base] + toff[base / kScanTile];
+  if ((int)blockIdx.x < fin_blocks) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)fin_blocks * 256;
+    for (; i <= ncell; i += stride) {
+      cell_start[base + k + i] = (i < ncell) ? (int)(cell_scan[base + i] + toff[(base + i) / kScanTile] - first) : gs.n[k];
+      cell_cnt[base + i] = 0ull;  // the histogram has been scanned: leave it empty for the next build (no memset per frame)
+    }
+  } else {
+    const int n = gs.n[k];
+    const int nb = (int)gridDim.x - fin_blocks;
+    for (int i = ((int)blockIdx.x - fin_blocks) * 256 + threadIdx.x; i < n; i += nb * 256) {
+      const int c = cell_of_pt[gs.tgt_off[k] + i];
+      const int pos = (int)(cell_scan[base + c] + toff[(base + c) / kScanTile] - first) + rank_of_pt[gs.tgt_off[k] + i];
+      gp[gs.tgt_off[k] + pos] = double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
+    }
+  }
+}
+void launch_grid_finalize_scatter_all(const GridSet& gs, const unsigned long long* cell_scan, const unsigned long long* totals,
+                                      int tiles, int* cell_start, unsigned long long* cell_cnt, const int* cell_of_pt,
+                                      const int* rank_of_pt, double4* gp, hipStream_t s) {
+  long long m = 1;
+  for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.ncell[k] + 1);
+  const int fin_blocks = (int)std::min<long long>((m + 255) / 256, 2048);
+  int sc_blocks = (max_n(gs) + 255) / 256;
+  if (sc_blocks > 1024) sc_blocks = 1024;
+  hipLaunchKernelGGL(k_grid_finalize_scatter_all, dim3(fin_blocks + sc_blocks, kKinds), dim3(256), 0, s, gs, cell_scan, totals,
+                     tiles, fin_blocks, cell_start, cell_cnt, cell_of_pt, rank_of_pt, gp);
 }
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
                              const int* rank_of_pt, double4* gp, hipStream_t s) {
