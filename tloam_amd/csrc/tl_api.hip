@@ -171,7 +171,7 @@ static void reduce_box_rows(const double* box_rows, double boxes[kKinds][6]) {
 }
 // known_boxes: the clouds' bounds are already on the host (targets: taken at set_target) -- no launch, no wait
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], const CloudRef clouds[kKinds],
-                     GridView out[kKinds], const double (*known_boxes)[6]) {
+                     GridView out[kKinds], const double (*known_boxes)[6], FrameInitHook* frame) {
   GridSet gs;
   memset(&gs, 0, sizeof(gs));
   size_t tgt_total = 0;
@@ -254,7 +254,14 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     out[k].cell_start = G.cell_start.p + gs.cell_base[k] + k;
   }
   if (cell_total == 0) return TLOAM_OK;
-  launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream);
+  if (frame) {  // the start of the scan_match rides on the first launch (the query-tile histogram is sized by the grids)
+    const size_t ntiles = (size_t)build_tile_count(out, frame->n_slots);
+    HIPC(c, c->tile_cnt.reserve(ntiles + 1));
+    frame->fi.tile_cnt = c->tile_cnt.p;
+    frame->fi.n_tile_cnt = (int)ntiles + 1;
+    frame->consumed = true;
+  }
+  launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream, frame);
   const int tiles = scan_tiles_only(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
   if (tiles > 0) {
     launch_grid_finalize_scatter_all(gs, G.cell_scan.p, G.scan_tmp.p, tiles, G.cell_start.p, G.cell_cnt.p, G.cell_of_pt.p,
@@ -266,7 +273,7 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   }
   return TLOAM_OK;
 }
-int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridView out[kKinds]) {
+int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridView out[kKinds], FrameInitHook* frame) {
   CloudRef clouds[kKinds];
   bool known = true;
   for (int k = 0; k < kKinds; ++k) {
@@ -274,7 +281,7 @@ int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridV
     clouds[k] = CloudRef{K.tx.p, K.ty.p, K.tz.p, K.tgt_set ? K.n_tgt : 0};
     if (radius[k] > 0.0 && clouds[k].n > 0 && !c->tgt_box_valid[k]) known = false;
   }
-  return build_grids_over(c, G, radius, clouds, out, known ? c->tgt_box : nullptr);
+  return build_grids_over(c, G, radius, clouds, out, known ? c->tgt_box : nullptr, frame);
 }
 // bounds of the target clouds registered so far, taken while the hand-over call is synchronising anyway
 int enqueue_target_bounds(tloam_ctx* c) {
@@ -678,16 +685,6 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   }
   int rc = ensure_common(c);
   if (rc != TLOAM_OK) return rc;
-  // ---- :889-915 four search structures over the submap clouds: one launch per build phase for all kinds,
-  //      one host sync (bounding boxes)
-  {
-    double radius[kKinds];
-    GridView views[kKinds];
-    for (int k = 0; k < kKinds; ++k) radius[k] = kind_radius(c->cfg, k);
-    rc = build_grids(c, c->grids, radius, views);
-    if (rc != TLOAM_OK) return rc;
-    for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
-  }
   // ---- per-source-slot arrays (:931-949 weights = 1, residual slots = 0)
   size_t off = 0;
   for (int k = 0; k < kKinds; ++k) {
@@ -716,23 +713,34 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   c->k3_grid = k3_grid_for((int)total_cap);
   c->k3_single = k3_single_pass((int)total_cap, c->k3_grid);
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
-  // ---- ONE launch: scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
-  //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve
+  // ---- the start of the frame -- scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
+  //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve -- rides on the
+  //      first launch of the grid build
+  FrameInitHook hook;
+  memset(&hook, 0, sizeof(hook));
+  for (int k = 0; k < kKinds; ++k) { hook.fi.src_aos[k] = c->kd[k].src_aos.p; hook.fi.slot_off[k] = c->sv.slot_off[k]; }
+  hook.fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
+  for (int i = 0; i < 6; ++i) hook.fi.x[i] = x[i];
+  hook.fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
+  hook.b = FrameInitBufs{c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p};
+  hook.n_slots = c->sv.slot_off[kKinds];
+  // ---- :889-915 four search structures over the submap clouds: one launch per build phase for all kinds
   {
-    FrameInit fi;
-    for (int k = 0; k < kKinds; ++k) { fi.src_aos[k] = c->kd[k].src_aos.p; fi.slot_off[k] = c->sv.slot_off[k]; }
-    fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
-    for (int i = 0; i < 6; ++i) fi.x[i] = x[i];
-    fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
-    {
-      GridView gviews[kKinds];
-      for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
-      const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off[kKinds]);
-      HIPC(c, c->tile_cnt.reserve(ntiles + 1));
-      fi.tile_cnt = c->tile_cnt.p;
-      fi.n_tile_cnt = (int)ntiles + 1;
-    }
-    launch_frame_init(fi, c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p, c->stream);
+    double radius[kKinds];
+    GridView views[kKinds];
+    for (int k = 0; k < kKinds; ++k) radius[k] = kind_radius(c->cfg, k);
+    rc = build_grids(c, c->grids, radius, views, &hook);
+    if (rc != TLOAM_OK) return rc;
+    for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
+  }
+  if (!hook.consumed) {  // (no grid launch: cannot happen with >= 10 targets per kind, kept for safety)
+    GridView gviews[kKinds];
+    for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
+    const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off[kKinds]);
+    HIPC(c, c->tile_cnt.reserve(ntiles + 1));
+    hook.fi.tile_cnt = c->tile_cnt.p;
+    hook.fi.n_tile_cnt = (int)ntiles + 1;
+    launch_frame_init(hook.fi, hook.b, c->stream);
   }
   c->wait_us = 0.0;
   c->mu = 1.0;  // :961

@@ -188,9 +188,82 @@ struct GridSet {
   double inv_cell[kKinds];
   int dim[kKinds][3];
 };
+struct FrameInit {
+  const double* src_aos[kKinds];
+  int slot_off[kKinds + 1];
+  double x[6];
+  int no_eval_reuse;  // development knob, copied into the state
+  unsigned long long* tile_cnt;  // query-tile histogram of the first builder pass, zeroed here (n_tile_cnt entries)
+  int n_tile_cnt;
+};
+struct FrameInitBufs {
+  double *sx, *sy, *sz, *w_src;
+  unsigned long long* flags;
+  GnState* st;
+  int* seg_n;
+};
+// start of a scan_match folded into the first launch of the grid build (k_grid_count_all): `on` = 0 leaves the launch
+// as it was; `consumed` tells the caller whether a launch carried it (no targets at all = no grid launch)
+struct FrameInitHook {
+  FrameInit fi;
+  FrameInitBufs b;
+  int n_slots;
+  bool consumed;
+};
+#if defined(__HIPCC__)
+// start-of-Solve values of the minimiser (Ceres defaults: initial_trust_region_radius 1e4, min_mu 1e-8);
+// the sweep point is the current pose
+__device__ __forceinline__ void arm_solver(GnState& s) {
+  s.radius = 1e4;
+  s.mu = 1e-8;
+  s.reuse = 0;
+  s.subspace_1d = 0;
+  s.phase = PH_ITER0;
+  s.iteration = 0;
+  s.invalid = 0;
+  s.step_successful = 1;
+  s.done = 0;
+  s.gmax = 1e300;
+  s.T_eval = s.T_cur;
+  s.Rt_eval = to_rt(s.T_cur);
+}
+// Start of a scan_match: de-interleave the four source clouds into the concatenated SoA slot arrays, set the GNC
+// weights to 1 and the flag-scan terminator to 0 (registration.cpp:931-949); block 0 also zeroes the minimiser state,
+// installs `parameters` = log(predict) (:881) and arms the first Solve.  Called by `nblocks` blocks of 256 threads.
+__device__ __forceinline__ void frame_init_body(const FrameInit& fi, const FrameInitBufs& b, int block, int nblocks) {
+  const int n = fi.slot_off[kKinds];
+  for (int slot = block * 256 + (int)threadIdx.x; slot < n; slot += nblocks * 256) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < kKinds; ++q) k += (slot >= fi.slot_off[q]) ? 1 : 0;
+    const double* a = fi.src_aos[k] + 3 * (size_t)(slot - fi.slot_off[k]);
+    b.sx[slot] = a[0]; b.sy[slot] = a[1]; b.sz[slot] = a[2];
+    b.w_src[slot] = 1.0;
+  }
+  for (int i = block * 256 + (int)threadIdx.x; i < fi.n_tile_cnt; i += nblocks * 256) fi.tile_cnt[i] = 0ull;
+  if (block == 0) {
+    constexpr int kWords = (int)(sizeof(GnState) / sizeof(double));
+    for (int i = threadIdx.x; i < kWords; i += 256) reinterpret_cast<double*>(b.st)[i] = 0.0;
+    if (threadIdx.x < 8) b.seg_n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) b.flags[n] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      GnState* st = b.st;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) st->x[i] = fi.x[i];
+      st->T_cur = se3_exp(st->x);
+      st->no_eval_reuse = fi.no_eval_reuse;
+      st->prev_planar = __builtin_inf();   // registration.cpp:952-959
+      st->run_build = 1;                   // the first outer iteration always builds
+      arm_solver(*st);
+    }
+  }
+}
+#endif
+void launch_frame_init(const FrameInit& fi, const FrameInitBufs& b, hipStream_t s);
 void launch_bbox_all(const GridSet& gs, double* out /*[4][64][6], device or pinned host*/, hipStream_t s);
 void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
-                           hipStream_t s);
+                           hipStream_t s, const FrameInitHook* frame = nullptr);
 void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_scan, int* cell_start,
                               unsigned long long* cell_cnt /* re-zeroed */, hipStream_t s);
 // medium-size builds: tile-local scan only (returns the tile count, 0 = not applicable), then finalize + scatter in ONE
@@ -209,16 +282,6 @@ struct BuildParams {
   double edge_dir_thres;
 };
 // start-of-frame initialisation, one launch
-struct FrameInit {
-  const double* src_aos[kKinds];
-  int slot_off[kKinds + 1];
-  double x[6];
-  int no_eval_reuse;  // development knob, copied into the state
-  unsigned long long* tile_cnt;  // query-tile histogram of the first builder pass, zeroed here (n_tile_cnt entries)
-  int n_tile_cnt;
-};
-void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, double* w_src,
-                       unsigned long long* flags, GnState* st, int* seg_n, hipStream_t s);
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,

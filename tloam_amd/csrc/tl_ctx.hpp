@@ -215,8 +215,10 @@ struct tloam_ctx {
 namespace tlh {
 // tl_api.hip
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
-                     tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr);
-int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], tl::GridView out[tl::kKinds]);
+                     tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr,
+                     tl::FrameInitHook* frame = nullptr);
+int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], tl::GridView out[tl::kKinds],
+                tl::FrameInitHook* frame = nullptr);
 int enqueue_target_bounds(tloam_ctx* c);
 void finish_target_bounds(tloam_ctx* c);
 }  // namespace tlh

@@ -1074,22 +1074,6 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
   }
 }
 #define TL_GN_CONSUME gn_consume_uniform
-// start-of-Solve values of the minimiser (Ceres defaults: initial_trust_region_radius 1e4, min_mu 1e-8);
-// the sweep point is the current pose
-__device__ __forceinline__ void arm_solver(GnState& s) {
-  s.radius = 1e4;
-  s.mu = 1e-8;
-  s.reuse = 0;
-  s.subspace_1d = 0;
-  s.phase = PH_ITER0;
-  s.iteration = 0;
-  s.invalid = 0;
-  s.step_successful = 1;
-  s.done = 0;
-  s.gmax = 1e300;
-  s.T_eval = s.T_cur;
-  s.Rt_eval = to_rt(s.T_cur);
-}
 __global__ void k_solve_init(GnState* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->T_cur = se3_exp(st->x);
@@ -1097,46 +1081,16 @@ __global__ void k_solve_init(GnState* st) {
 }
 void launch_solve_init(GnState* st, hipStream_t s) { hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(64), 0, s, st); }
 
-// Start of a scan_match in one launch: de-interleave the four source clouds into the concatenated SoA slot
-// arrays, set the GNC weights to 1 and the flag-scan terminator to 0 (registration.cpp:931-949); block 0
-// also zeroes the minimiser state, installs `parameters` = log(predict) (:881) and arms the first Solve.
-__global__ __launch_bounds__(256) void k_frame_init(FrameInit fi, double* __restrict__ sx, double* __restrict__ sy,
-                                                    double* __restrict__ sz, double* __restrict__ w_src,
-                                                    unsigned long long* __restrict__ flags, GnState* st,
-                                                    int* __restrict__ seg_n) {
-  const int n = fi.slot_off[kKinds];
-  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
-    int k = 0;
-#pragma unroll
-    for (int q = 1; q < kKinds; ++q) k += (slot >= fi.slot_off[q]) ? 1 : 0;
-    const double* a = fi.src_aos[k] + 3 * (size_t)(slot - fi.slot_off[k]);
-    sx[slot] = a[0]; sy[slot] = a[1]; sz[slot] = a[2];
-    w_src[slot] = 1.0;
-  }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < fi.n_tile_cnt; i += gridDim.x * 256) fi.tile_cnt[i] = 0ull;
-  if (blockIdx.x == 0) {
-    constexpr int kWords = (int)(sizeof(GnState) / sizeof(double));
-    for (int i = threadIdx.x; i < kWords; i += 256) reinterpret_cast<double*>(st)[i] = 0.0;
-    if (threadIdx.x < 8) seg_n[threadIdx.x] = 0;
-    if (threadIdx.x == 0) flags[n] = 0ull;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) st->x[i] = fi.x[i];
-      st->T_cur = se3_exp(st->x);
-      st->no_eval_reuse = fi.no_eval_reuse;
-      st->prev_planar = __builtin_inf();   // registration.cpp:952-959
-      st->run_build = 1;                   // the first outer iteration always builds
-      arm_solver(*st);
-    }
-  }
+// Start of a scan_match as a launch of its own (frame_init_body, tl_common.hpp); normally the first launch of the grid
+// build carries it (k_grid_count_all)
+__global__ __launch_bounds__(256) void k_frame_init(FrameInit fi, FrameInitBufs b) {
+  frame_init_body(fi, b, (int)blockIdx.x, (int)gridDim.x);
 }
-void launch_frame_init(const FrameInit& fi, double* sx, double* sy, double* sz, double* w_src,
-                       unsigned long long* flags, GnState* st, int* seg_n, hipStream_t s) {
+void launch_frame_init(const FrameInit& fi, const FrameInitBufs& b, hipStream_t s) {
   const int n = fi.slot_off[kKinds];
   int blocks = (n + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, s, fi, sx, sy, sz, w_src, flags, st, seg_n);
+  hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, s, fi, b);
 }
 
 __global__ void k_set_eval(GnState* st, const double* se3) {

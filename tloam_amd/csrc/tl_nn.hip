@@ -18,6 +18,7 @@
 // eig[2] > 3 eig[1], |dir.z| > 0.85, plane validity > 0.2, knn_dist > 0.2) are evaluated with
 // the same un-fused fp64 operation order as the CPU oracle, so a correspondence flips in/out on
 // the device only where it flips on the host.
+#include <string.h>
 #include <algorithm>
 
 #include "tl_common.hpp"
@@ -262,9 +263,15 @@ void launch_bbox_all(const GridSet& gs, double* out, hipStream_t s) {
 }
 
 
-__global__ void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ cell_cnt, int* __restrict__ cell_of_pt,
-                                 int* __restrict__ rank_of_pt) {
+// (y == kKinds: the rows of blocks that carry the start of the scan_match, see FrameInitHook)
+__global__ __launch_bounds__(256) void k_grid_count_all(GridSet gs, unsigned long long* __restrict__ cell_cnt,
+                                                        int* __restrict__ cell_of_pt, int* __restrict__ rank_of_pt,
+                                                        FrameInit fi, FrameInitBufs fb) {
   const int k = blockIdx.y;
+  if (k == kKinds) {
+    frame_init_body(fi, fb, (int)blockIdx.x, (int)gridDim.x);
+    return;
+  }
   const int n = gs.n[k];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int cx = clampi(cell_coord(gs.tx[k][i], gs.org[k][0], gs.inv_cell[k], gs.dim[k][0]), 0, gs.dim[k][0] - 1);
@@ -282,10 +289,16 @@ static int max_n(const GridSet& gs) {
   return m;
 }
 void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
-                           hipStream_t s) {
+                           hipStream_t s, const FrameInitHook* frame) {
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_grid_count_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_cnt, cell_of_pt, rank_of_pt);
+  FrameInit fi;
+  FrameInitBufs fb;
+  memset(&fi, 0, sizeof(fi));
+  memset(&fb, 0, sizeof(fb));
+  if (frame) { fi = frame->fi; fb = frame->b; }
+  hipLaunchKernelGGL(k_grid_count_all, dim3(blocks, kKinds + (frame ? 1 : 0)), dim3(256), 0, s, gs, cell_cnt, cell_of_pt,
+                     rank_of_pt, fi, fb);
 }
 // cell_start of kind k lives at cell_start[cell_base[k] + k ...] (ncell + 1 entries per kind), relative to the
 // kind's own point block

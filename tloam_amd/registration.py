@@ -241,6 +241,11 @@ class HipRegistration:
                                 "this path has no CPU fallback")
         self._n = {}
         self._cb = None
+        # marshalling buffers of scan_match (column-major 4x4 in / out), allocated once: the binding adds ~3 us per
+        # call instead of ~10
+        self._pred_buf, self._res_buf = (C.c_double * 16)(), (C.c_double * 16)()
+        self._pred_view = np.frombuffer(self._pred_buf).reshape(4, 4).T
+        self._res_view = np.frombuffer(self._res_buf).reshape(4, 4).T
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -310,14 +315,15 @@ class HipRegistration:
         self.set_input_target(target)
 
     def scan_match(self, predict, omega=None, scan=None):
-        res = np.zeros(16)
+        self._pred_view[...] = predict
+        self._res_view[...] = 0.0
         st = Stats()
         om = None if omega is None else np.ascontiguousarray(omega, float)
         if scan is not None:
             assert scan.dtype == np.float64 and scan.flags.c_contiguous
-        rc = self.L.tloam_scan_match(self.h, _dp(_colmajor(predict)), _dp(om), _dp(res), _dp(scan),
+        rc = self.L.tloam_scan_match(self.h, self._pred_buf, _dp(om), self._res_buf, _dp(scan),
                                      0 if scan is None else len(scan), C.byref(st))
-        return rc, res.reshape(4, 4).T.copy(), st.as_dict()
+        return rc, self._res_view.copy(), st.as_dict()
 
     def sm_begin(self, predict, omega=None):
         om = None if omega is None else np.ascontiguousarray(omega, float)
