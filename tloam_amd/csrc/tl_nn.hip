@@ -587,30 +587,44 @@ __global__ __launch_bounds__(256) void k_query_scatter(SlotView sv, const int* _
 //            their packed-key lists with two (four) xor-shuffle rounds; lane 0 of the group finishes the fit.
 template <int K, int LPQ>
 __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk,
-                                         int2* __restrict__ lds_rows) {
+                                         int2* __restrict__ lds_rows, double radius) {
   const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
   const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
   const int cz = cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]);
-  int x0 = cx - 1, x1 = cx + 1;
+  int x0 = cx - 1;
   if (x0 < 0) x0 = 0;
-  if (x1 >= g.dim[0]) x1 = g.dim[0] - 1;
   constexpr int NR = (9 + LPQ - 1) / LPQ;  // rows per lane
   int rs[NR], re[NR];
-  // The row's two table entries (start of cell x0, end of cell x1) are at most three ints apart: ONE 16-byte
-  // request per row instead of two 4-byte ones -- K1 is bound by the number of scattered requests the CU's
-  // address unit retires (~55 per query), not by bytes.  (Reads up to 12 bytes past the last entry of the
-  // table: inside the allocation slack of DBuf.)
+  // CLIPPED walk: only the cells the search ball can reach.  A neighbour is kept only below the radius (radius_cut), so
+  // a cell whose nearest point is farther than radius * (1 + 1e-6) from the query holds nothing that can be kept: per
+  // axis the distance to the lower / upper neighbour slab follows from the query's position inside its own cell, a row
+  // (dy, dz) is walked only if dy^2 + dz^2 <= reach^2 and its outer cells only if the x term still fits.  With
+  // cell = radius, on average 20.6 of the 27 cells survive (the volume of cube (+) ball): a quarter of the candidate
+  // records is never fetched.  The margin (2e-6 relative on the squares) dwarfs the rounding of these few products.
+  const double cl = g.cell, reach = radius * (1.0 + 1e-6), c2 = reach * reach;
+  const double fx = (pw.x - g.org[0]) * g.inv_cell - (double)cx, fy = (pw.y - g.org[1]) * g.inv_cell - (double)cy,
+               fz = (pw.z - g.org[2]) * g.inv_cell - (double)cz;
+  const double dxl = fx * cl, dxr = (1.0 - fx) * cl, dyl = fy * cl, dyr = (1.0 - fy) * cl, dzl = fz * cl, dzr = (1.0 - fz) * cl;
+  const double sxl = dxl * dxl, sxr = dxr * dxr, syl = dyl * dyl, syr = dyr * dyr, szl = dzl * dzl, szr = dzr * dzr;
+  // The row's table entries (start of its first cell, end of its last) are at most three ints apart: ONE 16-byte
+  // request per row instead of two 4-byte ones.  (Reads up to 12 bytes past the last entry of the table: inside the
+  // allocation slack of DBuf.)
   typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
-  const int span = x1 + 1 - x0;  // 1 .. 3 (<= 0: no cell in range)
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int r = sub + i * LPQ;
-    const int z = cz - 1 + r / 3, y = cy - 1 + r % 3;
-    const bool in = (r < 9) && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+    const int rz = r / 3, ry = r % 3;
+    const int z = cz - 1 + rz, y = cy - 1 + ry;
+    const double s2 = (rz == 0 ? szl : (rz == 2 ? szr : 0.0)) + (ry == 0 ? syl : (ry == 2 ? syr : 0.0));
+    int xa = cx - ((s2 + sxl <= c2) ? 1 : 0), xb = cx + ((s2 + sxr <= c2) ? 1 : 0);
+    if (xa < 0) xa = 0;
+    if (xb >= g.dim[0]) xb = g.dim[0] - 1;
+    const bool in = (r < 9) && (s2 <= c2) && (xa <= xb) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
     const size_t base = in ? ((size_t)z * g.dim[1] + y) * g.dim[0] + x0 : 0;
     const int4u t = *reinterpret_cast<const int4u*>(g.cell_start + base);
-    rs[i] = in ? t.x : 0;
-    re[i] = in ? (span == 3 ? t.w : (span == 2 ? t.z : t.y)) : 0;
+    const int ia = xa - x0, ib = xb + 1 - x0;  // 0..1, 1..3
+    rs[i] = in ? (ia == 0 ? t.x : t.y) : 0;
+    re[i] = in ? (ib == 3 ? t.w : (ib == 2 ? t.z : t.y)) : 0;
   }
   topk_clear<K>(tk);
   if (LPQ == 1) {
@@ -658,6 +672,9 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     for (int u = 0; u < kCpt; ++u) next(jc[u], vc[u]);
 #pragma unroll
     for (int u = 0; u < kCpt; ++u) rc[u] = pts.p[jc[u]];
+#ifdef TLOAM_K1_DBG_NOWALK  // timing experiment only: row resolution and the first trip, no candidate loop
+    total = 0;
+#endif
     for (int left = total; __any(left > 0); left -= kCpt) {
       int jn[kCpt];
       bool vn[kCpt];
@@ -759,12 +776,16 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
   const double radius = A.bp.radius[kind];
   if (kind == TLOAM_KIND_SPHERE) {
     TopK<1> tk;
-    knn_rows<1, LPQ>(g, pts, pw, sub, tk, lds_rows);
+    knn_rows<1, LPQ>(g, pts, pw, sub, tk, lds_rows, radius);
     if (sub == 0) finish_sphere<PtsGlobal>(pts, tk, radius, rec);
   } else {
     TopK<5> tk;
-    knn_rows<5, LPQ>(g, pts, pw, sub, tk, lds_rows);
+    knn_rows<5, LPQ>(g, pts, pw, sub, tk, lds_rows, radius);
+#ifdef TLOAM_K1_DBG_NOFIT   // timing experiment only: the walk without the per-query fit
+    if (sub == 0) { rec.a[0] = tk.d[0] + tk.d[4]; rec.flag = (tk.j[4] >= 0) ? ((1ull << 32) | 1ull) : 0ull; }
+#else
     if (sub == 0) finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
+#endif
   }
   if (sub == 0) store_raw(A.sv, slot, rec);
 }
