@@ -1273,20 +1273,35 @@ __global__ __launch_bounds__(256) void k_weights(WeightArgs A, double* __restric
   for (int k = 0; k < kKinds; ++k) {
     const int n = A.cv.seg_n[k];
     const CorrSeg& seg = A.cv.k[k];
-    for (int i = tid; i < n; i += stride) {
-      const double c = seg.cost[i];
-      sum[k] += c;
-      if (!A.wp.active[k]) continue;
-      if (c == 0) continue;                          // :862
-      double w;
-      if (c >= A.wp.th1) w = 0.0;                    // :865
-      else if (c <= A.wp.th2) w = 1.0;               // :867
-      else {
-        w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
-        if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+    // four strided elements per trip, their (cost, index) pairs requested together (the loop is a chain of memory
+    // round trips: 14 per thread on a 1 M set); consumed in the same order as one by one, so the sums keep their bits
+    constexpr int kU = 4;
+    for (int i0 = tid; i0 < n; i0 += kU * stride) {
+      double cu[kU];
+      int iu[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * stride;
+        cu[u] = (i < n) ? seg.cost[i] : 0.0;
+        iu[u] = (i < n) ? seg.idx[i] : 0;
       }
-      const int slot = A.sv.slot_off[k] + (seg.idx[i] - A.sv.src_lo[k]);
-      A.sv.w_src[slot] = w;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (i0 + u * stride >= n) break;
+        const double c = cu[u];
+        sum[k] += c;
+        if (!A.wp.active[k]) continue;
+        if (c == 0) continue;                          // :862
+        double w;
+        if (c >= A.wp.th1) w = 0.0;                    // :865
+        else if (c <= A.wp.th2) w = 1.0;               // :867
+        else {
+          w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+          if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+        }
+        const int slot = A.sv.slot_off[k] + (iu[u] - A.sv.src_lo[k]);
+        A.sv.w_src[slot] = w;
+      }
     }
   }
   double v[5] = {sum[0], sum[1], sum[2], sum[3], bad};
