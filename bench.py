@@ -129,8 +129,10 @@ def k1_roofline(H, world):
     return {"kernel": "k_build_sorted<1>", "bound": "hbm", "launches": 20, "avg_launch_us": round(us, 2), "queries_per_launch": int(nq),
             "algorithmic_bytes_per_launch": alg, "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "exact k-NN over the 27-cell neighbourhood: ~70 candidate records examined per query (2-3 points per "
-                    "cell), ~34 VALU instructions each -- issue-bound, not bandwidth-bound (DESIGN.md section 5)"}
+            "note": "exact k-NN over the cells of the 27-cell neighbourhood the search ball can reach: ~25 candidate records per "
+                    "query (the busiest lane of a wave: ~40), 32-byte gathers; knock-out builds (scripts/k1_time.py): ~28 us "
+                    "set-up (query, nine cell-table rows, record out), ~82 us candidate walk, ~19 us per-query plane fit / "
+                    "eigen solve -- bound by the walk's gather traffic and its lane imbalance, not by HBM bytes (DESIGN.md section 5)"}
 
 
 def parse():
@@ -328,10 +330,14 @@ def main():
             if side.get("k1"):
                 roofline["roofline_k1"] = side["k1"]
             if args.workload == "kitti":
-                hk = dict(head["k3"])
-                hk.update({"kernel": "k3_accumulate<true>", "note": "same kernel family on the headline frames: 442 KB per "
-                           "launch, launch-latency bound (one wave per 128-correspondence chunk)"})
-                roofline["headline_workload_k3"] = hk
+                bb = head["k3"]["back_to_back"]
+                roofline["headline_workload_k3"] = {
+                    "kernel": "k_sweep_step_small (sweep + ticket + 6x6 step in one launch); the sweep alone = k3_accumulate<true>",
+                    "sweep_alone_back_to_back": bb,
+                    "note": "KITTI-cap sets (442 KB per sweep) are launch-latency bound, not bandwidth bound: in the frames the sweep "
+                            "runs fused with the minimiser step (no separate K3 launch to time, ~10.5 us per fused iteration in "
+                            "profiles/r02_bench_default_kernel_stats.csv); the figure here is the stand-alone sweep kernel on the "
+                            "frame's last correspondence set"}
         out = {
             "metric": "gauss_newton_iters_per_sec", "value": round(head["gn_iters_per_sec"], 2), "unit": "GN iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
