@@ -709,7 +709,10 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     for (int i = 0; i < NR; ++i) len = max(len, re[i] - rs[i]);
     // kU steps per trip: candidates s .. s + kU - 1 of each of this lane's rows are requested together (the walk of a
     // small frame is a latency chain: one record round trip per trip, so the trip carries as many as the rows allow)
-    constexpr int kU = (NR == 1) ? 4 : 2;
+#ifndef TLOAM_K1_WIDE_KU
+#define TLOAM_K1_WIDE_KU 4
+#endif
+    constexpr int kU = (NR == 1) ? TLOAM_K1_WIDE_KU : 2;
     for (int s = 0; s < len; s += kU) {
       double4 c[kU][NR];
 #pragma unroll
