@@ -675,7 +675,12 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #ifdef TLOAM_K1_DBG_NOWALK  // timing experiment only: row resolution and the first trip, no candidate loop
     total = 0;
 #endif
+#ifdef TLOAM_K1_DBG_MAXTRIPS  // timing experiment only: the walk cut off after a fixed number of trips
+    int trip_no = 0;
+    for (int left = total; __any(left > 0) && trip_no < TLOAM_K1_DBG_MAXTRIPS; left -= kCpt, ++trip_no) {
+#else
     for (int left = total; __any(left > 0); left -= kCpt) {
+#endif
       int jn[kCpt];
       bool vn[kCpt];
       double4 rn[kCpt];
