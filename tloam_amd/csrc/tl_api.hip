@@ -828,13 +828,18 @@ WeightParams weight_params(const tloam_ctx* c, double mu, const BuildParams& bp)
   return wp;
 }
 // :1049-1086 thresholds + weight update, :1091-1094 cost sums, publish (+ device-side loop control when ctl.fast)
-int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl) {
-  // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
+size_t total_seg_cap(const tloam_ctx* c) {
   size_t cap = 0;
   for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
+  return cap;
+}
+// one 1024-thread block does weights + sums + publish in a single launch
+bool finish_small_path(const tloam_ctx* c) { return c->nranks == 1 && total_seg_cap(c) <= 16384; }
+int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl) {
+  // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
+  const size_t cap = total_seg_cap(c);
   const int wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
-  const bool small_set = cap <= 16384;  // one 1024-thread block does weights + sums + publish in a single launch
-  if (c->nranks == 1 && small_set) {
+  if (finish_small_path(c)) {
     launch_weights_finish_small(c->cv, c->sv, wp, c->seg_n.p, c->sums16.p, c->state.p, hm, ctl, c->stream);
     return TLOAM_OK;
   }
@@ -995,9 +1000,18 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   double mus[kMaxOuterFast];
   HostMirror hms[kMaxOuterFast];
   double mu = initial_mu(c);
+  // KITTI-size frames: the finish of iteration k-1 does not get a launch of its own, it rides on the correspondence
+  // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
+  const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
+  WeightParams wp_prev;
+  OuterCtl ctl_prev{0.0, 0, 0};
   for (int iter = 0; iter < M; ++iter) {
     if (iter == 0) {
       rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
+    } else if (ride) {
+      FinishSmallArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, hms[iter - 1], ctl_prev, c->wpart.p, c->k3_ticket.p + 1};
+      launch_build_finish_small(c->sv, grids, bp, st, fin, c->stream);
+      launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, st, run_build, run_refresh, c->stream);
     } else {
       rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh);   // both alternatives, device-gated
     }
@@ -1009,8 +1023,13 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     mus[iter] = mu;
     hms[iter] = next_mirror(c, iter);
     const OuterCtl ctl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0};
-    rc = enqueue_finish(c, weight_params(c, mu, bp), hms[iter], ctl);
-    if (rc != TLOAM_OK) return rc;
+    if (ride && iter < M - 1) {
+      wp_prev = weight_params(c, mu, bp);
+      ctl_prev = ctl;
+    } else {
+      rc = enqueue_finish(c, weight_params(c, mu, bp), hms[iter], ctl);
+      if (rc != TLOAM_OK) return rc;
+    }
     mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
   }
   rc = wait_state(c, hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did

@@ -115,7 +115,8 @@ struct GnState {
   int stop;           // 0 running | 1 the loop has ended (plateau break :1108 or max_iterations) | 2 Solve out of budget
   int run_build;      // gates of the NEXT outer iteration's launches: builders + scan + compaction run iff the pose moved,
   int run_refresh;    // the refresh iff it did not (see k_refresh); both 0 once the loop has ended
-  int pad_loop;
+  int spec_build;     // written by the minimiser step: 1 iff the Solve has terminated at a pose other than x_build -- the gate of
+                      // a correspondence search that runs CONCURRENTLY with the finish of that Solve (k_build_finish_small)
   double dbg[8];      // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
@@ -399,6 +400,22 @@ void launch_outer_finish(const double* partial, int blocks, const int* seg_n, Gn
 void launch_outer_publish(const double* sums8, GnState* st, HostMirror hm, const unsigned long long* comm_err_or_null,
                           hipStream_t s);
 // weights + finish in one launch for small single-rank sets
+// KITTI-size frames, device-driven loop: the finish of outer iteration k-1 (the first sixteen blocks) and the
+// correspondence search of iteration k (the other blocks, gated on GnState::spec_build) in ONE launch -- they are
+// independent of each other
+bool build_finish_small_fits(const SlotView& sv);
+struct FinishSmallArgs {
+  const CorrView* cv;
+  const WeightParams* wp;
+  const int* seg_n;
+  double* sums16;
+  HostMirror hm;
+  OuterCtl ctl;
+  double* rows;   // [16][8] hand-over rows of the sixteen finish blocks
+  int* ticket;    // zero between launches
+};
+void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
+                               const FinishSmallArgs& fin, hipStream_t s);
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
                                  double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);

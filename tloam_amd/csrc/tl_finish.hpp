@@ -1,0 +1,243 @@
+// tl_finish.hpp -- end of an outer GNC iteration on the device: weight update (registration.cpp:858-876), cost sums
+// (:1091-1094), the loop decisions of :1108-1121 and the result slot.  Device code shared by tl_gn.hip (the large-set
+// finish kernels) and tl_nn.hip (the small-set finish, stand-alone and riding on the correspondence search of the next
+// iteration -- both in ONE translation unit so that they round alike).
+#pragma once
+
+#include "tl_common.hpp"
+
+namespace tl {
+
+struct WeightArgs {
+  CorrView cv;
+  SlotView sv;
+  WeightParams wp;
+};
+// sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded.
+// One lane per partial row (blocks == 64), fixed shuffle tree.
+// publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
+// (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
+// Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
+// state writes are done: the host-visible prefix first (16 words, one coalesced store), system-scope fence, then
+// the sequence number.
+// status >= 0 replaces the `incomplete` word of the copy (a launch that was gated off reports OS_SKIPPED without
+// touching the state itself).
+__device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
+  if (!hm.out) return;
+  __syncthreads();
+  if (tid >= 24) return;  // one store instruction of one wave: 3 segments x (7 words + sequence number), see MirrorSlot
+  const int seg = tid >> 3, pos = tid & 7, word = seg * 7 + pos;
+  unsigned long long w = hm.seq;
+  if (pos < 7) {
+    w = word < kMirrorWords ? reinterpret_cast<const unsigned long long*>(st)[word] : 0ull;
+    constexpr int kStatusWord = (int)(offsetof(GnState, incomplete) / 8);
+    static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
+    if (status >= 0 && word == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
+  }
+  __hip_atomic_store(&hm.out->w[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the
+// plateau test of registration.cpp:1108 and the "did the pose move" comparison that selects build or refresh are made
+// here, and the gates of the next iteration's launches are set accordingly; once the loop has ended `done` stays 1
+// (sweeps and steps are no-ops) and both gates are 0.
+__device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t, const OuterCtl& ctl) {
+  if (t < 4) {
+    st->kind_cost[t] = sums16[t];
+    st->n_corr[t] = (int)sums16[4 + t];
+  }
+  if (t == 0) {
+    st->bad_weights += (int)sums16[8];
+    st->incomplete = OS_OK;
+    if (!ctl.fast) {
+      arm_solver(*st);
+    } else {
+      const double cur = sums16[TLOAM_KIND_PLANAR];
+      if (fabs(cur - st->prev_planar) < ctl.cost_threshold) {   // :1108 (prev = +inf in the first iteration)
+        st->incomplete = OS_PLATEAU;
+        st->stop = 1;
+        st->run_build = st->run_refresh = 0;
+      } else {
+        st->prev_planar = cur;                                   // :1113-1116
+        if (ctl.last) {
+          st->stop = 1;
+          st->run_build = st->run_refresh = 0;
+        } else {
+          bool moved = false;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) moved = moved || (st->x[i] != st->x_build[i]);
+          st->run_build = moved ? 1 : 0;
+          st->run_refresh = moved ? 0 : 1;
+          arm_solver(*st);
+        }
+      }
+    }
+  }
+}
+// entry of a finish kernel: 0 go on | 1 gated off (loop ended earlier) | 2 the Solve has not terminated
+__device__ __forceinline__ int finish_gate(GnState* gate, const OuterCtl& ctl, int t) {
+  const int stop0 = ctl.fast ? gate->stop : 0, done0 = gate->done;
+  __syncthreads();  // every thread has read the flags before thread 0 changes them
+  if (stop0) return 1;
+  if (!done0) {
+    if (t == 0) {
+      gate->incomplete = OS_INCOMPLETE;
+      if (ctl.fast) { gate->stop = 2; gate->run_build = gate->run_refresh = 0; }
+    }
+    return 2;
+  }
+  return 0;
+}
+// Small sets on one rank (KITTI caps: <= 5.9 k factors): weight update, cost sums, publish and re-arm in ONE
+// launch of one 1024-thread block -- the frame is a chain of launch-latency-bound kernels, every boundary
+// removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
+// folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
+// Argument order: state, sizes, output and mirror first (preloaded SGPRs, see k3_accumulate).  The kernel is one
+// dependent chain of memory round trips on an otherwise idle GPU, so everything it will need is REQUESTED in its
+// first instructions: the loop flags (done / stop), the segment sizes and -- speculatively, bounded by the segment
+// capacities from the kernel arguments -- the first three (cost, index) pairs of every kind per thread (a KITTI-cap
+// set is 2500 / 2000 / 1200 / 200: all of it); the gate is evaluated when they are all back.
+// The arithmetic is that of 1024 logical threads in sixteen waves; two shapes run it and agree bit for bit:
+//   * ONE 1024-thread block (k_weights_finish_small): the waves' sums meet in LDS;
+//   * SIXTEEN 64-thread blocks at the head of k_build_finish_small (the finish riding on the correspondence search of
+//     the next iteration): each block is one of the waves, hands its five sums over with device-scope stores and takes a
+//     ticket, the last one adds the sixteen rows in the same order and publishes.  No block writes the state before
+//     every block has read the loop flags (the ticket), and every block sees the same flags.
+struct FinishRide {
+  double* rows;   // [16][8] hand-over rows (device memory)
+  int* ticket;    // zero between launches
+};
+// per-thread part: the gate (0 go on | 1 gated off: the loop ended earlier | 2 the Solve has not terminated), the
+// weights of this thread's factors and -- on lane 0 of every wave -- the wave's five sums
+__device__ __forceinline__ int finish_small_thread(const GnState* st, const int* __restrict__ seg_n, const OuterCtl& ctl,
+                                                   const WeightArgs& A, int tid, double v[5], int nseg[kKinds]) {
+  constexpr int kPre = 3;
+  double pc[kKinds][kPre];
+  int pi[kKinds][kPre];
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k)
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int i = tid + u * 1024;
+      const bool in = i < A.cv.k[k].cap;
+      pc[k][u] = in ? A.cv.k[k].cost[i] : 0.0;
+      pi[k][u] = in ? A.cv.k[k].idx[i] : 0;
+    }
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
+  const int stop0 = ctl.fast ? st->stop : 0, done0 = st->done;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) v[i] = 0.0;
+  if (stop0) return 1;
+  if (!done0) return 2;
+  double sum[kKinds] = {0, 0, 0, 0};
+  double bad = 0.0;
+  // (the side-channel costs and the index lists are only read here, the slot weights only written: say so, or the
+  //  possible aliasing serialises the thread's load -> load -> store chains)
+  double* __restrict__ w_src = A.sv.w_src;
+  auto one = [&](int k, double c, int id) {
+    sum[k] += c;
+    if (!A.wp.active[k]) return;
+    if (c == 0) return;                            // :862
+    double w;
+    if (c >= A.wp.th1) w = 0.0;                    // :865
+    else if (c <= A.wp.th2) w = 1.0;               // :867
+    else {
+      w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+      if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+    }
+    w_src[A.sv.slot_off[k] - A.sv.src_lo[k] + id] = w;
+  };
+#pragma unroll
+  for (int k = 0; k < kKinds; ++k) {
+    const int n = nseg[k];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)   // same element order per thread as a plain strided loop
+      if (tid + u * 1024 < n) one(k, pc[k][u], pi[k][u]);
+    const double* __restrict__ cost = A.cv.k[k].cost;
+    const int* __restrict__ idx = A.cv.k[k].idx;
+    for (int i = tid + kPre * 1024; i < n; i += 1024) one(k, cost[i], idx[i]);
+  }
+  v[0] = sum[0]; v[1] = sum[1]; v[2] = sum[2]; v[3] = sum[3]; v[4] = bad;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+  return 0;
+}
+// what a gated-off launch leaves behind (thread t of the block that publishes; every thread has read the flags)
+__device__ __forceinline__ void finish_gate_writes(GnState* gate, const OuterCtl& ctl, int g, int t) {
+  if (g == 2 && t == 0) {
+    gate->incomplete = OS_INCOMPLETE;
+    if (ctl.fast) { gate->stop = 2; gate->run_build = gate->run_refresh = 0; }
+  }
+}
+// the sixteen wave sums (red[wave][0..4]) -> sums16, the state, the result slot; t = thread of the publishing block
+__device__ __forceinline__ void finish_small_publish(GnState* st, double* __restrict__ sums16, const HostMirror& hm,
+                                                     const OuterCtl& ctl, const double (*red)[8], double* sh /*[16] LDS*/,
+                                                     const int nseg[kKinds], int t, int nthreads) {
+  if (t < 16) sh[t] = 0.0;
+  __syncthreads();
+  if (t < 5) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w][t];
+    sh[t < 4 ? t : 8] = s;
+  }
+  if (t >= 8 && t < 12) sh[t - 4] = (double)nseg[t - 8];
+  __syncthreads();
+  if (t < 16) sums16[t] = sh[t];
+  if (t < 64) publish_and_rearm(sh, st, t, ctl);
+  mirror_to_host(st, hm, t, nthreads);
+}
+__device__ __forceinline__ void weights_finish_small_body(GnState* st, const int* __restrict__ seg_n,
+                                                          double* __restrict__ sums16, const HostMirror& hm,
+                                                          const OuterCtl& ctl, const WeightArgs& A) {
+  __shared__ double red[16][8];
+  __shared__ double sh[16];
+  double v[5];
+  int nseg[kKinds];
+  const int g = finish_small_thread(st, seg_n, ctl, A, (int)threadIdx.x, v, nseg);
+  __syncthreads();  // every thread has read the flags before thread 0 changes them
+  if (g != 0) {
+    finish_gate_writes(st, ctl, g, (int)threadIdx.x);
+    mirror_to_host(st, hm, threadIdx.x, 1024, g == 1 ? (int)OS_SKIPPED : -1);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[wave][i] = v[i];
+  }
+  finish_small_publish(st, sums16, hm, ctl, red, sh, nseg, (int)threadIdx.x, 1024);
+}
+// block `wave` (0..15, 64 threads) of the riding shape
+__device__ __forceinline__ void weights_finish_small_ride(GnState* st, const int* __restrict__ seg_n,
+                                                          double* __restrict__ sums16, const HostMirror& hm,
+                                                          const OuterCtl& ctl, const WeightArgs& A, const FinishRide& R,
+                                                          int wave) {
+  __shared__ double red[16][8];
+  __shared__ double sh[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x;
+  double v[5];
+  int nseg[kKinds];
+  const int g = finish_small_thread(st, seg_n, ctl, A, wave * 64 + lane, v, nseg);
+  if (lane == 0 && g == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) __hip_atomic_store(R.rows + wave * 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the row has left the wave (and the flags have been read)
+  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 15) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  if (lane == 0) __hip_atomic_store(R.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (g != 0) {
+    finish_gate_writes(st, ctl, g, lane);
+    mirror_to_host(st, hm, lane, 64, g == 1 ? (int)OS_SKIPPED : -1);
+    return;
+  }
+  for (int i = lane; i < 16 * 8; i += 64)
+    red[i >> 3][i & 7] = ((i & 7) < 5) ? __hip_atomic_load(R.rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  finish_small_publish(st, sums16, hm, ctl, red, sh, nseg, lane, 64);
+}
+
+}  // namespace tl

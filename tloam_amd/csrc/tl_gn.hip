@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 
 #include "tl_common.hpp"
+#include "tl_finish.hpp"
 
 namespace tl {
 
@@ -1071,6 +1072,12 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
     st->gn_sweeps = sweeps;
     st->x_cost = x_cost; st->x_norm = x_norm; st->gmax = gmax; st->model_cost_change = mcc;
     st->radius = radius; st->mu = mu; st->step_norm = step_norm;
+    // has this Solve ended somewhere else than where the factor set was built?  (what publish_and_rearm will find when it
+    // compares x with x_build -- known here already, so the next search need not wait for the finish kernel)
+    bool moved = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) moved = moved || (x[i] != sm->x_build[i]);
+    st->spec_build = (done && moved) ? 1 : 0;
   }
 }
 #define TL_GN_CONSUME gn_consume_uniform
@@ -1255,11 +1262,6 @@ void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipSt
 // ================================================================================================
 //  K4: GNC-TLS weights (registration.cpp:858-876) + per-kind side-channel sums (:1091-1094)
 // ================================================================================================
-struct WeightArgs {
-  CorrView cv;
-  SlotView sv;
-  WeightParams wp;
-};
 // Gate: the host enqueues only as many sweeps as the Solve is expected to need; if the minimiser has not
 // terminated yet (st->done == 0) the weight update and the finish kernel do nothing, the finish kernel raises
 // st->incomplete, and the host tops the Solve up and runs them again.
@@ -1328,80 +1330,6 @@ void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& 
   hipLaunchKernelGGL(k_weights, dim3(blocks), dim3(256), 0, s, A, partial, st);
 }
 
-// sums16 = [kind_cost x4, n_corr x4 (as doubles), bad, 0...]; all-reduced by the host when sharded.
-// One lane per partial row (blocks == 64), fixed shuffle tree.
-// publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
-// (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
-// Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
-// state writes are done: the host-visible prefix first (16 words, one coalesced store), system-scope fence, then
-// the sequence number.
-// status >= 0 replaces the `incomplete` word of the copy (a launch that was gated off reports OS_SKIPPED without
-// touching the state itself).
-__device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
-  if (!hm.out) return;
-  __syncthreads();
-  if (tid >= 24) return;  // one store instruction of one wave: 3 segments x (7 words + sequence number), see MirrorSlot
-  const int seg = tid >> 3, pos = tid & 7, word = seg * 7 + pos;
-  unsigned long long w = hm.seq;
-  if (pos < 7) {
-    w = word < kMirrorWords ? reinterpret_cast<const unsigned long long*>(st)[word] : 0ull;
-    constexpr int kStatusWord = (int)(offsetof(GnState, incomplete) / 8);
-    static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
-    if (status >= 0 && word == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
-  }
-  __hip_atomic_store(&hm.out->w[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the
-// plateau test of registration.cpp:1108 and the "did the pose move" comparison that selects build or refresh are made
-// here, and the gates of the next iteration's launches are set accordingly; once the loop has ended `done` stays 1
-// (sweeps and steps are no-ops) and both gates are 0.
-__device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState* st, int t, const OuterCtl& ctl) {
-  if (t < 4) {
-    st->kind_cost[t] = sums16[t];
-    st->n_corr[t] = (int)sums16[4 + t];
-  }
-  if (t == 0) {
-    st->bad_weights += (int)sums16[8];
-    st->incomplete = OS_OK;
-    if (!ctl.fast) {
-      arm_solver(*st);
-    } else {
-      const double cur = sums16[TLOAM_KIND_PLANAR];
-      if (fabs(cur - st->prev_planar) < ctl.cost_threshold) {   // :1108 (prev = +inf in the first iteration)
-        st->incomplete = OS_PLATEAU;
-        st->stop = 1;
-        st->run_build = st->run_refresh = 0;
-      } else {
-        st->prev_planar = cur;                                   // :1113-1116
-        if (ctl.last) {
-          st->stop = 1;
-          st->run_build = st->run_refresh = 0;
-        } else {
-          bool moved = false;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) moved = moved || (st->x[i] != st->x_build[i]);
-          st->run_build = moved ? 1 : 0;
-          st->run_refresh = moved ? 0 : 1;
-          arm_solver(*st);
-        }
-      }
-    }
-  }
-}
-// entry of a finish kernel: 0 go on | 1 gated off (loop ended earlier) | 2 the Solve has not terminated
-__device__ __forceinline__ int finish_gate(GnState* gate, const OuterCtl& ctl, int t) {
-  const int stop0 = ctl.fast ? gate->stop : 0, done0 = gate->done;
-  __syncthreads();  // every thread has read the flags before thread 0 changes them
-  if (stop0) return 1;
-  if (!done0) {
-    if (t == 0) {
-      gate->incomplete = OS_INCOMPLETE;
-      if (ctl.fast) { gate->stop = 2; gate->run_build = gate->run_refresh = 0; }
-    }
-    return 2;
-  }
-  return 0;
-}
 __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ partial, int blocks,
                                                      const int* __restrict__ seg_n, double* __restrict__ sums16,
                                                      GnState* st_or_null, GnState* gate, HostMirror hm, OuterCtl ctl) {
@@ -1437,99 +1365,6 @@ __global__ __launch_bounds__(64) void k_outer_finish(const double* __restrict__ 
     publish_and_rearm(sh, st_or_null, t, ctl);
     mirror_to_host(st_or_null, hm, t, 64);
   }
-}
-// Small sets on one rank (KITTI caps: <= 5.9 k factors): weight update, cost sums, publish and re-arm in ONE
-// launch of one 1024-thread block -- the frame is a chain of launch-latency-bound kernels, every boundary
-// removed is ~4 us.  Same per-element arithmetic as k_weights; the sums are accumulated thread-strided and
-// folded by a fixed tree (deterministic, though not the 64-block order of the two-kernel path).
-// Argument order: state, sizes, output and mirror first (preloaded SGPRs, see k3_accumulate).  The kernel is one
-// dependent chain of memory round trips on an otherwise idle GPU, so everything it will need is REQUESTED in its
-// first instructions: the loop flags (done / stop), the segment sizes and -- speculatively, bounded by the segment
-// capacities from the kernel arguments -- the first three (cost, index) pairs of every kind per thread (a KITTI-cap
-// set is 2500 / 2000 / 1200 / 200: all of it); the gate is evaluated when they are all back.
-__global__ __launch_bounds__(1024) void k_weights_finish_small(GnState* st, const int* __restrict__ seg_n,
-                                                               double* __restrict__ sums16, HostMirror hm, OuterCtl ctl,
-                                                               WeightArgs A) {
-  __shared__ double red[16][8];
-  __shared__ double sh[16];
-  constexpr int kPre = 3;
-  double pc[kKinds][kPre];
-  int pi[kKinds][kPre];
-#pragma unroll
-  for (int k = 0; k < kKinds; ++k)
-#pragma unroll
-    for (int u = 0; u < kPre; ++u) {
-      const int i = threadIdx.x + u * 1024;
-      const bool in = i < A.cv.k[k].cap;
-      pc[k][u] = in ? A.cv.k[k].cost[i] : 0.0;
-      pi[k][u] = in ? A.cv.k[k].idx[i] : 0;
-    }
-  int nseg[kKinds];
-#pragma unroll
-  for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
-  {
-    const int g = finish_gate(st, ctl, threadIdx.x);  // gate, see k_weights
-    if (g != 0) {
-      mirror_to_host(st, hm, threadIdx.x, 1024, g == 1 ? (int)OS_SKIPPED : -1);
-      return;
-    }
-  }
-  double sum[kKinds] = {0, 0, 0, 0};
-  double bad = 0.0;
-  // (the side-channel costs and the index lists are only read here, the slot weights only written: say so, or the
-  //  possible aliasing serialises the thread's load -> load -> store chains)
-  double* __restrict__ w_src = A.sv.w_src;
-  auto one = [&](int k, double c, int id) {
-    sum[k] += c;
-    if (!A.wp.active[k]) return;
-    if (c == 0) return;                            // :862
-    double w;
-    if (c >= A.wp.th1) w = 0.0;                    // :865
-    else if (c <= A.wp.th2) w = 1.0;               // :867
-    else {
-      w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
-      if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
-    }
-    w_src[A.sv.slot_off[k] - A.sv.src_lo[k] + id] = w;
-  };
-#pragma unroll
-  for (int k = 0; k < kKinds; ++k) {
-    const int n = nseg[k];
-#pragma unroll
-    for (int u = 0; u < kPre; ++u)   // same element order per thread as a plain strided loop
-      if ((int)threadIdx.x + u * 1024 < n) one(k, pc[k][u], pi[k][u]);
-    const double* __restrict__ cost = A.cv.k[k].cost;
-    const int* __restrict__ idx = A.cv.k[k].idx;
-    for (int i = threadIdx.x + kPre * 1024; i < n; i += 1024) one(k, cost[i], idx[i]);
-  }
-  double v[5] = {sum[0], sum[1], sum[2], sum[3], bad};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
-    if (lane == 0) red[wave][i] = v[i];
-  }
-  if (threadIdx.x < 16) sh[threadIdx.x] = 0.0;
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    double t = 0.0;
-    for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
-    sh[threadIdx.x < 4 ? threadIdx.x : 8] = t;
-  }
-  if (threadIdx.x >= 64 && threadIdx.x < 68) sh[threadIdx.x - 60] = (double)nseg[threadIdx.x - 64];
-  __syncthreads();
-  if (threadIdx.x < 16) sums16[threadIdx.x] = sh[threadIdx.x];
-  if (threadIdx.x < 64) publish_and_rearm(sh, st, threadIdx.x, ctl);
-  mirror_to_host(st, hm, threadIdx.x, 1024);
-}
-void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
-                                 double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s) {
-  WeightArgs A;
-  A.cv = cv;
-  A.sv = sv;
-  A.wp = wp;
-  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, st, seg_n, sums16, hm, ctl, A);
 }
 void launch_outer_finish(const double* partial, int blocks, const int* seg_n, GnState* st_or_null, GnState* gate,
                          double* sums16, HostMirror hm, OuterCtl ctl, hipStream_t s) {

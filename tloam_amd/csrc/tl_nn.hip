@@ -23,6 +23,7 @@
 
 #include "tl_common.hpp"
 #include "tl_knn.hpp"
+#include "tl_finish.hpp"
 
 namespace tl {
 
@@ -879,6 +880,73 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   else
     hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
 }
+// ---- the small-set finish (tl_finish.hpp), stand-alone -----------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_weights_finish_small(GnState* st, const int* __restrict__ seg_n,
+                                                               double* __restrict__ sums16, HostMirror hm, OuterCtl ctl,
+                                                               WeightArgs A) {
+  weights_finish_small_body(st, seg_n, sums16, hm, ctl, A);
+}
+void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
+                                 double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s) {
+  WeightArgs A;
+  A.cv = cv;
+  A.sv = sv;
+  A.wp = wp;
+  hipLaunchKernelGGL(k_weights_finish_small, dim3(1), dim3(1024), 0, s, st, seg_n, sums16, hm, ctl, A);
+}
+// ---- ... and riding on the correspondence search of the NEXT outer iteration ---------------------------------------
+// The finish of iteration k-1 reads the old factor set's costs and writes slot weights, sums and the loop decisions;
+// the search of iteration k reads the source slots, the target grids and the pose the Solve ended at, and writes raw
+// records and flags: neither reads what the other writes, so they share a launch -- the first sixteen one-wave blocks
+// are the finish (weights_finish_small_ride), the others search sixteen lanes per query in slot order exactly as
+// k_build_sorted<16> does (one-wave blocks: the search is bound by what one CU's L1 looks up, so it wants to be spread
+// over all of them -- 1024-thread blocks on 147 CUs took twice as long).  The search cannot wait for the finish's
+// verdict (run_build), so it runs on the minimiser's own "ended somewhere else than x_build" (spec_build) unless an
+// EARLIER iteration has stopped the loop; when this finish stops the loop (plateau, last iteration) or finds the Solve
+// unfinished, the records written here are simply never compacted (k_prepare_small is gated on run_build).
+constexpr int kFinishBlocks = 16;
+__global__ __launch_bounds__(64) void k_build_finish_small(BuildArgs A, GnState* st, const int* __restrict__ seg_n,
+                                                           double* __restrict__ sums16, HostMirror hm, OuterCtl ctl,
+                                                           WeightArgs W, FinishRide R) {
+  if (blockIdx.x < kFinishBlocks) {
+    weights_finish_small_ride(st, seg_n, sums16, hm, ctl, W, R, (int)blockIdx.x);
+    return;
+  }
+  if (st->spec_build == 0 || st->stop != 0) return;
+  // block order as in k_build_sorted: chunks of kXcdChunk blocks dealt to the XCDs, back to front (edge kind first)
+  constexpr int kXcdChunk = 16;
+  const int b = (int)blockIdx.x - kFinishBlocks;
+  const int xcd = b & 7, in_xcd = b >> 3;
+  const int lb0 = ((in_xcd / kXcdChunk) * 8 + xcd) * kXcdChunk + in_xcd % kXcdChunk;
+  const int n = A.identity_n;
+  const int nblk = (int)(((long long)n * 16 + 63) / 64);
+  if (lb0 >= nblk) return;
+  const int t = (nblk - 1 - lb0) * 64 + (int)threadIdx.x;
+  const int i = t >> 4, sub = t & 15;
+  if (i >= n) return;
+  const double4 q = double4{A.sv.sx[i], A.sv.sy[i], A.sv.sz[i], __longlong_as_double((long long)i)};
+  query_one<16>(A, slot_kind(A.sv, i), st->T_cur, q, i, sub, nullptr);
+}
+bool build_finish_small_fits(const SlotView& sv) { return sv.slot_off[kKinds] > 0 && sv.slot_off[kKinds] <= kWideLimit; }
+void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
+                               const FinishSmallArgs& fin, hipStream_t s) {
+  const int n = sv.slot_off[kKinds];
+  BuildArgs A;
+  A.sv = sv;
+  A.bp = bp;
+  for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
+  memset(&A.tm, 0, sizeof(A.tm));   // slot order: no tiles
+  A.tm.sub = 1;
+  A.identity_n = n;
+  WeightArgs W;
+  W.cv = *fin.cv;
+  W.sv = sv;
+  W.wp = *fin.wp;
+  const unsigned build_blocks = (unsigned)(((16LL * n + 63) / 64 + 127) / 128 * 128);  // 8 XCDs x kXcdChunk, as launch_build
+  hipLaunchKernelGGL(k_build_finish_small, dim3(kFinishBlocks + build_blocks), dim3(64), 0, s, A, st, fin.seg_n, fin.sums16,
+                     fin.hm, fin.ctl, W, FinishRide{fin.rows, fin.ticket});
+}
+
 int build_tile_count(const GridView grids[kKinds], int n_slots) {
   int base = 0;
   for (int k = 0; k < kKinds; ++k) {
