@@ -352,6 +352,49 @@ def test_device_driven_loop_equals_host_driven_loop(hip_module, monkeypatch, sha
     H1.close(); H2.close()
 
 
+def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module, monkeypatch):
+    """The same comparison over 100 randomly drawn frame pairs -- noise, prediction error, outliers, binding caps, loop length,
+    plateau threshold and GNC factor all vary -- so that the rarer branches of the device-side control are met: a
+    plateau break after a Solve that moved the pose (the correspondence search that rode on that finish is then never
+    compacted), loops that end at max_iterations, Solves that outrun the learned sweep budget (top-up through the
+    stepwise path).  The branch census is asserted so that the test cannot silently stop covering them."""
+    rng = np.random.default_rng(2024)
+    census = {"plateau": 0, "max_iter": 0, "moved_then_plateau": 0, "frames": 0}
+    for case in range(100):
+        over = dict(max_iterations=int(rng.integers(2, 7)), cost_threshold=float(rng.choice([1e-3, 2e-2, 0.5, 5.0, 50.0])),
+                    gnc_factor=float(rng.choice([0.5, 1.0, 1.4, 2.0])))
+        if rng.random() < 0.4:
+            over.update(planar_maxnum=int(rng.integers(60, 400)), ground_maxnum=int(rng.integers(60, 400)),
+                        edge_maxnum=int(rng.integers(40, 200)), sphere_maxnum=int(rng.integers(10, 60)))
+        scale = float(rng.choice([0.3, 1.0, 4.0]))
+        pred_err = tuple(scale * np.array((0.012, -0.008, 0.004, 0.0015, -0.001, 0.002)) * rng.normal(1.0, 0.3, 6))
+        sc = synth.make_scene(seed=1000 + case, noise=float(rng.choice([0.0, 0.01, 0.02, 0.05])), pred_err=pred_err,
+                              outlier_frac=float(rng.choice([0.0, 0.05, 0.2])),
+                              n_src=synth.SMALL_SRC if case % 3 else synth.KITTI_SRC,
+                              n_tgt=synth.SMALL_TGT if case % 3 else synth.KITTI_TGT)
+        monkeypatch.delenv("TLOAM_NO_DEVICE_LOOP", raising=False)
+        H1 = hip_module.HipRegistration(hip_module.default_config(**over))
+        H1.set_frames(sc.source, sc.target)
+        monkeypatch.setenv("TLOAM_NO_DEVICE_LOOP", "1")      # read once, when the context is created
+        H2 = hip_module.HipRegistration(hip_module.default_config(**over))
+        H2.set_frames(sc.source, sc.target)
+        for frame in range(2):
+            rc1, T1, st1 = H1.scan_match(sc.T_pred)
+            rc2, T2, st2 = H2.scan_match(sc.T_pred)
+            assert rc1 == rc2 and rc1 in (0, -7), (case, rc1, rc2)
+            _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
+            census["frames"] += 1
+            if st1["converged_early"]:
+                census["plateau"] += 1
+                if st1["accepted_steps"] > 0 and st1["outer_iterations"] > 1:
+                    census["moved_then_plateau"] += 1
+            elif st1["outer_iterations"] == over["max_iterations"]:
+                census["max_iter"] += 1
+        H1.close(); H2.close()
+    assert census["plateau"] >= 15 and census["max_iter"] >= 15 and census["moved_then_plateau"] >= 3, census
+    print("census", census)
+
+
 @pytest.mark.parametrize("shape", ["small", "kitti"])
 def test_fused_sweep_step_is_exact(hip_module, monkeypatch, shape):
     """KITTI-size sets run a GN iteration as ONE launch (the sweep's last block folds the rows and runs the minimiser
