@@ -632,8 +632,13 @@ __device__ __forceinline__ Vec2 min_on_circle(double B0, double B1, double B2, d
 
 #ifdef TLOAM_STEP_PROFILE
 #define TL_STAMP(i) if (lane == 0) st->dbg[i] = (double)__builtin_readcyclecounter();
+#ifndef TLOAM_STAMP2_POS
+#define TLOAM_STAMP2_POS 4
+#endif
+#define TL_STAMP2_AT(pos) if (TLOAM_STAMP2_POS == pos) { TL_STAMP(2) }
 #else
 #define TL_STAMP(i)
+#define TL_STAMP2_AT(pos)
 #endif
 
 // ================================================================================================
@@ -822,6 +827,7 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
   const bool eval_reuse = sm->no_eval_reuse == 0;
   bool dirty_S = false, dirty_x = false;
   bool gn_inside = false;
+  TL_STAMP2_AT(1)
   for (;;) {
   // (the point `tot` was evaluated at is the candidate of the state as it came in -- sm->x_cand / sm->T_eval -- in
   //  every pass of this loop: a further pass only happens when the new candidate is bit-identical to it)
@@ -868,6 +874,7 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
       }
     }
   }
+  TL_STAMP2_AT(2)
   if (take_sweep) {
     // H (full 6x6) and g of the accepted point: LDS copy and device state, one element per lane
     const int mi = lane < 36 ? lane / 6 : 0, mj = lane < 36 ? lane - mi * 6 : 0;
@@ -877,6 +884,7 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
     if (lane < 36) { sm->H[lane] = h; st->H[lane] = h; }
     if (lane < 6) { sm->g[lane] = gg; st->g[lane] = gg; }
   }
+  TL_STAMP2_AT(3)
   while (!done) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient test deferred while need_gmax)
     if (iteration >= max_num_iterations) { done = 1; break; }
@@ -893,7 +901,7 @@ __device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* to
       break;
     }
     gn_inside = false;
-    TL_STAMP(2)
+    TL_STAMP2_AT(4)
     // ---- Jacobi-scaled system
     double Hs[21], gs[6], gc[6];
 #pragma unroll
@@ -1246,10 +1254,19 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
   const double wtot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
   __syncthreads();
+#ifdef TLOAM_STEP_PROFILE
+  const unsigned long long c_sweep = __builtin_readcyclecounter();
+#endif
   if (!k3_take_ticket(partials, red, ticket)) return;
+#ifdef TLOAM_STEP_PROFILE
+  if (threadIdx.x == 0) { st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter(); }
+#endif
   fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
   if (threadIdx.x < 64) gn_consume_uniform(st, tot, threadIdx.x, &s_in);
+#ifdef TLOAM_STEP_PROFILE
+  if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
+#endif
 }
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s) {
   hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, 0, st,
