@@ -54,12 +54,12 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
       const double cur = sums16[TLOAM_KIND_PLANAR];
       if (fabs(cur - st->prev_planar) < ctl.cost_threshold) {   // :1108 (prev = +inf in the first iteration)
         st->incomplete = OS_PLATEAU;
-        st->stop = 1;
+        __hip_atomic_store(&st->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st->run_build = st->run_refresh = 0;
       } else {
         st->prev_planar = cur;                                   // :1113-1116
         if (ctl.last) {
-          st->stop = 1;
+          __hip_atomic_store(&st->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           st->run_build = st->run_refresh = 0;
         } else {
           bool moved = false;
@@ -168,7 +168,10 @@ __device__ __forceinline__ int finish_small_thread(const GnState* st, const int*
 __device__ __forceinline__ void finish_gate_writes(GnState* gate, const OuterCtl& ctl, int g, int t) {
   if (g == 2 && t == 0) {
     gate->incomplete = OS_INCOMPLETE;
-    if (ctl.fast) { gate->stop = 2; gate->run_build = gate->run_refresh = 0; }
+    if (ctl.fast) {
+      __hip_atomic_store(&gate->stop, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (read by the riding search)
+      gate->run_build = gate->run_refresh = 0;
+    }
   }
 }
 // the sixteen wave sums (red[wave][0..4]) -> sums16, the state, the result slot; t = thread of the publishing block

@@ -912,7 +912,9 @@ __global__ __launch_bounds__(64) void k_build_finish_small(BuildArgs A, GnState*
     weights_finish_small_ride(st, seg_n, sums16, hm, ctl, W, R, (int)blockIdx.x);
     return;
   }
-  if (st->spec_build == 0 || st->stop != 0) return;
+  // (`stop` may be written by this launch's own finish while it is read here: either value is fine -- see above -- but
+  //  the access is made an atomic one so that it is not a data race)
+  if (st->spec_build == 0 || __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   // block order as in k_build_sorted: chunks of kXcdChunk blocks dealt to the XCDs, back to front (edge kind first)
   constexpr int kXcdChunk = 16;
   const int b = (int)blockIdx.x - kFinishBlocks;
