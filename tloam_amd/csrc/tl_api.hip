@@ -11,8 +11,7 @@
 
 using namespace tl;
 
-struct Uid128 { char bytes[128]; };
-constexpr int kMirrorSlots = 8;  // pinned result slots: one per outer iteration of a device-driven frame (slot 0: stepwise API)  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
+struct Uid128 { char bytes[128]; };  // == ncclUniqueId (rccl.h: char internal[128]), passed BY VALUE
 
 namespace {
 // ---- RCCL, loaded at run time so the library also loads where librccl is absent ----------------

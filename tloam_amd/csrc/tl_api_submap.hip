@@ -62,6 +62,10 @@ int submap_crop_voxel(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg) {
   W.slot_of_pt = S.slot_of_pt.p; W.urank = S.urank.p; W.members = S.members.p; W.sorted = S.sorted.p;
   W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
   W.n_out = S.counts.p;
+  // the last slot of the result mirror is free outside scanMatching: the sizes come back through it
+  W.host_seg = (c->h_mirror_dev && !c->no_host_mirror) ? &c->h_mirror_dev[kMirrorSlots - 1].w[0] : nullptr;
+  W.host_seq = W.host_seg ? ++c->mirror_seq : 0ull;
+  S.pending_seq = W.host_seq;
   launch_crop_voxel(J, W, c->stream);
   return TLOAM_OK;
 }
@@ -75,9 +79,19 @@ int submap_finish(tloam_ctx* c, size_t* n_edge, size_t* n_ground) {  // the ONE 
   SubmapState& S = c->submap;
   unsigned long long h[2] = {0, 0};
   int ov = 0;
-  HIPC(c, hipMemcpyAsync(h, S.counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipMemcpyAsync(&ov, S.overflow.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPC(c, hipStreamSynchronize(c->stream));
+  bool have = false;
+  if (S.pending_seq) {  // the sizes arrive in pinned memory with the last kernel (everything before it has completed)
+    const unsigned long long* seg = &c->h_mirror[kMirrorSlots - 1].w[0];
+    const int rc = wait_word(c, &seg[7], S.pending_seq);
+    if (rc < 0) return rc;
+    if (rc == TLOAM_OK) { h[0] = seg[0]; h[1] = seg[1]; ov = (int)seg[2]; have = true; }
+    S.pending_seq = 0ull;
+  }
+  if (!have) {
+    HIPC(c, hipMemcpyAsync(h, S.counts.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(&ov, S.overflow.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+  }
   if (ov) {
     c->last_error = "[VoxelDownSample] voxel_size is too small.";  // PointCloud2.cpp:370-372
     return TLOAM_E_INVALID;

@@ -325,6 +325,11 @@ struct VoxelWork {           // scratch, sized by the caller (see voxel_table_si
   unsigned long long* scan_tmp;
   int* overflow;             // set when a voxel index leaves [0, 2^21)
   unsigned long long* n_out; // [2] receives the sizes of the down-sampled clouds
+  // != nullptr: the sizes, the overflow flag and host_seq are also stored into one 64-byte segment of pinned host memory
+  // ([0] n_out[0], [1] n_out[1], [2] overflow, [7] host_seq) by ONE instruction of the last kernel -- the host polls the
+  // number instead of paying two device-to-host copies and a stream synchronisation
+  unsigned long long* host_seg;
+  unsigned long long host_seq;
   double* out[2][3];         // (x, y, z) of the down-sampled cloud per segment
 };
 size_t voxel_table_size(size_t n);

@@ -91,6 +91,7 @@ struct RingFrame {
 };
 struct SubmapState {
   bool inited = false;
+  unsigned long long pending_seq = 0ull;  // sequence number the last kernel of the update in flight stores into the host slot
   tloam_submap_config cfg;
   std::vector<RingFrame*> planar_ring, sphere_ring;  // oldest first (std::deque in the reference)
   DBuf<double> in_aos, in_aos2, wx, wy, wz, min_partial, vmin;
@@ -212,8 +213,13 @@ struct tloam_ctx {
     }                                                                                   \
   } while (0)
 
+// pinned result slots: one per outer iteration of a device-driven frame (slot 0: stepwise API); the last one also
+// carries the sizes of a submap update back (tl_api_submap.hip)
+constexpr int kMirrorSlots = 8;
+
 namespace tlh {
 // tl_api.hip
+int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
                      tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr,
                      tl::FrameInitHook* frame = nullptr);

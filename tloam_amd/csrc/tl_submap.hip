@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, VoxelWork W)
     W.n_out[0] = base1;
     W.n_out[1] = W.leader_scan[J.n] - base1;
   }
+  if (W.host_seg && i < 8) {  // ... and straight to the host (stream order: everything the host waits for precedes this kernel)
+    const unsigned long long w = i == 0 ? base1 : i == 1 ? W.leader_scan[J.n] - base1 : i == 2 ? (unsigned long long)W.overflow[0]
+                                 : i == 7 ? W.host_seq : 0ull;
+    __hip_atomic_store(&W.host_seg[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (i >= J.n) return;
   const int h = W.slot_of_pt[i];
   if (h < 0) return;
