@@ -31,7 +31,8 @@ DESIGN.md section 6).
 
 At N = 1 the line also carries: "m1_frame" (the 1 M frame: ms/frame, GN iter/s), "kitti_sequence" (200 DISTINCT
 KITTI-density frames: mean / p50 / p99, PCIe-inclusive figure), "adjacent_rows" (device submap update, PCA feature
-extraction), "odometry_loop" (set source + scan matching + submap update over a consistent synthetic street).
+extraction), "odometry_loop" (set source + scan matching + submap update over a consistent synthetic street),
+"multi_stream" (three independent frame streams sharing the one GPU: aggregate frames/s; not part of `value`).
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (the residual/Jacobian kernel K3, HIP events
 around every K3 launch of the timed region, algorithmic bytes 72/88/64 B per plane/line/point
@@ -378,6 +379,7 @@ def main():
             out["kitti_sequence"] = kitti_seq["report"]
             out["adjacent_rows"] = adjacent_rows(args, reg, torch, local_rank)
             out["odometry_loop"] = odometry_loop(args, reg, torch, local_rank)
+            out["multi_stream"] = multi_stream(args, reg, synth, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(head, side, args, kitti_seq)
         if kitti_seq is not None:   # the honest per-frame cost of the plug-in as wired in INTEGRATION.md section 1
@@ -599,6 +601,67 @@ def adjacent_rows(args, reg, torch, device):
             "feature_extract_ms": round(tf * 1e3, 4), "feature_cloud_points": int(len(cloud)),
             "feature_lists": [int(len(x)) for x in lists],
             "note": "host call to host return, incl. the upload of the per-scan clouds / the cloud and the list download"}
+
+
+def multi_stream(args, reg, synth, device, streams=3, frames=300):
+    """A single frame stream keeps one MI355X busy with kernels of a few blocks each.  Frames of DIFFERENT streams are
+    independent (BASELINE.json configs[4] puts one per GPU); this block runs `streams` of them on ONE GPU from one process
+    -- a context, a HIP stream and a host thread each (the C call releases the GIL) -- and reports the aggregate.  Not part
+    of `value`: a single vehicle's frames are sequential, the headline stays the latency of one stream.
+    Three streams: the HIP runtime multiplexes a process's streams onto four hardware queues (GPU_MAX_HW_QUEUES; more
+    queues measured worse) and torch's own default stream holds one of them in this process -- a fourth frame stream would
+    share a queue with another and serialise (scripts/multi_stream.py, without torch: 1 / 2 / 3 / 4 streams = 43 / 79 / 100 /
+    124 k GN iter/s, 8 streams 138 k)."""
+    import threading
+    sc = kitti_frame(synth, args.seed, 105)
+    try:
+        Hs = [reg.HipRegistration(reg.default_config(), device=device) for _ in range(streams)]
+        for H in Hs:
+            H.set_frames(sc.source, sc.target)
+            for _ in range(10):
+                H.scan_match(sc.T_pred)
+        its, bad = [0] * streams, [0] * streams
+        start = threading.Barrier(streams + 1)
+
+        # (an OpenMP runtime loaded by torch may have narrowed the main thread's affinity mask, which new threads
+        #  inherit: four polling threads on one core measure the scheduler, so each gets a core of its own)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            if len(cores) < streams + 1:
+                os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                cores = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = []
+
+        def run(i):
+            if len(cores) > streams:
+                try:
+                    os.sched_setaffinity(0, {cores[1 + i]})
+                except OSError:
+                    pass
+            start.wait()
+            for _ in range(frames):
+                rc, T, st = Hs[i].scan_match(sc.T_pred)
+                its[i] += st["gn_sweeps"]
+                bad[i] += rc != 0
+        th = [threading.Thread(target=run, args=(i,)) for i in range(streams)]
+        for t in th:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        for H in Hs:
+            H.close()
+        if sum(bad):
+            return {"error": "scan_match failed in %d calls" % sum(bad)}
+        return {"workload": "%d independent streams of the headline frame pair on one GPU, one context + one host thread each" % streams,
+                "streams": streams, "frames_per_stream": frames, "frames_per_sec": round(streams * frames / dt, 1),
+                "gn_iters_per_sec": round(sum(its) / dt, 1), "ms_per_frame_per_stream": round(dt / frames * 1e3, 4),
+                "host_cores_available": len(cores)}
+    except Exception as e:  # noqa: BLE001 -- a side measurement never takes the line down
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def odometry_loop(args, reg, torch, device):
