@@ -151,6 +151,31 @@ int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq)
     __builtin_ia32_pause();
   }
 }
+// One 64-byte segment of a result slot (MirrorSlot: seven payload words, then the sequence number XORed with them): wait
+// until the XOR of the eight words equals `seq` -- a segment that has only partly arrived does not check -- and copy the
+// payload out.  Same return convention as wait_word.
+int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]) {
+  for (unsigned spins = 1;; ++spins) {
+    unsigned long long w[8], x = 0ull;
+    for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= w[i]; }
+    if (x == seq) {
+      for (int i = 0; i < 7; ++i) payload[i] = w[i];
+      return TLOAM_OK;
+    }
+    if ((spins & 0x7ffu) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {
+        x = 0ull;
+        for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= w[i]; }
+        if (x != seq) return 1;
+        for (int i = 0; i < 7; ++i) payload[i] = w[i];
+        return TLOAM_OK;
+      }
+      if (e != hipErrorNotReady) HIPC(c, e);
+    }
+    __builtin_ia32_pause();
+  }
+}
 // The four search grids share one set of buffers (points and cell tables concatenated), so that every
 // phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
 // scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
@@ -374,14 +399,15 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
     ~Acc() { c->wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
   } acc{c, t0};
   if (hm.out) {
-    // the number in all three segments of the slot (MirrorSlot), then the prefix out of them
+    // all three segments of the slot (MirrorSlot), each verified against the number, then the prefix out of them
     const MirrorSlot* ms = c->h_mirror + slot;
     int rc = TLOAM_OK;
-    for (int sgm = 0; sgm < 3 && rc == TLOAM_OK; ++sgm) rc = wait_word(c, &ms->w[sgm * 8 + 7], hm.seq);
+    unsigned long long pay[3][7];
+    for (int sgm = 0; sgm < 3 && rc == TLOAM_OK; ++sgm) rc = wait_segment(c, &ms->w[sgm * 8], hm.seq, pay[sgm]);
     if (rc < 0) return rc;
     if (rc == TLOAM_OK) {
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(c->h_state + slot);
-      for (int w = 0; w < kMirrorWords; ++w) dst[w] = ms->w[(w / 7) * 8 + (w % 7)];
+      for (int w = 0; w < kMirrorWords; ++w) dst[w] = pay[w / 7][w % 7];
       c->h_state[slot].host_seq = hm.seq;
       return TLOAM_OK;
     }
@@ -709,8 +735,12 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     total_cap += round_up(std::max<size_t>(cap, 1), kChunk);
   }
   c->prebuilt = false;
-  c->k3_grid = k3_grid_for((int)total_cap);
-  c->k3_single = k3_single_pass((int)total_cap, c->k3_grid);
+  {
+    int caps[kKinds];
+    for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
+    k3_plan(caps, &c->k3_grid, &c->k3_single);
+    (void)total_cap;
+  }
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
   // ---- the start of the frame -- scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
   //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve -- rides on the
@@ -956,8 +986,9 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     if (rc != TLOAM_OK) return rc;
     if (!c->h_state->incomplete) break;
     if (c->h_state->incomplete == OS_COMM_ERROR) {
-      c->last_error = "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)";
-      return TLOAM_E_RCCL;
+      c->last_error = c->nranks > 1 ? "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)"
+                                    : "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
+      return c->nranks > 1 ? TLOAM_E_RCCL : TLOAM_E_HIP;
     }
     if (attempt > 0 || planned >= kSolveSweeps) {
       c->last_error = "the minimiser did not terminate within its evaluation budget";
@@ -995,7 +1026,7 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   GnState* st = c->state.p;
   const int* run_build = &st->run_build;
   const int* run_refresh = &st->run_refresh;
-  int planned[kMaxOuterFast], solve_start[kMaxOuterFast], used[kMaxOuterFast];
+  int planned[kMaxOuterFast] = {}, solve_start[kMaxOuterFast] = {}, used[kMaxOuterFast] = {};
   double mus[kMaxOuterFast];
   HostMirror hms[kMaxOuterFast];
   double mu = initial_mu(c);
@@ -1047,6 +1078,10 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
       return TLOAM_E_HIP;
     }
     if (S->incomplete == OS_SKIPPED) break;   // the loop had ended before this iteration
+    if (S->incomplete == OS_COMM_ERROR) {
+      c->last_error = "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
+      return TLOAM_E_HIP;
+    }
     if (S->incomplete == OS_INCOMPLETE) {
       // The Solve of this iteration ran out of its planned budget: the device stopped the loop there (the sweeps of
       // the later iterations, gated only on `done`, have meanwhile continued this same Solve; their builds, refreshes
@@ -1321,8 +1356,12 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
     c->k3_alg_bytes = alg_bytes_of(full);
     (void)nn;
   }
-  c->k3_grid = k3_grid_for((int)total_cap);
-  c->k3_single = k3_single_pass((int)total_cap, c->k3_grid);
+  {
+    int caps[kKinds];
+    for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
+    k3_plan(caps, &c->k3_grid, &c->k3_single);
+    (void)total_cap;
+  }
   HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
   return TLOAM_OK;
 }

@@ -82,9 +82,10 @@ int submap_finish(tloam_ctx* c, size_t* n_edge, size_t* n_ground) {  // the ONE 
   bool have = false;
   if (S.pending_seq) {  // the sizes arrive in pinned memory with the last kernel (everything before it has completed)
     const unsigned long long* seg = &c->h_mirror[kMirrorSlots - 1].w[0];
-    const int rc = wait_word(c, &seg[7], S.pending_seq);
+    unsigned long long pay[7];
+    const int rc = wait_segment(c, seg, S.pending_seq, pay);
     if (rc < 0) return rc;
-    if (rc == TLOAM_OK) { h[0] = seg[0]; h[1] = seg[1]; ov = (int)seg[2]; have = true; }
+    if (rc == TLOAM_OK) { h[0] = pay[0]; h[1] = pay[1]; ov = (int)pay[2]; have = true; }
     S.pending_seq = 0ull;
   }
   if (!have) {

@@ -102,10 +102,13 @@ struct GnState {
   double x_norm, gmax, model_cost_change;
   double g[6], H[36]; // robustified normal equations at x
   double S[6];        // Jacobi scaling (fixed at iteration 0 of each Solve)
-  // dogleg
-  double radius, mu, alpha, step_norm;
+  // dogleg (DoglegStrategy).  Kept in the form the step's hot path needs (tl_step.hpp): D = the clamped diagonal
+  // itself (min_diagonal_^2 .. max_diagonal_^2, i.e. Ceres' diagonal_ SQUARED), gn = the Gauss-Newton step in the
+  // Jacobi-scaled space (-y of (Hs + mu D) y = gs, i.e. gauss_newton_step_ / diagonal_), gn_norm = | gauss_newton_step_ |
+  double radius, mu, alpha, step_norm, gn_norm;
   double D[6], grad[6], gn[6], U[12], sg[2], sB[4];
   int reuse, subspace_1d;
+  int cand_gn;        // the candidate in the state (x_cand, T_eval, model_cost_change) is the Gauss-Newton step of the dogleg data above
   int phase, iteration, invalid, step_successful, done;
   int no_eval_reuse;  // development knob (TLOAM_NO_EVAL_REUSE): every evaluation runs its own sweep
   int comm_error;     // a mailbox exchange timed out (sharded contexts): published to the host as incomplete = 3
@@ -126,11 +129,12 @@ static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible pre
 // copy kernel plus a stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).
 // out == nullptr: off.
 // The slot is written WITHOUT any fence: it is three 64-byte segments, each carrying seven words of the prefix and,
-// last, the sequence number; one wave stores all 24 words with one instruction, every segment leaves the GPU as one
-// aligned 64-byte write (a full cache line for the host), so a segment whose number has arrived has arrived whole,
-// and the host waits for the number in all three.  (A system-scope release would first write back every dirty L2
-// line of the kernel, ~2 us; writing the number behind the words with only a wave-level wait is NOT safe: the two
-// cache lines travel through different L2 channels.)
+// last, the sequence number XORed with those seven words; one wave stores all 24 words with one instruction.  In
+// practice every segment leaves the GPU as one aligned 64-byte write (a full cache line for the host); the host does
+// not rely on that: it accepts a segment only when the XOR of its eight words equals the number it waits for
+// (tlh::wait_segment), so a torn segment reads as "not there yet".  (A system-scope release would first write back
+// every dirty L2 line of the kernel, ~2 us; writing the number behind the words with only a wave-level wait is NOT
+// safe: the two cache lines travel through different L2 channels.)
 struct MirrorSlot {
   unsigned long long w[24];
 };
@@ -218,6 +222,7 @@ __device__ __forceinline__ void arm_solver(GnState& s) {
   s.radius = 1e4;
   s.mu = 1e-8;
   s.reuse = 0;
+  s.cand_gn = 0;
   s.subspace_1d = 0;
   s.phase = PH_ITER0;
   s.iteration = 0;
@@ -370,7 +375,7 @@ void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long lo
 
 // K3 and the minimiser
 int k3_grid_for(int total_cap);
-bool k3_single_pass(int total_cap, int grid);  // one wave per chunk (small sets) vs the streaming variant
+void k3_plan(const int cap[kKinds], int* grid, bool* single);  // one wave per chunk (small sets) vs the streaming variant
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // sharded contexts: the sweep whose LAST block (ticket counter) also folds the block rows into out48 and, with a

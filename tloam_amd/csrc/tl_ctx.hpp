@@ -220,6 +220,7 @@ constexpr int kMirrorSlots = 8;
 namespace tlh {
 // tl_api.hip
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
+int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]);
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
                      tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr,
                      tl::FrameInitHook* frame = nullptr);

@@ -18,8 +18,11 @@ struct WeightArgs {
 // publish the outer iteration's sums into the state and re-arm the minimiser for the next ceres::Solve
 // (the pose, hence T_cur, is already exp(x) after a Solve) -- saves the separate init launch
 // Host mirror (HostMirror, tl_common.hpp).  Called by every thread of the (single) block once the block's own
-// state writes are done: the host-visible prefix first (16 words, one coalesced store), system-scope fence, then
-// the sequence number.
+// state writes are done: ONE store instruction of one wave writes the three 64-byte segments of the slot, each seven
+// words of the host-visible prefix and, last, the sequence number XORed with those seven words.  No fence; the speed
+// relies on "an aligned 64-byte segment written by one instruction leaves the GPU as one PCIe write" (a platform
+// property, not a language guarantee), the CORRECTNESS does not: the host accepts a segment only when the XOR of its
+// eight words equals the number it waits for (tlh::wait_segment), so a torn segment simply reads as "not there yet".
 // status >= 0 replaces the `incomplete` word of the copy (a launch that was gated off reports OS_SKIPPED without
 // touching the state itself).
 __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
@@ -27,13 +30,20 @@ __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirr
   __syncthreads();
   if (tid >= 24) return;  // one store instruction of one wave: 3 segments x (7 words + sequence number), see MirrorSlot
   const int seg = tid >> 3, pos = tid & 7, word = seg * 7 + pos;
-  unsigned long long w = hm.seq;
+  unsigned long long w = 0ull;
   if (pos < 7) {
     w = word < kMirrorWords ? reinterpret_cast<const unsigned long long*>(st)[word] : 0ull;
     constexpr int kStatusWord = (int)(offsetof(GnState, incomplete) / 8);
     static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
     if (status >= 0 && word == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
   }
+  // last word of the segment = sequence number XOR the segment's seven payload words: the host accepts a segment only
+  // when the XOR of its eight words equals the number it waits for, so a torn segment reads as "not there yet"
+  unsigned long long x = w;
+  x ^= __shfl_xor(x, 1, 64);
+  x ^= __shfl_xor(x, 2, 64);
+  x ^= __shfl_xor(x, 4, 64);
+  if (pos == 7) w = hm.seq ^ x;
   __hip_atomic_store(&hm.out->w[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the
@@ -69,6 +79,13 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
           st->run_refresh = moved ? 0 : 1;
           arm_solver(*st);
         }
+      }
+    }
+    if (st->comm_error) {   // an in-launch hand-over timed out (tagged rows of the fused GN iteration / a mailbox exchange)
+      st->incomplete = OS_COMM_ERROR;
+      if (ctl.fast) {
+        __hip_atomic_store(&st->stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st->run_build = st->run_refresh = 0;
       }
     }
   }
@@ -228,7 +245,9 @@ __device__ __forceinline__ void weights_finish_small_ride(GnState* st, const int
 #pragma unroll
     for (int i = 0; i < 5; ++i) __hip_atomic_store(R.rows + wave * 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the row has left the wave (and the flags have been read)
+  // the row has been acknowledged by the coherence point (and the flags have been read) before the ticket is taken: an
+  // explicit wait for the wave's write-through stores -- a workgroup-scope release emits none on gfx950 (see k3_take_ticket)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 15) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;

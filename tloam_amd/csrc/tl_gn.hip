@@ -320,7 +320,35 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const int* __restr
 }
 // Small correspondence sets (KITTI caps: <= 5.9 k factors): the grid has one wave per chunk of the
 // concatenated (planar | ground | edge | sphere) list, so wave gw owns exactly chunk gw -- one fetch, one
-// evaluation, no chunk loop and no modulo distribution.  Same per-wave arithmetic as sweep_all.
+// evaluation, no chunk loop and no modulo distribution.  A line or point correspondence costs ~3x the instructions of a
+// plane (three residual rows), and the launch ends when its slowest wave does: the chunks of those kinds are 64
+// correspondences (one per lane) instead of 128, which evens the waves out (single_chunk_of).
+#ifndef TLOAM_SMALL_LINE_CHUNK
+#define TLOAM_SMALL_LINE_CHUNK 64
+#endif
+__host__ __device__ constexpr int single_chunk_of(int kind) { return kind <= TLOAM_KIND_GROUND ? kChunk : TLOAM_SMALL_LINE_CHUNK; }
+// one correspondence per lane (the 64-chunks): the streams as 8-byte loads into the first slot of the chunk buffer
+template <int RES>
+__device__ __forceinline__ void fetch_one(const CorrSeg& seg, int j, ChunkBuf<RES>& b) {
+  b.px.x = seg.px[j]; b.py.x = seg.py[j]; b.pz.x = seg.pz[j];
+  b.ax.x = seg.ax[j]; b.ay.x = seg.ay[j]; b.az.x = seg.az[j];
+  b.w.x = seg.w[j];
+  if (RES == TLOAM_RES_PLANE) b.d.x = seg.d[j];
+  if (RES == TLOAM_RES_LINE) { b.bx.x = seg.bx[j]; b.by.x = seg.by[j]; b.bz.x = seg.bz[j]; }
+}
+template <int RES>
+__device__ __forceinline__ void sweep_single_kind(const Rt& T, const CorrSeg& seg, int n, int g, int lane, Acc& a) {
+  ChunkBuf<RES> b{};
+  if (single_chunk_of(RES == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE) == kChunk) {
+    const int j = g * kChunk + lane * 2;
+    fetch<RES, false>(seg, j, b);
+    consume<RES, false>(T, seg, j, n, b, a);
+  } else {
+    const int j = g * 64 + lane;
+    fetch_one<RES>(seg, j, b);
+    consume<RES, false>(T, seg, j, n < j + 1 ? n : j + 1, b, a);   // this lane's one correspondence
+  }
+}
 __device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, int gw, int lane,
                                              Acc& a, const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
 #pragma unroll
@@ -331,22 +359,18 @@ __device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __re
 #pragma unroll
   for (int k = 0; k < kKinds; ++k) {
     const int n = seg_n[k];
-    const int nchunks = (n + kChunk - 1) / kChunk;
+    const int nchunks = (n + single_chunk_of(k) - 1) / single_chunk_of(k);
     if (g >= 0 && g < nchunks) {
-      const int j = g * kChunk + lane * 2;
       if (k <= TLOAM_KIND_GROUND) {
+        const int j = g * kChunk + lane * 2;
         ChunkBuf<TLOAM_RES_PLANE> b;
         if (use_pre0 && k == 0) b = pre0;
         else fetch<TLOAM_RES_PLANE, false>(cv.k[k], j, b);
         consume<TLOAM_RES_PLANE, false>(T, cv.k[k], j, n, b, a);
       } else if (k == TLOAM_KIND_EDGE) {
-        ChunkBuf<TLOAM_RES_LINE> b;
-        fetch<TLOAM_RES_LINE, false>(cv.k[k], j, b);
-        consume<TLOAM_RES_LINE, false>(T, cv.k[k], j, n, b, a);
+        sweep_single_kind<TLOAM_RES_LINE>(T, cv.k[k], n, g, lane, a);
       } else {
-        ChunkBuf<TLOAM_RES_POINT> b;
-        fetch<TLOAM_RES_POINT, false>(cv.k[k], j, b);
-        consume<TLOAM_RES_POINT, false>(T, cv.k[k], j, n, b, a);
+        sweep_single_kind<TLOAM_RES_POINT>(T, cv.k[k], n, g, lane, a);
       }
     }
     g -= nchunks;
@@ -424,7 +448,11 @@ __device__ __forceinline__ bool k3_take_ticket(double* __restrict__ partials, co
     __hip_atomic_store(partials + (size_t)blockIdx.x * kAccStride + threadIdx.x,
                        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x],
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the wave's stores have completed (vmcnt) ...
+  // The row must have REACHED the coherence point before the ticket is taken: row store and ticket RMW travel through
+  // different L2 channels and are not ordered with each other.  A workgroup-scope release emits no vmcnt wait on gfx950
+  // (non-tgsplit), an agent-scope release would write back the XCD's whole L2 -- so wait for the wave's own write-through
+  // (sc1) stores explicitly, then meet the other waves.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                          // ... in every wave of the block
   if (threadIdx.x == 0)
     s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
@@ -466,6 +494,73 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
     s_tot[threadIdx.x] = t;
   }
   __syncthreads();
+}
+// ---- KITTI-size grids (<= kTaggedRows blocks): the rows ARE the flag ---------------------------------------------
+// Ticket hand-over above = row stores -> wait for their completion -> returning atomic -> (last block) row loads: three
+// dependent trips to the coherence point, ~2.2 us per GN iteration of a KITTI-size frame (phase stamps: 0.85 us from the
+// end of the sweep to the ticket, 1.35 us for the fold).  For a grid of a dozen blocks a FIXED consumer (block 0) that
+// polls the rows themselves needs one: every block stores its row as four 64-byte segments of (seven sums, check word)
+// with ONE write-through store instruction, check = tag XOR the seven sums, tag = a launch counter every block reads at
+// its start and the consumer advances at its end; the consumer re-reads all rows (device-scope loads) until every
+// segment checks, then folds them in the order fold_rows uses.  No ordering between any two words is relied on: a
+// segment that has only partly arrived -- or still holds an older launch's sums -- does not check.  All blocks of such a
+// grid are resident at once (a dozen blocks on 256 CUs); the spin is bounded all the same (~1 s, then the Solve is
+// stopped with GnState::comm_error).
+constexpr int kTaggedRows = 16;
+__device__ __forceinline__ unsigned long long xor8(unsigned long long x) {  // XOR over aligned groups of eight lanes
+  x ^= __shfl_xor(x, 1, 64);
+  x ^= __shfl_xor(x, 2, 64);
+  x ^= __shfl_xor(x, 4, 64);
+  return x;
+}
+__device__ __forceinline__ void k3_post_row_tagged(double* __restrict__ partials, const double (*red)[32], unsigned long long tag) {
+  if (threadIdx.x < kAccStride) {
+    const int t = threadIdx.x, seg = t >> 3, pos = t & 7, c = seg * 7 + pos;   // word t of the row carries sum c (pos < 7)
+    const double val = pos < 7 ? ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c] : 0.0;
+    unsigned long long w = (unsigned long long)__double_as_longlong(val);
+    const unsigned long long x = xor8(w);
+    if (pos == 7) w = tag ^ x;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + (size_t)blockIdx.x * kAccStride + t, w, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// all 256 threads of the consumer block; rows <= kTaggedRows.  false: timed out (a block of the grid never posted)
+__device__ __forceinline__ bool fold_rows_tagged(const double* __restrict__ partials, int rows, unsigned long long tag,
+                                                 double* s_grp /*[8*33]*/, double* s_tot) {
+  const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;   // word `word` of rows grp and grp + 8
+  const bool have0 = grp < rows, have1 = grp + 8 < rows;
+  const unsigned long long* p0 = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have0 ? grp : 0) * kAccStride + word;
+  const unsigned long long* p1 = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have1 ? grp + 8 : 0) * kAccStride + word;
+  unsigned long long w0, w1;
+  const unsigned long long t0 = wall_clock64();
+  bool ok_all;
+  for (;;) {
+    w0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (!have0 || xor8(w0) == tag) && (!have1 || xor8(w1) == tag);
+    ok_all = __syncthreads_and(ok ? 1 : 0) != 0;
+    if (ok_all) break;
+    if (wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock (uniform enough: every thread leaves within a poll)
+    __builtin_amdgcn_s_sleep(1);
+  }
+  ok_all = __syncthreads_and(ok_all ? 1 : 0) != 0;
+  const int seg = word >> 3, pos = word & 7, c = seg * 7 + pos;
+  const double a = (have0 && pos < 7) ? __longlong_as_double((long long)w0) : 0.0;
+  const double b = (have1 && pos < 7) ? __longlong_as_double((long long)w1) : 0.0;
+  // the tree of fold_rows (sixteen values per thread, fourteen of them zero here), literally, so that the fused
+  // iteration and sweep + separate reduce agree bit for bit
+  const double v = (((a + 0.0) + 0.0) + 0.0) + (((b + 0.0) + 0.0) + 0.0);
+  if (pos < 7) s_grp[grp * 33 + c] = v;
+  __syncthreads();
+  if (threadIdx.x < kReduceBuf) {
+    double t = 0.0;
+    if (threadIdx.x < kAccN)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += s_grp[g * 33 + threadIdx.x];
+    s_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  return ok_all;
 }
 __device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const double (*red)[32], const K3Fuse& fuse) {
   __shared__ double s_grp[8 * 33];
@@ -555,8 +650,22 @@ int k3_grid_for(int total_cap) {
   }
   return blocks;
 }
-// one wave per chunk: the grid (4 waves per block) covers every chunk the segments can hold
-bool k3_single_pass(int total_cap, int grid) { return (total_cap + kChunk - 1) / kChunk <= grid * 4; }
+// The sweep of a set with segment capacities cap[k] (multiples of kChunk): one wave per chunk (sweep_single: chunks of
+// single_chunk_of(kind) correspondences) while that fits the resident chip, the streaming variant otherwise.
+void k3_plan(const int cap[kKinds], int* grid, bool* single) {
+  long long waves = 0, total = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    waves += (cap[k] + single_chunk_of(k) - 1) / single_chunk_of(k);
+    total += cap[k];
+  }
+  if (waves <= 256 * 2 * 4 && !getenv("TLOAM_K3_BLOCKS")) {
+    *single = true;
+    *grid = (int)((waves + 3) / 4) < 1 ? 1 : (int)((waves + 3) / 4);
+    return;
+  }
+  *grid = k3_grid_for((int)total);
+  *single = ((total + kChunk - 1) / kChunk <= (long long)*grid * 4) && TLOAM_SMALL_LINE_CHUNK == kChunk;
+}
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kern = single ? k3_accumulate<true, false> : k3_accumulate<false, false>;
@@ -595,500 +704,10 @@ void launch_reduce(const double* partials, int grid, GnState* st, double* out48,
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st, out48);
 }
 
-__device__ __forceinline__ double rdlane(double v, int lane_const) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
-  return __hiloint2double(hi, lo);
-}
+}  // namespace tl
+#include "tl_step.hpp"   // K5: the minimiser step (gn_consume)
+namespace tl {
 
-struct Vec2 { double x, y; };
-// minimum of 0.5 x^T B x + g^T x on |x| = r (dogleg_strategy.cc FindMinimumOnTrustRegionBoundary;
-// Ceres roots a quartic -- the global minimiser is unique, here bracketed by sampling the angle
-// and polished by bisection on the tangential derivative).  Rare branch: only when the
-// Gauss-Newton step leaves the trust region.
-__device__ __forceinline__ Vec2 min_on_circle(double B0, double B1, double B2, double B3, double g0, double g1, double r) {
-  const int NS = 720;
-  double best = 1e300, bth = 0.0;
-  const double b01 = 0.5 * (B1 + B2);
-  for (int i = 0; i < NS; ++i) {
-    const double th = 2.0 * kPi * i / NS;
-    const double cx = r * cos(th), sx = r * sin(th);
-    const double f = 0.5 * (B0 * cx * cx + 2.0 * b01 * cx * sx + B3 * sx * sx) + g0 * cx + g1 * sx;
-    if (f < best) { best = f; bth = th; }
-  }
-  double lo = bth - 2.0 * kPi / NS, hi = bth + 2.0 * kPi / NS;
-  for (int it = 0; it < 200; ++it) {
-    const double th = 0.5 * (lo + hi);
-    const double cx = r * cos(th), sx = r * sin(th);
-    const double gx = B0 * cx + b01 * sx + g0;
-    const double gy = b01 * cx + B3 * sx + g1;
-    const double df = gx * (-sx) + gy * cx;
-    if (df > 0.0) hi = th; else lo = th;
-    if (hi - lo < 1e-16 * (1.0 + fabs(th))) break;
-  }
-  const double th = 0.5 * (lo + hi);
-  return Vec2{r * cos(th), r * sin(th)};
-}
-
-#ifdef TLOAM_STEP_PROFILE
-#define TL_STAMP(i) if (lane == 0) st->dbg[i] = (double)__builtin_readcyclecounter();
-#ifndef TLOAM_STAMP2_POS
-#define TLOAM_STAMP2_POS 4
-#endif
-#define TL_STAMP2_AT(pos) if (TLOAM_STAMP2_POS == pos) { TL_STAMP(2) }
-#else
-#define TL_STAMP(i)
-#define TL_STAMP2_AT(pos)
-#endif
-
-// ================================================================================================
-//  K5: Ceres TrustRegionMinimizer + DoglegStrategy on the 6x6 system, ONE WAVE, WAVE-UNIFORM: every lane carries the
-//  system in registers and executes the same instruction stream, so the Cholesky factorisation, the solves and the
-//  quadratic forms are plain register arithmetic with no cross-lane exchange on the critical path (round 1's
-//  lane-as-matrix-element form spent ~18 dependent LDS-crossbar round trips on them: 5.1-5.6 k cycles for the dogleg
-//  part against 1.7-2.2 k here), and the IEEE divisions / square roots of the chain (39 and 18 of them, 12-35
-//  dependent instructions each) are v_rcp_f64 / v_rsq_f64 + one Newton step (<= 1-2 ulp).  The two SE(3) "Plus"
-//  evaluations a step needs run in lockstep: even lanes the candidate, odd lanes Ceres' projected-gradient point.
-//  What is left is issue-bound: ~4 k wave instructions at >= 4 cycles each (a 64-wide fp64 instruction occupies the
-//  16-lane pipe for four cycles whether or not the lanes differ).
-//
-//  Consume one reduced sweep (tot: H upper triangle 0..20, g 21..26, cost 27 -- in LDS) and run the minimiser until
-//  the next sweep is needed or it is done.  Mirrors trust_region_minimizer.cc Minimize(): IterationZero, then per
-//  iteration ComputeTrustRegionStep -> candidate -> tolerances -> IsStepSuccessful -> Handle(Un)SuccessfulStep, with
-//  DoglegStrategy (SUBSPACE_DOGLEG) inlined.  The candidate sweep is fused (cost + Jacobian in one pass): Ceres
-//  evaluates the candidate cost-only and re-evaluates an accepted point with Jacobians -- same numbers, half the
-//  traffic.  The gradient-tolerance test of a freshly accepted point is evaluated together with the next candidate
-//  and, if it fires, the speculative iteration is rolled back.
-//  Evaluation reuse: when the minimiser asks for the evaluation of a point that is bit-identical to the one whose
-//  totals are in `tot` -- a rejected step retried inside the halved trust region re-creates exactly the same candidate
-//  (four times per Solve from the second outer iteration on) -- the answer is already here: count the
-//  evaluation and go round again instead of waiting for another sweep.  Residuals, Jacobians and side-channel costs
-//  are pure functions of the point, so nothing observable changes.
-// ================================================================================================
-__device__ __forceinline__ double fsqrt(double x) {  // x >= 0
-  const double r = fast_rsqrt(x);
-  return x > 0.0 ? x * r : x;
-}
-__device__ __forceinline__ double dot6(const double a[6], const double b[6]) {
-  return ((a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3])) + (a[4] * b[4] + a[5] * b[5]);
-}
-// a^T M b with M symmetric, stored as its upper triangle (ut)
-__device__ __forceinline__ double quad6(const double a[6], const double M[21], const double b[6]) {
-  double acc = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double row = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) row = __builtin_fma(M[i <= j ? ut(i, j) : ut(j, i)], b[j], row);
-    acc = __builtin_fma(a[i], row, acc);
-  }
-  return acc;
-}
-// (A) y = b, A symmetric positive definite (upper triangle in Au, destroyed).  false: a pivot is not positive /
-// finite or the result is not finite (Ceres: LINEAR_SOLVER_FAILURE).
-__device__ __forceinline__ bool chol6_uniform(double Au[21], const double b[6], double y[6]) {
-  bool ok = true;
-  double inv[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double pivot = Au[ut(k, k)];
-    if (!(pivot > 0.0) || !isfinite(pivot)) ok = false;
-    inv[k] = fast_rsqrt(pivot);                      // 1 / l_kk
-#pragma unroll
-    for (int j = k + 1; j < 6; ++j) Au[ut(k, j)] *= inv[k];   // row k of L^T
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) Au[ut(i, j)] = __builtin_fma(-Au[ut(k, i)], Au[ut(k, j)], Au[ut(i, j)]);
-  }
-  double z[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) z[k] = b[k];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {   // L z = b
-    z[k] *= inv[k];
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) z[i] = __builtin_fma(-Au[ut(k, i)], z[k], z[i]);
-  }
-#pragma unroll
-  for (int k = 5; k >= 0; --k) {  // L^T y = z
-    double t = z[k];
-#pragma unroll
-    for (int j = k + 1; j < 6; ++j) t = __builtin_fma(-Au[ut(k, j)], y[j], t);
-    y[k] = t * inv[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k)
-    if (!isfinite(y[k])) ok = false;
-  return ok;
-}
-
-// exp / product / log with the reciprocals and square roots of the chain on v_rcp / v_rsq (+ Newton)
-__device__ __forceinline__ Pose exp_fast2(const double a[6]) {
-  const double ox = a[3], oy = a[4], oz = a[5];
-  const double theta_sq = ox * ox + oy * oy + oz * oz;
-  Pose T;
-  const Vec3 om{ox, oy, oz}, u{a[0], a[1], a[2]};
-  if (theta_sq < kSophusEps * kSophusEps) {
-    const double theta_po4 = theta_sq * theta_sq;
-    const double imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
-    T.qw = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
-    T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
-    const Vec3 t = rotate(T, u);
-    T.tx = t.x; T.ty = t.y; T.tz = t.z;
-    return T;
-  }
-  const double inv_theta = fast_rsqrt(theta_sq);
-  const double theta = theta_sq * inv_theta;
-  double sh, ch;
-  sincos(0.5 * theta, &sh, &ch);
-  const double imag = sh * inv_theta;
-  T.qw = ch; T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
-  Vec3 t;
-  if (theta < kSophusEps) {
-    t = rotate(T, u);
-  } else {
-    const double c1 = 2.0 * imag * imag;                                            // (1 - cos t) / t^2
-    const double c2 = (theta - 2.0 * sh * ch) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
-    const Vec3 w1 = cross(om, u);
-    const Vec3 w2 = cross(om, w1);
-    t = u + c1 * w1 + c2 * w2;
-  }
-  T.tx = t.x; T.ty = t.y; T.tz = t.z;
-  return T;
-}
-__device__ __forceinline__ Pose compose_fast2(const Pose& A, const Pose& B) {
-  Pose C;
-  C.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
-  C.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
-  C.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
-  C.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
-  const double il = fast_rsqrt(C.qw * C.qw + C.qx * C.qx + C.qy * C.qy + C.qz * C.qz);
-  C.qw *= il; C.qx *= il; C.qy *= il; C.qz *= il;
-  const Vec3 rt = rotate(A, Vec3{B.tx, B.ty, B.tz});
-  C.tx = A.tx + rt.x; C.ty = A.ty + rt.y; C.tz = A.tz + rt.z;
-  return C;
-}
-__device__ __forceinline__ void log_fast2(const Pose& T, double a[6]) {
-  const double squared_n = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
-  const double w = T.qw;
-  double f, theta, c2;
-  if (squared_n < kSophusEps * kSophusEps) {
-    const double iw = fast_rcp(w);
-    f = 2.0 * iw - (2.0 / 3.0) * squared_n * (iw * iw * iw);
-    theta = 2.0 * squared_n * iw;
-    c2 = 1.0 / 12.0;
-  } else {
-    const double in_ = fast_rsqrt(squared_n);   // 1 / n
-    const double n = squared_n * in_;
-    if (fabs(w) < kSophusEps) {
-      f = (w > 0.0) ? kPi * in_ : -kPi * in_;
-      theta = f * n;
-      c2 = fast_rcp(theta * theta);  // cos(theta/2) -> 0
-    } else {
-      f = 2.0 * atan(n * fast_rcp(w)) * in_;
-      theta = f * n;
-      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : (1.0 - 0.5 * theta * w * in_) * fast_rcp(theta * theta);
-    }
-  }
-  const Vec3 om{f * T.qx, f * T.qy, f * T.qz};
-  const Vec3 t{T.tx, T.ty, T.tz};
-  const Vec3 w1 = cross(om, t);
-  const Vec3 w2 = cross(om, w1);
-  const Vec3 ups = t + (-0.5) * w1 + c2 * w2;
-  a[0] = ups.x; a[1] = ups.y; a[2] = ups.z;
-  a[3] = om.x;  a[4] = om.y;  a[5] = om.z;
-}
-
-// `sm`: the state as of the start of the launch, in LDS (one coalesced copy, see k_reduce_and_step); the cold part
-// of the state (H, g of the accepted point, the subspace basis) stays THERE and is read when needed -- the wave's
-// registers hold only what the chain works on.
-__device__ __forceinline__ void gn_consume_uniform(GnState* st, const double* tot /* LDS */, int lane, GnState* sm /* LDS */) {
-  TL_STAMP(1)
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-  const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
-  const int max_num_iterations = 4, max_consecutive_invalid = 5;
-  // ---- state (all wave-uniform)
-  int phase = sm->phase, iteration = sm->iteration, invalid = sm->invalid, step_successful = sm->step_successful;
-  int reuse = sm->reuse, subspace_1d = sm->subspace_1d, done = 0;
-  int evals = sm->gn_evaluations + 1, iters = sm->gn_iterations, accepted = sm->accepted_steps;
-  double x_cost = sm->x_cost, x_norm = sm->x_norm, gmax = sm->gmax, mcc = sm->model_cost_change;
-  double radius = sm->radius, mu = sm->mu, step_norm = sm->step_norm;
-  Pose T_cur = sm->T_cur, T_eval = sm->T_eval;
-  // The LDS copy is the home of the state; registers hold only what the chain is working on (the dogleg vectors D,
-  // grad, gn are read from / written to the copy where they are used: short live ranges keep the wave inside the
-  // 256 architectural VGPRs -- the first version shuttled 650 values per launch through accumulator registers).
-  double x[6], xc[6], S[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { x[i] = sm->x[i]; xc[i] = sm->x_cand[i]; S[i] = sm->S[i]; }
-  // ---- the new sweep
-  const double cost = tot[27];
-  const int sweeps = sm->gn_sweeps + 1;
-  const bool eval_reuse = sm->no_eval_reuse == 0;
-  bool dirty_S = false, dirty_x = false;
-  bool gn_inside = false;
-  TL_STAMP2_AT(1)
-  for (;;) {
-  // (the point `tot` was evaluated at is the candidate of the state as it came in -- sm->x_cand / sm->T_eval -- in
-  //  every pass of this loop: a further pass only happens when the new candidate is bit-identical to it)
-  const int phase_in = phase;
-  bool need_gmax = false;
-  bool take_sweep = false;   // the totals of this sweep become the system of the accepted point
-  if (phase == PH_ITER0) {
-    x_cost = cost;
-    take_sweep = true;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) S[i] = fast_rcp(1.0 + fsqrt(tot[ut(i, i)]));  // jacobi_scaling, fixed at iteration 0 of the Solve
-    x_norm = fsqrt(dot6(x, x));
-    step_successful = 1;
-    need_gmax = true;
-    dirty_S = true;
-  } else {
-    const double candidate_cost = cost;
-    double dx[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dx[i] = x[i] - xc[i];
-    if (fsqrt(dot6(dx, dx)) <= parameter_tolerance * (x_norm + parameter_tolerance)) done = 1;   // ParameterToleranceReached
-    else if (fabs(x_cost - candidate_cost) <= function_tolerance * x_cost) done = 1;             // FunctionToleranceReached
-    else {
-      const double rel = (x_cost - candidate_cost) / mcc;   // TrustRegionStepEvaluator::StepQuality (a decision: exact division)
-      if (rel > min_relative_decrease) {                    // HandleSuccessfulStep
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x[i] = xc[i];
-        T_cur = T_eval;
-        x_norm = fsqrt(dot6(x, x));
-        x_cost = candidate_cost;
-        take_sweep = true;
-        step_successful = 1;
-        accepted++;
-        need_gmax = true;
-        if (rel < 0.25) radius *= 0.5;                      // DoglegStrategy::StepAccepted
-        if (rel > 0.75) radius = fmax(radius, 3.0 * step_norm);
-        mu = fmax(1e-8, 2.0 * mu / 10.0);
-        reuse = 0;
-        dirty_x = true;
-      } else {                                              // HandleUnsuccessfulStep / StepRejected
-        step_successful = 0;
-        radius *= 0.5;
-        reuse = 1;
-      }
-    }
-  }
-  TL_STAMP2_AT(2)
-  if (take_sweep) {
-    // H (full 6x6) and g of the accepted point: LDS copy and device state, one element per lane
-    const int mi = lane < 36 ? lane / 6 : 0, mj = lane < 36 ? lane - mi * 6 : 0;
-    const int lo = mi < mj ? mi : mj, hi = mi < mj ? mj : mi;
-    const double h = tot[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
-    const double gg = tot[21 + (lane < 6 ? lane : 0)];
-    if (lane < 36) { sm->H[lane] = h; st->H[lane] = h; }
-    if (lane < 6) { sm->g[lane] = gg; st->g[lane] = gg; }
-  }
-  TL_STAMP2_AT(3)
-  while (!done) {
-    // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient test deferred while need_gmax)
-    if (iteration >= max_num_iterations) { done = 1; break; }
-    if (!need_gmax && step_successful && gmax <= gradient_tolerance) { done = 1; break; }
-    if (radius <= min_trust_region_radius) { done = 1; break; }
-    iteration++;
-    iters++;
-    // A rejected step retried with the dogleg data reused (reuse == 1) whose Gauss-Newton point is still inside
-    // the halved region yields, input for input, the candidate this launch has just built: x_cand, T_eval and
-    // the model cost change are already right -- skip the 6x6 work and the exp/log.
-    if (reuse && gn_inside && step_norm <= radius && !need_gmax) {
-      invalid = 0;
-      phase = PH_CAND;
-      break;
-    }
-    gn_inside = false;
-    TL_STAMP2_AT(4)
-    // ---- Jacobi-scaled system
-    double Hs[21], gs[6], gc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      gc[i] = sm->g[i];
-      gs[i] = S[i] * gc[i];
-#pragma unroll
-      for (int j = i; j < 6; ++j) Hs[ut(i, j)] = S[i] * sm->H[i * 6 + j] * S[j];
-    }
-    bool lin_ok = true;
-    if (!reuse) {  // DoglegStrategy::ComputeStep, fresh
-      reuse = 1;
-      double D[6], grad[6], gnv[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        D[i] = fsqrt(fmin(fmax(Hs[ut(i, i)], 1e-6), 1e32));  // min_diagonal_ / max_diagonal_
-        grad[i] = gs[i] * fast_rcp(D[i]);                      // ComputeGradient
-      }
-      // ComputeGaussNewtonStep: (Hs + mu D^2) y = gs ; on failure mu *= 10 while mu < max_mu (1.0)
-      bool ok = false;
-      double y[6] = {0, 0, 0, 0, 0, 0};
-      while (mu < 1.0) {
-        double A[21];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) A[i] = Hs[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) A[ut(i, i)] = __builtin_fma(mu * D[i], D[i], A[ut(i, i)]);
-        if (chol6_uniform(A, gs, y)) { ok = true; break; }
-        mu *= 10.0;
-      }
-      if (!ok) lin_ok = false;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) gnv[i] = ok ? -D[i] * y[i] : sm->gn[i];
-      {  // the dogleg data of this point: LDS copy + device state, one element per lane
-        const int k6 = lane < 6 ? lane : 0;
-        double dv = D[0], gv = grad[0], nv = gnv[0];
-#pragma unroll
-        for (int i = 1; i < 6; ++i) { dv = (k6 == i) ? D[i] : dv; gv = (k6 == i) ? grad[i] : gv; nv = (k6 == i) ? gnv[i] : nv; }
-        if (lane < 6) { sm->D[lane] = dv; sm->grad[lane] = gv; sm->gn[lane] = nv; st->D[lane] = dv; st->grad[lane] = gv; st->gn[lane] = nv; }
-      }
-      subspace_1d = -1;  // ComputeSubspaceModel is deferred until a step actually leaves the trust region
-    }
-    double D[6], grad[6], gnv[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { D[i] = sm->D[i]; grad[i] = sm->grad[i]; gnv[i] = sm->gn[i]; }
-    TL_STAMP(3)
-    double step[6] = {0, 0, 0, 0, 0, 0};
-    bool valid = false;
-    const double gn2 = dot6(gnv, gnv);
-    if (lin_ok && gn2 == 0.0 && dot6(grad, grad) == 0.0) lin_ok = false;  // rank-0 subspace (Ceres: failure)
-    if (lin_ok) {  // ComputeSubspaceDoglegStep
-      const double gnn = fsqrt(gn2);
-      double iD[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) iD[i] = fast_rcp(D[i]);
-      if (gnn <= radius) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) step[i] = gnv[i] * iD[i];
-        step_norm = gnn;
-        gn_inside = true;
-      } else {
-        // the Gauss-Newton step leaves the trust region (rare): the 2-D subspace model lives in the LDS copy
-        if (subspace_1d < 0) {
-          // ComputeSubspaceModel: orthonormal basis of span{grad, gn}, larger column first; g and B of the 2-D model
-          const double n0 = fsqrt(dot6(grad, grad));
-          const bool gfirst = n0 >= gnn;
-          const double nf = gfirst ? n0 : gnn, ns = gfirst ? gnn : n0;
-          const double inf_ = fast_rcp(nf);
-          double u0[6], u1[6], second[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) { u0[i] = (gfirst ? grad[i] : gnv[i]) * inf_; second[i] = gfirst ? gnv[i] : grad[i]; }
-          const double proj = dot6(u0, second);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) u1[i] = second[i] - proj * u0[i];
-          const double nr = fsqrt(dot6(u1, u1));
-          if (ns == 0.0 || nr <= 1e-14 * nf) {
-            subspace_1d = 1;
-          } else {
-            subspace_1d = 0;
-            const double inr = fast_rcp(nr);
-            double v0[6], v1[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { u1[i] *= inr; v0[i] = u0[i] * iD[i]; v1[i] = u1[i] * iD[i]; }
-            const double b0 = quad6(v0, Hs, v0), b1 = quad6(v0, Hs, v1), b3 = quad6(v1, Hs, v1);
-            const double g0 = dot6(u0, grad), g1 = dot6(u1, grad);
-            if (lane == 0) {
-#pragma unroll
-              for (int i = 0; i < 6; ++i) { sm->U[i] = u0[i]; sm->U[6 + i] = u1[i]; st->U[i] = u0[i]; st->U[6 + i] = u1[i]; }
-              sm->sg[0] = g0; sm->sg[1] = g1; sm->sB[0] = b0; sm->sB[1] = b1; sm->sB[2] = b1; sm->sB[3] = b3;
-              st->sg[0] = g0; st->sg[1] = g1; st->sB[0] = b0; st->sB[1] = b1; st->sB[2] = b1; st->sB[3] = b3;
-            }
-          }
-        }
-        if (subspace_1d) {
-          const double k = -radius * fast_rsqrt(dot6(grad, grad));
-#pragma unroll
-          for (int i = 0; i < 6; ++i) step[i] = k * grad[i] * iD[i];
-        } else {
-          const Vec2 m2 = min_on_circle(sm->sB[0], sm->sB[1], sm->sB[1], sm->sB[3], sm->sg[0], sm->sg[1], radius);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) step[i] = (sm->U[i] * m2.x + sm->U[6 + i] * m2.y) * iD[i];
-        }
-        step_norm = radius;
-      }
-      mcc = -dot6(step, gs) - 0.5 * quad6(step, Hs, step);  // model_cost_change_
-      valid = mcc > 0.0;
-    }
-    TL_STAMP(4)
-    // ---- candidate Plus(x, delta) on the even lanes and projected-gradient point Plus(x, -g) on the odd lanes
-    if (valid || need_gmax) {
-      double din[6];
-      const bool odd = (lane & 1) != 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) din[i] = odd ? -gc[i] : (valid ? step[i] * S[i] : 0.0);
-      const Pose C = compose_fast2(exp_fast2(din), T_cur);  // exp(in) * exp(x)   registration.cpp:162-173
-      double out[6];
-      log_fast2(C, out);
-      if (need_gmax) {
-        need_gmax = false;
-        double m = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) m = fmax(m, fabs(x[i] - rdlane(out[i], 1)));
-        gmax = m;  // || x - Plus(x, -g) ||_inf
-        if (gmax <= gradient_tolerance) {  // the accepted point was already converged: roll back
-          iteration--;
-          iters--;
-          done = 1;
-          break;
-        }
-      }
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) xc[i] = rdlane(out[i], 0);
-        T_eval.qw = rdlane(C.qw, 0); T_eval.qx = rdlane(C.qx, 0); T_eval.qy = rdlane(C.qy, 0); T_eval.qz = rdlane(C.qz, 0);
-        T_eval.tx = rdlane(C.tx, 0); T_eval.ty = rdlane(C.ty, 0); T_eval.tz = rdlane(C.tz, 0);
-        dirty_x = true;
-      }
-    }
-    if (!valid) {  // HandleInvalidStep -> DoglegStrategy::StepIsInvalid
-      gn_inside = false;
-      if (++invalid >= max_consecutive_invalid) { done = 1; break; }
-      mu *= 10.0;
-      reuse = 0;
-      step_successful = 0;
-      continue;
-    }
-    invalid = 0;
-    phase = PH_CAND;
-    break;  // the next K3 sweep evaluates x_cand
-  }
-  if (done || !eval_reuse || phase_in != PH_CAND || phase != PH_CAND) break;
-  const Pose& Th = sm->T_eval;
-  bool same = T_eval.qw == Th.qw && T_eval.qx == Th.qx && T_eval.qy == Th.qy && T_eval.qz == Th.qz &&
-              T_eval.tx == Th.tx && T_eval.ty == Th.ty && T_eval.tz == Th.tz;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) same = same && (xc[i] == sm->x_cand[i]);
-  if (!same) break;
-  evals++;  // served from the totals in hand
-  }
-  TL_STAMP(5)
-  // ---- write back (lane 0; only what this launch changed)
-  if (lane == 0) {
-    if (dirty_x) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { st->x[i] = x[i]; st->x_cand[i] = xc[i]; }
-      st->T_cur = T_cur; st->T_eval = T_eval;
-      st->Rt_eval = to_rt(T_eval);
-    }
-    if (dirty_S) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) st->S[i] = S[i];
-    }
-    st->phase = phase; st->iteration = iteration; st->invalid = invalid; st->step_successful = step_successful;
-    st->reuse = reuse; st->subspace_1d = subspace_1d; st->done = done;
-    st->gn_evaluations = evals; st->gn_iterations = iters; st->accepted_steps = accepted;
-    st->gn_sweeps = sweeps;
-    st->x_cost = x_cost; st->x_norm = x_norm; st->gmax = gmax; st->model_cost_change = mcc;
-    st->radius = radius; st->mu = mu; st->step_norm = step_norm;
-    // has this Solve ended somewhere else than where the factor set was built?  (what publish_and_rearm will find when it
-    // compares x with x_build -- known here already, so the next search need not wait for the finish kernel)
-    bool moved = false;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) moved = moved || (x[i] != sm->x_build[i]);
-    st->spec_build = (done && moved) ? 1 : 0;
-  }
-}
-#define TL_GN_CONSUME gn_consume_uniform
 __global__ void k_solve_init(GnState* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->T_cur = se3_exp(st->x);
@@ -1127,12 +746,13 @@ __device__ __forceinline__ void load_state_lds(const GnState* st, GnState* sm, i
 }
 __global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __restrict__ in48) {
   __shared__ double tot[kReduceBuf];
+  __shared__ double scr[32];
   __shared__ GnState s_in;
   if (threadIdx.x < kReduceBuf) tot[threadIdx.x] = in48[threadIdx.x];
   load_state_lds(st, &s_in, threadIdx.x);
   __syncthreads();
   if (s_in.done) return;
-  TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
+  gn_consume(st, tot, threadIdx.x, &s_in, scr);
 }
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
@@ -1141,6 +761,7 @@ void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
 // rank order and advance the minimiser -- identically on every rank
 __global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
   __shared__ double tot[kMboxSlot];
+  __shared__ double scr[32];
   __shared__ GnState s_in;
   load_state_lds(st, &s_in, threadIdx.x);
   __syncthreads();
@@ -1156,7 +777,7 @@ __global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
     if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
     return;
   }
-  TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
+  gn_consume(st, tot, threadIdx.x, &s_in, scr);
 }
 void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s) {
   hipLaunchKernelGGL(k_gn_step_mbox, dim3(1), dim3(64), 0, s, st, mb);
@@ -1215,7 +836,7 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
   }
   fold_rows<false>(partials, rows, lds, tot);  // (its barriers also publish s_in)
   if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
-  if (threadIdx.x < 64) TL_GN_CONSUME(st, tot, threadIdx.x, &s_in);
+  if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, lds /* free again: the fold is over */);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
@@ -1227,7 +848,7 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
 // (which block will be last is not known), so the step starts without a memory round trip of its own.  Against
 // sweep + step as two launches this removes a kernel boundary, the step's dispatch and its row / state loads from the
 // dependent chain of every GN iteration (measured: the hand-over adds 1.8 us to the 3.65 us sweep of a KITTI-cap set).
-__global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __restrict__ seg0, int stride0, int cap0, int pad_,
+__global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __restrict__ seg0, int stride0, int cap0, int tagged,
                                                              GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                              double* __restrict__ partials, int* __restrict__ ticket,
                                                              CorrView cv) {
@@ -1235,7 +856,6 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
   __shared__ double s_grp[8 * 33];
   __shared__ double tot[kReduceBuf];
   __shared__ GnState s_in;
-  (void)pad_;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
   ChunkBuf<TLOAM_RES_PLANE> pre;
@@ -1247,6 +867,10 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
     if (threadIdx.x < kWords)
       reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
   }
+  // launch counter of the tagged hand-over (words 2..3 of the ticket buffer): read by every block before any block can
+  // have advanced it -- the consumer does so only after every block's row, which carries the tag, has arrived
+  unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
+  const unsigned long long epoch0 = *epoch;
   if (st->done) return;            // after a tolerance exit the remaining launches are no-ops (uniform over the grid)
   const Rt T = st->Rt_eval;
   Acc a;
@@ -1257,19 +881,36 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
 #ifdef TLOAM_STEP_PROFILE
   const unsigned long long c_sweep = __builtin_readcyclecounter();
 #endif
-  if (!k3_take_ticket(partials, red, ticket)) return;
+  if (tagged) {
+    // a dozen blocks: the rows are the flag, block 0 is the consumer (see k3_post_row_tagged)
+    k3_post_row_tagged(partials, red, epoch0 + 1ull);
+    if (blockIdx.x != 0) return;
 #ifdef TLOAM_STEP_PROFILE
-  if (threadIdx.x == 0) { st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter(); }
+    if (threadIdx.x == 0) { st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter(); }
 #endif
-  fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
-  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
-  if (threadIdx.x < 64) gn_consume_uniform(st, tot, threadIdx.x, &s_in);
+    const bool ok = fold_rows_tagged(partials, (int)gridDim.x, epoch0 + 1ull, s_grp, tot);
+    if (threadIdx.x == 0) *epoch = epoch0 + 1ull;   // (plain store: read by the next launch)
+    if (!ok) {  // a block of the grid never posted: stop the Solve; the finish kernel reports OS_COMM_ERROR
+      if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
+      return;
+    }
+  } else {
+    if (!k3_take_ticket(partials, red, ticket)) return;
+#ifdef TLOAM_STEP_PROFILE
+    if (threadIdx.x == 0) { st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter(); }
+#endif
+    fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  }
+  if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, s_grp /* free again: the fold is over */);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
 }
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, 0, st,
+  static const bool no_tagged = getenv("TLOAM_NO_TAGGED_ROWS") != nullptr;   // A/B knob: ticket hand-over for every grid size
+  const int tagged = (grid <= kTaggedRows && !no_tagged) ? 1 : 0;
+  hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
                      cv.seg_n, partials, ticket, cv);
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {

@@ -236,8 +236,13 @@ __global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, VoxelWork W)
     W.n_out[1] = W.leader_scan[J.n] - base1;
   }
   if (W.host_seg && i < 8) {  // ... and straight to the host (stream order: everything the host waits for precedes this kernel)
-    const unsigned long long w = i == 0 ? base1 : i == 1 ? W.leader_scan[J.n] - base1 : i == 2 ? (unsigned long long)W.overflow[0]
-                                 : i == 7 ? W.host_seq : 0ull;
+    unsigned long long w = i == 0 ? base1 : i == 1 ? W.leader_scan[J.n] - base1 : i == 2 ? (unsigned long long)W.overflow[0] : 0ull;
+    // word 7 = sequence number XOR the payload words (tlh::wait_segment: a torn segment reads as "not there yet")
+    unsigned long long x = w;
+    x ^= __shfl_xor(x, 1, 64);
+    x ^= __shfl_xor(x, 2, 64);
+    x ^= __shfl_xor(x, 4, 64);
+    if (i == 7) w = W.host_seq ^ x;
     __hip_atomic_store(&W.host_seg[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (i >= J.n) return;
