@@ -58,9 +58,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
 # THIS command, summarised by scripts/pmc_summary.py with the gfx950 x2 FETCH_SIZE correction).  PMC counters
 # cannot be read from inside the process, so the line quotes the committed summary and says so.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json"),
-                                os.path.join(ROOT, "profiles", "r01_pmc_k3_bench_m1.json")) if os.path.exists(p)),
-                   os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json"))
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt.json"),
+                                os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json")) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt.json"))
+PMC_SUMMARY_COLD = os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt_cold.json")
+
+
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def pmc_traffic(world):
@@ -68,12 +77,17 @@ def pmc_traffic(world):
         return None, None
     try:
         d = json.load(open(PMC_SUMMARY))
-        return float(d["traffic_bytes_per_launch_all"]), {
+        now = _sha16(os.path.join(ROOT, "tloam_amd", "csrc", "tl_gn.hip"))
+        det = {
             "source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; a committed "
                       "summary quoted here, not a counter read by this run)" % os.path.basename(PMC_SUMMARY),
             "fetch_bytes_per_launch": d["fetch_bytes_per_launch_all"],
             "write_bytes_per_launch": d["write_bytes_per_launch_all"],
-            "working_sweeps_traffic": d["traffic_bytes_per_launch_working"]}
+            "working_sweeps_traffic": d["traffic_bytes_per_launch_working"],
+            # the summary records the hash of the kernel source it was measured on: a K3 edited since then makes it stale
+            "kernel_source_sha16": {"measured_on": d.get("kernel_source_sha16"), "now": now},
+            "stale": d.get("kernel_source_sha16") != now}
+        return float(d["traffic_bytes_per_launch_all"]), det
     except Exception:
         return None, None
 
@@ -97,23 +111,29 @@ def measured_copy_bandwidth(torch, device):
     return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def prebuilt_k3(reg, synth, device):
+def prebuilt_k3(reg, synth, device, scale=1):
     """SURVEY 8(d) config 3, K3-only variant: the pre-built 760k:200k:40k set (74.88 MB algorithmic bytes per
     evaluation, timing weights U(0,1) with 10 % exact zeros), >= 100 launches after 10 warm-ups, median of the
-    per-batch means (one HIP event pair around each batch of 20 consecutive launches)."""
-    sets, _, x_eval = synth.make_prebuilt(seed=1, weights="timing")
+    per-batch means (one HIP event pair around each batch of 20 consecutive launches).
+    scale = 4: the same mix four times as large (3.04 M : 0.8 M : 0.16 M, 299.5 MB per sweep) -- the working set of
+    back-to-back sweeps then exceeds the 256 MiB Infinity Cache, every byte of every launch comes from HBM ("cold")."""
+    n = (760_000 * scale, 200_000 * scale, 40_000 * scale)
+    sets, _, x_eval = synth.make_prebuilt(seed=1, n_plane=n[0], n_line=n[1], n_point=n[2], weights="timing")
     H = reg.HipRegistration(device=device)
     for rt in range(3):
         H.set_correspondences(rt, *sets[rt])
+    del sets
+    batch = 20 if scale == 1 else 10
     H.time_accumulate(x_eval, 10)
-    us = sorted(H.time_accumulate(x_eval, 20) for _ in range(6))
+    us = sorted(H.time_accumulate(x_eval, batch) for _ in range(6))
     H.close()
     med = 0.5 * (us[2] + us[3])
-    alg = 760_000 * 72.0 + 200_000 * 88.0 + 40_000 * 64.0
-    return {"workload": "pre-built 1 M set, plane:line:point = 760k:200k:40k (SURVEY 8(d) config 3, K3 only)",
-            "launches": 120, "avg_launch_us": round(med, 3), "algorithmic_bytes_per_launch": alg, "bound": "hbm",
+    alg = n[0] * 72.0 + n[1] * 88.0 + n[2] * 64.0
+    return {"workload": "pre-built set, plane:line:point = %dk:%dk:%dk (SURVEY 8(d) config 3%s, K3 only)" %
+                        (n[0] // 1000, n[1] // 1000, n[2] // 1000, "" if scale == 1 else " x%d" % scale),
+            "launches": 6 * batch, "avg_launch_us": round(med, 3), "algorithmic_bytes_per_launch": alg, "bound": "hbm",
             "achieved": round(alg / (med * 1e-6) / 1e9, 1), "frac": round(alg / (med * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "contract: >= 70 % <=> <= 13.4 us"}
+            "note": "contract: >= 70 %% <=> <= %.1f us" % (alg / 0.7 / HBM_PEAK_GBS / 1e3)}
 
 
 def k1_roofline(H, world):
@@ -204,9 +224,9 @@ def main():
     big = 1 << 30
     WL = {
         "kitti": dict(n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, cfg=reg.default_config(),
-                      name="synthetic KITTI-density frame pair (9.4k src / 83.5k tgt pts, reference caps 2500/2000/1200/200; "
-                           "ego-motion + constant-velocity prediction of frame 105 of the reference's KITTI-00 trajectory) "
-                           "-- BASELINE.json configs[1]"),
+                      name="synthetic KITTI-density sequence, every step a DISTINCT frame pair (9.4k src / 83.5k tgt pts per frame, "
+                           "reference caps 2500/2000/1200/200; ego-motion + constant-velocity prediction from the reference's "
+                           "KITTI-00 trajectory), all frames resident in HBM before the timed region -- BASELINE.json configs[1]"),
         "m1": dict(n_src=synth.M1_SRC, n_tgt=synth.M1_TGT,
                    cfg=reg.default_config(planar_maxnum=big, ground_maxnum=big, edge_maxnum=big, sphere_maxnum=big),
                    name="synthetic 1M-correspondence frame (1.0M src / 1.0M tgt pts, plane:line:point = 760k:200k:40k, "
@@ -214,32 +234,44 @@ def main():
     }
 
     def run_frames(wl, steps, warmup, seed):
-        """One context, one frame pair resident in HBM, `warmup` untimed + `steps` timed scan_match calls between
-        barriers.  Returns the whole-job numbers (all-reduced) and rank 0's K3 event timings."""
+        """One context, `warmup` untimed + `steps` timed scan_match calls between barriers, every input resident in HBM
+        before the clock starts.  KITTI-density workload: every step is its OWN frame of the synthetic sequence (frames
+        0 .. warmup + steps - 1, staged in the context's HBM frame store and activated by an O(1) tloam_frame_select) --
+        the context sees a stream of distinct frames, as it does behind the reference's front end, so its learned sweep
+        budgets are predictions from OTHER frames.  1 M workload: one frame pair (the characterisation frame).
+        Returns the whole-job numbers (all-reduced) and rank 0's K3 event timings."""
         W = WL[wl]
-        # headline: frame 105 of the KITTI-density sequence -- the modal case, 10 executed GN iterations -- (ego-motion and constant-velocity prediction of the
-        # reference's KITTI-00 trajectory); the 1 M frame: the default pose pair of the generator
-        scene = kitti_frame(synth, seed, 105) if wl == "kitti" else synth.make_scene(seed=seed, n_src=W["n_src"], n_tgt=W["n_tgt"])
         H = reg.HipRegistration(W["cfg"], device=local_rank)
-        H.set_frames(scene.source, scene.target)   # inputs resident in HBM before the timed region
+        if wl == "kitti":
+            scenes = [kitti_scene(synth, seed, f) for f in range(warmup + steps)]
+            for f, sc in enumerate(scenes):
+                H.set_frames(sc.source, sc.target)   # PCIe hand-over, outside the timed region
+                H.frame_stash(f)
+        else:
+            scenes = [synth.make_scene(seed=seed, n_src=W["n_src"], n_tgt=W["n_tgt"])]
+            H.set_frames(scenes[0].source, scenes[0].target)
         H.k3_timer(reset=True)                      # arm HIP event pairs around (every 3rd) K3 launch
 
-        def step():
-            rc, T, st = H.scan_match(scene.T_pred)
+        def step(i):
+            sc = scenes[i % len(scenes)]
+            if wl == "kitti":
+                H.frame_select(i)
+            rc, T, st = H.scan_match(sc.T_pred)
             if rc != 0:
                 raise SystemExit(f"scan_match failed: {reg.STATUS.get(rc, rc)}")
-            return T, st
+            return sc, T, st
 
-        for _ in range(warmup):
-            T, st = step()
+        for i in range(warmup):
+            scene, T, st = step(i)
         H.k3_timer(reset=True)
         barrier()
         t0 = time.perf_counter()
         gn_iters = 0      # executed GN iterations: residual/Jacobian sweep + 6x6 step (tloam_stats.gn_sweeps)
         gn_evals = 0      # solver evaluations served (some from the totals of the previous sweep, see gn_sweeps)
         host_wait = 0     # microseconds the calling thread spent waiting for the device (tloam_stats.host_wait_us)
-        for _ in range(steps):
-            T, st = step()
+        worst = 0.0
+        for i in range(steps):
+            scene, T, st = step(warmup + i)
             gn_iters += st["gn_sweeps"]
             gn_evals += st["gn_evaluations"]
             host_wait += st["host_wait_us"]
@@ -253,6 +285,24 @@ def main():
             gi = torch.tensor([float(gn_iters)], dtype=torch.float64, device=cdev)
             dist.all_reduce(gi, op=dist.ReduceOp.SUM)     # whole-job GN iterations
             gn_iters_job = float(gi.item())
+        repeated = None
+        if wl == "kitti" and rank == 0:
+            # side figure (round 2's headline): ONE frame pair repeated -- every prediction of the context is perfect
+            sc105 = kitti_scene(synth, seed, 105)
+            H.frame_select(-1)
+            H.set_frames(sc105.source, sc105.target)
+            for _ in range(20):
+                H.scan_match(sc105.T_pred)
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            itr = 0
+            for _ in range(100):
+                _, _, str_ = H.scan_match(sc105.T_pred)
+                itr += str_["gn_sweeps"]
+            dtr = time.perf_counter() - tr
+            repeated = {"workload": "frame 105 of the sequence, the same pair 100 times (not part of value)",
+                        "ms_per_frame": round(dtr / 100 * 1e3, 4), "gn_iters_per_sec": round(itr / dtr, 1),
+                        "gn_iters_per_frame": itr / 100}
         k3_us, k3_n, _ = H.k3_timer()                    # working sweeps
         k3_all_us, k3_all_n = H.k3_timer_all()            # every sampled K3 launch incl. no-ops after a tolerance exit
         # cross-check without per-launch event overhead: ONE event pair around 60 consecutive launches of the same
@@ -280,7 +330,13 @@ def main():
                                "frac": round(alg / (bb_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "one HIP event pair around 60 consecutive launches on the last correspondence "
                                        "set, after the timed region (no per-launch event overhead; launch gaps included)"}}
-        return {"workload": W["name"], "ms_per_frame": elapsed / steps * 1e3, "gn_iters_per_sec": gn_iters_job / elapsed,
+        if k3_all_n == 0:   # fused sweep + step launches carry no event pair (tloam_k3_timer covers k3_accumulate dispatches only)
+            k3.update({"sampled": False, "achieved": None, "frac": None, "avg_launch_us": None,
+                       "launch_sampling": "not sampled: KITTI-size sets run sweep + minimiser step as ONE launch "
+                                          "(k_sweep_step_small), which the per-dispatch K3 timer does not cover"})
+            k3["working_sweeps"] = None
+        return {"workload": W["name"], "repeated_pair": repeated, "distinct_frames": len(scenes) if wl == "kitti" else 1,
+                "ms_per_frame": elapsed / steps * 1e3, "gn_iters_per_sec": gn_iters_job / elapsed,
                 "gn_iters_per_frame": gn_iters / steps, "solver_evaluations_per_frame": gn_evals / steps, "n_corr": n_corr,
                 "outer_iterations": st["outer_iterations"], "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3])),
                 "host_wait_us_per_frame": round(host_wait / steps, 1), "k3": k3, "k1": k1, "scene": scene, "cfg": W["cfg"]}
@@ -314,12 +370,33 @@ def main():
                                 "traffic": traffic, "traffic_detail": traffic_detail, "kernel": "k3_accumulate<false, false>",
                                 "avg_launch_us": pk["avg_launch_us"], "launches": pk["launches"],
                                 "algorithmic_bytes_per_launch": pk["algorithmic_bytes_per_launch"], "workload": pk["workload"],
+                                "working_set": "l3_resident: the 74.88 MB of the contract's configuration (SURVEY 8(d) config 3) stay in "
+                                               "the 256 MiB Infinity Cache across back-to-back launches, as they do across the sweeps of "
+                                               "a Solve; `cold` below is the same kernel with every byte from HBM",
                                 "launch_timing": "one HIP event pair per batch of 20 consecutive launches on the context's stream, "
                                                  "median of the 6 batch means (120 launches after 10 warm-ups)",
                                 "note": pk["note"]}
                     bw = measured_copy_bandwidth(torch, f"cuda:{local_rank}")
                     roofline["measured_copy_GBps"] = round(bw, 1)
                     roofline["frac_of_measured_copy"] = round(roofline["achieved"] / bw, 4)
+                    # the same kernel on a working set beyond the Infinity Cache: 4 x the set (299.5 MB per sweep)
+                    pc = prebuilt_k3(reg, synth, local_rank, scale=4)
+                    cold = {k: pc[k] for k in ("workload", "launches", "avg_launch_us", "algorithmic_bytes_per_launch", "achieved", "frac")}
+                    cold.update({"peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_measured_copy": round(pc["achieved"] / bw, 4),
+                                 "working_set": "299.5 MB per sweep > 256 MiB Infinity Cache: back-to-back sweeps evict each other, "
+                                                "every launch streams from HBM",
+                                 "launch_timing": "one HIP event pair per batch of 10 consecutive launches, median of 6 batch means"})
+                    if os.path.exists(PMC_SUMMARY_COLD):
+                        try:
+                            dc = json.load(open(PMC_SUMMARY_COLD))
+                            cold["traffic"] = float(dc["traffic_bytes_per_launch_all"])
+                            cold["traffic_detail"] = {"source": "profiles/" + os.path.basename(PMC_SUMMARY_COLD) + " (committed PMC summary)",
+                                                      "fetch_bytes_per_launch": dc["fetch_bytes_per_launch_all"],
+                                                      "write_bytes_per_launch": dc["write_bytes_per_launch_all"],
+                                                      "stale": dc.get("kernel_source_sha16") != _sha16(os.path.join(ROOT, "tloam_amd", "csrc", "tl_gn.hip"))}
+                        except Exception:  # noqa: BLE001
+                            pass
+                    roofline["cold"] = cold
                 except Exception as e:  # noqa: BLE001  (side measurements never take the line down)
                     roofline = None
                     in_frame["side_measurements_error"] = repr(e)[:200]
@@ -336,8 +413,8 @@ def main():
                     "kernel": "k_sweep_step_small (sweep + ticket + 6x6 step in one launch); the sweep alone = k3_accumulate<true>",
                     "sweep_alone_back_to_back": bb,
                     "note": "KITTI-cap sets (442 KB per sweep) are launch-latency bound, not bandwidth bound: in the frames the sweep "
-                            "runs fused with the minimiser step (no separate K3 launch to time, ~10.5 us per fused iteration in "
-                            "profiles/r02_bench_default_kernel_stats.csv); the figure here is the stand-alone sweep kernel on the "
+                            "runs fused with the minimiser step (no separate K3 launch to time, ~9 us per fused iteration in "
+                            "profiles/r03_bench_default_kernel_stats.csv); the figure here is the stand-alone sweep kernel on the "
                             "frame's last correspondence set"}
         out = {
             "metric": "gauss_newton_iters_per_sec", "value": round(head["gn_iters_per_sec"], 2), "unit": "GN iter/s",
@@ -352,9 +429,12 @@ def main():
                        "parallelism": (f"{world} independent frame streams, one per GPU, no data-path collective (replicas, "
                                        "BASELINE.json configs[4]); the sharded single frame is reported under sharded_1m")
                        if multi else "1 GPU",
+                       "distinct_frames": head["distinct_frames"],
                        "pose_err_vs_truth_m": head["pose_err_vs_truth_m"]},
             "roofline": roofline,
         }
+        if head.get("repeated_pair"):
+            out["config"]["repeated_pair"] = head["repeated_pair"]
         if side is not None and side is not head:
             out["m1_frame"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in side.items()
                                if k in ("workload", "ms_per_frame", "gn_iters_per_sec", "gn_iters_per_frame",
@@ -530,19 +610,30 @@ def kitti_frame(synth, seed, f):
                             pred_err=pred_err)
 
 
+_SCENES = {}
+
+
+def kitti_scene(synth, seed, f):
+    """kitti_frame, cached: the headline, the sequence block and the CPU check run over the same frames"""
+    key = (seed, f)
+    if key not in _SCENES:
+        _SCENES[key] = kitti_frame(synth, seed, f)
+    return _SCENES[key]
+
+
 def kitti_sequence(args, reg, synth, torch, device):
     """KITTI-density sequence on one GPU: per frame the eight clouds are handed over (PCIe), then ONE
     scan_match is timed with the clouds resident (the bracket of front_end.cpp:320-322)."""
     nf = args.kitti_frames
     H = reg.HipRegistration(reg.default_config(), device=device)
-    warm = kitti_frame(synth, args.seed, 0)
+    warm = kitti_scene(synth, args.seed, 0)
     H.set_frames(warm.source, warm.target)
     for _ in range(5):
         H.scan_match(warm.T_pred)
     ms, ms_up, it, ev, terr, poses = [], [], 0, 0, [], {}
     n_corr = None
     for f in range(nf):
-        sc = kitti_frame(synth, args.seed, f)
+        sc = kitti_scene(synth, args.seed, f)
         t0 = time.perf_counter()
         H.set_frames(sc.source, sc.target)
         torch.cuda.synchronize()
@@ -613,7 +704,7 @@ def multi_stream(args, reg, synth, device, streams=3, frames=300):
     share a queue with another and serialise (scripts/multi_stream.py, without torch: 1 / 2 / 3 / 4 streams = 43 / 79 / 100 /
     124 k GN iter/s, 8 streams 138 k)."""
     import threading
-    sc = kitti_frame(synth, args.seed, 105)
+    sc = kitti_scene(synth, args.seed, 105)
     try:
         Hs = [reg.HipRegistration(reg.default_config(), device=device) for _ in range(streams)]
         for H in Hs:
@@ -760,7 +851,7 @@ def cpu_baseline(head, side, args, kitti_seq=None):
         K1 = ob.Oracle(ko, builder_threads=1, eval_threads=1)   # parity build, single thread: the checker
         tms, tms1, dts, drs, its = [], [], [], [], 0
         for f, T_gpu in sorted(kitti_seq["poses"].items()):
-            sc = kitti_frame(synth, args.seed, f)
+            sc = kitti_scene(synth, args.seed, f)
             K1.set_frames(sc.source, sc.target)
             t0 = time.perf_counter()
             rc, T_cpu, stc = K1.scan_match(sc.T_pred)

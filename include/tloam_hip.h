@@ -37,10 +37,11 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 4  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+#define TLOAM_ABI_VERSION 5  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
                                * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us
                                * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
-                               *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned */
+                               *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned
+                               * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve) */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -137,6 +138,19 @@ int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
  * frame instead of one per cloud.  xyz_aos[k] may be NULL when n[k] == 0. */
 int tloam_set_source_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
 int tloam_set_target_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
+/* Frames staged ahead of their solve.  The reference's caller hands a Frame over and solves it at once (front_end.cpp:314,
+ * :321); a caller that receives scans while the previous solve is still running -- or a replay / benchmark that wants its
+ * frames resident in HBM before the clock starts -- can hand frames over early and activate them later at no cost:
+ *   tloam_frame_stash(ctx, slot)   moves the clouds currently registered with the context (whatever tloam_set_source* /
+ *                                  tloam_set_target* left there: eight clouds, their bounds) into slot `slot` (>= 0) of a frame
+ *                                  store kept in HBM; the context is left without registered clouds.  A slot that was in
+ *                                  use is overwritten.
+ *   tloam_frame_select(ctx, slot)  makes the clouds of `slot` the registered ones (buffers are exchanged, nothing is copied or
+ *                                  synchronised); slot -1 = back to the context's own.  While a slot is selected,
+ *                                  tloam_set_source* / tloam_set_target* write into that slot's frame.
+ * TLOAM_E_NOT_READY between tloam_sm_begin and tloam_sm_end, TLOAM_E_INVALID for an unknown slot. */
+int tloam_frame_stash(tloam_ctx* ctx, int slot);
+int tloam_frame_select(tloam_ctx* ctx, int slot);
 
 /* ---- RegistrationInterface::scanMatching (registration.cpp:879-1133) -------------------
  * predict/result: 4x4 column-major.  omega_perturb3: the unit vector the reference draws

@@ -39,6 +39,11 @@ def main():
             res[f"traffic_bytes_per_launch_{tag}"] = f + w
             res[f"fetch_bytes_per_launch_{tag}"] = f
             res[f"write_bytes_per_launch_{tag}"] = w
+    # the kernel source the counters were collected on (bench.py flags a summary as stale when tl_gn.hip has changed since)
+    import hashlib, os
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tloam_amd", "csrc", "tl_gn.hip")
+    if os.path.exists(src):
+        res["kernel_source_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
     json.dump(res, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

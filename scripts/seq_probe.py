@@ -10,7 +10,7 @@ nf = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 H = reg.HipRegistration(reg.default_config())
 rows = []
 for f in range(nf):
-    sc = bench.kitti_frame(synth, 0, f)
+    sc = bench.kitti_scene(synth, 0, f)
     H.set_frames(sc.source, sc.target); torch.cuda.synchronize()
     t1 = time.perf_counter(); rc, T, st = H.scan_match(sc.T_pred); t2 = time.perf_counter()
     rows.append(((t2 - t1) * 1e3, st["gn_sweeps"], st["gn_evaluations"], st["outer_iterations"], st["accepted_steps"], st["converged_early"], st["host_wait_us"]))

@@ -12,7 +12,7 @@ for ms in (1, 2, 3):
     x, st = H.solve(x_eval)
     buf = np.zeros(400)
     n = H.L.tloam_debug_state(H.h, buf.ctypes.data_as(C.POINTER(C.c_double)), 400)
-    dbg = buf[n-8:n]
+    dbg = buf[n-12:n]
     d = np.diff(dbg[:7])
-    print("sweeps", ms, "cycles (last block): sweep-end->ticket %d | fold %d pre %d dogleg %d step %d plus %d writeback+tail %d | ticket->end %d" % (
-        dbg[0]-dbg[7], d[0], d[1], d[2], d[3], d[4], d[5], dbg[6]-dbg[0]))
+    print("sweeps", ms, "cycles (consumer block): entry->pose %d | evaluate %d | reduce %d | post %d | wait+fold %d decide %d dogleg %d model %d plus %d write-back %d | entry->end %d" % (
+        dbg[9]-dbg[8], dbg[10]-dbg[9], dbg[7]-dbg[10], dbg[0]-dbg[7], d[0], d[1], d[2], d[3], d[4], d[5], dbg[6]-dbg[8]))

@@ -412,3 +412,39 @@ def test_fused_sweep_step_is_exact(hip_module, monkeypatch, shape):
         assert rc1 == rc2 == 0
         _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
     H1.close(); H2.close()
+
+
+def test_staged_frames_equal_direct_hand_over(hip_module):
+    """tloam_frame_stash / tloam_frame_select: frames handed over ahead of their solve and activated later give,
+    bit for bit, what handing each frame over right before its solve gives -- in any activation order -- and an unknown
+    slot / a call inside a solve are refused."""
+    reg = hip_module
+    scenes = [synth.make_scene(seed=40 + i) for i in range(3)]
+    ref = []
+    Hd = reg.HipRegistration()
+    for sc in scenes:
+        Hd.set_frames(sc.source, sc.target)
+        rc, T, st = Hd.scan_match(sc.T_pred)
+        assert rc == 0
+        ref.append((T, st))
+    Hd.close()
+    H = reg.HipRegistration()
+    for i, sc in enumerate(scenes):
+        H.set_frames(sc.source, sc.target)
+        H.frame_stash(i)
+    assert H.L.tloam_frame_select(H.h, 7) == -1            # TLOAM_E_INVALID: never stashed
+    for i in (2, 0, 1, 1, 2):
+        H.frame_select(i)
+        rc, T, st = H.scan_match(scenes[i].T_pred)
+        assert rc == 0
+        assert np.array_equal(T, ref[i][0])
+        assert st["n_corr"] == ref[i][1]["n_corr"] and st["gn_evaluations"] == ref[i][1]["gn_evaluations"]
+    # a frame handed over while a slot is selected lands in that slot; the context's own frame is untouched
+    H.frame_select(-1)
+    H.set_frames(scenes[0].source, scenes[0].target)
+    rc, T, _ = H.scan_match(scenes[0].T_pred)
+    assert rc == 0 and np.array_equal(T, ref[0][0])
+    H.frame_select(1)
+    assert H.sm_begin(scenes[1].T_pred) == 0
+    assert H.L.tloam_frame_select(H.h, 0) == -6            # TLOAM_E_NOT_READY inside a solve
+    H.close()

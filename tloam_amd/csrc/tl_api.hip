@@ -262,17 +262,21 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   }
   const size_t nc = (size_t)std::max<long long>(cell_total, 1);
   HIPC(c, G.gp.reserve(std::max<size_t>(tgt_total, 1))); HIPC(c, G.cell_of_pt.reserve(std::max<size_t>(tgt_total, 1)));
-  HIPC(c, G.cell_start.reserve(nc + kKinds + 1)); HIPC(c, G.rank_of_pt.reserve(tgt_total + 1));
+  HIPC(c, G.rank_of_pt.reserve(tgt_total + 1));
+  // The cell count follows the bounding boxes, which change from frame to frame: a table that has to grow does so with
+  // room to spare (a re-allocation inside scanMatching costs ~0.7 ms -- three times the frame)
+  const size_t nc_res = (nc + 1 > G.cell_cnt.cap || nc + kKinds + 1 > G.cell_start.cap) ? 2 * nc + 64 : nc;
+  HIPC(c, G.cell_start.reserve(nc_res + kKinds + 1));
   {
     // the cell histogram is all-zero between builds (k_grid_finalize_all re-zeroes what a build used): only a
     // (re)allocation has to be cleared
     const size_t before = G.cell_cnt.cap;
-    HIPC(c, G.cell_cnt.reserve(nc + 1));
+    HIPC(c, G.cell_cnt.reserve(nc_res + 1));
     if (G.cell_cnt.cap != before)
       HIPC(c, hipMemsetAsync(G.cell_cnt.p, 0, G.cell_cnt.cap * sizeof(unsigned long long), c->stream));
   }
-  HIPC(c, G.cell_scan.reserve(nc + 1));
-  HIPC(c, G.scan_tmp.reserve(scan_tmp_elems(nc + 1)));
+  HIPC(c, G.cell_scan.reserve(nc_res + 1));
+  HIPC(c, G.scan_tmp.reserve(scan_tmp_elems(nc_res + 1)));
   for (int k = 0; k < kKinds; ++k) {
     out[k].gp = G.gp.p + gs.tgt_off[k];
     out[k].cell_start = G.cell_start.p + gs.cell_base[k] + k;
@@ -280,7 +284,7 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   if (cell_total == 0) return TLOAM_OK;
   if (frame) {  // the start of the scan_match rides on the first launch (the query-tile histogram is sized by the grids)
     const size_t ntiles = (size_t)build_tile_count(out, frame->n_slots);
-    HIPC(c, c->tile_cnt.reserve(ntiles + 1));
+    HIPC(c, c->tile_cnt.reserve(ntiles + 1 > c->tile_cnt.cap ? 2 * ntiles + 64 : ntiles + 1));
     frame->fi.tile_cnt = c->tile_cnt.p;
     frame->fi.n_tile_cnt = (int)ntiles + 1;
     frame->consumed = true;
@@ -420,8 +424,15 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 // one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
+bool solve_small_path(const tloam_ctx* c) { return c->nranks == 1 && c->k3_single && !c->no_fused_small && solve_small_fits(c->k3_grid); }
 int enqueue_solve(tloam_ctx* c, bool armed, int sweeps) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
+  if (sweeps > 0 && solve_small_path(c)) {
+    // KITTI-size set: the whole Solve (up to `sweeps` evaluations) is one launch (k_solve_small)
+    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, c->stream);
+    c->batch_launches++;
+    return TLOAM_OK;
+  }
   for (int sweep = 0; sweep < sweeps; ++sweep) {
     if (c->nranks > 1) {
       // sharded GN iteration = 2 launches (+ the collective): the sweep, whose last block folds the rows into the
@@ -465,6 +476,8 @@ int ensure_common(tloam_ctx* c) {
   if (!c->k3_ticket.p) {
     HIPC(c, c->k3_ticket.reserve(4));
     HIPC(c, hipMemsetAsync(c->k3_ticket.p, 0, 4 * sizeof(int), c->stream));
+    HIPC(c, c->k3_bcast.reserve(16));
+    HIPC(c, hipMemsetAsync(c->k3_bcast.p, 0, 16 * sizeof(unsigned long long), c->stream));
   }
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;
@@ -476,6 +489,24 @@ double alg_bytes_of(const int n[kKinds]) {
          64.0 * (double)n[TLOAM_KIND_SPHERE];
 }
 
+}  // namespace
+
+namespace {
+// exchange the registered clouds of the context with a FrameClouds (pointers and counts only)
+void exchange_clouds(tloam_ctx* c, FrameClouds& F) {
+  for (int k = 0; k < kKinds; ++k) {
+    KindData& K = c->kd[k];
+    std::swap(K.n_src_full, F.n_src_full[k]); std::swap(K.src_lo, F.src_lo[k]); std::swap(K.n_src, F.n_src[k]);
+    std::swap(K.n_tgt, F.n_tgt[k]);
+    std::swap(K.src_aos, F.src_aos[k]); std::swap(K.tgt_aos, F.tgt_aos[k]);
+    std::swap(K.tx, F.tx[k]); std::swap(K.ty, F.ty[k]); std::swap(K.tz, F.tz[k]);
+    std::swap(K.src_set, F.src_set[k]); std::swap(K.tgt_set, F.tgt_set[k]);
+    for (int a = 0; a < 6; ++a) std::swap(c->tgt_box[k][a], F.tgt_box[k][a]);
+    std::swap(c->tgt_box_valid[k], F.tgt_box_valid[k]);
+    K.grid_valid = false;   // the search grids belong to the frame they were built over
+  }
+  c->have_build = false;
+}
 }  // namespace
 
 // ================================================================================================
@@ -581,7 +612,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int r = 0; r < kMaxRanks; ++r)
     if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
   if (c->mbox_local) (void)hipFree(c->mbox_local);
-  c->mbox_ctr.release(); c->k3_ticket.release();
+  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_bcast.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
@@ -594,6 +625,10 @@ void tloam_destroy(tloam_ctx* c) {
   c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qrec.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
   c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release();
+  if (c->frame_selected >= 0) exchange_clouds(c, *c->frame_store[c->frame_selected]);
+  for (auto* f : c->frame_store)
+    if (f) { f->release(); delete f; }
+  c->frame_store.clear();
   c->submap.release();
   c->feat.release();
   if (c->h_state) (void)hipHostFree(c->h_state);
@@ -688,6 +723,37 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   HIPC(c, hipStreamSynchronize(c->stream));
   if (rc == TLOAM_OK) finish_target_bounds(c);
   return rc;
+}
+
+// ---- frames staged ahead of their solve ------------------------------------------------------------
+int tloam_frame_stash(tloam_ctx* c, int slot) {
+  if (!c || slot < 0 || slot > (1 << 20)) return TLOAM_E_INVALID;
+  if (c->active) return TLOAM_E_NOT_READY;
+  HIPC(c, hipSetDevice(c->device));
+  if ((size_t)slot >= c->frame_store.size()) c->frame_store.resize((size_t)slot + 1, nullptr);
+  if (c->frame_selected == slot) { c->frame_selected = -1; return TLOAM_OK; }   // the slot's frame is the registered one: it stays in the slot
+  if (c->frame_selected >= 0) return TLOAM_E_NOT_READY;   // another slot's frame is registered: select -1 first
+  if (!c->frame_store[slot]) {
+    c->frame_store[slot] = new (std::nothrow) FrameClouds();
+    if (!c->frame_store[slot]) return TLOAM_E_INVALID;
+  } else {
+    HIPC(c, hipStreamSynchronize(c->stream));   // nothing in flight may still read the buffers being replaced
+    c->frame_store[slot]->release();
+    *c->frame_store[slot] = FrameClouds();
+  }
+  exchange_clouds(c, *c->frame_store[slot]);
+  return TLOAM_OK;
+}
+
+int tloam_frame_select(tloam_ctx* c, int slot) {
+  if (!c || slot < -1) return TLOAM_E_INVALID;
+  if (c->active) return TLOAM_E_NOT_READY;
+  if (slot >= 0 && ((size_t)slot >= c->frame_store.size() || !c->frame_store[slot])) return TLOAM_E_INVALID;
+  if (slot == c->frame_selected) return TLOAM_OK;
+  if (c->frame_selected >= 0) exchange_clouds(c, *c->frame_store[c->frame_selected]);   // the context's own clouds back
+  if (slot >= 0) exchange_clouds(c, *c->frame_store[slot]);
+  c->frame_selected = slot;
+  return TLOAM_OK;
 }
 
 // ---- scanMatching, stepwise ---------------------------------------------------------------------
@@ -804,10 +870,12 @@ void outer_params(const tloam_ctx* c, BuildParams* bp, GridView grids[kKinds]) {
 int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
   const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off[kKinds]);
-  HIPC(c, c->tile_cnt.reserve(ntiles + 1)); HIPC(c, c->tile_scan.reserve(ntiles + 1));
-  HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)ntiles, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
+  // (tile counts follow the bounding boxes like the cell tables: grow with room to spare)
+  const size_t nt_res = (ntiles + 1 > c->tile_cnt.cap || ntiles + 1 > c->tile_scan.cap) ? 2 * ntiles + 64 : ntiles;
+  HIPC(c, c->tile_cnt.reserve(nt_res + 1)); HIPC(c, c->tile_scan.reserve(nt_res + 1));
+  HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)nt_res, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
   HIPC(c, c->qrec.reserve(n_slots + 1));
-  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(ntiles + 1, n_slots + 1))));
+  HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(nt_res + 1, n_slots + 1))));
   return TLOAM_OK;
 }
 // :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
@@ -844,6 +912,7 @@ int planned_sweeps_for(tloam_ctx* c, int iter) {
   const int* hist = &c->planned_sweeps[3 * (size_t)iter];
   int planned = hist[0] == 0 ? kSolveSweeps  // first frame of this context: the full budget
                              : std::min(std::max(std::max(hist[0], hist[1]), std::max(hist[2], 1)), kSolveSweeps);
+  if (solve_small_path(c)) planned = kSolveSweeps;   // one launch runs the Solve to its end: nothing to predict
   if (c->dbg_planned_sweeps > 0) planned = std::min(c->dbg_planned_sweeps, kSolveSweeps);
   return planned;
 }
@@ -1016,6 +1085,58 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
 // iteration on an otherwise idle GPU.)  Returns 1 when the frame has to be finished by the stepwise path (a Solve
 // ran out of its planned budget): the context is then positioned at that outer iteration.
 namespace {
+struct DeviceLoopPlan {
+  int planned[kMaxOuterFast] = {}, solve_start[kMaxOuterFast] = {}, used[kMaxOuterFast] = {};
+  double mus[kMaxOuterFast] = {};
+  HostMirror hms[kMaxOuterFast];
+};
+// enqueue outer iterations first .. M-1.  first == 0: the frame's first iteration (always builds).  first > 0: a restart
+// behind a stand-alone finish of iteration first - 1 that has set the gates (run_build / run_refresh) on the device.
+int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildParams& bp, const GridView grids[kKinds],
+                             DeviceLoopPlan& P) {
+  const int M = c->cfg.max_iterations;
+  GnState* st = c->state.p;
+  const int* run_build = &st->run_build;
+  const int* run_refresh = &st->run_refresh;
+  // KITTI-size frames: the finish of iteration k-1 does not get a launch of its own, it rides on the correspondence
+  // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
+  const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
+  bool pending = false;   // the finish of the previous iteration has not been enqueued yet (it rides on this search)
+  WeightParams wp_prev;
+  OuterCtl ctl_prev{0.0, 0, 0};
+  int rc = TLOAM_OK;
+  for (int iter = first; iter < M; ++iter) {
+    if (iter == 0) {
+      rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
+    } else if (pending) {
+      FinishSmallArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, P.hms[iter - 1], ctl_prev, c->wpart.p, c->k3_ticket.p + 1};
+      launch_build_finish_small(c->sv, grids, bp, st, fin, c->stream);
+      launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, st, run_build, run_refresh, c->stream);
+      pending = false;
+    } else {
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh);   // both alternatives, device-gated
+    }
+    if (rc != TLOAM_OK) return rc;
+    P.planned[iter] = planned_sweeps_for(c, iter);
+    P.solve_start[iter] = c->batch_launches;
+    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter]);
+    if (rc != TLOAM_OK) return rc;
+    P.mus[iter] = mu;
+    P.hms[iter] = next_mirror(c, iter);
+    const OuterCtl ctl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0};
+    if (ride && iter < M - 1) {
+      wp_prev = weight_params(c, mu, bp);
+      ctl_prev = ctl;
+      pending = true;
+    } else {
+      rc = enqueue_finish(c, weight_params(c, mu, bp), P.hms[iter], ctl);
+      if (rc != TLOAM_OK) return rc;
+    }
+    mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
+  }
+  return TLOAM_OK;
+}
+
 int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   const int M = c->cfg.max_iterations;
   BuildParams bp;
@@ -1024,56 +1145,20 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   int rc = outer_reserve(c, grids);
   if (rc != TLOAM_OK) return rc;
   GnState* st = c->state.p;
-  const int* run_build = &st->run_build;
-  const int* run_refresh = &st->run_refresh;
-  int planned[kMaxOuterFast] = {}, solve_start[kMaxOuterFast] = {}, used[kMaxOuterFast] = {};
-  double mus[kMaxOuterFast];
-  HostMirror hms[kMaxOuterFast];
-  double mu = initial_mu(c);
-  // KITTI-size frames: the finish of iteration k-1 does not get a launch of its own, it rides on the correspondence
-  // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
-  const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
-  WeightParams wp_prev;
-  OuterCtl ctl_prev{0.0, 0, 0};
-  for (int iter = 0; iter < M; ++iter) {
-    if (iter == 0) {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
-    } else if (ride) {
-      FinishSmallArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, hms[iter - 1], ctl_prev, c->wpart.p, c->k3_ticket.p + 1};
-      launch_build_finish_small(c->sv, grids, bp, st, fin, c->stream);
-      launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, st, run_build, run_refresh, c->stream);
-    } else {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh);   // both alternatives, device-gated
-    }
-    if (rc != TLOAM_OK) return rc;
-    planned[iter] = planned_sweeps_for(c, iter);
-    solve_start[iter] = c->batch_launches;
-    rc = enqueue_solve(c, /*armed=*/true, planned[iter]);
-    if (rc != TLOAM_OK) return rc;
-    mus[iter] = mu;
-    hms[iter] = next_mirror(c, iter);
-    const OuterCtl ctl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0};
-    if (ride && iter < M - 1) {
-      wp_prev = weight_params(c, mu, bp);
-      ctl_prev = ctl;
-    } else {
-      rc = enqueue_finish(c, weight_params(c, mu, bp), hms[iter], ctl);
-      if (rc != TLOAM_OK) return rc;
-    }
-    mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
-  }
-  rc = wait_state(c, hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did
+  DeviceLoopPlan P;
+  rc = enqueue_outer_iterations(c, 0, initial_mu(c), bp, grids, P);
+  if (rc != TLOAM_OK) return rc;
+  rc = wait_state(c, P.hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did
   if (rc != TLOAM_OK) return rc;
   // ---- the frame's bookkeeping, iteration by iteration, from the mirrored slots
-  int resume = 0;
+  int topups = 0;
   for (int iter = 0; iter < M; ++iter) {
-    used[iter] = 0;
     if (iter < M - 1) {   // (written before the last slot: already there -- this only unpacks it)
-      rc = wait_state(c, hms[iter], iter);
+      rc = wait_state(c, P.hms[iter], iter);
       if (rc != TLOAM_OK) return rc;
     }
     const GnState* S = &c->h_state[iter];
-    if (S->host_seq != hms[iter].seq) {
+    if (S->host_seq != P.hms[iter].seq) {
       c->last_error = "device-driven loop: the result slot of an outer iteration was not written";
       return TLOAM_E_HIP;
     }
@@ -1085,38 +1170,55 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     if (S->incomplete == OS_INCOMPLETE) {
       // The Solve of this iteration ran out of its planned budget: the device stopped the loop there (the sweeps of
       // the later iterations, gated only on `done`, have meanwhile continued this same Solve; their builds, refreshes
-      // and finish kernels were gated off).  Top the Solve up to its full budget and finish the iteration with the
-      // host deciding; the rest of the frame then goes through the stepwise path.
-      HIPC(c, hipMemsetAsync(&st->stop, 0, sizeof(int), c->stream));
-      rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps);
-      if (rc != TLOAM_OK) return rc;
-      const HostMirror hm = next_mirror(c, 0);
-      rc = enqueue_finish(c, weight_params(c, mus[iter], bp), hm, OuterCtl{c->cfg.cost_threshold, 0, 0});
-      if (rc != TLOAM_OK) return rc;
-      rc = wait_state(c, hm, 0);
-      if (rc != TLOAM_OK) return rc;
-      S = &c->h_state[0];
-      if (S->incomplete) {
+      // and finish kernels were gated off).  Top the Solve up to its full budget, finish the iteration with the DEVICE
+      // deciding as usual, and enqueue the rest of the frame behind it: one more wait instead of a host round trip per
+      // remaining outer iteration.
+      if (++topups > M) {
         c->last_error = "the minimiser did not terminate within its evaluation budget";
         return TLOAM_E_INVALID;
       }
-      resume = 1;
+      HIPC(c, hipMemsetAsync(&st->stop, 0, sizeof(int), c->stream));
+      P.solve_start[iter] = c->batch_launches;
+      P.planned[iter] = kSolveSweeps;
+      rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps);
+      if (rc != TLOAM_OK) return rc;
+      P.hms[iter] = next_mirror(c, iter);
+      rc = enqueue_finish(c, weight_params(c, P.mus[iter], bp), P.hms[iter], OuterCtl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0});
+      if (rc != TLOAM_OK) return rc;
+      if (iter + 1 < M) {
+        rc = enqueue_outer_iterations(c, iter + 1, P.mus[iter] * exp((double)(iter + 1) * c->cfg.gnc_factor), bp, grids, P);
+        if (rc != TLOAM_OK) return rc;
+      }
+      rc = wait_state(c, P.hms[M - 1], M - 1);
+      if (rc != TLOAM_OK) return rc;
+      if (iter < M - 1) {
+        rc = wait_state(c, P.hms[iter], iter);
+        if (rc != TLOAM_OK) return rc;
+      }
+      S = &c->h_state[iter];
+      if (S->incomplete == OS_INCOMPLETE) {
+        c->last_error = "the minimiser did not terminate within its evaluation budget";
+        return TLOAM_E_INVALID;
+      }
+      if (S->incomplete == OS_COMM_ERROR) {
+        c->last_error = "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
+        return TLOAM_E_HIP;
+      }
     }
     const int sweeps_before = c->stats.gn_sweeps;
     // the compact set of this iteration was (re)built iff the pose had moved since the last build
     if (iter == 0 || memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) != 0) memcpy(c->build_x, c->stats.se3, sizeof(c->build_x));
     c->have_build = true;
-    c->mu = mus[iter];
+    c->mu = P.mus[iter];
     bool wv = false;
-    const bool fin = account_outer(c, iter, *S, mus[iter], sweeps_before, &wv);
-    used[iter] = std::min(S->gn_sweeps - sweeps_before, planned[iter]);
+    const bool fin = account_outer(c, iter, *S, P.mus[iter], sweeps_before, &wv);
+    P.used[iter] = std::min(S->gn_sweeps - sweeps_before, P.planned[iter]);
     if (wv) *weight_violation = true;
-    if (fin) { resume = 0; break; }
-    if (resume) break;
+    if (fin) break;
   }
-  rc = harvest_k3_events_multi(c, M, solve_start, used);
+  rc = harvest_k3_events_multi(c, M, P.solve_start, P.used);
   if (rc != TLOAM_OK) return rc;
-  return resume;  // 1: the caller continues stepwise from c->iter
+  return 0;
 }
 }  // namespace
 

@@ -120,7 +120,7 @@ struct GnState {
   int run_refresh;    // the refresh iff it did not (see k_refresh); both 0 once the loop has ended
   int spec_build;     // written by the minimiser step: 1 iff the Solve has terminated at a pose other than x_build -- the gate of
                       // a correspondence search that runs CONCURRENTLY with the finish of that Solve (k_build_finish_small)
-  double dbg[8];      // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
+  double dbg[12];     // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
 static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible prefix of GnState");
@@ -397,6 +397,10 @@ void launch_gn_step(GnState* st, const double* in48, hipStream_t s);  // consume
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s);
 // small sets on one rank: sweep + step in ONE launch (ticket: zero between launches)
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s);
+// sets whose sweep is a grid of a dozen blocks: a whole ceres::Solve (up to max_sweeps evaluations) in ONE launch
+bool solve_small_fits(int grid);
+void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
+                        hipStream_t s);
 // K4
 struct WeightParams {
   double th1, th2, mu, noise_bound_sq;

@@ -34,6 +34,8 @@ struct DBuf {
     T* q = nullptr;
     hipError_t e = hipMalloc((void**)&q, want * sizeof(T) + 256);
     if (e != hipSuccess) return e;
+    static const bool trace = getenv("TLOAM_DEBUG_ALLOC") != nullptr;   // development aid: (re)allocations inside the timed path show up here
+    if (trace) fprintf(stderr, "[tloam alloc] %zu -> %zu elements of %zu B\n", cap, want, sizeof(T));
     if (p) (void)hipFree(p);
     p = q;
     cap = want;
@@ -67,6 +69,18 @@ struct KindData {
   DBuf<double> c_buf;
   size_t c_cap = 0, c_stride = 0;
   size_t pre_lo = 0, pre_n_full = 0;  // pre-built sets: this rank's block
+};
+
+// the clouds of one registered frame (what setInputSource / setInputTarget hand over), movable as a unit
+struct FrameClouds {
+  size_t n_src_full[tl::kKinds] = {}, src_lo[tl::kKinds] = {}, n_src[tl::kKinds] = {}, n_tgt[tl::kKinds] = {};
+  DBuf<double> src_aos[tl::kKinds], tgt_aos[tl::kKinds], tx[tl::kKinds], ty[tl::kKinds], tz[tl::kKinds];
+  bool src_set[tl::kKinds] = {}, tgt_set[tl::kKinds] = {};
+  double tgt_box[tl::kKinds][6] = {};
+  bool tgt_box_valid[tl::kKinds] = {};
+  void release() {
+    for (int k = 0; k < tl::kKinds; ++k) { src_aos[k].release(); tgt_aos[k].release(); tx[k].release(); ty[k].release(); tz[k].release(); }
+  }
 };
 
 struct GridBuffers {
@@ -167,6 +181,8 @@ struct tloam_ctx {
   tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
   tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;
+  std::vector<tlh::FrameClouds*> frame_store;   // tloam_frame_stash / tloam_frame_select
+  int frame_selected = -1;                      // slot whose clouds are the registered ones (-1: the context's own)
   int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)
   std::vector<int> planned_sweeps; // per outer iteration x 3: sweeps the Solve needed in the last three frames
   bool prebuilt = false;
@@ -183,6 +199,7 @@ struct tloam_ctx {
   tl::MboxView mbox{};
   DBuf<unsigned long long> mbox_ctr;
   DBuf<int> k3_ticket;
+  DBuf<unsigned long long> k3_bcast;   // candidate-pose broadcast of the one-launch Solve (k_solve_small)
   // scanMatching host state
   bool active = false;
   bool have_build = false;   // the compact set matches build_x

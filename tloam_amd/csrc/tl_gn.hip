@@ -51,6 +51,17 @@ __device__ __forceinline__ double fast_rsqrt(double x) {  // v_rsq_f64 + one New
   return __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
 }
 
+// This translation unit is compiled with -ffp-contract=off: the residual code below is inlined into several kernels (the
+// streaming sweep, the one-wave-per-chunk sweep, the one-launch Solve) and has to round alike in all of them -- the tests
+// compare those paths bit for bit, and with contraction left to the optimiser (`fast`, and in practice `on` as well) the
+// same source line was fused differently from kernel to kernel.  Every fused multiply-add is therefore spelled out.
+__device__ __forceinline__ double fdot(Vec3 a, Vec3 b) { return __builtin_fma(a.z, b.z, __builtin_fma(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ double fdot_add(Vec3 a, Vec3 b, double c) {
+  return __builtin_fma(a.x, b.x, __builtin_fma(a.y, b.y, __builtin_fma(a.z, b.z, c)));
+}
+__device__ __forceinline__ Vec3 fcross(Vec3 a, Vec3 b) {
+  return {__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
+}
 // T * p with T as a row-major rotation matrix + translation (what SE3::operator* computes through the
 // quaternion sandwich, sophus so3.hpp:358-367; same value to rounding, 9 FMAs instead of ~21 ops)
 __device__ __forceinline__ Vec3 act_rt(const Rt& T, Vec3 p) {
@@ -83,8 +94,8 @@ __device__ __forceinline__ void acc_row(Acc& a, const double J[6], double r, dou
 // PointToPlaneErr::Evaluate (registration.cpp:96-117) through ResidualBlock::Evaluate + CauchyLoss(1)
 __device__ __forceinline__ double eval_plane(const Rt& T, Vec3 p, Vec3 n, double d, double w, Acc& a) {
   const Vec3 pw = act_rt(T, p);
-  const double r = dot(n, pw) + d;           // :100 (unweighted)
-  const Vec3 c = cross(pw, n);               // n^T (-hat(pw)) = (pw x n)^T   :110,:112
+  const double r = fdot_add(n, pw, d);       // :100 (unweighted)
+  const Vec3 c = fcross(pw, n);              // n^T (-hat(pw)) = (pw x n)^T   :110,:112
   const double J[6] = {n.x * w, n.y * w, n.z * w, c.x * w, c.y * w, c.z * w};
   const double s = r * r;                    // squared norm of the block; also *cost = r^2  :101
   acc_row(a, J, r, cauchy(a, s));
@@ -94,19 +105,19 @@ __device__ __forceinline__ double eval_plane(const Rt& T, Vec3 p, Vec3 n, double
 // PointToLineErr::Evaluate (registration.cpp:55-88)
 __device__ __forceinline__ double eval_line(const Rt& T, Vec3 p, Vec3 la, Vec3 lb, double w, Acc& a) {
   const Vec3 pw = act_rt(T, p);
-  const Vec3 nu = cross(pw - la, pw - lb);   // :62
+  const Vec3 nu = fcross(pw - la, pw - lb);  // :62
   const Vec3 e = lb - la;                    // :80  (|la - lb| = |e|, :63)
-  const double k = w * fast_rsqrt(dot(e, e));
+  const double k = w * fast_rsqrt(fdot(e, e));
   const double r0 = nu.x * k, r1 = nu.y * k, r2 = nu.z * k;    // :65-67  nu / |de| * w
-  const double rs = r0 + r1 + r2;
+  const double rs = (r0 + r1) + r2;
   // J = hat(e) [I w, -hat(pw) w] / |de|  :77-83 ; hat(a) hat(b) = b a^T - (a.b) I  =>
   // -hat(e) hat(pw) = (e.pw) I - pw e^T
-  const double ep = dot(e, pw);
+  const double ep = fdot(e, pw);
   const double ex = e.x * k, ey = e.y * k, ez = e.z * k, epk = ep * k;
-  const double J0[6] = {0.0, -ez, ey, epk - pw.x * ex, -pw.x * ey, -pw.x * ez};
-  const double J1[6] = {ez, 0.0, -ex, -pw.y * ex, epk - pw.y * ey, -pw.y * ez};
-  const double J2[6] = {-ey, ex, 0.0, -pw.z * ex, -pw.z * ey, epk - pw.z * ez};
-  const double rho1 = cauchy(a, r0 * r0 + r1 * r1 + r2 * r2);
+  const double J0[6] = {0.0, -ez, ey, __builtin_fma(-pw.x, ex, epk), -(pw.x * ey), -(pw.x * ez)};
+  const double J1[6] = {ez, 0.0, -ex, -(pw.y * ex), __builtin_fma(-pw.y, ey, epk), -(pw.y * ez)};
+  const double J2[6] = {-ey, ex, 0.0, -(pw.z * ex), -(pw.z * ey), __builtin_fma(-pw.z, ez, epk)};
+  const double rho1 = cauchy(a, __builtin_fma(r2, r2, __builtin_fma(r1, r1, r0 * r0)));
   acc_row(a, J0, r0, rho1);
   acc_row(a, J1, r1, rho1);
   acc_row(a, J2, r2, rho1);
@@ -117,12 +128,12 @@ __device__ __forceinline__ double eval_line(const Rt& T, Vec3 p, Vec3 la, Vec3 l
 __device__ __forceinline__ double eval_point(const Rt& T, Vec3 p, Vec3 q, double w, Acc& a) {
   const Vec3 pw = act_rt(T, p);
   const double r0 = (q.x - pw.x) * w, r1 = (q.y - pw.y) * w, r2 = (q.z - pw.z) * w;  // :26-30
-  const double rs = r0 + r1 + r2;
+  const double rs = (r0 + r1) + r2;
   const double wx = pw.x * w, wy = pw.y * w, wz = pw.z * w;
   const double J0[6] = {-w, 0.0, 0.0, 0.0, -wz, wy};   // [-I w, hat(pw) w]  :39-40
   const double J1[6] = {0.0, -w, 0.0, wz, 0.0, -wx};
   const double J2[6] = {0.0, 0.0, -w, -wy, wx, 0.0};
-  const double rho1 = cauchy(a, r0 * r0 + r1 * r1 + r2 * r2);
+  const double rho1 = cauchy(a, __builtin_fma(r2, r2, __builtin_fma(r1, r1, r0 * r0)));
   acc_row(a, J0, r0, rho1);
   acc_row(a, J1, r1, rho1);
   acc_row(a, J2, r2, rho1);
@@ -175,10 +186,11 @@ __device__ __forceinline__ void rs_step_swap(double (&v)[32]) {
 // point 7).  fetch() is branch-free -- every lane always issues every load (the segments are padded
 // by one chunk, so a tail lane reads valid memory and is masked in consume()) -- which lets the
 // compiler count outstanding loads exactly and wait with vmcnt(N) for the OLDER chunk only.
-template <int RES>
-struct ChunkBuf {
+struct ChunkData {
   double2 px, py, pz, ax, ay, az, bx, by, bz, d, w;
 };
+template <int RES>
+using ChunkBuf = ChunkData;   // (one type: which streams are filled / used is the RES of the function handling it)
 // uniform base pointer (SGPR pair) + 32-bit per-lane byte offset: lets the compiler use the
 // `global_load_dwordx4 v, v_off, s[base]` addressing form (one offset VGPR for all streams)
 template <bool NT>
@@ -329,51 +341,67 @@ __device__ __forceinline__ void sweep_all(const CorrView& cv, const int* __restr
 __host__ __device__ constexpr int single_chunk_of(int kind) { return kind <= TLOAM_KIND_GROUND ? kChunk : TLOAM_SMALL_LINE_CHUNK; }
 // one correspondence per lane (the 64-chunks): the streams as 8-byte loads into the first slot of the chunk buffer
 template <int RES>
-__device__ __forceinline__ void fetch_one(const CorrSeg& seg, int j, ChunkBuf<RES>& b) {
+__device__ __forceinline__ void fetch_one(const CorrSeg& seg, int j, ChunkData& b) {
   b.px.x = seg.px[j]; b.py.x = seg.py[j]; b.pz.x = seg.pz[j];
   b.ax.x = seg.ax[j]; b.ay.x = seg.ay[j]; b.az.x = seg.az[j];
   b.w.x = seg.w[j];
   if (RES == TLOAM_RES_PLANE) b.d.x = seg.d[j];
   if (RES == TLOAM_RES_LINE) { b.bx.x = seg.bx[j]; b.by.x = seg.by[j]; b.bz.x = seg.bz[j]; }
 }
-template <int RES>
-__device__ __forceinline__ void sweep_single_kind(const Rt& T, const CorrSeg& seg, int n, int g, int lane, Acc& a) {
-  ChunkBuf<RES> b{};
-  if (single_chunk_of(RES == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE) == kChunk) {
-    const int j = g * kChunk + lane * 2;
-    fetch<RES, false>(seg, j, b);
-    consume<RES, false>(T, seg, j, n, b, a);
-  } else {
-    const int j = g * 64 + lane;
-    fetch_one<RES>(seg, j, b);
-    consume<RES, false>(T, seg, j, n < j + 1 ? n : j + 1, b, a);   // this lane's one correspondence
+// The chunk of wave gw: the kinds' chunk ranges follow each other in CAPACITY order (capacities are kernel arguments:
+// known before any device memory has been read), so every wave can request its streams in its first instructions --
+// the planar segment straight from the preloaded (base, stride, capacity), the others as soon as the kernel-argument
+// block has been read -- while the minimiser state (done flag, pose) and the segment sizes are still on their way.
+// (Mapping by the actual sizes made every wave but the first planar ones wait for state -> sizes -> data: three
+// dependent trips, ~0.8 us on the launch's slowest waves.)  A chunk beyond its segment's size does nothing.
+struct SingleWork {
+  int kind;   // -1: no chunk (grid padding)
+  int j;      // first correspondence of this lane
+};
+__device__ __forceinline__ SingleWork single_work_of(const CorrView& cv, int cap0, int gw, int lane) {
+  SingleWork wk{-1, 0};
+  int g = gw;
+  const int n0 = cap0 / kChunk;   // (preloaded: the planar waves need nothing else)
+  if (g < n0) { wk.kind = 0; wk.j = g * kChunk + lane * 2; return wk; }
+  g -= n0;
+#pragma unroll
+  for (int k = 1; k < kKinds; ++k) {
+    const int c = single_chunk_of(k), nk = cv.k[k].cap / c;
+    if (wk.kind < 0 && g < nk) { wk.kind = k; wk.j = (c == kChunk) ? g * kChunk + lane * 2 : g * 64 + lane; }
+    g -= nk;
+  }
+  if (wk.kind >= 0 && g >= 0) {}  // (g has gone negative once a kind matched)
+  return wk;
+}
+__device__ __forceinline__ void single_fetch(const CorrView& cv, const double* __restrict__ seg0, int stride0, const SingleWork& wk,
+                                             ChunkData& b) {
+  if (wk.kind == TLOAM_KIND_PLANAR) fetch_spec<false>(seg0, stride0, wk.j, b);
+  else if (wk.kind == TLOAM_KIND_GROUND) fetch<TLOAM_RES_PLANE, false>(cv.k[TLOAM_KIND_GROUND], wk.j, b);
+  else if (wk.kind == TLOAM_KIND_EDGE) {
+    if (single_chunk_of(TLOAM_KIND_EDGE) == kChunk) fetch<TLOAM_RES_LINE, false>(cv.k[TLOAM_KIND_EDGE], wk.j, b);
+    else fetch_one<TLOAM_RES_LINE>(cv.k[TLOAM_KIND_EDGE], wk.j, b);
+  } else if (wk.kind == TLOAM_KIND_SPHERE) {
+    if (single_chunk_of(TLOAM_KIND_SPHERE) == kChunk) fetch<TLOAM_RES_POINT, false>(cv.k[TLOAM_KIND_SPHERE], wk.j, b);
+    else fetch_one<TLOAM_RES_POINT>(cv.k[TLOAM_KIND_SPHERE], wk.j, b);
   }
 }
-__device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, int gw, int lane,
-                                             Acc& a, const ChunkBuf<TLOAM_RES_PLANE>& pre0, bool use_pre0) {
+__device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, const SingleWork& wk,
+                                             const ChunkData& b, Acc& a) {
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
   a.pe = 1;
-  int g = gw;
-#pragma unroll
-  for (int k = 0; k < kKinds; ++k) {
-    const int n = seg_n[k];
-    const int nchunks = (n + single_chunk_of(k) - 1) / single_chunk_of(k);
-    if (g >= 0 && g < nchunks) {
-      if (k <= TLOAM_KIND_GROUND) {
-        const int j = g * kChunk + lane * 2;
-        ChunkBuf<TLOAM_RES_PLANE> b;
-        if (use_pre0 && k == 0) b = pre0;
-        else fetch<TLOAM_RES_PLANE, false>(cv.k[k], j, b);
-        consume<TLOAM_RES_PLANE, false>(T, cv.k[k], j, n, b, a);
-      } else if (k == TLOAM_KIND_EDGE) {
-        sweep_single_kind<TLOAM_RES_LINE>(T, cv.k[k], n, g, lane, a);
-      } else {
-        sweep_single_kind<TLOAM_RES_POINT>(T, cv.k[k], n, g, lane, a);
-      }
-    }
-    g -= nchunks;
+  if (wk.kind < 0) return;
+  const int n = seg_n[wk.kind];
+  if (wk.kind <= TLOAM_KIND_GROUND) {
+    if (wk.kind == TLOAM_KIND_PLANAR) consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_PLANAR], wk.j, n, b, a);
+    else consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_GROUND], wk.j, n, b, a);
+  } else if (wk.kind == TLOAM_KIND_EDGE) {
+    const int ne = single_chunk_of(TLOAM_KIND_EDGE) == kChunk ? n : (n < wk.j + 1 ? n : wk.j + 1);   // 64-chunks: this lane's one
+    consume<TLOAM_RES_LINE, false>(T, cv.k[TLOAM_KIND_EDGE], wk.j, ne, b, a);
+  } else {
+    const int ne = single_chunk_of(TLOAM_KIND_SPHERE) == kChunk ? n : (n < wk.j + 1 ? n : wk.j + 1);
+    consume<TLOAM_RES_POINT, false>(T, cv.k[TLOAM_KIND_SPHERE], wk.j, ne, b, a);
   }
 }
 // wave total of the 28 sums: component c ends up (complete) in lanes 2c and 2c+1
@@ -524,42 +552,50 @@ __device__ __forceinline__ void k3_post_row_tagged(double* __restrict__ partials
                        __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// all 256 threads of the consumer block; rows <= kTaggedRows.  false: timed out (a block of the grid never posted)
-__device__ __forceinline__ bool fold_rows_tagged(const double* __restrict__ partials, int rows, unsigned long long tag,
-                                                 double* s_grp /*[8*33]*/, double* s_tot) {
-  const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;   // word `word` of rows grp and grp + 8
-  const bool have0 = grp < rows, have1 = grp + 8 < rows;
-  const unsigned long long* p0 = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have0 ? grp : 0) * kAccStride + word;
-  const unsigned long long* p1 = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have1 ? grp + 8 : 0) * kAccStride + word;
-  unsigned long long w0, w1;
+// ONE wave of the consumer block; rows <= kTaggedRows = 16, i.e. at most 64 segments: lane = (row, segment).  Every lane
+// re-reads the eight words of its segment (device-scope loads) and XORs them in registers -- no cross-lane exchange, no LDS,
+// no barrier per poll -- until every segment of every row checks; the sums then go through LDS once and are added in the
+// order fold_rows uses (so the fused iteration and sweep + separate reduce agree bit for bit).
+// false: timed out (a block of the grid never posted).  s_rows: LDS, kTaggedRows * 28 doubles.
+__device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ partials, int rows, unsigned long long tag,
+                                                 double* s_rows, double* s_tot, int lane) {
+  const int r = lane >> 2, sgm = lane & 3;
+  const bool have = r < rows;
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have ? r : 0) * kAccStride + sgm * 8;
+  unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
   bool ok_all;
-  for (;;) {
-    w0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool ok = (!have0 || xor8(w0) == tag) && (!have1 || xor8(w1) == tag);
-    ok_all = __syncthreads_and(ok ? 1 : 0) != 0;
+  for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long x = w[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) x ^= w[i];
+    ok_all = __all((!have || x == tag) ? 1 : 0) != 0;
     if (ok_all) break;
-    if (wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock (uniform enough: every thread leaves within a poll)
+    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock
     __builtin_amdgcn_s_sleep(1);
   }
-  ok_all = __syncthreads_and(ok_all ? 1 : 0) != 0;
-  const int seg = word >> 3, pos = word & 7, c = seg * 7 + pos;
-  const double a = (have0 && pos < 7) ? __longlong_as_double((long long)w0) : 0.0;
-  const double b = (have1 && pos < 7) ? __longlong_as_double((long long)w1) : 0.0;
-  // the tree of fold_rows (sixteen values per thread, fourteen of them zero here), literally, so that the fused
-  // iteration and sweep + separate reduce agree bit for bit
-  const double v = (((a + 0.0) + 0.0) + 0.0) + (((b + 0.0) + 0.0) + 0.0);
-  if (pos < 7) s_grp[grp * 33 + c] = v;
-  __syncthreads();
-  if (threadIdx.x < kReduceBuf) {
-    double t = 0.0;
-    if (threadIdx.x < kAccN)
+  if (have) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) t += s_grp[g * 33 + threadIdx.x];
-    s_tot[threadIdx.x] = t;
+    for (int i = 0; i < 7; ++i) s_rows[r * 28 + sgm * 7 + i] = __longlong_as_double((long long)w[i]);
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS stores are in order; this also stops the compiler
+  if (lane < kReduceBuf) {
+    double t = 0.0;
+    if (lane < kAccN) {
+      // fold_rows: group g holds rows g and g + 8 (of sixteen values per thread fourteen are zero here), the groups are
+      // added in order -- literally, zeros included
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const double a = g < rows ? s_rows[g * 28 + lane] : 0.0;
+        const double b = g + 8 < rows ? s_rows[(g + 8) * 28 + lane] : 0.0;
+        t += (((a + 0.0) + 0.0) + 0.0) + (((b + 0.0) + 0.0) + 0.0);
+      }
+    }
+    s_tot[lane] = t;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   return ok_all;
 }
 __device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const double (*red)[32], const K3Fuse& fuse) {
@@ -596,16 +632,22 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
   const unsigned long long wc0 = wall_clock64();  // 100 MHz, one base for the whole device
 #endif
-  ChunkBuf<TLOAM_RES_PLANE> pre;
-  const bool spec = (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cap0;
-  if (spec) fetch_spec<!SINGLE && TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
+  ChunkData pre;
+  SingleWork wk{-1, 0};
+  const bool spec = !SINGLE && (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cap0;
+  if (SINGLE) {
+    wk = single_work_of(cv, cap0, gw, lane);
+    single_fetch(cv, seg0, stride0, wk, pre);
+  } else if (spec) {
+    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
+  }
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
   Acc a;
 #ifdef TLOAM_K3_PROFILE
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
-  if (SINGLE) sweep_single(cv, seg_n, T, gw, lane, a, pre, spec);
+  if (SINGLE) sweep_single(cv, seg_n, T, wk, pre, a);
   else sweep_all(cv, seg_n, T, gw, gridDim.x * 4, lane, a, pre, spec);
 #ifdef TLOAM_K3_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
@@ -854,13 +896,17 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
                                                              CorrView cv) {
   __shared__ double red[4][32];
   __shared__ double s_grp[8 * 33];
+  __shared__ double s_rows[kTaggedRows * 28];
   __shared__ double tot[kReduceBuf];
   __shared__ GnState s_in;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
-  ChunkBuf<TLOAM_RES_PLANE> pre;
-  const bool spec = (gw + 1) * kChunk <= cap0;
-  if (spec) fetch_spec<false>(seg0, stride0, gw * kChunk + lane * 2, pre);
+#ifdef TLOAM_STEP_PROFILE
+  const unsigned long long c_entry = __builtin_readcyclecounter();
+#endif
+  ChunkData pre;
+  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
+  single_fetch(cv, seg0, stride0, wk, pre);
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
     static_assert(kWords <= 256, "one word per thread");
@@ -873,8 +919,15 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
   const unsigned long long epoch0 = *epoch;
   if (st->done) return;            // after a tolerance exit the remaining launches are no-ops (uniform over the grid)
   const Rt T = st->Rt_eval;
+#ifdef TLOAM_STEP_PROFILE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long c_pose = __builtin_readcyclecounter();
+#endif
   Acc a;
-  sweep_single(cv, seg_n, T, gw, lane, a, pre, spec);
+  sweep_single(cv, seg_n, T, wk, pre, a);
+#ifdef TLOAM_STEP_PROFILE
+  const unsigned long long c_eval = __builtin_readcyclecounter();
+#endif
   const double wtot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
   __syncthreads();
@@ -884,11 +937,14 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
   if (tagged) {
     // a dozen blocks: the rows are the flag, block 0 is the consumer (see k3_post_row_tagged)
     k3_post_row_tagged(partials, red, epoch0 + 1ull);
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;   // the consumer is ONE wave: poll, fold, step
 #ifdef TLOAM_STEP_PROFILE
-    if (threadIdx.x == 0) { st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter(); }
+    if (threadIdx.x == 0) {
+      st->dbg[7] = (double)c_sweep; st->dbg[0] = (double)__builtin_readcyclecounter();
+      st->dbg[8] = (double)c_entry; st->dbg[9] = (double)c_pose; st->dbg[10] = (double)c_eval;
+    }
 #endif
-    const bool ok = fold_rows_tagged(partials, (int)gridDim.x, epoch0 + 1ull, s_grp, tot);
+    const bool ok = poll_fold_tagged(partials, (int)gridDim.x, epoch0 + 1ull, s_rows, tot, (int)threadIdx.x);
     if (threadIdx.x == 0) *epoch = epoch0 + 1ull;   // (plain store: read by the next launch)
     if (!ok) {  // a block of the grid never posted: stop the Solve; the finish kernel reports OS_COMM_ERROR
       if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
@@ -912,6 +968,117 @@ void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, 
   const int tagged = (grid <= kTaggedRows && !no_tagged) ? 1 : 0;
   hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
                      cv.seg_n, partials, ticket, cv);
+}
+// ---- one ceres::Solve of a KITTI-size set in ONE launch ----------------------------------------------------------
+// The sweeps of a Solve are a chain: sweep -> 6x6 step -> sweep of the candidate -> ...  As launches every link pays a kernel
+// boundary (~1.5 us), the state and stream loads again (~1 us), and the host has to GUESS how many links to enqueue (a wrong
+// guess costs a round trip and a second pass over the frame's launch list).  For a grid of <= kTaggedRows blocks -- all
+// resident at once on a 256-CU part -- the chain runs inside one launch instead: every wave keeps its chunk of
+// correspondences in registers; per GN iteration the blocks post their rows (k3_post_row_tagged), wave 0 of block 0 polls
+// and folds them, runs the minimiser step (gn_consume) and publishes the candidate pose -- two 64-byte segments (seven
+// words + check word, as the rows) that the other waves poll; a control word says go on / stop.  Tags carry the launch
+// counter and the iteration, so nothing has to be reset between launches.  Nothing else changes: the same sweep arithmetic
+// per wave, the same fold order, the same step.
+// max_sweeps: evaluations this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
+constexpr int kBcastWords = 16;
+__device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
+                                                   bool go_on, int lane) {
+  if (lane < kBcastWords) {
+    const int sgm = lane >> 3, pos = lane & 7, v = sgm * 7 + pos;   // values 0..8: R, 9..11: t, 12: control, 13: spare
+    unsigned long long w = 0ull;
+    if (pos < 7) {
+      if (v < 9) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.r[v]);
+      else if (v < 12) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.t[v - 9]);
+      else if (v == 12) w = go_on ? 1ull : 2ull;
+    }
+    const unsigned long long x = xor8(w);
+    if (pos == 7) w = tag ^ x;
+    __hip_atomic_store(bcast + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// every lane reads all sixteen words (uniform addresses: one transaction per instruction) until both segments check.
+// Returns 1: go on with T, 2: stop, 0: timed out.
+__device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restrict__ bcast, unsigned long long tag, Rt& T) {
+  unsigned long long w[kBcastWords];
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < kBcastWords; ++i) w[i] = __hip_atomic_load(bcast + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long x0 = w[0], x1 = w[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { x0 ^= w[i]; x1 ^= w[8 + i]; }
+    if (x0 == tag && x1 == tag) break;
+    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) return 0;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int v = 0; v < 12; ++v) {
+    const double d = __longlong_as_double((long long)w[(v / 7) * 8 + (v % 7)]);
+    if (v < 9) T.r[v] = d; else T.t[v - 9] = d;
+  }
+  return (int)w[8 + 5];   // value 12 = segment 1, position 5
+}
+__global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
+                                                        GnState* __restrict__ st, const int* __restrict__ seg_n,
+                                                        double* __restrict__ partials, int* __restrict__ ticket,
+                                                        unsigned long long* __restrict__ bcast, CorrView cv) {
+  __shared__ double red[4][32];
+  __shared__ double s_scr[32];
+  __shared__ double s_rows[kTaggedRows * 28];
+  __shared__ double tot[kReduceBuf];
+  __shared__ GnState s_in;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  ChunkData pre;
+  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
+  single_fetch(cv, seg0, stride0, wk, pre);   // this wave's correspondences: requested once, kept in registers for the whole Solve
+  {
+    constexpr int kWords = (int)(sizeof(GnState) / 8);
+    static_assert(kWords <= 256, "one word per thread");
+    if (threadIdx.x < kWords)
+      reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
+  }
+  unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
+  const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (see k_sweep_step_small: read by every block before it can change)
+  if (st->done) return;            // a Solve that has already ended (uniform over the grid)
+  Rt T = st->Rt_eval;
+  const bool consumer = blockIdx.x == 0 && wave == 0;
+  for (int it = 0;; ++it) {
+    Acc a;
+    sweep_single(cv, seg_n, T, wk, pre, a);
+    const double wtot = wave_reduce_acc(a, lane);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
+    __syncthreads();
+    k3_post_row_tagged(partials, red, tag0 | (unsigned long long)it);
+    if (consumer) {
+      const bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | (unsigned long long)it, s_rows, tot, lane);
+      if (!ok) {  // a block of the grid never posted: stop the Solve; the finish kernel reports OS_COMM_ERROR
+        if (lane == 0) { st->done = 1; st->comm_error = 1; *epoch = tag0 >> 8; }
+        solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), false, lane);
+        return;
+      }
+      gn_consume(st, tot, lane, &s_in, s_scr);
+      const bool go_on = s_in.done == 0 && it + 1 < max_sweeps;
+      solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), go_on, lane);
+      if (!go_on) {
+        if (lane == 0) *epoch = tag0 >> 8;   // (plain store: read by the next launch)
+        return;
+      }
+      T = s_in.Rt_eval;
+    } else {
+      const int verdict = solve_wait_pose(bcast, tag0 | (unsigned long long)(it + 1), T);
+      if (verdict != 1) return;
+    }
+  }
+}
+void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
+                     cv.seg_n, partials, ticket, bcast, cv);
+}
+bool solve_small_fits(int grid) {
+  static const bool off = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;   // A/B knob: one launch per GN iteration
+  return grid <= kTaggedRows && !off;
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);

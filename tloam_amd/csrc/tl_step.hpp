@@ -69,8 +69,23 @@ __device__ __forceinline__ double fsqrt(double x) {  // x >= 0
   const double r = fast_rsqrt(x);
   return x > 0.0 ? x * r : x;
 }
-__device__ __forceinline__ double dot6(const double a[6], const double b[6]) {
-  return ((a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3])) + (a[4] * b[4] + a[5] * b[5]);
+__device__ __forceinline__ double dot6(const double a[6], const double b[6]) {   // three independent two-term chains
+  return (__builtin_fma(a[1], b[1], a[0] * b[0]) + __builtin_fma(a[3], b[3], a[2] * b[2])) + __builtin_fma(a[5], b[5], a[4] * b[4]);
+}
+// cross / rotate / quaternion product with every multiply-add spelled out (this unit is compiled with -ffp-contract=off)
+__device__ __forceinline__ Vec3 cross_f(Vec3 a, Vec3 b) {
+  return {__builtin_fma(a.y, b.z, -(a.z * b.y)), __builtin_fma(a.z, b.x, -(a.x * b.z)), __builtin_fma(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ Vec3 rotate_f(const Pose& T, Vec3 p) {   // so3.hpp:358-367: p + w uv + v x uv, uv = 2 (v x p)
+  const Vec3 v{T.qx, T.qy, T.qz};
+  Vec3 uv = cross_f(v, p);
+  uv = uv + uv;
+  const Vec3 c2 = cross_f(v, uv);
+  return {__builtin_fma(T.qw, uv.x, p.x) + c2.x, __builtin_fma(T.qw, uv.y, p.y) + c2.y, __builtin_fma(T.qw, uv.z, p.z) + c2.z};
+}
+__device__ __forceinline__ Vec3 axpy2(Vec3 u, double c1, Vec3 w1, double c2, Vec3 w2) {   // u + c1 w1 + c2 w2
+  return {__builtin_fma(c2, w2.x, __builtin_fma(c1, w1.x, u.x)), __builtin_fma(c2, w2.y, __builtin_fma(c1, w1.y, u.y)),
+          __builtin_fma(c2, w2.z, __builtin_fma(c1, w1.z, u.z))};
 }
 // a^T M b with M symmetric, stored as its upper triangle (ut)
 __device__ __forceinline__ double quad6(const double a[6], const double M[21], const double b[6]) {
@@ -127,15 +142,15 @@ __device__ __forceinline__ bool chol6_uniform(double Au[21], const double b[6], 
 // (sophus so3.hpp:583-619 + se3.hpp:761-785; so3.hpp:325-340 + se3.hpp:304-309; so3.hpp:247-290 + se3.hpp:223-256)
 __device__ __forceinline__ Pose exp_fast2(const double a[6]) {
   const double ox = a[3], oy = a[4], oz = a[5];
-  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  const double theta_sq = __builtin_fma(oz, oz, __builtin_fma(oy, oy, ox * ox));
   Pose T;
   const Vec3 om{ox, oy, oz}, u{a[0], a[1], a[2]};
   if (theta_sq < kSophusEps * kSophusEps) {
     const double theta_po4 = theta_sq * theta_sq;
-    const double imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
-    T.qw = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    const double imag = __builtin_fma(1.0 / 3840.0, theta_po4, __builtin_fma(-(1.0 / 48.0), theta_sq, 0.5));
+    T.qw = __builtin_fma(1.0 / 384.0, theta_po4, __builtin_fma(-(1.0 / 8.0), theta_sq, 1.0));
     T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
-    const Vec3 t = rotate(T, u);
+    const Vec3 t = rotate_f(T, u);
     T.tx = t.x; T.ty = t.y; T.tz = t.z;
     return T;
   }
@@ -147,36 +162,36 @@ __device__ __forceinline__ Pose exp_fast2(const double a[6]) {
   T.qw = ch; T.qx = imag * ox; T.qy = imag * oy; T.qz = imag * oz;
   Vec3 t;
   if (theta < kSophusEps) {
-    t = rotate(T, u);
+    t = rotate_f(T, u);
   } else {
     const double c1 = 2.0 * imag * imag;                                            // (1 - cos t) / t^2
-    const double c2 = (theta - 2.0 * sh * ch) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
-    const Vec3 w1 = cross(om, u);
-    const Vec3 w2 = cross(om, w1);
-    t = u + c1 * w1 + c2 * w2;
+    const double c2 = __builtin_fma(-2.0 * sh, ch, theta) * inv_theta * inv_theta * inv_theta;  // (t - sin t) / t^3
+    const Vec3 w1 = cross_f(om, u);
+    const Vec3 w2 = cross_f(om, w1);
+    t = axpy2(u, c1, w1, c2, w2);
   }
   T.tx = t.x; T.ty = t.y; T.tz = t.z;
   return T;
 }
 __device__ __forceinline__ Pose compose_fast2(const Pose& A, const Pose& B) {
   Pose C;
-  C.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
-  C.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
-  C.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
-  C.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
-  const double il = fast_rsqrt(C.qw * C.qw + C.qx * C.qx + C.qy * C.qy + C.qz * C.qz);
+  C.qw = __builtin_fma(-A.qz, B.qz, __builtin_fma(-A.qy, B.qy, __builtin_fma(-A.qx, B.qx, A.qw * B.qw)));
+  C.qx = __builtin_fma(-A.qz, B.qy, __builtin_fma(A.qy, B.qz, __builtin_fma(A.qx, B.qw, A.qw * B.qx)));
+  C.qy = __builtin_fma(-A.qx, B.qz, __builtin_fma(A.qz, B.qx, __builtin_fma(A.qy, B.qw, A.qw * B.qy)));
+  C.qz = __builtin_fma(-A.qy, B.qx, __builtin_fma(A.qx, B.qy, __builtin_fma(A.qz, B.qw, A.qw * B.qz)));
+  const double il = fast_rsqrt(__builtin_fma(C.qz, C.qz, __builtin_fma(C.qy, C.qy, __builtin_fma(C.qx, C.qx, C.qw * C.qw))));
   C.qw *= il; C.qx *= il; C.qy *= il; C.qz *= il;
-  const Vec3 rt = rotate(A, Vec3{B.tx, B.ty, B.tz});
+  const Vec3 rt = rotate_f(A, Vec3{B.tx, B.ty, B.tz});
   C.tx = A.tx + rt.x; C.ty = A.ty + rt.y; C.tz = A.tz + rt.z;
   return C;
 }
 __device__ __forceinline__ void log_fast2(const Pose& T, double a[6]) {
-  const double squared_n = T.qx * T.qx + T.qy * T.qy + T.qz * T.qz;
+  const double squared_n = __builtin_fma(T.qz, T.qz, __builtin_fma(T.qy, T.qy, T.qx * T.qx));
   const double w = T.qw;
   double f, theta, c2;
   if (squared_n < kSophusEps * kSophusEps) {
     const double iw = fast_rcp(w);
-    f = 2.0 * iw - (2.0 / 3.0) * squared_n * (iw * iw * iw);
+    f = __builtin_fma(-(2.0 / 3.0) * squared_n, iw * iw * iw, 2.0 * iw);
     theta = 2.0 * squared_n * iw;
     c2 = 1.0 / 12.0;
   } else {
@@ -189,14 +204,14 @@ __device__ __forceinline__ void log_fast2(const Pose& T, double a[6]) {
     } else {
       f = 2.0 * atan(n * fast_rcp(w)) * in_;
       theta = f * n;
-      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : (1.0 - 0.5 * theta * w * in_) * fast_rcp(theta * theta);
+      c2 = (fabs(theta) < kSophusEps) ? 1.0 / 12.0 : __builtin_fma(-0.5 * theta * w, in_, 1.0) * fast_rcp(theta * theta);
     }
   }
   const Vec3 om{f * T.qx, f * T.qy, f * T.qz};
   const Vec3 t{T.tx, T.ty, T.tz};
-  const Vec3 w1 = cross(om, t);
-  const Vec3 w2 = cross(om, w1);
-  const Vec3 ups = t + (-0.5) * w1 + c2 * w2;
+  const Vec3 w1 = cross_f(om, t);
+  const Vec3 w2 = cross_f(om, w1);
+  const Vec3 ups = axpy2(t, -0.5, w1, c2, w2);
   a[0] = ups.x; a[1] = ups.y; a[2] = ups.z;
   a[3] = om.x;  a[4] = om.y;  a[5] = om.z;
 }
@@ -358,7 +373,7 @@ __device__ __forceinline__ StepResult step_compute(StepVars& v, GnState* st, con
       }
       v.step_norm = v.radius;
     }
-    v.mcc = -dot6(step, gs) - 0.5 * quad6(step, Hs, step);  // model_cost_change_
+    v.mcc = __builtin_fma(-0.5, quad6(step, Hs, step), -dot6(step, gs));  // model_cost_change_
     valid = v.mcc > 0.0;
   }
   TL_STAMP(4)

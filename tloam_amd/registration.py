@@ -113,6 +113,8 @@ def load_library():
         "tloam_set_target": (C.c_int, [vp, C.c_int, dp, sz]),
         "tloam_set_source_frame": (C.c_int, [vp, C.POINTER(dp), C.POINTER(sz)]),
         "tloam_set_target_frame": (C.c_int, [vp, C.POINTER(dp), C.POINTER(sz)]),
+        "tloam_frame_stash": (C.c_int, [vp, C.c_int]),
+        "tloam_frame_select": (C.c_int, [vp, C.c_int]),
         "tloam_scan_match": (C.c_int, [vp, dp, dp, dp, dp, sz, C.POINTER(Stats)]),
         "tloam_sm_begin": (C.c_int, [vp, dp, dp]),
         "tloam_sm_outer": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(Stats)]),
@@ -162,7 +164,7 @@ def load_library():
 EXPORTED_SYMBOLS = (
     "tloam_abi_version", "tloam_status_string", "tloam_last_error", "tloam_default_config", "tloam_create",
     "tloam_destroy", "tloam_set_source", "tloam_set_target", "tloam_set_source_frame", "tloam_set_target_frame",
-    "tloam_scan_match", "tloam_sm_begin",
+    "tloam_frame_stash", "tloam_frame_select", "tloam_scan_match", "tloam_sm_begin",
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
@@ -313,6 +315,16 @@ class HipRegistration:
     def set_frames(self, source, target):
         self.set_input_source(source)
         self.set_input_target(target)
+
+    def frame_stash(self, slot):
+        """tloam_frame_stash: the registered clouds move into slot `slot` of the HBM frame store."""
+        self._check(self.L.tloam_frame_stash(self.h, int(slot)), "tloam_frame_stash")
+
+    def frame_select(self, slot):
+        """tloam_frame_select: the clouds of `slot` become the registered ones (-1: the context's own); O(1)."""
+        rc = self.L.tloam_frame_select(self.h, int(slot))
+        if rc != 0:
+            self._check(rc, "tloam_frame_select")
 
     def scan_match(self, predict, omega=None, scan=None):
         self._pred_view[...] = predict
