@@ -230,6 +230,10 @@ int tloam_k3_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* launche
 /* the same over EVERY K3 launch, including the no-op launches enqueued after a solver tolerance exit
  * (the population a kernel trace averages over) */
 int tloam_k3_timer_all(tloam_ctx* ctx, double* total_us, int64_t* launches);
+/* Test aid: the DEVICE SE(3) arithmetic the minimiser step uses (vendored-Sophus restatements sophus/so3.hpp:583-619,
+ * se3.hpp:761-785 exp; so3.hpp:247-290, se3.hpp:223-256 log; registration.cpp:162-173 Plus), n items.  out26 per item:
+ * [0..6] exp(delta) as (qw qx qy qz tx ty tz), [7..12] log(exp(x)), [13..18] Plus(x, delta), [19..25] exp(x) (shared form). */
+int tloam_debug_se3(tloam_ctx* ctx, int n, const double* x6, const double* delta6, double* out26);
 /* debugging aid: raw copy of the device-resident minimiser state; returns its size in doubles */
 int tloam_debug_state(tloam_ctx* ctx, double* out, int n_doubles);
 /* development aid: the per-block partial rows of the last K3 launch (32 doubles per block); returns the

@@ -79,9 +79,17 @@ def test_scan_match_stepwise_parity(hip_module, seed):
                 assert len(ch["b"]) == len(co["b"]) > 0
                 np.testing.assert_allclose(ch["b"], co["b"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(ch["d"], co["d"], rtol=0, atol=1e-9)
-            np.testing.assert_allclose(ch["w"], co["w"], rtol=1e-9, atol=1e-15)
-            np.testing.assert_allclose(ch["cost"], co["cost"], rtol=1e-7, atol=1e-14)
-            np.testing.assert_allclose(H.get_weights(kind), O.get_weights(kind), rtol=1e-7, atol=1e-12)
+            # What bounds the agreement, iteration by iteration (the tolerances say so instead of being uniformly loose):
+            #  * iteration 0 runs on weights that are exactly 1 and ends at a converged point.  Its side-channel costs are
+            #    r^2 with r ~ 1e-3 m the difference of coordinates ~50 m: r carries ~1e-14 absolute = ~1e-11 relative
+            #    rounding whatever the summation order, the cost twice that -- 1e-9 with margin;
+            #  * iteration 1 captures the weights derived from those costs (w ~ 1e-7 / |r|): 1e-8;
+            #  * from iteration 1 on the side-channel costs are those of a REJECTED candidate -- a point
+            #    obtained by solving a 6x6 system of condition ~1e8 built from weights ~1e-5, tens of metres away: last-bit
+            #    differences come back amplified by that condition number, in the costs and in everything derived from them.
+            np.testing.assert_allclose(ch["w"], co["w"], rtol=(0.0, 1e-8)[it] if it <= 1 else 1e-6, atol=1e-15)
+            np.testing.assert_allclose(ch["cost"], co["cost"], rtol=1e-9 if it == 0 else 1e-6, atol=1e-16 if it == 0 else 1e-13)
+            np.testing.assert_allclose(H.get_weights(kind), O.get_weights(kind), rtol=1e-8 if it == 0 else 1e-6, atol=1e-13)
         assert (st_h["gn_iterations"], st_h["accepted_steps"], st_h["gn_evaluations"]) == \
                (st_o["gn_iterations"], st_o["accepted_steps"], st_o["gn_evaluations"]), (it, st_h, st_o)
         np.testing.assert_allclose(st_h["se3"], st_o["se3"], rtol=0, atol=1e-9)
@@ -89,9 +97,10 @@ def test_scan_match_stepwise_parity(hip_module, seed):
         # the linear system itself, per outer iteration: H, g and the cost at the accepted iterate of this Solve
         Hh, gh, ch_ = H.get_normal_equations()
         Ho, go, co_ = O.get_normal_equations()
-        np.testing.assert_allclose(Hh, Ho, rtol=1e-9, atol=1e-9 * np.abs(Ho).max())
-        np.testing.assert_allclose(gh, go, rtol=1e-7, atol=1e-9 * max(np.abs(go).max(), np.abs(Ho).max() * 1e-6))
-        assert abs(ch_ - co_) <= 1e-9 * abs(co_) and abs(ch_ - st_h["solver_cost"]) == 0.0
+        tol = (1e-12, 1e-8)[it] if it <= 1 else 1e-6    # (the weights the system is built from: exactly 1, to 1e-8, to 1e-6)
+        np.testing.assert_allclose(Hh, Ho, rtol=tol, atol=tol * np.abs(Ho).max())
+        np.testing.assert_allclose(gh, go, rtol=0, atol=max(tol, 1e-11) * max(np.abs(go).max(), np.abs(Ho).max() * 1e-3))
+        assert abs(ch_ - co_) <= tol * abs(co_) and abs(ch_ - st_h["solver_cost"]) == 0.0
         assert done_h == done_o
         if done_h:
             break

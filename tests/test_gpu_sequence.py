@@ -1,7 +1,8 @@
-"""-m gpu: the first 200 frames of the synthetic KITTI-density sequence (BASELINE.json configs[1], SURVEY 8(d)
-config 2: ego-motion and constant-velocity prediction of the reference's published KITTI-00 trajectory), HIP path
-through the C ABI against the CPU port frame by frame: pose within the north-star tolerance, identical minimiser
-counters and correspondence counts on every frame."""
+"""-m gpu: the synthetic KITTI-density sequence (BASELINE.json configs[1], SURVEY 8(d) config 2: ego-motion and
+constant-velocity prediction of the reference's published KITTI-00 trajectory), HIP path through the C ABI against the CPU
+port frame by frame: pose within the north-star tolerance, identical minimiser counters and correspondence counts on every
+frame -- the first 200 frames, then every 10th frame of all 4540 (the turns, the straights, the long loop closures of the
+trajectory all show up in the prediction error the frame starts from)."""
 import numpy as np
 import pytest
 
@@ -30,6 +31,29 @@ def test_kitti_density_sequence_200_frames_hip_vs_port(hip_module):
         for k in ("outer_iterations", "gn_evaluations", "gn_iterations", "accepted_steps", "n_corr", "converged_early",
                   "bad_weights"):
             assert st_h[k] == st_o[k], (f, k, st_h[k], st_o[k])
-        np.testing.assert_allclose(st_h["kind_cost"], st_o["kind_cost"], rtol=1e-7, atol=1e-14)
+        np.testing.assert_allclose(st_h["kind_cost"], st_o["kind_cost"], rtol=1e-6, atol=1e-14)   # (rejected-candidate costs: see test_gpu_parity)
     assert worst_t < 1e-9 and worst_r < 1e-9, (worst_t, worst_r)   # observed: ~1e-15
+    H.close()
+
+
+def test_kitti_density_sequence_every_10th_frame_of_4540_hip_vs_port(hip_module):
+    H = hip_module.HipRegistration(hip_module.default_config())
+    O = ob.Oracle(ob.make_config())
+    worst_t = worst_r = 0.0
+    n = 0
+    for f in range(200, 4540, 10):
+        sc = bench.kitti_frame(synth, 0, f)
+        H.set_frames(sc.source, sc.target)
+        O.set_frames(sc.source, sc.target)
+        rc_h, T_h, st_h = H.scan_match(sc.T_pred)
+        rc_o, T_o, st_o = O.scan_match(sc.T_pred)
+        assert rc_h == 0 and rc_o == 0, (f, rc_h, rc_o)
+        dt, dr = pose_delta(T_h, T_o)
+        assert dt < 1e-6 and dr < 1e-6, (f, dt, dr)
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
+        for k in ("outer_iterations", "gn_evaluations", "gn_iterations", "accepted_steps", "n_corr", "converged_early",
+                  "bad_weights"):
+            assert st_h[k] == st_o[k], (f, k, st_h[k], st_o[k])
+        n += 1
+    assert n == 434 and worst_t < 1e-9 and worst_r < 1e-9, (n, worst_t, worst_r)
     H.close()

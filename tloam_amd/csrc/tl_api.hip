@@ -807,7 +807,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     k3_plan(caps, &c->k3_grid, &c->k3_single);
     (void)total_cap;
   }
-  HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
+  HIPC(c, c->partials.reserve(std::max<size_t>((size_t)c->k3_grid * kAccStride, 4096)));
   // ---- the start of the frame -- scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
   //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve -- rides on the
   //      first launch of the grid build
@@ -1464,7 +1464,7 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
     k3_plan(caps, &c->k3_grid, &c->k3_single);
     (void)total_cap;
   }
-  HIPC(c, c->partials.reserve((size_t)c->k3_grid * kAccStride));
+  HIPC(c, c->partials.reserve(std::max<size_t>((size_t)c->k3_grid * kAccStride, 4096)));
   return TLOAM_OK;
 }
 
@@ -1651,6 +1651,20 @@ int tloam_k3_timer(tloam_ctx* c, int reset, double* total_us, int64_t* launches,
   return TLOAM_OK;
 }
 
+// test aid: the device SE(3) arithmetic of the minimiser step (k_debug_se3), n items of (x, delta) -> 26 doubles each
+int tloam_debug_se3(tloam_ctx* c, int n, const double* x, const double* delta, double* out26) {
+  if (!c || n < 1 || !x || !delta || !out26) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  HIPC(c, c->misc.reserve((size_t)n * 38 + 8));
+  double* dx = c->misc.p; double* dd = dx + 6 * (size_t)n; double* dout = dd + 6 * (size_t)n;
+  HIPC(c, hipMemcpyAsync(dx, x, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipMemcpyAsync(dd, delta, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream));
+  launch_debug_se3(dx, dd, n, dout, c->stream);
+  HIPC(c, hipMemcpyAsync(out26, dout, sizeof(double) * 26 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
 // debugging aid: raw copy of the device-resident minimiser state (layout: tl_common.hpp GnState)
 int tloam_debug_state(tloam_ctx* c, double* out, int n_doubles) {
   if (!c || !out) return TLOAM_E_INVALID;
@@ -1665,7 +1679,7 @@ int tloam_debug_partials(tloam_ctx* c, double* out, int n_doubles) {
   if (!c || !out) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   HIPC(c, hipStreamSynchronize(c->stream));
-  const size_t n = std::min((size_t)c->k3_grid * kAccStride, (size_t)std::max(n_doubles, 0));
+  const size_t n = std::min(c->partials.cap, (size_t)std::max(n_doubles, 0));   // (rows, then whatever a profiling build put behind them)
   HIPC(c, hipMemcpy(out, c->partials.p, n * sizeof(double), hipMemcpyDeviceToHost));
   return c->k3_grid;
 }

@@ -433,5 +433,6 @@ void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds],
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
                                  double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);
+void launch_debug_se3(const double* x, const double* delta, int n, double* out /* 26 per item */, hipStream_t s);
 
 }  // namespace tl

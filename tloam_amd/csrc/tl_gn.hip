@@ -1043,23 +1043,39 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   if (st->done) return;            // a Solve that has already ended (uniform over the grid)
   Rt T = st->Rt_eval;
   const bool consumer = blockIdx.x == 0 && wave == 0;
+#ifdef TLOAM_STEP_PROFILE
+  // development aid (scripts/solve_profile.py): wall-clock (100 MHz) stamps of the consumer wave and of one producer wave
+  // (block gridDim/2) per GN iteration, in the spare part of the row buffer
+  unsigned long long* const prof = reinterpret_cast<unsigned long long*>(partials) + 1024;
+  const bool prof_p = (int)blockIdx.x == (int)gridDim.x / 2 && wave == 0 && lane == 0;
+#define TL_PROF(cond, slot) if (cond) prof[(slot)] = wall_clock64();
+#else
+#define TL_PROF(cond, slot)
+#endif
+  TL_PROF(consumer && lane == 0, 0)
   for (int it = 0;; ++it) {
     Acc a;
     sweep_single(cv, seg_n, T, wk, pre, a);
+    TL_PROF(prof_p, 64 + it * 8 + 1)
     const double wtot = wave_reduce_acc(a, lane);
     if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
     __syncthreads();
     k3_post_row_tagged(partials, red, tag0 | (unsigned long long)it);
+    TL_PROF(prof_p, 64 + it * 8 + 2)
+    TL_PROF(consumer && lane == 0, 8 + it * 8 + 0)
     if (consumer) {
       const bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | (unsigned long long)it, s_rows, tot, lane);
+      TL_PROF(lane == 0, 8 + it * 8 + 1)
       if (!ok) {  // a block of the grid never posted: stop the Solve; the finish kernel reports OS_COMM_ERROR
         if (lane == 0) { st->done = 1; st->comm_error = 1; *epoch = tag0 >> 8; }
         solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), false, lane);
         return;
       }
       gn_consume(st, tot, lane, &s_in, s_scr);
+      TL_PROF(lane == 0, 8 + it * 8 + 2)
       const bool go_on = s_in.done == 0 && it + 1 < max_sweeps;
       solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), go_on, lane);
+      TL_PROF(lane == 0, 8 + it * 8 + 3)
       if (!go_on) {
         if (lane == 0) *epoch = tag0 >> 8;   // (plain store: read by the next launch)
         return;
@@ -1067,6 +1083,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
       T = s_in.Rt_eval;
     } else {
       const int verdict = solve_wait_pose(bcast, tag0 | (unsigned long long)(it + 1), T);
+      TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
       if (verdict != 1) return;
     }
   }
@@ -1082,6 +1099,32 @@ bool solve_small_fits(int grid) {
 }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
+}
+
+// ---- test aid: the DEVICE SE(3) arithmetic of the minimiser step, exposed one operation at a time --------------------
+// out (per item, 26 doubles): [0..6] exp(delta) as (qw qx qy qz tx ty tz), [7..12] log(exp(x)), [13..18] Plus(x, delta) =
+// log(exp(delta) * exp(x)) exactly as gn_consume forms it (exp_fast2 / compose_fast2 / log_fast2), [19..25] exp(x) through the
+// host/device-shared se3_exp (what k_solve_init uses).  One thread per item.
+__global__ void k_debug_se3(const double* __restrict__ x, const double* __restrict__ delta, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double xv[6], dv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { xv[k] = x[6 * i + k]; dv[k] = delta[6 * i + k]; }
+  const Pose E = exp_fast2(dv);
+  const Pose X = exp_fast2(xv);
+  double lx[6], pl[6];
+  log_fast2(X, lx);
+  log_fast2(compose_fast2(E, X), pl);
+  const Pose X2 = se3_exp(xv);
+  double* o = out + 26 * (size_t)i;
+  o[0] = E.qw; o[1] = E.qx; o[2] = E.qy; o[3] = E.qz; o[4] = E.tx; o[5] = E.ty; o[6] = E.tz;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { o[7 + k] = lx[k]; o[13 + k] = pl[k]; }
+  o[19] = X2.qw; o[20] = X2.qx; o[21] = X2.qy; o[22] = X2.qz; o[23] = X2.tx; o[24] = X2.ty; o[25] = X2.tz;
+}
+void launch_debug_se3(const double* x, const double* delta, int n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_se3, dim3((n + 63) / 64), dim3(64), 0, s, x, delta, n, out);
 }
 
 // ================================================================================================

@@ -136,6 +136,7 @@ def load_library():
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
+        "tloam_debug_se3": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
         "tloam_submap_default_config": (None, [C.POINTER(SubmapConfig)]),
         "tloam_submap_init": (C.c_int, [vp, C.POINTER(SubmapConfig), dp, sz, dp, sz, dp, sz, dp, sz]),
@@ -168,7 +169,7 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
-    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials",
+    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
