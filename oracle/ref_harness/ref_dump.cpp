@@ -21,6 +21,15 @@
 // Input file (little endian), written by tests/golden_ref_tools/export_ref_inputs.py:
 //   int32 n_outer; double cfg[16] (the TLS: keys in the order of tloam_tls_config); double T_pred[16] (row-major);
 //   then 8 clouds in the order src planar, ground, edge, sphere, tgt planar, ground, edge, sphere: int64 n; double xyz[3n].
+//
+// The minimiser's bookkeeping -- where parity is actually won or lost -- is dumped as well, again
+// without touching the reference: scanMatching keeps its ceres::Solver::Summary to itself (registration.cpp:1046-1047), so
+// this file DEFINES ceres::Solve(options, problem, summary).  The reference's object file binds to that definition (an
+// executable's own symbols come first), which forwards to the real one in libceres (dlsym RTLD_NEXT on the mangled name)
+// and then writes the Summary: one "s" line per Solve call, one "i" line per minimiser iteration (cost, cost change, step
+// accepted or rejected, trust-region radius).  libceres must be linked SHARED for this (the CMake recipe checks).
+#include <dlfcn.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +40,32 @@
 #include <yaml-cpp/yaml.h>
 
 #include "tloam/models/registration/registration.hpp"
+
+#include <ceres/ceres.h>
+
+namespace {
+std::FILE* g_solve_log = nullptr;   // where the interposed ceres::Solve writes (the case's .ref.txt)
+int g_run = 0, g_call = 0;          // max_iterations of the current run, index of the Solve call inside it
+}  // namespace
+
+namespace ceres {
+// interposed: see the header comment.  Same signature as ceres/solver.h declares.
+void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
+  using Fn = void (*)(const Solver::Options&, Problem*, Solver::Summary*);
+  static Fn real = reinterpret_cast<Fn>(dlsym(RTLD_NEXT, "_ZN5ceres5SolveERKNS_6Solver7OptionsEPNS_7ProblemEPNS0_7SummaryE"));
+  if (!real) { std::fprintf(stderr, "ref_dump: the real ceres::Solve was not found behind this one (static libceres?)\n"); std::abort(); }
+  real(options, problem, summary);
+  if (g_solve_log) {
+    std::fprintf(g_solve_log, "s %d %d initial_cost %.17g final_cost %.17g successful %d unsuccessful %d termination %d\n", g_run,
+                 g_call, summary->initial_cost, summary->final_cost, summary->num_successful_steps,
+                 summary->num_unsuccessful_steps, static_cast<int>(summary->termination_type));
+    for (const IterationSummary& it : summary->iterations)
+      std::fprintf(g_solve_log, "i %d %d %d cost %.17g change %.17g step_ok %d radius %.17g step_norm %.17g\n", g_run, g_call,
+                   it.iteration, it.cost, it.cost_change, it.step_is_successful ? 1 : 0, it.trust_region_radius, it.step_norm);
+  }
+  ++g_call;
+}
+}  // namespace ceres
 
 namespace {
 bool read_cloud(std::ifstream& f, std::shared_ptr<open3d::geometry::PointCloud2>& c) {
@@ -91,7 +126,10 @@ int main(int argc, char** argv) {
       std::FILE* out = std::fopen((out_dir + "/" + name + ".ref.txt").c_str(), "w");
       if (!out) { ++failures; continue; }
       std::fprintf(out, "# %s: T_result (row-major 4x4) of the reference's scanMatching with max_iterations = k\n", name.c_str());
+      g_solve_log = out;
       for (int k = 1; k <= n_outer; ++k) {
+        g_run = k;
+        g_call = 0;
         tloam::LocalRegistration reg(tls_node(cfg, k));          // registration.cpp:182-206
         reg.setInputSource(src);                                 // :232-239
         reg.setInputTarget(tgt);                                 // :241-248
@@ -103,6 +141,7 @@ int main(int argc, char** argv) {
           for (int c = 0; c < 4; ++c) std::fprintf(out, " %.17g", pose.matrix()(r, c));
         std::fprintf(out, "\n");
       }
+      g_solve_log = nullptr;
       std::fclose(out);
     }
   }

@@ -31,6 +31,20 @@ def _read_ref(path):
     return out
 
 
+def _read_solves(path):
+    """the ceres::Solver::Summary of every ceres::Solve call, as ref_dump's interposer wrote them:
+    {(run k, call j): {"iters": [(cost, cost_change, step_is_successful, radius), ...], "initial_cost", "final_cost"}}"""
+    out = {}
+    for line in open(path):
+        v = line.split()
+        if line.startswith("s "):
+            out[(int(v[1]), int(v[2]))] = {"iters": [], "initial_cost": float(v[4]), "final_cost": float(v[6]),
+                                           "successful": int(v[8]), "unsuccessful": int(v[10])}
+        elif line.startswith("i "):
+            out[(int(v[1]), int(v[2]))]["iters"].append((float(v[5]), float(v[7]), int(v[9]), float(v[11])))
+    return out
+
+
 @pytest.mark.skipif(not REF, reason="tests/golden_ref/ is empty: the reference cannot be built in this image "
                                     "(oracle/ref_harness/CMakeLists.txt needs Eigen3, Ceres 2.0, Open3D 0.12, yaml-cpp, ROS)")
 @pytest.mark.parametrize("path", REF or ["-"], ids=[os.path.basename(p)[5:-8] for p in REF] or ["none"])
@@ -38,9 +52,9 @@ def test_oracle_and_golden_match_the_reference(path):
     import json
     from oracle import binding as ob
     from tloam_amd import synth
-    z = np.load(os.path.join(ROOT, "tests", "golden", os.path.basename(path)[:-8] + ".npz"), allow_pickle=False)
+    from test_golden import load_case
+    z, cfg, _ = load_case(os.path.join(ROOT, "tests", "golden", os.path.basename(path)[:-8] + ".npz"))
     ref = _read_ref(path)
-    cfg = json.loads(str(z["cfg_json"]))
     for k, T_ref in sorted(ref.items()):
         # golden vector: the pose after outer iteration k
         dt, dr = pose_delta(synth.se3_exp_np(z[f"it{k - 1}_x"]), T_ref)
@@ -53,13 +67,37 @@ def test_oracle_and_golden_match_the_reference(path):
         assert rc == 0
         dt, dr = pose_delta(T, T_ref)
         assert dt < 1e-6 and dr < 1e-6, ("oracle", k, dt, dr)
+    # Where parity is actually won or lost: the accept / reject bookkeeping of every ceres::Solve.  The full
+    # run's Summaries (one per outer iteration) against the oracle stepped through the same frame: number of minimiser
+    # iterations, number of successful steps, final cost.
+    solves = _read_solves(path)
+    n_outer = max(ref)
+    if any(k[0] == n_outer for k in solves):
+        O = ob.Oracle(ob.make_config(**cfg))
+        for kind in range(4):
+            O.set_source(kind, z[f"src{kind}"]); O.set_target(kind, z[f"tgt{kind}"])
+        assert O.sm_begin(z["T_pred"]) == 0
+        prev = dict(gn_iterations=0, accepted_steps=0)
+        for j in range(n_outer):
+            rc, done, st = O.sm_outer()
+            assert rc == 0
+            S = solves[(n_outer, j)]
+            assert len(S["iters"]) - 1 == st["gn_iterations"] - prev["gn_iterations"], ("iterations", j)
+            assert S["successful"] - 1 == st["accepted_steps"] - prev["accepted_steps"], ("accepted", j)   # Ceres counts iteration 0 as successful
+            assert abs(S["final_cost"] - st["solver_cost"]) <= 1e-9 * abs(S["final_cost"]), ("final cost", j)
+            prev = st
+            if done:
+                break
 
 
 def test_exporter_writes_the_harness_inputs(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden_ref_tools"))
     import export_ref_inputs as ex
     names = ex.main(str(tmp_path))
-    assert len(names) >= 5 and "case_small_rotation_perturbed" not in names   # the Random() case cannot be pinned
+    assert len(names) >= 7 and "case_small_rotation_perturbed" not in names   # the Random() case cannot be pinned
+    assert {"case_kitti_caps", "case_kitti_caps_no_sphere"} <= set(names)     # the size the metric is quoted on IS exportable
+    big = open(tmp_path / "case_kitti_caps.bin", "rb").read()
+    assert np.frombuffer(big[4 + 256: 4 + 264], np.int64)[0] > 2500            # more planar source points than the cap
     raw = open(tmp_path / (names[0] + ".bin"), "rb").read()
     z = np.load(os.path.join(ROOT, "tests", "golden", names[0] + ".npz"), allow_pickle=False)
     assert np.frombuffer(raw[:4], np.int32)[0] == int(z["n_outer"])
@@ -72,6 +110,7 @@ def test_harness_compiles_the_reference_itself_and_needs_the_real_packages(tmp_p
     src = open(os.path.join(ROOT, "oracle", "ref_harness", "ref_dump.cpp")).read()
     cm = open(os.path.join(ROOT, "oracle", "ref_harness", "CMakeLists.txt")).read()
     assert '#include "tloam/models/registration/registration.hpp"' in src and "tloam::LocalRegistration reg(" in src
+    assert "RTLD_NEXT" in src and "summary->iterations" in src     # the Solve summaries come from an interposer, not from an edited reference
     assert "${TLOAM_REFERENCE_DIR}/src/models/registration/registration.cpp" in cm
     for pkg in ("Eigen3", "Ceres", "Open3D", "yaml-cpp"):
         assert f"find_package({pkg}" in cm
