@@ -65,7 +65,7 @@ def make_config(**over) -> TlsConfig:
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "tloam_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "io_oracle.c", "tloam_oracle.h")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -81,7 +81,7 @@ def build_fast():
         key = "unknown"
     tag = hashlib.sha1(key.encode()).hexdigest()[:10]
     out = os.path.join(_HERE, "_build", f"liboracle_fast_{tag}.so")
-    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "tloam_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("tloam_oracle.c", "submap_oracle.c", "io_oracle.c", "tloam_oracle.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "fast", f"FAST_OUT=_build/liboracle_fast_{tag}.so"], stdout=subprocess.DEVNULL)
     return out
@@ -452,3 +452,29 @@ def extract_planar_sphere(xyz, cfg: FeatureConfig | None = None):
     rc = lib().orc_extract_planar_sphere(C.byref(cfg), _dp(a), C.c_size_t(n), *args)
     assert rc == 0, rc
     return tuple(l[: c.value].copy() for l, c in zip(lists, cnt))
+
+
+# ---- wire / disk formats (io_oracle.c): readVelodyneToO3d (read_file.hpp:307-327), savePose (front_end.cpp:169-179)
+def read_velodyne(path):
+    """-> (xyz (n,3) float64, intensity (n,) float64) exactly as the reference's reader would fill PointCloud2"""
+    L = lib()
+    L.orc_read_velodyne.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_size_t)]
+    cap = os.path.getsize(path) // 16 + 2
+    xyz = np.zeros((cap, 3)); it = np.zeros(cap)
+    n = C.c_size_t(0)
+    rc = L.orc_read_velodyne(str(path).encode(), _dp(xyz), _dp(it), cap, C.byref(n))
+    if rc != 0:
+        raise OSError(f"cannot open {path}")
+    assert n.value <= cap
+    return xyz[: n.value].copy(), it[: n.value].copy()
+
+
+def format_pose(T):
+    """the line FrontEnd::savePose writes for the 4x4 pose T, as bytes"""
+    L = lib()
+    L.orc_format_pose.argtypes = [C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1024)
+    m = np.ascontiguousarray(np.asarray(T, float).reshape(4, 4)).reshape(-1)   # row-major
+    n = L.orc_format_pose(_dp(m), buf, 1024)
+    assert n > 0
+    return buf.raw[:n]

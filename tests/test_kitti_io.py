@@ -27,6 +27,56 @@ def test_partial_trailing_record_is_ignored(tmp_path):
     np.arange(10, dtype="<f4").tofile(p)                              # 2 records + 2 stray floats
     got, _ = kio.read_velodyne_bin(p, reference_eof_quirk=False)
     assert np.array_equal(got, [[0, 1, 2], [4, 5, 6]])
+    got, gi = kio.read_velodyne_bin(p)                                # the reference keeps what the short read did get
+    assert np.array_equal(got, [[0, 1, 2], [4, 5, 6], [8, 9, 0]]) and np.array_equal(gi, [3, 7, 1])
+
+
+def _adversarial_files(tmp_path):
+    """what a reader can meet: whole records, NaN records, every length of trailing partial record (1 .. 15 bytes), an empty
+    file, a file shorter than one record, partial bytes that make a NaN, denormals, infinities"""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-80, 80, (37, 4)).astype("<f4")
+    base[5, 2] = np.nan; base[11, 3] = np.nan; base[20, 0] = np.inf; base[21, 1] = -np.inf; base[22, 0] = 1e-42   # denormal
+    blob = base.tobytes()
+    files = {}
+    for extra in range(16):
+        files[f"tail{extra:02d}"] = blob + bytes(rng.integers(0, 256, extra, dtype=np.uint8))
+    files["empty"] = b""
+    files["short3"] = b"\x01\x02\x03"
+    files["nan_tail"] = blob + np.array([1.0, np.nan], "<f4").tobytes()             # partial record whose y is NaN: dropped
+    files["nan_high_bytes"] = blob + np.array([1.0, 2.0, 3.0], "<f4").tobytes() + b"\xff\xff"   # intensity bytes ff ff 80 3f: not a NaN
+    files["all_nan"] = np.full((3, 4), np.nan, "<f4").tobytes()
+    out = {}
+    for name, data in files.items():
+        p = tmp_path / (name + ".bin")
+        p.write_bytes(data)
+        out[name] = str(p)
+    return out
+
+
+def test_reader_equals_the_c_restatement_of_the_reference_byte_for_byte(tmp_path):
+    from oracle import binding as ob
+    for name, path in _adversarial_files(tmp_path).items():
+        xyz, inten = kio.read_velodyne_bin(path)
+        oxyz, ointen = ob.read_velodyne(path)
+        assert xyz.shape == oxyz.shape, name
+        assert xyz.tobytes() == oxyz.tobytes() and inten.tobytes() == ointen.tobytes(), name
+    assert len(kio.read_velodyne_bin(str(tmp_path / "empty.bin"))[0]) == 1       # one default point, as the reference
+    assert len(kio.read_velodyne_bin(str(tmp_path / "all_nan.bin"))[0]) == 1
+
+
+def test_pose_writer_equals_the_c_restatement_byte_for_byte():
+    from oracle import binding as ob
+    rng = np.random.default_rng(4)
+    cases = [np.eye(4), np.zeros((4, 4)), -np.zeros((4, 4))]
+    for scale in (1e-300, 1e-12, 1e-5, 1e-4, 0.1, 1.0, 999999.5, 1e6, 1e7, 1e22, 1e300):
+        cases.append(rng.normal(size=(4, 4)) * scale)
+    T = np.eye(4); T[0, 0] = 0.1 + 0.2; T[0, 1] = 123456.5; T[0, 2] = 1234567.0; T[0, 3] = 0.0001; T[1, 0] = 0.00001
+    T[1, 1] = -0.0; T[1, 2] = np.inf; T[1, 3] = -np.inf; T[2, 0] = np.nan; T[2, 1] = -np.nan; T[2, 2] = 2.5e-7; T[2, 3] = 100000.0
+    cases.append(T)
+    for T in cases:
+        assert kio.format_pose_line(T).encode() == ob.format_pose(T), T
+
 
 
 def test_save_pose_format(tmp_path):

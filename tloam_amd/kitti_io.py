@@ -5,7 +5,8 @@ the KITTI odometry pose text, so that real KITTI-00 can be replayed when the dat
   format_pose_line    FrontEnd::savePose           src/front_end/front_end.cpp:169-179
   read_poses          the trajectory format of     doc/tloam_00.txt .. tloam_10.txt (12 numbers per line)
 
-Host-side I/O only: nothing here touches the device or the oracle."""
+Host-side I/O only: nothing here touches the device or the oracle (oracle/io_oracle.c restates the same two reference
+functions in C; tests/test_kitti_io.py holds this module against it byte for byte)."""
 from __future__ import annotations
 
 import numpy as np
@@ -16,19 +17,25 @@ def read_velodyne_bin(path: str, reference_eof_quirk: bool = True):
 
     Follows read_file.hpp:314-324: records containing a NaN are dropped (`!point.HasNaNs()`); x/y/z are
     widened to double, intensity too.  Quirk kept on request: the reference's loop condition
-    (`readFile.good() && !readFile.eof()`) only turns false AFTER a read has failed, so one extra,
-    default-constructed point (0, 0, 0, intensity 1, `Point4f()` read_file.hpp:89) is appended at end of file.
-    A trailing partial record is ignored (the failed read leaves the default point as well -- same quirk)."""
-    raw = np.fromfile(path, dtype="<f4")
-    n = raw.size // 4
-    rec = raw[: n * 4].reshape(n, 4)
+    (`readFile.good() && !readFile.eof()`, :315) is tested BEFORE the two reads of an iteration, every iteration starts
+    from a fresh `Point4f()` = (0, 0, 0, intensity 1) (read_file.hpp:89) and appends it unless it holds a NaN -- also the
+    iteration in which a read comes up short.  So a file that ends on a record boundary yields ONE extra point
+    (0, 0, 0, 1); a trailing partial record yields a point made of the bytes that were there (istream::read stores what it
+    got) over the defaults -- the intensity is only read when x, y, z were complete -- and no extra point after it.
+    reference_eof_quirk=False: whole, NaN-free records only."""
+    blob = np.fromfile(path, dtype=np.uint8)
+    n = blob.size // 16
+    rec = blob[: n * 16].view("<f4").reshape(n, 4)
+    if reference_eof_quirk:
+        last = np.array([0.0, 0.0, 0.0, 1.0], "<f4")          # Point4f()
+        tail = blob[n * 16:]                                   # 0 .. 15 bytes of a partial record
+        lb = last.view(np.uint8).copy()
+        lb[: tail.size] = tail                                 # (fewer than 12 bytes: only x, y, z are touched -- same bytes)
+        rec = np.vstack([rec, lb.view("<f4").reshape(1, 4)])
     keep = ~np.isnan(rec).any(axis=1)
     rec = rec[keep]
     xyz = rec[:, :3].astype(np.float64)
     inten = rec[:, 3].astype(np.float64)
-    if reference_eof_quirk:
-        xyz = np.vstack([xyz, np.zeros((1, 3))])
-        inten = np.concatenate([inten, [1.0]])
     return np.ascontiguousarray(xyz), inten
 
 
@@ -39,7 +46,12 @@ def write_velodyne_bin(path: str, xyz, intensity=None):
 
 
 def _fmt(v: float) -> str:
-    """`ofs << double` with the stream defaults: precision 6, %g style."""
+    """`ofs << double` with the stream defaults: precision 6, %g style (libstdc++ formats through vsnprintf("%.*g"):
+    a NaN keeps its sign bit, "-nan", which Python's own formatting drops)."""
+    v = float(v)
+    if v != v:
+        import math
+        return "-nan" if math.copysign(1.0, v) < 0 else "nan"
     return "%g" % v
 
 
