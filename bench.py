@@ -479,11 +479,13 @@ def main():
 
 def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier, cdev="cuda"):
     """BASELINE.json configs[3]: the SAME frame on every rank, source points sharded in contiguous index blocks,
-    targets replicated, the 48 doubles of the normal equations exchanged once per GN sweep -- by the library's own
-    one-shot peer mailbox over xGMI (every rank stores its row into every rank's buffer; HIP IPC handles all-gathered
-    here) or, if that cannot be set up on every rank, by one RCCL all-reduce on the compute stream.  Besides the whole
-    frame the block times the sweep alone and the sweep + exchange: their difference is the
-    latency the exchange adds to a GN iteration.  Any failure is reported in the block instead of taking the headline down."""
+    targets replicated, the 48 doubles of the normal equations exchanged once per GN sweep.  BOTH exchanges are timed in
+    the same run, each in a context of its own: the library's one-shot peer mailbox over xGMI (every rank stores its row
+    into every rank's buffer; HIP IPC handles all-gathered here) and one RCCL all-reduce (ncclAllReduce of 48 f64 on the
+    compute stream) -- the form the north star names.  Per exchange: the whole frame, the sweep alone and the sweep +
+    exchange: their difference is the latency the exchange adds to a GN iteration.  A mode
+    that cannot be set up on every rank (RCCL refuses two ranks on one device: TLOAM_BENCH_ONE_DEVICE) is reported as
+    such; the top-level figures are those of the fastest mode that ran."""
     res = {"workload": "one 1M-correspondence frame, source points sharded x%d, targets replicated, one exchange of "
                        "48 f64 per GN sweep" % world, "scaling": "strong", "n_gpus": world}
 
@@ -493,26 +495,18 @@ def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world,
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return float(flag.item()) == 0.0
 
-    H = None
-    try:
-        scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
-        mode, err = None, None
-        if os.environ.get("TLOAM_BENCH_NO_MAILBOX") != "1":
-            H = reg.HipRegistration(cfg, device=local_rank)
+    scene = synth.make_scene(seed=args.seed, n_src=n_src, n_tgt=n_tgt)
+
+    def init(H, mode):
+        err = None
+        if mode == "mailbox":
             try:
                 handles = [None] * world
                 dist.all_gather_object(handles, H.comm_mailbox_export())
                 H.comm_init_mailbox(rank, world, handles)
             except Exception as e:  # noqa: BLE001
                 err = e
-            if agreed(err):
-                mode = "mailbox"
-            else:
-                res["mailbox_error"] = repr(err)[:200] if err is not None else "failed on another rank"
-                H.close()
-                H = None
-        if mode is None:
-            H = reg.HipRegistration(cfg, device=local_rank)
+        else:
             uid = [None]
             if rank == 0:
                 try:
@@ -520,58 +514,80 @@ def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world,
                 except Exception as e:  # noqa: BLE001
                     uid = [e]
             dist.broadcast_object_list(uid, src=0)
-            err = None
             try:
                 if isinstance(uid[0], Exception):
                     raise uid[0]
+                if os.environ.get("TLOAM_BENCH_ONE_DEVICE") == "1":
+                    raise RuntimeError("RCCL refuses two ranks on one device (TLOAM_BENCH_ONE_DEVICE=1)")
                 H.comm_init_rccl(rank, world, uid[0])
             except Exception as e:  # noqa: BLE001
                 err = e
+        return err
+
+    def run_mode(mode):
+        out = {"exchange": ("one-shot peer mailbox over xGMI (no collective library on the data path)" if mode == "mailbox"
+                            else "ncclAllReduce (RCCL) of 48 f64 on the compute stream")}
+        H = reg.HipRegistration(cfg, device=local_rank)
+        try:
+            err = init(H, mode)
             if not agreed(err):
-                raise RuntimeError(f"sharded-path initialisation failed on some rank ({err})")
-            mode = "rccl"
-        res["exchange"] = ("one-shot peer mailbox over xGMI (no collective library on the data path)" if mode == "mailbox"
-                           else "ncclAllReduce (RCCL) of 48 f64 on the compute stream")
-        H.set_frames(scene.source, scene.target)
-        ok = 1.0
-        for _ in range(max(min(args.warmup, 3), 1)):
-            rc, T, st = H.scan_match(scene.T_pred)
-            ok = ok if rc == 0 else 0.0
-        barrier()
-        t0 = time.perf_counter()
-        it = 0
-        steps = args.m1_steps
-        for _ in range(steps):
-            rc, T, st = H.scan_match(scene.T_pred)
-            ok = ok if rc == 0 else 0.0
-            it += st["gn_sweeps"]
-        barrier()
-        dt = time.perf_counter() - t0
-        tt = torch.tensor([dt, -ok], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0].item())
-        if float(tt[1].item()) != -1.0:
-            raise RuntimeError("scan_match failed on at least one rank")
-        D = np.linalg.inv(T) @ scene.T_true
-        res.update({"frames": steps, "ms_per_frame": round(dt / steps * 1e3, 4), "gn_iters_per_sec": round(it / dt, 2),
-                    "gn_iters_per_frame": it / steps, "n_corr": st["n_corr"],
-                    "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3]))})
-        # the sweep alone / sweep + exchange on this frame's set (collective calls; max over ranks)
-        x = np.asarray(st["se3"], float)
-        H.time_sharded_sweep(x, 10, True)
-        t_ex = sorted(H.time_sharded_sweep(x, 40, True) for _ in range(3))[1]
-        t_no = sorted(H.time_sharded_sweep(x, 40, False) for _ in range(3))[1]
-        tt = torch.tensor([t_ex, t_no], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        res["per_sweep_us"] = {"sweep_plus_exchange": round(float(tt[0].item()), 3), "sweep_alone": round(float(tt[1].item()), 3),
-                               "exchange_adds": round(float(tt[0].item() - tt[1].item()), 3),
-                               "note": "40 back-to-back launches per HIP event pair, median of 3, max over ranks; the sweep "
-                                       "covers this rank's 1/%d of the set, its last block folds the rows" % world}
-    except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
-        res["error"] = f"{type(e).__name__}: {e}"
-    finally:
-        if H is not None:
+                out["error"] = repr(err)[:200] if err is not None else "initialisation failed on another rank"
+                return out
+            H.set_frames(scene.source, scene.target)
+            ok = 1.0
+            for _ in range(max(min(args.warmup, 3), 1)):
+                rc, T, st = H.scan_match(scene.T_pred)
+                ok = ok if rc == 0 else 0.0
+            barrier()
+            t0 = time.perf_counter()
+            it = 0
+            steps = args.m1_steps
+            for _ in range(steps):
+                rc, T, st = H.scan_match(scene.T_pred)
+                ok = ok if rc == 0 else 0.0
+                it += st["gn_sweeps"]
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt, -ok], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0].item())
+            if float(tt[1].item()) != -1.0:
+                out["error"] = "scan_match failed on at least one rank"
+                return out
+            D = np.linalg.inv(T) @ scene.T_true
+            out.update({"frames": steps, "ms_per_frame": round(dt / steps * 1e3, 4), "gn_iters_per_sec": round(it / dt, 2),
+                        "gn_iters_per_frame": it / steps, "n_corr": st["n_corr"],
+                        "pose_err_vs_truth_m": float(np.linalg.norm(D[:3, 3]))})
+            # the sweep alone / sweep + exchange on this frame's set (collective calls; max over ranks)
+            x = np.asarray(st["se3"], float)
+            H.time_sharded_sweep(x, 10, True)
+            t_ex = sorted(H.time_sharded_sweep(x, 40, True) for _ in range(3))[1]
+            t_no = sorted(H.time_sharded_sweep(x, 40, False) for _ in range(3))[1]
+            tt = torch.tensor([t_ex, t_no], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out["per_sweep_us"] = {"sweep_plus_exchange": round(float(tt[0].item()), 3), "sweep_alone": round(float(tt[1].item()), 3),
+                                   "exchange_adds": round(float(tt[0].item() - tt[1].item()), 3),
+                                   "note": "40 back-to-back launches per HIP event pair, median of 3, max over ranks; the sweep "
+                                           "covers this rank's 1/%d of the set, its last block folds the rows" % world}
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+            out["error"] = f"{type(e).__name__}: {e}"
+        finally:
             H.close()
+        return out
+
+    modes = [m for m in ("mailbox", "rccl") if not (m == "mailbox" and os.environ.get("TLOAM_BENCH_NO_MAILBOX") == "1")]
+    for m in modes:
+        res[m] = run_mode(m)
+    ran = [m for m in modes if "ms_per_frame" in res[m]]
+    if ran:
+        best = min(ran, key=lambda m: res[m]["ms_per_frame"])
+        for k in ("exchange", "frames", "ms_per_frame", "gn_iters_per_sec", "gn_iters_per_frame", "n_corr", "pose_err_vs_truth_m",
+                  "per_sweep_us"):
+            if k in res[best]:
+                res[k] = res[best][k]
+        res["fastest_exchange"] = best
+    else:
+        res["error"] = "; ".join("%s: %s" % (m, res[m].get("error")) for m in modes)
     return res
 
 

@@ -128,3 +128,69 @@ def test_native_rccl_single_rank(hip_module):
             R.set_correspondences(rt, *sets[rt])
     xa, _ = A.solve(x_eval); xb, _ = B.solve(x_eval)
     assert np.array_equal(xa, xb)
+
+
+def _worker_timeout(rank, world, port, q):
+    """rank 1 sets the mailbox up and then never enters the solve: rank 0's exchanges must give up after their bounded wait"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tloam_amd import registration as reg
+        sc = synth.make_scene(seed=31)
+        H = reg.HipRegistration()
+        init_comm(H, "mailbox", rank, world)
+        H.set_frames(sc.source, sc.target)
+        if rank == 0:
+            t0 = time.perf_counter()
+            rc, T, st = H.scan_match(sc.T_pred)
+            dt = time.perf_counter() - t0
+            msg = H.L.tloam_last_error(H.h).decode()
+            q.put(dict(rc=rc, seconds=dt, msg=msg))
+        dist.barrier()      # rank 1 stays alive (its buffer mapped) until rank 0 has given up
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module):
+    """The bounded wait of the peer mailbox: a rank whose peer never posts does not hang -- every
+    exchange gives up after ~2 s, the Solve is stopped and scan_match returns TLOAM_E_RCCL with a message that says why."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_timeout, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60); assert p.exitcode == 0
+    assert res["rc"] == -5, res                                  # TLOAM_E_RCCL
+    assert "timed out" in res["msg"] and "peer" in res["msg"], res
+    assert 1.5 < res["seconds"] < 40.0, res                      # bounded: a few exchanges of ~2 s each, not forever
+
+
+def test_bench_n_gpus_path_runs_on_one_device(hip_module):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
+    the one GPU a test box has (TLOAM_BENCH_ONE_DEVICE=1: launcher collectives over gloo): the replica headline aggregates
+    over the ranks, and the sharded 1 M frame reports BOTH exchanges -- the mailbox with its figures, RCCL with the reason it
+    cannot run two ranks on one device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TLOAM_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--m1-steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_step"] == 2
+    sh = d["sharded_1m"]
+    assert sh["n_gpus"] == 2 and "mailbox" in sh and "rccl" in sh
+    assert sh["mailbox"]["ms_per_frame"] > 0 and sh["mailbox"]["per_sweep_us"]["sweep_plus_exchange"] > 0, sh["mailbox"]
+    assert "one device" in sh["rccl"].get("error", ""), sh["rccl"]
+    assert sh["fastest_exchange"] == "mailbox" and sh["ms_per_frame"] == sh["mailbox"]["ms_per_frame"]
+    assert sh["pose_err_vs_truth_m"] < 1e-2
