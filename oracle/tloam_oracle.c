@@ -305,9 +305,17 @@ void orc_eig3_sym(const double cov[9], double ev[3], double V[9]) {
         double apq = A[p * 3 + q];
         if (apq == 0.0) continue;
         double app = A[p * 3 + p], aqq = A[q * 3 + q];
-        double tau = (aqq - app) / (2.0 * apq);
-        double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
-        double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+        /* the rotation that annihilates a_pq: t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (a_qq - a_pp) / (2 a_pq),
+         * c = 1 / sqrt(1 + t^2), s = t c -- written without tau and t: with d = a_qq - a_pp, b = 2 a_pq, h = hypot(d, b),
+         * u = |d| + h:  t = sgn |b| / u,  c = u / hypot(u, b),  s = sgn |b| / hypot(u, b).  Same rotation, and the
+         * dependent chain is two square roots and one division long instead of three divisions and two square roots
+         * (the device restates exactly this, tl_knn.hpp: the per-query fit of K1 is one such chain after another). */
+        double d = aqq - app, b = 2.0 * apq;
+        double h = sqrt(d * d + b * b);
+        double u = fabs(d) + h;
+        double r = sqrt(u * u + b * b);
+        double cs = u / r, sn = fabs(b) / r;
+        if (!(d == 0.0 || (d > 0.0) == (b > 0.0))) sn = -sn; /* sgn(tau), tau = +-0 counting as positive */
         /* A <- G^T A G */
         for (int k = 0; k < 3; ++k) {
           double akp = A[k * 3 + p], akq = A[k * 3 + q];

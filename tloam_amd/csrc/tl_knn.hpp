@@ -302,9 +302,16 @@ __device__ __forceinline__ void jacobi_rotate(Sym3& m) {
   const double apq = m.a[P][Q];
   if (apq == 0.0) return;
   const double app = m.a[P][P], aqq = m.a[Q][Q];
-  const double tau = (aqq - app) / (2.0 * apq);
-  const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
-  const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+  // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), c = 1 / sqrt(1 + t^2), s = t c without tau and t (oracle: orc_eig3_sym, the
+  // same operations in the same order): the dependent chain is sqrt -> sqrt -> div instead of div -> sqrt -> div -> sqrt -> div,
+  // and the per-query fit of an edge is ~20 such rotations one after the other on a lane that has nothing else to do
+  const double d = aqq - app, b = 2.0 * apq;
+  const double h = sqrt(d * d + b * b);
+  const double u = fabs(d) + h;
+  const double r = sqrt(u * u + b * b);
+  const double cs = u / r;
+  double sn = fabs(b) / r;
+  if (!(d == 0.0 || (d > 0.0) == (b > 0.0))) sn = -sn;   // sgn(tau), tau = +-0 counting as positive
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double akp = m.a[k][P], akq = m.a[k][Q];

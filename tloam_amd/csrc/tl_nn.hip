@@ -719,6 +719,9 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #define TLOAM_K1_WIDE_KU 4
 #endif
     constexpr int kU = (NR == 1) ? TLOAM_K1_WIDE_KU : 2;
+#ifdef TLOAM_K1_DBG_NOWALK  // timing experiment only
+    len = 0;
+#endif
     for (int s = 0; s < len; s += kU) {
       double4 c[kU][NR];
 #pragma unroll
@@ -735,6 +738,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     }
     // merge across the quad: after xor-1 and xor-2 every lane holds the global list (the lanes' candidate
     // sets are disjoint, +inf entries fall through)
+#ifndef TLOAM_K1_DBG_NOMERGE  // timing experiment only: without the cross-lane merge
 #pragma unroll
     for (int x = 1; x < LPQ; x <<= 1) {
       double ok[K + 1];
@@ -743,6 +747,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #pragma unroll
       for (int m = 0; m < K + 1; ++m) key_insert<K + 1>(L, ok[m]);
     }
+#endif
     if (!keys_ambiguous<K + 1>(L, keep_mask)) {  // (the same verdict on all lanes of the quad)
       keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
     } else {  // redo with the exact (d, original index) order
