@@ -425,11 +425,12 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
 bool solve_small_path(const tloam_ctx* c) { return c->nranks == 1 && c->k3_single && !c->no_fused_small && solve_small_fits(c->k3_grid); }
-int enqueue_solve(tloam_ctx* c, bool armed, int sweeps) {
+// prep: the launch also prepares the factor set (only with solve_small_path and SlotView::flagb, see self_prepare_path)
+int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const SolvePrep* prep = nullptr) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   if (sweeps > 0 && solve_small_path(c)) {
     // KITTI-size set: the whole Solve (up to `sweeps` evaluations) is one launch (k_solve_small)
-    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, c->stream);
+    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, prep, c->seg_n.p, c->stream);
     c->batch_launches++;
     return TLOAM_OK;
   }
@@ -569,6 +570,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
+  c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -807,6 +809,16 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     k3_plan(caps, &c->k3_grid, &c->k3_single);
     (void)total_cap;
   }
+  {
+    // the one-launch Solve compacts the factor set itself when every kind's flag bytes fit a wave (SlotView::flagb)
+    bool fits = solve_small_path(c) && prepare_small_fits(c->sv) && !c->no_self_prepare;
+    for (int k = 0; k < kKinds; ++k) fits = fits && c->kd[k].n_src <= (size_t)kFlagbStride;
+    c->sv.flagb = nullptr;
+    if (fits) {
+      HIPC(c, c->flagb.reserve((size_t)kKinds * kFlagbStride));
+      c->sv.flagb = c->flagb.p;
+    }
+  }
   HIPC(c, c->partials.reserve(std::max<size_t>((size_t)c->k3_grid * kAccStride, 4096)));
   // ---- the start of the frame -- scan-frame sources AoS -> SoA slots, weights = 1 (:931-949), flag-scan terminator,
   //      minimiser state zeroed with `parameters` = x (passed by value) and armed for the first Solve -- rides on the
@@ -882,11 +894,14 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
 // caps, the compaction AND the alternative (refresh) are one launch (k_prepare_small) -- `also_refresh` says whether this
 // call stands for both alternatives of a device-gated iteration.
 bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv) && !c->no_fused_small; }
+// the Solve launch that follows prepares the set itself: no k_prepare_small
+bool self_prepare_path(const tloam_ctx* c) { return c->sv.flagb != nullptr && prepare_small_path(c) && solve_small_path(c); }
 int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate,
-                  const int* refresh_gate = nullptr) {
+                  const int* refresh_gate = nullptr, bool prepare_in_solve = false) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
   launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
                c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+  if (prepare_in_solve) return TLOAM_OK;
   if (prepare_small_path(c)) {
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
     return TLOAM_OK;
@@ -1105,21 +1120,34 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   WeightParams wp_prev;
   OuterCtl ctl_prev{0.0, 0, 0};
   int rc = TLOAM_OK;
+  // the scan + caps + compaction (or the refresh) of an iteration: a launch of its own (k_prepare_small), or the prologue of
+  // the one-launch Solve (SolvePrep)
+  const bool in_solve = self_prepare_path(c);
+  SolvePrep prep;
+  memset(&prep, 0, sizeof(prep));
+  prep.sv = c->sv;
+  for (int k = 0; k < kKinds; ++k) prep.maxnum[k] = bp.maxnum[k];
   for (int iter = first; iter < M; ++iter) {
     if (iter == 0) {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr);
+      rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr, nullptr, in_solve);
+      prep.run_build = nullptr;
+      prep.run_refresh = nullptr;
     } else if (pending) {
       FinishSmallArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, P.hms[iter - 1], ctl_prev, c->wpart.p, c->k3_ticket.p + 1};
       launch_build_finish_small(c->sv, grids, bp, st, fin, c->stream);
-      launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, st, run_build, run_refresh, c->stream);
+      if (!in_solve) launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, st, run_build, run_refresh, c->stream);
+      prep.run_build = run_build;
+      prep.run_refresh = run_refresh;
       pending = false;
     } else {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh);   // both alternatives, device-gated
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve);   // both alternatives, device-gated
+      prep.run_build = run_build;
+      prep.run_refresh = run_refresh;
     }
     if (rc != TLOAM_OK) return rc;
     P.planned[iter] = planned_sweeps_for(c, iter);
     P.solve_start[iter] = c->batch_launches;
-    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter]);
+    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], in_solve ? &prep : nullptr);
     if (rc != TLOAM_OK) return rc;
     P.mus[iter] = mu;
     P.hms[iter] = next_mirror(c, iter);

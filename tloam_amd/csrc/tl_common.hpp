@@ -64,6 +64,7 @@ struct CorrView {
 };
 
 // ---- per-source-slot arrays of one scan_match (concatenated over kinds) ----------------------
+constexpr int kFlagbStride = 4096;   // 64 lanes x 64 slots
 struct SlotView {
   const double *sx, *sy, *sz;  // source points (sensor frame)
   double* w_src;               // GNC weights
@@ -73,6 +74,10 @@ struct SlotView {
   double* raw;
   unsigned long long* flags;   // low 32: counted, high 32: valid (then scanned in place -> exclusive prefix)
   unsigned long long* scan;    // exclusive scan of flags
+  // the same two bits per slot as ONE BYTE (bit 0 valid, bit 1 counted) at [kind * kFlagbStride + slot-in-kind], or null:
+  // what the one-launch Solve reads when it compacts the factor set itself (k_solve_small, SolvePrep) -- a lane takes in
+  // 64 slots with four 16-byte loads.  Only for frames whose kinds have at most kFlagbStride source points each.
+  unsigned char* flagb;
   int slot_off[kKinds + 1];    // concatenated slot ranges per kind
   int src_lo[kKinds];          // global index of local slot 0 (sharded contexts)
 };
@@ -399,8 +404,16 @@ void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipSt
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s);
 // sets whose sweep is a grid of a dozen blocks: a whole ceres::Solve (up to max_sweeps evaluations) in ONE launch
 bool solve_small_fits(int grid);
+// The factor set of an outer iteration prepared by the Solve launch itself (no k_prepare_small launch in front of it):
+// flagb == null means "already prepared" (stepwise API, topped-up Solves).
+struct SolvePrep {
+  SlotView sv;
+  int maxnum[kKinds];
+  const int* run_build;     // device gates of the outer loop; null: always build (the frame's first iteration)
+  const int* run_refresh;
+};
 void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        hipStream_t s);
+                        const SolvePrep* prep_or_null, int* seg_n, hipStream_t s);
 // K4
 struct WeightParams {
   double th1, th2, mu, noise_bound_sq;

@@ -153,6 +153,7 @@ struct tloam_ctx {
   DBuf<double> sx, sy, sz, w_src, raw;
   DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
+  DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
   GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
@@ -168,6 +169,7 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
+  bool no_self_prepare = false;    // TLOAM_NO_SELF_PREPARE: k_prepare_small in front of every one-launch Solve (A/B, tests)
   bool no_fused_small = false;     // TLOAM_NO_FUSED_SMALL: KITTI-size sets keep sweep and step as two launches (A/B, tests)
   bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows

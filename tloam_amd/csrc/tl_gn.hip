@@ -385,14 +385,13 @@ __device__ __forceinline__ void single_fetch(const CorrView& cv, const double* _
     else fetch_one<TLOAM_RES_POINT>(cv.k[TLOAM_KIND_SPHERE], wk.j, b);
   }
 }
-__device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, const SingleWork& wk,
-                                             const ChunkData& b, Acc& a) {
+__device__ __forceinline__ void sweep_single_n(const CorrView& cv, int n, const Rt& T, const SingleWork& wk,
+                                               const ChunkData& b, Acc& a) {
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
   a.pe = 1;
   if (wk.kind < 0) return;
-  const int n = seg_n[wk.kind];
   if (wk.kind <= TLOAM_KIND_GROUND) {
     if (wk.kind == TLOAM_KIND_PLANAR) consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_PLANAR], wk.j, n, b, a);
     else consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_GROUND], wk.j, n, b, a);
@@ -403,6 +402,10 @@ __device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __re
     const int ne = single_chunk_of(TLOAM_KIND_SPHERE) == kChunk ? n : (n < wk.j + 1 ? n : wk.j + 1);
     consume<TLOAM_RES_POINT, false>(T, cv.k[TLOAM_KIND_SPHERE], wk.j, ne, b, a);
   }
+}
+__device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, const SingleWork& wk,
+                                             const ChunkData& b, Acc& a) {
+  sweep_single_n(cv, wk.kind >= 0 ? seg_n[wk.kind] : 0, T, wk, b, a);
 }
 // wave total of the 28 sums: component c ends up (complete) in lanes 2c and 2c+1
 __device__ __forceinline__ double wave_reduce_acc(const Acc& a, int lane) {
@@ -1018,10 +1021,147 @@ __device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restr
   }
   return (int)w[8 + 5];   // value 12 = segment 1, position 5
 }
+// ---- the Solve prepares its own factor set (SolvePrep) ------------------------------------------------------------------
+// What k_prepare_small does in a launch of its own -- caps in index order (registration.cpp:448/:538/:592/:735), compaction,
+// or the refresh of an unchanged set -- done by every wave for ITS chunk: the kind's flag bytes (at most kFlagbStride, 64 per
+// lane) become two 64-bit masks per lane, the cap is one select in the counted mask, a position of the compact set is found by
+// a search over the lanes' prefix counts and a select in the valid mask, and the wave fetches its correspondences straight from
+// the slot arrays the search wrote -- writing them to the compact arrays on the side, for the finish kernel and the host.
+// Same added set, same order, same records as k_prepare_small (the prefix sums are integers): tests/test_gpu_parity.py compares
+// the device-driven loop (this path) with the stepwise API (k_prepare_small) bit for bit.
+__device__ __forceinline__ unsigned flag_nibble(unsigned x) {   // bit 0 of the four bytes of x -> bits 0..3
+  return (((x & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+}
+__device__ __forceinline__ int select64(unsigned long long m, int r) {   // position of the r-th (from 0) set bit; r < popcount(m)
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll((m >> pos) & ((1ull << w) - 1ull));
+    if (r >= c) { r -= c; pos += w; }
+  }
+  return pos;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  *total = __shfl(incl, 63, 64);
+  return incl - v;
+}
+struct FlagBytes { uint4 q[4]; };
+__device__ __forceinline__ void load_flag_bytes(const unsigned char* __restrict__ flagb, int kind, int lane, FlagBytes& f) {
+  const uint4* p = reinterpret_cast<const uint4*>(flagb + (size_t)kind * kFlagbStride) + lane * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f.q[i] = p[i];
+}
+// local slot (within the kind) of compact position p, p < total
+__device__ __forceinline__ int slot_of_position(int p, int pv, unsigned vlo, unsigned vhi) {
+  int L = 0;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const int pc = __shfl(pv, L + s, 64);   // (L + s <= 63)
+    if (pc <= p) L += s;
+  }
+  const int r = p - __shfl(pv, L, 64);
+  const unsigned long long word = (unsigned long long)(unsigned)__shfl((int)vlo, L, 64) |
+                                  ((unsigned long long)(unsigned)__shfl((int)vhi, L, 64) << 32);
+  return L * 64 + select64(word, r);
+}
+// one correspondence from the slot arrays into half `H` (0: .x, 1: .y) of the chunk registers + the compact arrays
+template <int H>
+__device__ __forceinline__ void take_slot(const SlotView& sv, const CorrSeg& seg, int kind, int local, int p, ChunkData& b) {
+  const int slot = sv.slot_off[kind] + local;
+  const double px = sv.sx[slot], py = sv.sy[slot], pz = sv.sz[slot], w = sv.w_src[slot];
+  const double2* q = reinterpret_cast<const double2*>(sv.raw + (size_t)slot * 8);
+  const double2 q0 = q[0], q1 = q[1];
+  double2 q2 = double2{0.0, 0.0};
+  double d = 0.0;
+  if (kind == TLOAM_KIND_EDGE) q2 = q[2];
+  if (kind <= TLOAM_KIND_GROUND) d = q[3].x;
+#define TL_PUT(field, val) if (H == 0) b.field.x = (val); else b.field.y = (val);
+  TL_PUT(px, px) TL_PUT(py, py) TL_PUT(pz, pz) TL_PUT(ax, q0.x) TL_PUT(ay, q0.y) TL_PUT(az, q1.x) TL_PUT(w, w)
+  TL_PUT(bx, q1.y) TL_PUT(by, q2.x) TL_PUT(bz, q2.y) TL_PUT(d, d)
+#undef TL_PUT
+  seg.idx[p] = local + sv.src_lo[kind];
+  seg.px[p] = px; seg.py[p] = py; seg.pz[p] = pz;
+  seg.ax[p] = q0.x; seg.ay[p] = q0.y; seg.az[p] = q1.x;
+  if (kind == TLOAM_KIND_EDGE) { seg.bx[p] = q1.y; seg.by[p] = q2.x; seg.bz[p] = q2.y; }
+  if (kind <= TLOAM_KIND_GROUND) seg.d[p] = d;
+  seg.w[p] = w;        // weight captured by value at construction (registration.hpp:51,76,96)
+  seg.cost[p] = 0.0;   // fresh side-channel slot (registration.cpp:1118-1121)
+}
+// BUILD: returns the size of the wave's kind and fills b with the wave's chunk
+__device__ __forceinline__ int self_compact(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int lane, const FlagBytes& f,
+                                            ChunkData& b, int* __restrict__ seg_n_out) {
+  const int kind = wk.kind;
+  const int nk = P.sv.slot_off[kind + 1] - P.sv.slot_off[kind];
+  unsigned vlo = 0u, vhi = 0u, clo = 0u, chi = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned wd[4] = {f.q[i].x, f.q[i].y, f.q[i].z, f.q[i].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int nib = i * 4 + c;   // slots 4 nib .. 4 nib + 3 of this lane
+      const unsigned v = flag_nibble(wd[c]), ct = flag_nibble(wd[c] >> 1);
+      if (nib < 8) { vlo |= v << (4 * nib); clo |= ct << (4 * nib); }
+      else { vhi |= v << (4 * (nib - 8)); chi |= ct << (4 * (nib - 8)); }
+    }
+  }
+  unsigned long long valid = (unsigned long long)vlo | ((unsigned long long)vhi << 32);
+  unsigned long long counted = (unsigned long long)clo | ((unsigned long long)chi << 32);
+  {  // bytes past the kind's last slot are whatever an earlier, larger frame left there
+    const int mine = nk - lane * 64;
+    const unsigned long long keep = mine >= 64 ? ~0ull : (mine <= 0 ? 0ull : ((1ull << mine) - 1ull));
+    valid &= keep;
+    counted &= keep;
+  }
+  // added(i) <=> valid(i) && #counted before i < maxnum
+  int ctot;
+  const int cc = __popcll(counted);
+  const int pc = wave_excl_scan(cc, lane, &ctot);
+  const int room = P.maxnum[kind] - pc;
+  if (room <= 0) valid = 0ull;
+  else if (room <= cc) valid &= (2ull << select64(counted, room - 1)) - 1ull;   // up to and including the room-th counted slot
+  int total;
+  const int vc = __popcll(valid);
+  const int pv = wave_excl_scan(vc, lane, &total);
+  const CorrSeg& seg = cv.k[kind];
+  if (total > seg.cap) total = seg.cap;   // cannot happen (cap >= min(n, maxnum)); defensive, as in k_prepare_small
+  vlo = (unsigned)valid; vhi = (unsigned)(valid >> 32);
+  const bool two = single_chunk_of(kind) == kChunk;
+  const int p0 = wk.j, p1 = wk.j + 1;
+  // (every lane takes part in the searches: they exchange through the whole wave)
+  const int l0 = total > 0 ? slot_of_position(p0 < total ? p0 : total - 1, pv, vlo, vhi) : 0;
+  if (p0 < total) take_slot<0>(P.sv, seg, kind, l0, p0, b);
+  if (two) {
+    const int l1 = total > 0 ? slot_of_position(p1 < total ? p1 : total - 1, pv, vlo, vhi) : 0;
+    if (p1 < total) take_slot<1>(P.sv, seg, kind, l1, p1, b);
+  }
+  if (wk.j == 0 && lane == 0) seg_n_out[kind] = total;   // (the kind's first chunk)
+  return total;
+}
+// REFRESH: the set of the previous iteration with new captured weights and zeroed slots (k_refresh); b holds the chunk
+__device__ __forceinline__ void self_refresh(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int n, ChunkData& b) {
+  const int kind = wk.kind;
+  const CorrSeg& seg = cv.k[kind];
+  const bool two = single_chunk_of(kind) == kChunk;
+  if (wk.j < n) {
+    const double w = P.sv.w_src[P.sv.slot_off[kind] + (seg.idx[wk.j] - P.sv.src_lo[kind])];
+    b.w.x = w; seg.w[wk.j] = w; seg.cost[wk.j] = 0.0;
+  }
+  if (two && wk.j + 1 < n) {
+    const double w = P.sv.w_src[P.sv.slot_off[kind] + (seg.idx[wk.j + 1] - P.sv.src_lo[kind])];
+    b.w.y = w; seg.w[wk.j + 1] = w; seg.cost[wk.j + 1] = 0.0;
+  }
+}
 __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
                                                         GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                         double* __restrict__ partials, int* __restrict__ ticket,
-                                                        unsigned long long* __restrict__ bcast, CorrView cv) {
+                                                        unsigned long long* __restrict__ bcast, CorrView cv, SolvePrep prep,
+                                                        int* __restrict__ seg_n_out) {
   __shared__ double red[4][32];
   __shared__ double s_scr[32];
   __shared__ double s_rows[kTaggedRows * 28];
@@ -1032,6 +1172,10 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   ChunkData pre;
   const SingleWork wk = single_work_of(cv, cap0, gw, lane);
   single_fetch(cv, seg0, stride0, wk, pre);   // this wave's correspondences: requested once, kept in registers for the whole Solve
+  // (with SolvePrep: speculatively -- right if the set is kept or refreshed; a set that is rebuilt is fetched from the slots)
+  FlagBytes fbytes;
+  const bool self_prep = prep.sv.flagb != nullptr;
+  if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
     static_assert(kWords <= 256, "one word per thread");
@@ -1040,9 +1184,25 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   }
   unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
   const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (see k_sweep_step_small: read by every block before it can change)
+  const bool consumer = blockIdx.x == 0 && wave == 0;
+  int n_mine = 0;
+  bool built = false;
+  if (self_prep) {
+    const bool build = !prep.run_build || *prep.run_build != 0;
+    if (build) {
+      if (wk.kind >= 0) n_mine = self_compact(prep, cv, wk, lane, fbytes, pre, seg_n_out);
+      built = true;
+    } else {
+      if (wk.kind >= 0) {
+        n_mine = seg_n[wk.kind];
+        if (prep.run_refresh && *prep.run_refresh != 0) self_refresh(prep, cv, wk, n_mine, pre);
+      }
+    }
+  } else if (wk.kind >= 0) {
+    n_mine = seg_n[wk.kind];
+  }
   if (st->done) return;            // a Solve that has already ended (uniform over the grid)
   Rt T = st->Rt_eval;
-  const bool consumer = blockIdx.x == 0 && wave == 0;
 #ifdef TLOAM_STEP_PROFILE
   // development aid (scripts/solve_profile.py): wall-clock (100 MHz) stamps of the consumer wave and of one producer wave
   // (block gridDim/2) per GN iteration, in the spare part of the row buffer
@@ -1055,11 +1215,15 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   TL_PROF(consumer && lane == 0, 0)
   for (int it = 0;; ++it) {
     Acc a;
-    sweep_single(cv, seg_n, T, wk, pre, a);
+    sweep_single_n(cv, n_mine, T, wk, pre, a);
     TL_PROF(prof_p, 64 + it * 8 + 1)
     const double wtot = wave_reduce_acc(a, lane);
     if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
     __syncthreads();
+    if (it == 0 && built && consumer && lane < 6) {   // the set was built at this pose (k_prepare_small's x_build = x)
+      s_in.x_build[lane] = s_in.x[lane];
+      st->x_build[lane] = s_in.x[lane];
+    }
     k3_post_row_tagged(partials, red, tag0 | (unsigned long long)it);
     TL_PROF(prof_p, 64 + it * 8 + 2)
     TL_PROF(consumer && lane == 0, 8 + it * 8 + 0)
@@ -1089,9 +1253,12 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   }
 }
 void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        hipStream_t s) {
+                        const SolvePrep* prep_or_null, int* seg_n, hipStream_t s) {
+  SolvePrep P;
+  if (prep_or_null) P = *prep_or_null;
+  else memset(&P, 0, sizeof(P));
   hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
-                     cv.seg_n, partials, ticket, bcast, cv);
+                     cv.seg_n, partials, ticket, bcast, cv, P, seg_n);
 }
 bool solve_small_fits(int grid) {
   static const bool off = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;   // A/B knob: one launch per GN iteration

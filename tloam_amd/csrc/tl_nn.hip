@@ -487,8 +487,19 @@ __device__ __forceinline__ void finish_knn5(int kind, const P& pts, const TopK<5
   r.flag = valid ? ((1ull << 32) | 1ull) : 0ull;
 }
 
+// the (counted | valid << 32) flag of a slot, and its one-byte twin for the self-compacting Solve (SlotView::flagb)
+__device__ __forceinline__ void store_flag(const SlotView& sv, int slot, unsigned long long flag) {
+  sv.flags[slot] = flag;
+  if (sv.flagb) {
+    int kind = 0;
+#pragma unroll
+    for (int k = 1; k < kKinds; ++k) kind += (slot >= sv.slot_off[k]) ? 1 : 0;
+    sv.flagb[kind * kFlagbStride + (slot - sv.slot_off[kind])] =
+        (unsigned char)(((flag >> 32) != 0ull ? 1 : 0) | ((flag & 0xffffffffull) != 0ull ? 2 : 0));
+  }
+}
 __device__ __forceinline__ void store_raw(const SlotView& sv, int slot, const RawRec& r) {
-  sv.flags[slot] = r.flag;
+  store_flag(sv, slot, r.flag);
   if ((r.flag >> 32) == 0ull) return;  // no factor: the compaction never looks at the record
   double2* q = reinterpret_cast<double2*>(sv.raw + (size_t)slot * 8);
   q[0] = double2{r.a[0], r.a[1]};
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   const GridView& g = A.grid[kind];
   if (!A.bp.active[kind] || g.n <= 0) {  // inactive kind / empty target: no factor, nothing counted...
     // ...except the sphere builder, whose counter also advances for points WITHOUT a neighbour (:551)
-    A.sv.flags[slot] = (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull;
+    store_flag(A.sv, slot, (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull);
     tile_of_slot[slot] = -1;
     return;
   }
@@ -779,7 +790,7 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
                                           int sub, int2* __restrict__ lds_rows) {
   const GridView& g = A.grid[kind];
   if (!A.bp.active[kind] || g.n <= 0) {   // (never reached in sorted order: k_query_bin leaves these slots out, same flags)
-    if (sub == 0) A.sv.flags[slot] = (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull;
+    if (sub == 0) store_flag(A.sv, slot, (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull);
     return;
   }
   const Vec3 pw = act(T, Vec3{q.x, q.y, q.z});
