@@ -233,9 +233,15 @@ def _frame_fingerprint(H, T, st):
     return out
 
 
-def _assert_same_frame(f1, f2):
+def _assert_same_frame(f1, f2, cost_sum_rtol=0.0):
+    """cost_sum_rtol: the four side-channel cost SUMS (registration.cpp:1091-1094) are added up by the one-launch Solve in
+    the order its waves hold the factors, by the finish kernel of the other Solve paths in the order of its 1024 threads --
+    the same numbers in a different tree.  Everything else (pose, every single cost, weight, index, counter) is compared exactly."""
     assert np.array_equal(f1["T"], f2["T"])
     for k, v in f1["stats"].items():
+        if k == "kind_cost" and cost_sum_rtol > 0:
+            np.testing.assert_allclose(np.asarray(v), np.asarray(f2["stats"][k]), rtol=cost_sum_rtol, atol=0)
+            continue
         assert np.array_equal(np.asarray(v), np.asarray(f2["stats"][k])), k
     for k in f1:
         if k not in ("T", "stats"):
@@ -419,7 +425,7 @@ def test_fused_sweep_step_is_exact(hip_module, monkeypatch, shape):
         rc1, T1, st1 = H1.scan_match(sc.T_pred)
         rc2, T2, st2 = H2.scan_match(sc.T_pred)
         assert rc1 == rc2 == 0
-        _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2))
+        _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2), cost_sum_rtol=1e-13)
     H1.close(); H2.close()
 
 

@@ -426,11 +426,23 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
 bool solve_small_path(const tloam_ctx* c) { return c->nranks == 1 && c->k3_single && !c->no_fused_small && solve_small_fits(c->k3_grid); }
 // prep: the launch also prepares the factor set (only with solve_small_path and SlotView::flagb, see self_prepare_path)
-int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const SolvePrep* prep = nullptr) {
+// finish: ... and finishes the outer iteration, possibly running the following ones too (SolveFinish; needs prep).
+// wp: the weight thresholds of the outer iteration this Solve belongs to (null: a Solve outside scanMatching) -- the
+// one-launch Solve adds up the finish sums of its last evaluation for the finish kernel that follows.
+int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp = nullptr, const SolvePrep* prep = nullptr,
+                  const SolveFinish* finish = nullptr) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   if (sweeps > 0 && solve_small_path(c)) {
     // KITTI-size set: the whole Solve (up to `sweeps` evaluations) is one launch (k_solve_small)
-    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, prep, c->seg_n.p, c->stream);
+    SolveFinish F;
+    if (prep && finish) {
+      F = *finish;
+    } else {
+      memset(&F, 0, sizeof(F));
+      if (wp) { F.have_wp = 1; F.wp[0] = *wp; }
+    }
+    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, prep, c->seg_n.p, &F,
+                       c->stream);
     c->batch_launches++;
     return TLOAM_OK;
   }
@@ -571,6 +583,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
+  c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1056,10 +1069,10 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   //      are served by the evaluation reuse); the weight update and the finish kernel are gated on the
   //      minimiser having terminated, and raise `incomplete` otherwise -- then the Solve is topped up.
   const int planned = planned_sweeps_for(c, iter);
-  rc = enqueue_solve(c, /*armed=*/true, planned);  // armed by sm_begin / the previous iteration's finish kernel
-  if (rc != TLOAM_OK) return rc;
   const double mu = c->mu;
   const WeightParams wp = weight_params(c, mu, bp);
+  rc = enqueue_solve(c, /*armed=*/true, planned, &wp);  // armed by sm_begin / the previous iteration's finish kernel
+  if (rc != TLOAM_OK) return rc;
   const OuterCtl host_decides{c->cfg.cost_threshold, 0, 0};
   const int sweeps_before = c->stats.gn_sweeps;
   for (int attempt = 0;; ++attempt) {
@@ -1078,7 +1091,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
       c->last_error = "the minimiser did not terminate within its evaluation budget";
       return TLOAM_E_INVALID;
     }
-    rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps - planned);  // top up, then weights + finish again
+    rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps - planned, &wp);  // top up, then weights + finish again
     if (rc != TLOAM_OK) return rc;
   }
   const GnState& S = *c->h_state;
@@ -1127,6 +1140,40 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   memset(&prep, 0, sizeof(prep));
   prep.sv = c->sv;
   for (int k = 0; k < kKinds; ++k) prep.maxnum[k] = bp.maxnum[k];
+  // ... and the finish of an iteration (weights, sums, loop decisions, result slot): a launch of its own / riding on the next
+  // search, or the tail of the one-launch Solve, which then goes on with the next iteration itself while the pose stands still
+  const bool fin_in_solve = in_solve && finish_small_path(c) && !c->no_finish_in_solve && M <= kMaxOuterInLaunch;
+  SolveFinish F;
+  memset(&F, 0, sizeof(F));
+  if (fin_in_solve) {
+    F.enabled = 1;
+    F.have_wp = 1;
+    F.n_iter = M;
+    F.cost_threshold = c->cfg.cost_threshold;
+    F.sums16 = c->sums16.p;
+    double m = mu;
+    for (int iter = first; iter < M; ++iter) {
+      P.mus[iter] = m;
+      P.hms[iter] = next_mirror(c, iter);
+      F.wp[iter] = weight_params(c, m, bp);
+      F.hm[iter] = P.hms[iter];
+      m = m * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
+    }
+    for (int iter = first; iter < M; ++iter) {
+      // iteration `iter`: the search if the pose moved (always in the frame's first), then the Solve + finish -- a launch
+      // that returns at once when an earlier one has already run this iteration
+      rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, iter == 0 ? nullptr : run_build, nullptr, /*prepare_in_solve=*/true);
+      if (rc != TLOAM_OK) return rc;
+      prep.run_build = iter == 0 ? nullptr : run_build;
+      prep.run_refresh = iter == 0 ? nullptr : run_refresh;
+      F.first_iter = iter;
+      P.planned[iter] = planned_sweeps_for(c, iter);
+      P.solve_start[iter] = c->batch_launches;
+      rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], &F.wp[iter], &prep, &F);
+      if (rc != TLOAM_OK) return rc;
+    }
+    return TLOAM_OK;
+  }
   for (int iter = first; iter < M; ++iter) {
     if (iter == 0) {
       rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr, nullptr, in_solve);
@@ -1147,7 +1194,8 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
     if (rc != TLOAM_OK) return rc;
     P.planned[iter] = planned_sweeps_for(c, iter);
     P.solve_start[iter] = c->batch_launches;
-    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], in_solve ? &prep : nullptr);
+    const WeightParams wp_iter = weight_params(c, mu, bp);
+    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], &wp_iter, in_solve ? &prep : nullptr);
     if (rc != TLOAM_OK) return rc;
     P.mus[iter] = mu;
     P.hms[iter] = next_mirror(c, iter);
@@ -1208,10 +1256,11 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
       HIPC(c, hipMemsetAsync(&st->stop, 0, sizeof(int), c->stream));
       P.solve_start[iter] = c->batch_launches;
       P.planned[iter] = kSolveSweeps;
-      rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps);
+      const WeightParams wp_top = weight_params(c, P.mus[iter], bp);
+      rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps, &wp_top);
       if (rc != TLOAM_OK) return rc;
       P.hms[iter] = next_mirror(c, iter);
-      rc = enqueue_finish(c, weight_params(c, P.mus[iter], bp), P.hms[iter], OuterCtl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0});
+      rc = enqueue_finish(c, wp_top, P.hms[iter], OuterCtl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0});
       if (rc != TLOAM_OK) return rc;
       if (iter + 1 < M) {
         rc = enqueue_outer_iterations(c, iter + 1, P.mus[iter] * exp((double)(iter + 1) * c->cfg.gnc_factor), bp, grids, P);

@@ -125,6 +125,11 @@ struct GnState {
   int run_refresh;    // the refresh iff it did not (see k_refresh); both 0 once the loop has ended
   int spec_build;     // written by the minimiser step: 1 iff the Solve has terminated at a pose other than x_build -- the gate of
                       // a correspondence search that runs CONCURRENTLY with the finish of that Solve (k_build_finish_small)
+  int next_outer;     // device-driven loop: the outer iteration to run next (advanced by every finish).  A one-launch Solve that
+                      // also finishes its iteration may run the FOLLOWING ones too (SolveFinish); the launches enqueued for
+                      // those find their iteration taken and return
+  int fin_valid;      // fin_sum / fin_bad hold the finish sums of the Solve that has just ended (k_solve_small); consumed by the finish
+  double fin_sum[kKinds], fin_bad;
   double dbg[12];     // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };
 constexpr int kMirrorWords = 16;  // x[6], x_cost, kind_cost[4], n_corr[4] (2 words), 6 ints (3 words)
@@ -412,13 +417,28 @@ struct SolvePrep {
   const int* run_build;     // device gates of the outer loop; null: always build (the frame's first iteration)
   const int* run_refresh;
 };
-void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        const SolvePrep* prep_or_null, int* seg_n, hipStream_t s);
 // K4
 struct WeightParams {
   double th1, th2, mu, noise_bound_sq;
   int active[kKinds];
 };
+// The finish of the outer iterations a one-launch Solve may run itself (device-driven loop, KITTI-size sets): every wave
+// updates the weights of the factors it holds and adds their side-channel costs up, the consumer wave makes the loop
+// decisions and writes the result slot; if the loop goes on with an unchanged pose the launch refreshes its correspondences
+// in registers and runs the next Solve as well.  enabled == 0: the launch ends with the Solve and leaves the sums in the
+// state for the finish kernel (GnState::fin_valid).
+constexpr int kMaxOuterInLaunch = 8;
+struct SolveFinish {
+  int enabled;
+  int have_wp;               // wp[first_iter ..] are set: the launch adds up the finish sums of its Solve(s)
+  int first_iter, n_iter;    // outer iteration this launch was enqueued for; max_iterations
+  double cost_threshold;     // registration.cpp:1108
+  double* sums16;
+  WeightParams wp[kMaxOuterInLaunch];   // per outer iteration
+  HostMirror hm[kMaxOuterInLaunch];
+};
+void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
+                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s);
 // (gated on st->done: see k_weights)
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
                     int blocks, const GnState* st, hipStream_t s);

@@ -169,6 +169,7 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
+  bool no_finish_in_solve = false; // TLOAM_NO_FINISH_IN_SOLVE: the finish of an outer iteration stays a launch of its own (A/B, tests)
   bool no_self_prepare = false;    // TLOAM_NO_SELF_PREPARE: k_prepare_small in front of every one-launch Solve (A/B, tests)
   bool no_fused_small = false;     // TLOAM_NO_FUSED_SMALL: KITTI-size sets keep sweep and step as two launches (A/B, tests)
   bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)

@@ -25,9 +25,15 @@ struct WeightArgs {
 // eight words equals the number it waits for (tlh::wait_segment), so a torn segment simply reads as "not there yet".
 // status >= 0 replaces the `incomplete` word of the copy (a launch that was gated off reports OS_SKIPPED without
 // touching the state itself).
+__device__ __forceinline__ void mirror_wave(const GnState* st, const HostMirror& hm, int tid, int status = -1);
 __device__ __forceinline__ void mirror_to_host(const GnState* st, const HostMirror& hm, int tid, int nthreads, int status = -1) {
   if (!hm.out) return;
   __syncthreads();
+  mirror_wave(st, hm, tid, status);
+}
+// the store itself, by lanes 0..23 of ONE wave (tid = lane); st may be the state's image in LDS
+__device__ __forceinline__ void mirror_wave(const GnState* st, const HostMirror& hm, int tid, int status) {
+  if (!hm.out) return;
   if (tid >= 24) return;  // one store instruction of one wave: 3 segments x (7 words + sequence number), see MirrorSlot
   const int seg = tid >> 3, pos = tid & 7, word = seg * 7 + pos;
   unsigned long long w = 0ull;
@@ -58,6 +64,8 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
   if (t == 0) {
     st->bad_weights += (int)sums16[8];
     st->incomplete = OS_OK;
+    st->fin_valid = 0;
+    if (ctl.fast) st->next_outer += 1;
     if (!ctl.fast) {
       arm_solver(*st);
     } else {
@@ -181,6 +189,20 @@ __device__ __forceinline__ int finish_small_thread(const GnState* st, const int*
     for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
   return 0;
 }
+// The weight update of ONE factor by the wave that holds it (the one-launch Solve ending its outer iteration itself,
+// SolveFinish): what `one()` above stores into the slot weight, from the factor's own side-channel cost.  Returns the weight the
+// factor captures at the next (refresh) iteration (w_old where the reference leaves the weight alone).
+__device__ __forceinline__ double refreshed_weight(const WeightParams& wp, int kind, double c, double w_old, double* __restrict__ w_src,
+                                                   int slot) {
+  if (!wp.active[kind]) return w_old;
+  if (c == 0) return w_old;                        // :862
+  double w;
+  if (c >= wp.th1) w = 0.0;                        // :865
+  else if (c <= wp.th2) w = 1.0;                   // :867
+  else w = sqrt(wp.noise_bound_sq * wp.mu * (wp.mu + 1) / c) - wp.mu;  // :870
+  w_src[slot] = w;
+  return w;
+}
 // what a gated-off launch leaves behind (thread t of the block that publishes; every thread has read the flags)
 __device__ __forceinline__ void finish_gate_writes(GnState* gate, const OuterCtl& ctl, int g, int t) {
   if (g == 2 && t == 0) {
@@ -200,6 +222,10 @@ __device__ __forceinline__ void finish_small_publish(GnState* st, double* __rest
   if (t < 5) {
     double s = 0.0;
     for (int w = 0; w < 16; ++w) s += red[w][t];
+    // a Solve that ran as ONE launch has added the costs of its last evaluation up itself, in ITS order (k_solve_small:
+    // post_ext_row); its finish -- in that launch or here -- publishes those sums, so that the device-driven loop and the
+    // stepwise API agree bit for bit
+    if (st->fin_valid) s = t < 4 ? st->fin_sum[t] : st->fin_bad;
     sh[t < 4 ? t : 8] = s;
   }
   if (t >= 8 && t < 12) sh[t - 4] = (double)nseg[t - 8];

@@ -233,8 +233,11 @@ __device__ __forceinline__ void fetch_spec(const double* base, int stride, int j
   b.d = ld2o(base + SS_D * st, o);
 #undef ld2o
 }
+// cost_out: the lane's two costs, for the wave that keeps its correspondences across Solves and ends the outer iteration
+// itself (k_solve_small); untouched (the caller's zeros) where the lane has no factor.
 template <int RES, bool NT>
-__device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a) {
+__device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a,
+                                        double2* cost_out = nullptr) {
   const int rem = n - j;  // >= 2: both correspondences of this lane, 1: the first only, <= 0: none
   if (rem <= 0) return;
   double c0, c1 = 0.0;
@@ -260,6 +263,7 @@ __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, 
     if (rem > 1) *reinterpret_cast<double2*>(seg.cost + j) = double2{c0, c1};
     else seg.cost[j] = c0;
   }
+  if (cost_out) *cost_out = double2{c0, c1};
 }
 
 // All chunks i0, i0+W, i0+2W, ... (< nchunks) of one segment.  DEPTH 2: software-pipelined, the loads of
@@ -360,7 +364,11 @@ struct SingleWork {
 };
 __device__ __forceinline__ SingleWork single_work_of(const CorrView& cv, int cap0, int gw, int lane) {
   SingleWork wk{-1, 0};
-  int g = gw;
+  // wave 0 of the grid holds no chunk: in the one-launch Solve (k_solve_small) it is the consumer of the rows -- it folds
+  // them and takes the minimiser's step while the others evaluate -- and the one-launch-per-iteration kernels map the same
+  // way so that all of them add the same waves up in the same rows
+  int g = gw - 1;
+  if (g < 0) return wk;
   const int n0 = cap0 / kChunk;   // (preloaded: the planar waves need nothing else)
   if (g < n0) { wk.kind = 0; wk.j = g * kChunk + lane * 2; return wk; }
   g -= n0;
@@ -386,21 +394,21 @@ __device__ __forceinline__ void single_fetch(const CorrView& cv, const double* _
   }
 }
 __device__ __forceinline__ void sweep_single_n(const CorrView& cv, int n, const Rt& T, const SingleWork& wk,
-                                               const ChunkData& b, Acc& a) {
+                                               const ChunkData& b, Acc& a, double2* cost_out = nullptr) {
 #pragma unroll
   for (int i = 0; i < 27; ++i) a.v[i] = 0.0;
   a.pm = 0.5;
   a.pe = 1;
   if (wk.kind < 0) return;
   if (wk.kind <= TLOAM_KIND_GROUND) {
-    if (wk.kind == TLOAM_KIND_PLANAR) consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_PLANAR], wk.j, n, b, a);
-    else consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_GROUND], wk.j, n, b, a);
+    if (wk.kind == TLOAM_KIND_PLANAR) consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_PLANAR], wk.j, n, b, a, cost_out);
+    else consume<TLOAM_RES_PLANE, false>(T, cv.k[TLOAM_KIND_GROUND], wk.j, n, b, a, cost_out);
   } else if (wk.kind == TLOAM_KIND_EDGE) {
     const int ne = single_chunk_of(TLOAM_KIND_EDGE) == kChunk ? n : (n < wk.j + 1 ? n : wk.j + 1);   // 64-chunks: this lane's one
-    consume<TLOAM_RES_LINE, false>(T, cv.k[TLOAM_KIND_EDGE], wk.j, ne, b, a);
+    consume<TLOAM_RES_LINE, false>(T, cv.k[TLOAM_KIND_EDGE], wk.j, ne, b, a, cost_out);
   } else {
     const int ne = single_chunk_of(TLOAM_KIND_SPHERE) == kChunk ? n : (n < wk.j + 1 ? n : wk.j + 1);
-    consume<TLOAM_RES_POINT, false>(T, cv.k[TLOAM_KIND_SPHERE], wk.j, ne, b, a);
+    consume<TLOAM_RES_POINT, false>(T, cv.k[TLOAM_KIND_SPHERE], wk.j, ne, b, a, cost_out);
   }
 }
 __device__ __forceinline__ void sweep_single(const CorrView& cv, const int* __restrict__ seg_n, const Rt& T, const SingleWork& wk,
@@ -703,6 +711,7 @@ void k3_plan(const int cap[kKinds], int* grid, bool* single) {
     waves += (cap[k] + single_chunk_of(k) - 1) / single_chunk_of(k);
     total += cap[k];
   }
+  waves += 1;   // wave 0 of the grid holds no chunk (single_work_of)
   if (waves <= 256 * 2 * 4 && !getenv("TLOAM_K3_BLOCKS")) {
     *single = true;
     *grid = (int)((waves + 3) / 4) < 1 ? 1 : (int)((waves + 3) / 4);
@@ -972,55 +981,6 @@ void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, 
   hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
                      cv.seg_n, partials, ticket, cv);
 }
-// ---- one ceres::Solve of a KITTI-size set in ONE launch ----------------------------------------------------------
-// The sweeps of a Solve are a chain: sweep -> 6x6 step -> sweep of the candidate -> ...  As launches every link pays a kernel
-// boundary (~1.5 us), the state and stream loads again (~1 us), and the host has to GUESS how many links to enqueue (a wrong
-// guess costs a round trip and a second pass over the frame's launch list).  For a grid of <= kTaggedRows blocks -- all
-// resident at once on a 256-CU part -- the chain runs inside one launch instead: every wave keeps its chunk of
-// correspondences in registers; per GN iteration the blocks post their rows (k3_post_row_tagged), wave 0 of block 0 polls
-// and folds them, runs the minimiser step (gn_consume) and publishes the candidate pose -- two 64-byte segments (seven
-// words + check word, as the rows) that the other waves poll; a control word says go on / stop.  Tags carry the launch
-// counter and the iteration, so nothing has to be reset between launches.  Nothing else changes: the same sweep arithmetic
-// per wave, the same fold order, the same step.
-// max_sweeps: evaluations this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
-constexpr int kBcastWords = 16;
-__device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
-                                                   bool go_on, int lane) {
-  if (lane < kBcastWords) {
-    const int sgm = lane >> 3, pos = lane & 7, v = sgm * 7 + pos;   // values 0..8: R, 9..11: t, 12: control, 13: spare
-    unsigned long long w = 0ull;
-    if (pos < 7) {
-      if (v < 9) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.r[v]);
-      else if (v < 12) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.t[v - 9]);
-      else if (v == 12) w = go_on ? 1ull : 2ull;
-    }
-    const unsigned long long x = xor8(w);
-    if (pos == 7) w = tag ^ x;
-    __hip_atomic_store(bcast + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// every lane reads all sixteen words (uniform addresses: one transaction per instruction) until both segments check.
-// Returns 1: go on with T, 2: stop, 0: timed out.
-__device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restrict__ bcast, unsigned long long tag, Rt& T) {
-  unsigned long long w[kBcastWords];
-  const unsigned long long t0 = wall_clock64();
-  for (unsigned spins = 1;; ++spins) {
-#pragma unroll
-    for (int i = 0; i < kBcastWords; ++i) w[i] = __hip_atomic_load(bcast + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long x0 = w[0], x1 = w[8];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) { x0 ^= w[i]; x1 ^= w[8 + i]; }
-    if (x0 == tag && x1 == tag) break;
-    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) return 0;
-    __builtin_amdgcn_s_sleep(1);
-  }
-#pragma unroll
-  for (int v = 0; v < 12; ++v) {
-    const double d = __longlong_as_double((long long)w[(v / 7) * 8 + (v % 7)]);
-    if (v < 9) T.r[v] = d; else T.t[v - 9] = d;
-  }
-  return (int)w[8 + 5];   // value 12 = segment 1, position 5
-}
 // ---- the Solve prepares its own factor set (SolvePrep) ------------------------------------------------------------------
 // What k_prepare_small does in a launch of its own -- caps in index order (registration.cpp:448/:538/:592/:735), compaction,
 // or the refresh of an unchanged set -- done by every wave for ITS chunk: the kind's flag bytes (at most kFlagbStride, 64 per
@@ -1057,17 +1017,60 @@ __device__ __forceinline__ void load_flag_bytes(const unsigned char* __restrict_
 #pragma unroll
   for (int i = 0; i < 4; ++i) f.q[i] = p[i];
 }
+// The added set of one kind, as the wave sees it: this lane's 64 slots as a mask, the exclusive prefix of the lanes'
+// counts and the size of the set.   added(i) <=> valid(i) && #counted before i < maxnum
+struct KindSet {
+  unsigned vlo, vhi;   // this lane's added slots (64 lane + bit)
+  int pv;              // added slots in front of this lane
+  int total;
+};
+__device__ __forceinline__ KindSet kind_set_of(const SolvePrep& P, const CorrView& cv, int kind, int lane, const FlagBytes& f) {
+  const int nk = P.sv.slot_off[kind + 1] - P.sv.slot_off[kind];
+  unsigned vlo = 0u, vhi = 0u, clo = 0u, chi = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned wd[4] = {f.q[i].x, f.q[i].y, f.q[i].z, f.q[i].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int nib = i * 4 + c;   // slots 4 nib .. 4 nib + 3 of this lane
+      const unsigned v = flag_nibble(wd[c]), ct = flag_nibble(wd[c] >> 1);
+      if (nib < 8) { vlo |= v << (4 * nib); clo |= ct << (4 * nib); }
+      else { vhi |= v << (4 * (nib - 8)); chi |= ct << (4 * (nib - 8)); }
+    }
+  }
+  unsigned long long valid = (unsigned long long)vlo | ((unsigned long long)vhi << 32);
+  unsigned long long counted = (unsigned long long)clo | ((unsigned long long)chi << 32);
+  {  // bytes past the kind's last slot are whatever an earlier, larger frame left there
+    const int mine = nk - lane * 64;
+    const unsigned long long keep = mine >= 64 ? ~0ull : (mine <= 0 ? 0ull : ((1ull << mine) - 1ull));
+    valid &= keep;
+    counted &= keep;
+  }
+  int ctot;
+  const int cc = __popcll(counted);
+  const int pc = wave_excl_scan(cc, lane, &ctot);
+  const int room = P.maxnum[kind] - pc;
+  if (room <= 0) valid = 0ull;
+  else if (room <= cc) valid &= (2ull << select64(counted, room - 1)) - 1ull;   // up to and including the room-th counted slot
+  KindSet ks;
+  const int vc = __popcll(valid);
+  ks.pv = wave_excl_scan(vc, lane, &ks.total);
+  if (ks.total > cv.k[kind].cap) ks.total = cv.k[kind].cap;   // cannot happen (cap >= min(n, maxnum)); defensive, as in k_prepare_small
+  ks.vlo = (unsigned)valid;
+  ks.vhi = (unsigned)(valid >> 32);
+  return ks;
+}
 // local slot (within the kind) of compact position p, p < total
-__device__ __forceinline__ int slot_of_position(int p, int pv, unsigned vlo, unsigned vhi) {
+__device__ __forceinline__ int slot_of_position(int p, const KindSet& ks) {
   int L = 0;
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
-    const int pc = __shfl(pv, L + s, 64);   // (L + s <= 63)
+    const int pc = __shfl(ks.pv, L + s, 64);   // (L + s <= 63)
     if (pc <= p) L += s;
   }
-  const int r = p - __shfl(pv, L, 64);
-  const unsigned long long word = (unsigned long long)(unsigned)__shfl((int)vlo, L, 64) |
-                                  ((unsigned long long)(unsigned)__shfl((int)vhi, L, 64) << 32);
+  const int r = p - __shfl(ks.pv, L, 64);
+  const unsigned long long word = (unsigned long long)(unsigned)__shfl((int)ks.vlo, L, 64) |
+                                  ((unsigned long long)(unsigned)__shfl((int)ks.vhi, L, 64) << 32);
   return L * 64 + select64(word, r);
 }
 // one correspondence from the slot arrays into half `H` (0: .x, 1: .y) of the chunk registers + the compact arrays
@@ -1093,116 +1096,236 @@ __device__ __forceinline__ void take_slot(const SlotView& sv, const CorrSeg& seg
   seg.w[p] = w;        // weight captured by value at construction (registration.hpp:51,76,96)
   seg.cost[p] = 0.0;   // fresh side-channel slot (registration.cpp:1118-1121)
 }
-// BUILD: returns the size of the wave's kind and fills b with the wave's chunk
+// BUILD: returns the size of the wave's kind, fills b with the wave's chunk and slot[] with its correspondences' slots
 __device__ __forceinline__ int self_compact(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int lane, const FlagBytes& f,
-                                            ChunkData& b, int* __restrict__ seg_n_out) {
+                                            ChunkData& b, int slot[2]) {
   const int kind = wk.kind;
-  const int nk = P.sv.slot_off[kind + 1] - P.sv.slot_off[kind];
-  unsigned vlo = 0u, vhi = 0u, clo = 0u, chi = 0u;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned wd[4] = {f.q[i].x, f.q[i].y, f.q[i].z, f.q[i].w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int nib = i * 4 + c;   // slots 4 nib .. 4 nib + 3 of this lane
-      const unsigned v = flag_nibble(wd[c]), ct = flag_nibble(wd[c] >> 1);
-      if (nib < 8) { vlo |= v << (4 * nib); clo |= ct << (4 * nib); }
-      else { vhi |= v << (4 * (nib - 8)); chi |= ct << (4 * (nib - 8)); }
-    }
-  }
-  unsigned long long valid = (unsigned long long)vlo | ((unsigned long long)vhi << 32);
-  unsigned long long counted = (unsigned long long)clo | ((unsigned long long)chi << 32);
-  {  // bytes past the kind's last slot are whatever an earlier, larger frame left there
-    const int mine = nk - lane * 64;
-    const unsigned long long keep = mine >= 64 ? ~0ull : (mine <= 0 ? 0ull : ((1ull << mine) - 1ull));
-    valid &= keep;
-    counted &= keep;
-  }
-  // added(i) <=> valid(i) && #counted before i < maxnum
-  int ctot;
-  const int cc = __popcll(counted);
-  const int pc = wave_excl_scan(cc, lane, &ctot);
-  const int room = P.maxnum[kind] - pc;
-  if (room <= 0) valid = 0ull;
-  else if (room <= cc) valid &= (2ull << select64(counted, room - 1)) - 1ull;   // up to and including the room-th counted slot
-  int total;
-  const int vc = __popcll(valid);
-  const int pv = wave_excl_scan(vc, lane, &total);
+  const KindSet ks = kind_set_of(P, cv, kind, lane, f);
+  const int total = ks.total;
   const CorrSeg& seg = cv.k[kind];
-  if (total > seg.cap) total = seg.cap;   // cannot happen (cap >= min(n, maxnum)); defensive, as in k_prepare_small
-  vlo = (unsigned)valid; vhi = (unsigned)(valid >> 32);
   const bool two = single_chunk_of(kind) == kChunk;
   const int p0 = wk.j, p1 = wk.j + 1;
   // (every lane takes part in the searches: they exchange through the whole wave)
-  const int l0 = total > 0 ? slot_of_position(p0 < total ? p0 : total - 1, pv, vlo, vhi) : 0;
+  const int l0 = total > 0 ? slot_of_position(p0 < total ? p0 : total - 1, ks) : 0;
   if (p0 < total) take_slot<0>(P.sv, seg, kind, l0, p0, b);
+  slot[0] = P.sv.slot_off[kind] + l0;
+  slot[1] = slot[0];
   if (two) {
-    const int l1 = total > 0 ? slot_of_position(p1 < total ? p1 : total - 1, pv, vlo, vhi) : 0;
+    const int l1 = total > 0 ? slot_of_position(p1 < total ? p1 : total - 1, ks) : 0;
     if (p1 < total) take_slot<1>(P.sv, seg, kind, l1, p1, b);
+    slot[1] = P.sv.slot_off[kind] + l1;
   }
-  if (wk.j == 0 && lane == 0) seg_n_out[kind] = total;   // (the kind's first chunk)
   return total;
 }
-// REFRESH: the set of the previous iteration with new captured weights and zeroed slots (k_refresh); b holds the chunk
-__device__ __forceinline__ void self_refresh(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int n, ChunkData& b) {
+// the slots of the wave's correspondences of a set that is kept or refreshed
+__device__ __forceinline__ void slots_of_chunk(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int n, int slot[2]) {
   const int kind = wk.kind;
   const CorrSeg& seg = cv.k[kind];
   const bool two = single_chunk_of(kind) == kChunk;
+  const int base = P.sv.slot_off[kind] - P.sv.src_lo[kind];
+  slot[0] = wk.j < n ? base + seg.idx[wk.j] : P.sv.slot_off[kind];
+  slot[1] = (two && wk.j + 1 < n) ? base + seg.idx[wk.j + 1] : slot[0];
+}
+// REFRESH: the set of the previous iteration with new captured weights and zeroed slots (k_refresh); b holds the chunk
+__device__ __forceinline__ void self_refresh(const SolvePrep& P, const CorrView& cv, const SingleWork& wk, int n, const int slot[2],
+                                             ChunkData& b) {
+  const CorrSeg& seg = cv.k[wk.kind];
+  const bool two = single_chunk_of(wk.kind) == kChunk;
   if (wk.j < n) {
-    const double w = P.sv.w_src[P.sv.slot_off[kind] + (seg.idx[wk.j] - P.sv.src_lo[kind])];
+    const double w = P.sv.w_src[slot[0]];
     b.w.x = w; seg.w[wk.j] = w; seg.cost[wk.j] = 0.0;
   }
   if (two && wk.j + 1 < n) {
-    const double w = P.sv.w_src[P.sv.slot_off[kind] + (seg.idx[wk.j + 1] - P.sv.src_lo[kind])];
+    const double w = P.sv.w_src[slot[1]];
     b.w.y = w; seg.w[wk.j + 1] = w; seg.cost[wk.j + 1] = 0.0;
   }
 }
+
+// ---- the sums of an outer iteration's finish, carried by the Solve itself -------------------------------------------------
+// updateWeight (registration.cpp:858-876) and the cost sums (:1091-1094) look at the side-channel costs of the LAST
+// evaluation of the Solve -- which the wave that evaluated them still holds.  Every sweep, every wave adds up the costs of
+// its chunk (lane order, one shuffle tree) and counts the factors whose new weight would leave [0, 1] (the reference's
+// assert, :871); the block's waves meet in LDS, the block posts the four kind sums and the count as ONE more 64-byte
+// segment beside its row, and the consumer adds the blocks' segments in row order.  When the minimiser says "done" the
+// sums of the finish are already there: no pass over the costs, no hand-over of its own.
+// Only a factor whose cost is within 1e-9 (relative) of an end of the band (th2, th1) can round out of [0, 1]: with
+// c = th1 (1 - d) the weight is ~ mu d / 2 against an error of a few 1e-16 mu, at the other end 1 - w ~ (mu + 1) d / 2
+// against a few 1e-16 (mu + 1); for those few (and for every factor in the band once the band is narrower than that) the
+// reference's expression is evaluated as it stands.
+__device__ __forceinline__ bool weight_out_of_range(const WeightParams& wp, int kind, double c) {
+  if (!wp.active[kind]) return false;
+  if (c == 0) return false;                      // :862
+  if (c >= wp.th1 || c <= wp.th2) return false;  // :865 / :867
+  if (c < wp.th1 * (1.0 - 1e-9) && c > wp.th2 * (1.0 + 1e-9)) return false;
+  const double w = sqrt(wp.noise_bound_sq * wp.mu * (wp.mu + 1) / c) - wp.mu;  // :870
+  return !(w >= 0.0 && w <= 1.0);
+}
+constexpr int kExtRowBase = 512;   // the blocks' extra segments: words kExtRowBase + 8 block .. of the row buffer
+// (called by every thread of the block after the barrier; xs[w] = {cost sum, count} of wave w, xk[w] its kind or -1)
+__device__ __forceinline__ void post_ext_row(double* __restrict__ partials, const double (*xs)[2], const int* xk, unsigned long long tag) {
+  const int t = (int)threadIdx.x - 32;   // lanes 32 .. 39 of wave 0 (the row itself is posted by lanes 0 .. 31)
+  if (t < 0 || t >= 8) return;
+  double val = 0.0;
+  if (t < 4) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (xk[w] == t) val += xs[w][0];
+  } else if (t == 4) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) val += xs[w][1];
+  }
+  unsigned long long wd = (unsigned long long)__double_as_longlong(val);
+  const unsigned long long x = xor8(wd);
+  if (t == 7) wd = tag ^ x;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + kExtRowBase + (size_t)blockIdx.x * 8 + t, wd, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// the consumer wave: waits for the extra segment of every row (they were stored right behind the rows it has just folded)
+// and adds them in row order -> fin[0..4] in LDS.  false: timed out.
+__device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partials, int rows, unsigned long long tag, double* s_ext /*[16*8]*/,
+                                              double* fin /*[8]*/, int lane) {
+  const bool have = lane < rows;
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + kExtRowBase + (size_t)(have ? lane : 0) * 8;
+  unsigned long long w[8];
+  const unsigned long long t0 = wall_clock64();
+  bool ok_all;
+  for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long x = w[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) x ^= w[i];
+    ok_all = __all((!have || x == tag) ? 1 : 0) != 0;
+    if (ok_all) break;
+    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (have) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s_ext[lane * 8 + i] = __longlong_as_double((long long)w[i]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane < 8) {
+    double t = 0.0;
+    if (lane < 5)
+      for (int r = 0; r < rows; ++r) t += s_ext[r * 8 + lane];
+    fin[lane] = t;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return ok_all;
+}
+
+// ---- small Solves in ONE launch ---------------------------------------------------------------------------------------------
+// A KITTI-size Solve is a chain sweep -> rows -> fold -> 6x6 step -> next pose, one to five times; as one launch per link
+// it pays a launch boundary (~1.5 us of dispatch plus the ramp of a dozen blocks, plus every wave re-reading its chunk) per
+// GN iteration, and the host must guess how many links to enqueue (planned_sweeps_for: learned budgets; a frame that breaks the
+// guess costs a round trip and a second pass over the frame's launch list).  For a grid of <= kTaggedRows blocks -- all
+// resident at once on a 256-CU part -- the chain runs inside one launch instead: every wave keeps its chunk of
+// correspondences in registers; per GN iteration the blocks post their rows (k3_post_row_tagged), wave 0 of block 0 -- which
+// holds no chunk (single_work_of) -- polls and folds them, runs the minimiser step (gn_consume) and publishes the candidate pose:
+// two 64-byte segments (seven words + check word, as the rows) that the other waves poll; a control word says what comes next.
+// Tags carry the launch counter and the hand-over number, so nothing has to be reset between launches.  The same sweep
+// arithmetic per wave, the same fold order, the same step as the one-launch-per-iteration kernels.
+// max_sweeps: evaluations a Solve of this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
+constexpr int kBcastWords = 16;
+// verdict: 1 go on with this Solve | 2 the Solve is over | 3 next outer iteration in this launch, from this pose | 4 leave |
+// 5 hand-over failed, leave
+__device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
+                                                   int verdict, int lane) {
+  if (lane < kBcastWords) {
+    const int sgm = lane >> 3, pos = lane & 7, v = sgm * 7 + pos;   // values 0..8: R, 9..11: t, 12: control, 13: spare
+    unsigned long long w = 0ull;
+    if (pos < 7) {
+      if (v < 9) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.r[v]);
+      else if (v < 12) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.t[v - 9]);
+      else if (v == 12) w = (unsigned long long)verdict;
+    }
+    const unsigned long long x = xor8(w);
+    if (pos == 7) w = tag ^ x;
+    __hip_atomic_store(bcast + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// every lane reads all sixteen words (uniform addresses: one transaction per instruction) until both segments check.
+// Returns the control word (see solve_publish_pose), 0: timed out.
+__device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restrict__ bcast, unsigned long long tag, Rt& T) {
+  unsigned long long w[kBcastWords];
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < kBcastWords; ++i) w[i] = __hip_atomic_load(bcast + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long x0 = w[0], x1 = w[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { x0 ^= w[i]; x1 ^= w[8 + i]; }
+    if (x0 == tag && x1 == tag) break;
+    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) return 0;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int v = 0; v < 12; ++v) {
+    const double d = __longlong_as_double((long long)w[(v / 7) * 8 + (v % 7)]);
+    if (v < 9) T.r[v] = d; else T.t[v - 9] = d;
+  }
+  return (int)w[8 + 5];   // value 12 = segment 1, position 5
+}
+
+// ---- the consumer wave's end of an outer iteration (SolveFinish): sums -> state, loop decisions, re-arm, result slot -------
+// fin[0..3]: the kinds' cost sums of the Solve's last evaluation, fin[4]: weights out of range (poll_fold_ext); nseg: the set.
+// Returns 3: the loop goes on with an unchanged pose -- this launch runs the next outer iteration too | 4: leave (the loop
+// has ended, or the pose moved and the correspondence search has to run first).  One wave.
+__device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LDS image, current */, const SolveFinish& F, int oi,
+                                                  const double* fin, const int nseg[kKinds], double* sh /* LDS [16] */, int lane) {
+  constexpr int kWords = (int)(offsetof(GnState, dbg) / 8);
+  const OuterCtl ctl{F.cost_threshold, 1, oi == F.n_iter - 1 ? 1 : 0};
+  int next = 4;
+  if (!sm->done) {   // the Solve ran out of this launch's evaluation budget (finish_gate: 2): the host tops it up
+    if (lane == 0) {
+      sm->incomplete = OS_INCOMPLETE;
+      sm->stop = 2;
+      sm->run_build = sm->run_refresh = 0;
+    }
+  } else {
+    if (lane < 16) {
+      double v = 0.0;
+      if (lane < 4) v = fin[lane];
+      else if (lane < 8) v = (double)(lane == 4 ? nseg[0] : (lane == 5 ? nseg[1] : (lane == 6 ? nseg[2] : nseg[3])));   // (no indexed array: registers)
+      else if (lane == 8) v = fin[4];
+      sh[lane] = v;
+      F.sums16[lane] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    publish_and_rearm(sh, sm, lane, ctl);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    next = (sm->stop == 0 && sm->run_build == 0 && sm->run_refresh != 0 && oi + 1 < F.n_iter) ? 3 : 4;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // the image into the device state (every word up to the development stamps), the result slot, and -- once the loop has
+  // ended -- the slots of the iterations that will not run (what their gated-off finish kernels would have written)
+  for (int w = lane; w < kWords; w += 64) reinterpret_cast<unsigned long long*>(st)[w] = reinterpret_cast<const unsigned long long*>(sm)[w];
+  mirror_wave(sm, F.hm[oi], lane);
+  if (sm->stop != 0)
+    for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(sm, F.hm[j], lane, (int)OS_SKIPPED);
+  return next;
+}
+
 __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
                                                         GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                         double* __restrict__ partials, int* __restrict__ ticket,
                                                         unsigned long long* __restrict__ bcast, CorrView cv, SolvePrep prep,
-                                                        int* __restrict__ seg_n_out) {
+                                                        int* __restrict__ seg_n_out, SolveFinish F) {
   __shared__ double red[4][32];
+  __shared__ double xs[4][2];
+  __shared__ int xk[4];
   __shared__ double s_scr[32];
   __shared__ double s_rows[kTaggedRows * 28];
+  __shared__ double s_ext[kTaggedRows * 8];
+  __shared__ double s_fin[8];
+  __shared__ double s_sh[16];
   __shared__ double tot[kReduceBuf];
   __shared__ GnState s_in;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
-  ChunkData pre;
-  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
-  single_fetch(cv, seg0, stride0, wk, pre);   // this wave's correspondences: requested once, kept in registers for the whole Solve
-  // (with SolvePrep: speculatively -- right if the set is kept or refreshed; a set that is rebuilt is fetched from the slots)
-  FlagBytes fbytes;
+  const bool consumer = gw == 0;   // (holds no chunk: single_work_of)
   const bool self_prep = prep.sv.flagb != nullptr;
-  if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
-  {
-    constexpr int kWords = (int)(sizeof(GnState) / 8);
-    static_assert(kWords <= 256, "one word per thread");
-    if (threadIdx.x < kWords)
-      reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
-  }
   unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
-  const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (see k_sweep_step_small: read by every block before it can change)
-  const bool consumer = blockIdx.x == 0 && wave == 0;
-  int n_mine = 0;
-  bool built = false;
-  if (self_prep) {
-    const bool build = !prep.run_build || *prep.run_build != 0;
-    if (build) {
-      if (wk.kind >= 0) n_mine = self_compact(prep, cv, wk, lane, fbytes, pre, seg_n_out);
-      built = true;
-    } else {
-      if (wk.kind >= 0) {
-        n_mine = seg_n[wk.kind];
-        if (prep.run_refresh && *prep.run_refresh != 0) self_refresh(prep, cv, wk, n_mine, pre);
-      }
-    }
-  } else if (wk.kind >= 0) {
-    n_mine = seg_n[wk.kind];
-  }
-  if (st->done) return;            // a Solve that has already ended (uniform over the grid)
-  Rt T = st->Rt_eval;
 #ifdef TLOAM_STEP_PROFILE
   // development aid (scripts/solve_profile.py): wall-clock (100 MHz) stamps of the consumer wave and of one producer wave
   // (block gridDim/2) per GN iteration, in the spare part of the row buffer
@@ -1212,53 +1335,206 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
 #else
 #define TL_PROF(cond, slot)
 #endif
-  TL_PROF(consumer && lane == 0, 0)
-  for (int it = 0;; ++it) {
-    Acc a;
-    sweep_single_n(cv, n_mine, T, wk, pre, a);
-    TL_PROF(prof_p, 64 + it * 8 + 1)
-    const double wtot = wave_reduce_acc(a, lane);
-    if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
-    __syncthreads();
-    if (it == 0 && built && consumer && lane < 6) {   // the set was built at this pose (k_prepare_small's x_build = x)
-      s_in.x_build[lane] = s_in.x[lane];
-      st->x_build[lane] = s_in.x[lane];
+  // Hand-overs of a launch -- rows to the consumer, poses / verdicts from it -- are numbered in the order they happen (both
+  // sides count alike): rows of GN iteration: tag0 | step, the pose that answers them: tag0 | step + 1.
+  if (consumer) {
+    // =================== wave 0 of block 0: folds the rows, takes the minimiser's step, ends the outer iteration ===================
+    FlagBytes fb[kKinds];
+    if (self_prep) {
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) load_flag_bytes(prep.sv.flagb, k, lane, fb[k]);
     }
-    k3_post_row_tagged(partials, red, tag0 | (unsigned long long)it);
-    TL_PROF(prof_p, 64 + it * 8 + 2)
-    TL_PROF(consumer && lane == 0, 8 + it * 8 + 0)
-    if (consumer) {
-      const bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | (unsigned long long)it, s_rows, tot, lane);
-      TL_PROF(lane == 0, 8 + it * 8 + 1)
-      if (!ok) {  // a block of the grid never posted: stop the Solve; the finish kernel reports OS_COMM_ERROR
-        if (lane == 0) { st->done = 1; st->comm_error = 1; *epoch = tag0 >> 8; }
-        solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), false, lane);
+    {
+      constexpr int kWords = (int)(sizeof(GnState) / 8);
+      for (int w = lane; w < kWords; w += 64)
+        reinterpret_cast<unsigned long long*>(&s_in)[w] = reinterpret_cast<const unsigned long long*>(st)[w];
+    }
+    if (lane < 32) red[0][lane] = 0.0;
+    if (lane == 0) { xs[0][0] = 0.0; xs[0][1] = 0.0; xk[0] = -1; }
+    const unsigned long long tag0 = (*epoch + 1ull) << 8;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int oi = F.first_iter;
+    // device-driven loop with the finish in the launch: nothing to do once the loop has ended, or when an earlier launch has
+    // run this outer iteration already (every wave of the grid reads the same two words: no block of this launch writes
+    // them before every block has posted a row, i.e. has read them)
+    if (F.enabled && (s_in.stop != 0 || s_in.next_outer != oi)) return;
+    int nseg[kKinds];
+    {
+      const bool build = self_prep && (!prep.run_build || *prep.run_build != 0);
+      if (build) {
+#pragma unroll
+        for (int k = 0; k < kKinds; ++k) nseg[k] = kind_set_of(prep, cv, k, lane, fb[k]).total;
+        if (lane < kKinds) seg_n_out[lane] = lane == 0 ? nseg[0] : (lane == 1 ? nseg[1] : (lane == 2 ? nseg[2] : nseg[3]));
+        if (lane < 6) {   // the set is built at this pose (k_prepare_small's x_build = x)
+          s_in.x_build[lane] = s_in.x[lane];
+          st->x_build[lane] = s_in.x[lane];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
+      }
+    }
+    if (s_in.done) return;            // a Solve that has already ended (uniform over the grid)
+    TL_PROF(lane == 0, 0)
+    unsigned long long step = 0;
+    for (;;) {   // outer iterations run by this launch (exactly one unless F.enabled)
+      int verdict = 2;
+      for (int it = 0;; ++it) {
+        __syncthreads();   // the block's other waves have put their sums into LDS
+        k3_post_row_tagged(partials, red, tag0 | step);
+        post_ext_row(partials, xs, xk, tag0 | step);
+        TL_PROF(lane == 0, 8 + it * 8 + 0)
+        bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | step, s_rows, tot, lane);
+        TL_PROF(lane == 0, 8 + it * 8 + 1)
+        if (ok) {
+          gn_consume(st, tot, lane, &s_in, s_scr);
+          TL_PROF(lane == 0, 8 + it * 8 + 2)
+          verdict = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
+          // the finish sums of this evaluation are wanted only if it was the Solve's last one
+          if (verdict == 2 && F.have_wp) ok = poll_fold_ext(partials, (int)gridDim.x, tag0 | step, s_ext, s_fin, lane);
+        }
+        if (!ok) {  // a block of the grid never posted: stop the Solve and report OS_COMM_ERROR
+          if (lane == 0) {
+            s_in.done = 1; s_in.comm_error = 1;
+            st->done = 1; st->comm_error = 1;
+            if (F.enabled) {
+              s_in.incomplete = OS_COMM_ERROR;
+              st->incomplete = OS_COMM_ERROR;
+              st->stop = 1; st->run_build = 0; st->run_refresh = 0;
+            }
+            *epoch = tag0 >> 8;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (F.enabled) {
+            mirror_wave(&s_in, F.hm[oi], lane, (int)OS_COMM_ERROR);
+            for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
+          }
+          solve_publish_pose(bcast, &s_in, tag0 | (step + 1ull), 5, lane);
+          return;
+        }
+        solve_publish_pose(bcast, &s_in, tag0 | (step + 1ull), verdict, lane);
+        TL_PROF(lane == 0, 8 + it * 8 + 3)
+        step += 2ull;
+        if (verdict != 1) break;
+      }
+      if (!F.enabled) {
+        // the launch ends with the Solve; a finish kernel that follows takes its sums from the state (fin_valid)
+        if (F.have_wp && lane < 5) {
+          const double v = s_fin[lane];
+          if (lane < 4) st->fin_sum[lane] = v; else st->fin_bad = v;
+        }
+        if (lane == 0) { st->fin_valid = F.have_wp ? 1 : 0; *epoch = tag0 >> 8; }   // (plain stores: read by the next launch)
         return;
       }
-      gn_consume(st, tot, lane, &s_in, s_scr);
-      TL_PROF(lane == 0, 8 + it * 8 + 2)
-      const bool go_on = s_in.done == 0 && it + 1 < max_sweeps;
-      solve_publish_pose(bcast, &s_in, tag0 | (unsigned long long)(it + 1), go_on, lane);
-      TL_PROF(lane == 0, 8 + it * 8 + 3)
-      if (!go_on) {
-        if (lane == 0) *epoch = tag0 >> 8;   // (plain store: read by the next launch)
+      const int next = finish_by_consumer(st, &s_in, F, oi, s_fin, nseg, s_sh, lane);
+      solve_publish_pose(bcast, &s_in, tag0 | step, next, lane);   // (the pose: exp(x), what the re-armed minimiser starts from)
+      step += 1ull;
+      if (next != 3) {
+        if (lane == 0) *epoch = tag0 >> 8;
         return;
       }
-      T = s_in.Rt_eval;
+      oi += 1;
+    }
+  }
+  // =================== every other wave: one chunk of correspondences, in registers for the whole launch ===================
+  ChunkData pre;
+  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
+  single_fetch(cv, seg0, stride0, wk, pre);   // requested in the wave's first instructions
+  // (with SolvePrep: speculatively -- right if the set is kept or refreshed; a set that is rebuilt is fetched from the slots)
+  FlagBytes fbytes;
+  if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
+  const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (read by every block before it can change: see above)
+  if (lane == 0) xk[wave] = wk.kind;
+  int oi = F.first_iter;
+  if (F.enabled && (st->stop != 0 || st->next_outer != oi)) return;
+  int n_mine = 0;
+  int slot[2] = {0, 0};
+  if (wk.kind >= 0) {
+    const bool build = self_prep && (!prep.run_build || *prep.run_build != 0);
+    if (build) {
+      n_mine = self_compact(prep, cv, wk, lane, fbytes, pre, slot);
     } else {
-      const int verdict = solve_wait_pose(bcast, tag0 | (unsigned long long)(it + 1), T);
-      TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
-      if (verdict != 1) return;
+      n_mine = seg_n[wk.kind];
+      if (self_prep) {
+        slots_of_chunk(prep, cv, wk, n_mine, slot);
+        if (prep.run_refresh && *prep.run_refresh != 0) self_refresh(prep, cv, wk, n_mine, slot, pre);
+      }
     }
+  }
+  if (st->done) return;            // a Solve that has already ended (uniform over the grid)
+  Rt T = st->Rt_eval;
+  unsigned long long step = 0;
+  for (;;) {
+    int verdict;
+    double2 last_cost = double2{0.0, 0.0};
+    for (int it = 0;; ++it) {
+      Acc a;
+      last_cost = double2{0.0, 0.0};
+      sweep_single_n(cv, n_mine, T, wk, pre, a, &last_cost);
+      TL_PROF(prof_p, 64 + it * 8 + 1)
+      const double wtot = wave_reduce_acc(a, lane);
+      if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
+      if (F.have_wp) {   // this chunk's part of the finish sums (see post_ext_row)
+        double cs = last_cost.x + last_cost.y;   // (a lane without a second / any factor holds 0 there)
+        double bad = 0.0;
+        if (wk.kind >= 0) {
+          const bool two = single_chunk_of(wk.kind) == kChunk;
+          if (wk.j < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.x)) bad += 1.0;
+          if (two && wk.j + 1 < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.y)) bad += 1.0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          cs += __shfl_down(cs, off, 64);
+          bad += __shfl_down(bad, off, 64);
+        }
+        if (lane == 0) { xs[wave][0] = cs; xs[wave][1] = bad; }
+      }
+      __syncthreads();
+      k3_post_row_tagged(partials, red, tag0 | step);     // (wave 0 of the block; in block 0 that is the consumer)
+      post_ext_row(partials, xs, xk, tag0 | step);
+      TL_PROF(prof_p, 64 + it * 8 + 2)
+      verdict = solve_wait_pose(bcast, tag0 | (step + 1ull), T);
+      TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
+      step += 2ull;
+      if (verdict != 1) break;
+    }
+    if (!F.enabled || verdict != 2) return;
+    // ---- the Solve is over: this chunk's new GNC weights (updateWeight, :858-876) from the costs of its last evaluation,
+    //      while the consumer ends the iteration
+    double2 w_new = pre.w;
+    if (wk.kind >= 0) {
+      const bool two = single_chunk_of(wk.kind) == kChunk;
+      if (wk.j < n_mine) {
+        w_new.x = refreshed_weight(F.wp[oi], wk.kind, last_cost.x, pre.w.x, prep.sv.w_src, slot[0]);
+      }
+      if (two && wk.j + 1 < n_mine) {
+        w_new.y = refreshed_weight(F.wp[oi], wk.kind, last_cost.y, pre.w.y, prep.sv.w_src, slot[1]);
+      }
+    }
+    const int next = solve_wait_pose(bcast, tag0 | step, T);
+    step += 1ull;
+    if (next != 3) return;
+    // ---- the next outer iteration on the same correspondences: new captured weights, zeroed side-channel slots (k_refresh)
+    if (wk.kind >= 0) {
+      const CorrSeg& seg = cv.k[wk.kind];
+      const bool two = single_chunk_of(wk.kind) == kChunk;
+      pre.w = w_new;
+      if (wk.j < n_mine) { seg.w[wk.j] = w_new.x; seg.cost[wk.j] = 0.0; }
+      if (two && wk.j + 1 < n_mine) { seg.w[wk.j + 1] = w_new.y; seg.cost[wk.j + 1] = 0.0; }
+    }
+    oi += 1;
   }
 }
 void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        const SolvePrep* prep_or_null, int* seg_n, hipStream_t s) {
+                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s) {
   SolvePrep P;
   if (prep_or_null) P = *prep_or_null;
   else memset(&P, 0, sizeof(P));
+  SolveFinish F;
+  if (finish_or_null) F = *finish_or_null;
+  else memset(&F, 0, sizeof(F));
   hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
-                     cv.seg_n, partials, ticket, bcast, cv, P, seg_n);
+                     cv.seg_n, partials, ticket, bcast, cv, P, seg_n, F);
 }
 bool solve_small_fits(int grid) {
   static const bool off = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;   // A/B knob: one launch per GN iteration

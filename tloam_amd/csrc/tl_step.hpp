@@ -555,7 +555,7 @@ __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS
     bool moved = false;
 #pragma unroll
     for (int i = 0; i < 6; ++i) moved = moved || (sm->x[i] != sm->x_build[i]);
-    if (lane == 0) st->spec_build = (v.done && moved) ? 1 : 0;
+    if (lane == 0) sm->spec_build = st->spec_build = (v.done && moved) ? 1 : 0;
   }
 }
 
