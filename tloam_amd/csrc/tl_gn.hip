@@ -1145,9 +1145,9 @@ __device__ __forceinline__ void self_refresh(const SolvePrep& P, const CorrView&
 // updateWeight (registration.cpp:858-876) and the cost sums (:1091-1094) look at the side-channel costs of the LAST
 // evaluation of the Solve -- which the wave that evaluated them still holds.  Every sweep, every wave adds up the costs of
 // its chunk (lane order, one shuffle tree) and counts the factors whose new weight would leave [0, 1] (the reference's
-// assert, :871); the block's waves meet in LDS, the block posts the four kind sums and the count as ONE more 64-byte
-// segment beside its row, and the consumer adds the blocks' segments in row order.  When the minimiser says "done" the
-// sums of the finish are already there: no pass over the costs, no hand-over of its own.
+// assert, :871) and posts the two numbers as a 64-byte segment of its own -- AFTER its block's row, off the path the next
+// pose waits on; the consumer, once the minimiser says "done", adds the waves' segments per kind in wave order.  By then
+// they have long arrived: no pass over the costs, no hand-over of its own.
 // Only a factor whose cost is within 1e-9 (relative) of an end of the band (th2, th1) can round out of [0, 1]: with
 // c = th1 (1 - d) the weight is ~ mu d / 2 against an error of a few 1e-16 mu, at the other end 1 - w ~ (mu + 1) d / 2
 // against a few 1e-16 (mu + 1); for those few (and for every factor in the band once the band is narrower than that) the
@@ -1160,31 +1160,27 @@ __device__ __forceinline__ bool weight_out_of_range(const WeightParams& wp, int 
   const double w = sqrt(wp.noise_bound_sq * wp.mu * (wp.mu + 1) / c) - wp.mu;  // :870
   return !(w >= 0.0 && w <= 1.0);
 }
-constexpr int kExtRowBase = 512;   // the blocks' extra segments: words kExtRowBase + 8 block .. of the row buffer
-// (called by every thread of the block after the barrier; xs[w] = {cost sum, count} of wave w, xk[w] its kind or -1)
-__device__ __forceinline__ void post_ext_row(double* __restrict__ partials, const double (*xs)[2], const int* xk, unsigned long long tag) {
-  const int t = (int)threadIdx.x - 32;   // lanes 32 .. 39 of wave 0 (the row itself is posted by lanes 0 .. 31)
-  if (t < 0 || t >= 8) return;
-  double val = 0.0;
-  if (t < 4) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) if (xk[w] == t) val += xs[w][0];
-  } else if (t == 4) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) val += xs[w][1];
-  }
-  unsigned long long wd = (unsigned long long)__double_as_longlong(val);
+constexpr int kExtRowBase = 512;   // the waves' extra segments: words kExtRowBase + 8 wave .. of the row buffer (wave = 4 block + wave in block)
+// lanes 0..7 of the wave: (cost sum, count, kind, 0, 0, 0, 0, tag ^ xor) -- cs / bad: the wave totals (lane 0's are used)
+__device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, int gw, double cs, double bad, int kind, unsigned long long tag,
+                                                 int lane) {
+  if (lane >= 8) return;
+  unsigned long long wd = 0ull;
+  const double cs0 = rdlane(cs, 0), bad0 = rdlane(bad, 0);
+  if (lane == 0) wd = (unsigned long long)__double_as_longlong(cs0);
+  else if (lane == 1) wd = (unsigned long long)__double_as_longlong(bad0);
+  else if (lane == 2) wd = (unsigned long long)(long long)kind;
   const unsigned long long x = xor8(wd);
-  if (t == 7) wd = tag ^ x;
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + kExtRowBase + (size_t)blockIdx.x * 8 + t, wd, __ATOMIC_RELAXED,
+  if (lane == 7) wd = tag ^ x;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + kExtRowBase + (size_t)gw * 8 + lane, wd, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-// the consumer wave: waits for the extra segment of every row (they were stored right behind the rows it has just folded)
-// and adds them in row order -> fin[0..4] in LDS.  false: timed out.
-__device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partials, int rows, unsigned long long tag, double* s_ext /*[16*8]*/,
+// the consumer wave: waits for the extra segment of every other wave of the grid (stored right behind the rows it folded a
+// step ago) and adds them per kind in wave order -> fin[0..4] in LDS.  false: timed out.  nwaves <= 64.
+__device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partials, int nwaves, unsigned long long tag, double* s_ext /*[64*3]*/,
                                               double* fin /*[8]*/, int lane) {
-  const bool have = lane < rows;
-  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + kExtRowBase + (size_t)(have ? lane : 0) * 8;
+  const bool have = lane >= 1 && lane < nwaves;   // (wave 0 is this one)
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + kExtRowBase + (size_t)(have ? lane : 1) * 8;
   unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
   bool ok_all;
@@ -1199,15 +1195,17 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  if (have) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) s_ext[lane * 8 + i] = __longlong_as_double((long long)w[i]);
-  }
+  s_ext[lane * 3 + 0] = have ? __longlong_as_double((long long)w[0]) : 0.0;
+  s_ext[lane * 3 + 1] = have ? __longlong_as_double((long long)w[1]) : 0.0;
+  s_ext[lane * 3 + 2] = have ? (double)(long long)w[2] : -1.0;   // the wave's kind
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane < 8) {
     double t = 0.0;
-    if (lane < 5)
-      for (int r = 0; r < rows; ++r) t += s_ext[r * 8 + lane];
+    if (lane < 4) {
+      for (int r = 1; r < nwaves; ++r) if (s_ext[r * 3 + 2] == (double)lane) t += s_ext[r * 3 + 0];
+    } else if (lane == 4) {
+      for (int r = 1; r < nwaves; ++r) t += s_ext[r * 3 + 1];
+    }
     fin[lane] = t;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1312,11 +1310,10 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
                                                         unsigned long long* __restrict__ bcast, CorrView cv, SolvePrep prep,
                                                         int* __restrict__ seg_n_out, SolveFinish F) {
   __shared__ double red[4][32];
-  __shared__ double xs[4][2];
-  __shared__ int xk[4];
   __shared__ double s_scr[32];
   __shared__ double s_rows[kTaggedRows * 28];
-  __shared__ double s_ext[kTaggedRows * 8];
+  __shared__ double s_ext[64 * 3];
+  static_assert(kTaggedRows * 4 <= 64, "one lane of the consumer per wave of the grid");
   __shared__ double s_fin[8];
   __shared__ double s_sh[16];
   __shared__ double tot[kReduceBuf];
@@ -1350,7 +1347,6 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
         reinterpret_cast<unsigned long long*>(&s_in)[w] = reinterpret_cast<const unsigned long long*>(st)[w];
     }
     if (lane < 32) red[0][lane] = 0.0;
-    if (lane == 0) { xs[0][0] = 0.0; xs[0][1] = 0.0; xk[0] = -1; }
     const unsigned long long tag0 = (*epoch + 1ull) << 8;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int oi = F.first_iter;
@@ -1382,7 +1378,6 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
       for (int it = 0;; ++it) {
         __syncthreads();   // the block's other waves have put their sums into LDS
         k3_post_row_tagged(partials, red, tag0 | step);
-        post_ext_row(partials, xs, xk, tag0 | step);
         TL_PROF(lane == 0, 8 + it * 8 + 0)
         bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | step, s_rows, tot, lane);
         TL_PROF(lane == 0, 8 + it * 8 + 1)
@@ -1391,7 +1386,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
           TL_PROF(lane == 0, 8 + it * 8 + 2)
           verdict = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
           // the finish sums of this evaluation are wanted only if it was the Solve's last one
-          if (verdict == 2 && F.have_wp) ok = poll_fold_ext(partials, (int)gridDim.x, tag0 | step, s_ext, s_fin, lane);
+          if (verdict == 2 && F.have_wp) ok = poll_fold_ext(partials, (int)gridDim.x * 4, tag0 | step, s_ext, s_fin, lane);
         }
         if (!ok) {  // a block of the grid never posted: stop the Solve and report OS_COMM_ERROR
           if (lane == 0) {
@@ -1444,7 +1439,6 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   FlagBytes fbytes;
   if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
   const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (read by every block before it can change: see above)
-  if (lane == 0) xk[wave] = wk.kind;
   int oi = F.first_iter;
   if (F.enabled && (st->stop != 0 || st->next_outer != oi)) return;
   int n_mine = 0;
@@ -1474,7 +1468,9 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
       TL_PROF(prof_p, 64 + it * 8 + 1)
       const double wtot = wave_reduce_acc(a, lane);
       if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
-      if (F.have_wp) {   // this chunk's part of the finish sums (see post_ext_row)
+      __syncthreads();
+      k3_post_row_tagged(partials, red, tag0 | step);     // (wave 0 of the block; in block 0 that is the consumer)
+      if (F.have_wp) {   // this chunk's part of the finish sums, behind the row (see post_ext_segment)
         double cs = last_cost.x + last_cost.y;   // (a lane without a second / any factor holds 0 there)
         double bad = 0.0;
         if (wk.kind >= 0) {
@@ -1487,11 +1483,8 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
           cs += __shfl_down(cs, off, 64);
           bad += __shfl_down(bad, off, 64);
         }
-        if (lane == 0) { xs[wave][0] = cs; xs[wave][1] = bad; }
+        post_ext_segment(partials, gw, cs, bad, wk.kind, tag0 | step, lane);
       }
-      __syncthreads();
-      k3_post_row_tagged(partials, red, tag0 | step);     // (wave 0 of the block; in block 0 that is the consumer)
-      post_ext_row(partials, xs, xk, tag0 | step);
       TL_PROF(prof_p, 64 + it * 8 + 2)
       verdict = solve_wait_pose(bcast, tag0 | (step + 1ull), T);
       TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
