@@ -463,3 +463,50 @@ def test_staged_frames_equal_direct_hand_over(hip_module):
     assert H.sm_begin(scenes[1].T_pred) == 0
     assert H.L.tloam_frame_select(H.h, 0) == -6            # TLOAM_E_NOT_READY inside a solve
     H.close()
+
+
+def test_concurrent_frame_streams_share_the_gpu(hip_module):
+    """Three contexts, three host threads, one GPU: the launches of different streams interleave, a block of a one-launch
+    Solve starts late, a wave is slow to look at a hand-over -- nothing may depend on that.  Every frame of every stream
+    must come out bit-identical to the same frame solved alone, with no hand-over timing out (a missed hand-over costs a
+    full second: the run is bounded well below that per frame).  Regression test for a message overwritten before every
+    wave had read it (the end-of-iteration verdict of k_solve_small)."""
+    import threading
+    import time
+    scenes = [synth.make_scene(seed=40 + i, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT) for i in range(3)]
+    alone = []
+    for sc in scenes:
+        H = hip_module.HipRegistration()
+        H.set_frames(sc.source, sc.target)
+        rc, T, st = H.scan_match(sc.T_pred)
+        assert rc == 0
+        alone.append(_frame_fingerprint(H, T, st))
+        H.close()
+    Hs = [hip_module.HipRegistration() for _ in scenes]
+    for H, sc in zip(Hs, scenes):
+        H.set_frames(sc.source, sc.target)
+    frames = 150
+    out = [None] * 3
+    worst = [0.0] * 3
+    start = threading.Barrier(3)
+
+    def run(i):
+        start.wait()
+        bad = []
+        for f in range(frames):
+            t = time.perf_counter()
+            rc, T, st = Hs[i].scan_match(scenes[i].T_pred)
+            worst[i] = max(worst[i], time.perf_counter() - t)
+            if rc != 0:
+                bad.append((f, rc, Hs[i].L.tloam_last_error(Hs[i].h).decode()))
+        out[i] = (bad, _frame_fingerprint(Hs[i], T, st))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(3):
+        bad, fp = out[i]
+        assert bad == [], bad[:3]
+        assert worst[i] < 0.25, worst           # (a frame is ~0.25 ms; a timed-out hand-over would be 1 s)
+        _assert_same_frame(alone[i], fp)
+    for H in Hs: H.close()

@@ -489,8 +489,8 @@ int ensure_common(tloam_ctx* c) {
   if (!c->k3_ticket.p) {
     HIPC(c, c->k3_ticket.reserve(4));
     HIPC(c, hipMemsetAsync(c->k3_ticket.p, 0, 4 * sizeof(int), c->stream));
-    HIPC(c, c->k3_bcast.reserve(16));
-    HIPC(c, hipMemsetAsync(c->k3_bcast.p, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIPC(c, c->k3_bcast.reserve(64));   // two messages of 16 words, a cache line apart each (k_solve_small: poses / end-of-iteration verdicts)
+    HIPC(c, hipMemsetAsync(c->k3_bcast.p, 0, 64 * sizeof(unsigned long long), c->stream));
   }
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;

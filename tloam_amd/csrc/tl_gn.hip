@@ -1225,6 +1225,11 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
 // arithmetic per wave, the same fold order, the same step as the one-launch-per-iteration kernels.
 // max_sweeps: evaluations a Solve of this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
 constexpr int kBcastWords = 16;
+// The verdict that ends an outer iteration (3 / 4) follows the "Solve is over" message (2) without anything from the other
+// waves in between -- a wave that is slow to look (the GPU shared with other streams) would find the second message where it
+// expects the first and wait for ever: it has a place of its own.  Every other message is answered by a row of every block
+// before the next one is written.
+constexpr int kBcastSecond = 32;   // words
 // verdict: 1 go on with this Solve | 2 the Solve is over | 3 next outer iteration in this launch, from this pose | 4 leave |
 // 5 hand-over failed, leave
 __device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
@@ -1422,7 +1427,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
         return;
       }
       const int next = finish_by_consumer(st, &s_in, F, oi, s_fin, nseg, s_sh, lane);
-      solve_publish_pose(bcast, &s_in, tag0 | step, next, lane);   // (the pose: exp(x), what the re-armed minimiser starts from)
+      solve_publish_pose(bcast + kBcastSecond, &s_in, tag0 | step, next, lane);   // (the pose: exp(x), what the re-armed minimiser starts from)
       step += 1ull;
       if (next != 3) {
         if (lane == 0) *epoch = tag0 >> 8;
@@ -1504,7 +1509,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
         w_new.y = refreshed_weight(F.wp[oi], wk.kind, last_cost.y, pre.w.y, prep.sv.w_src, slot[1]);
       }
     }
-    const int next = solve_wait_pose(bcast, tag0 | step, T);
+    const int next = solve_wait_pose(bcast + kBcastSecond, tag0 | step, T);
     step += 1ull;
     if (next != 3) return;
     // ---- the next outer iteration on the same correspondences: new captured weights, zeroed side-channel slots (k_refresh)
