@@ -983,6 +983,8 @@ int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, c
 // host bookkeeping of a finished outer iteration from the mirrored state S (:1089-1121); returns whether the loop ends.
 // *weight_violation: the reference's assert (:871) would have fired in this iteration.
 bool account_outer(tloam_ctx* c, int iter, const GnState& S, double mu, int sweeps_before, bool* weight_violation) {
+  // (an iteration that ran inside the launch of an earlier one was never planned: planned_sweeps_for has not sized the history)
+  if (c->planned_sweeps.size() < 3 * ((size_t)iter + 1)) c->planned_sweeps.resize(3 * ((size_t)iter + 1), 0);
   int* hist = &c->planned_sweeps[3 * (size_t)iter];
   {
     const int used = std::min(std::max(S.gn_sweeps - sweeps_before, 1), kSolveSweeps);
@@ -1117,7 +1119,40 @@ struct DeviceLoopPlan {
   int planned[kMaxOuterFast] = {}, solve_start[kMaxOuterFast] = {}, used[kMaxOuterFast] = {};
   double mus[kMaxOuterFast] = {};
   HostMirror hms[kMaxOuterFast];
+  // finish-in-the-Solve mode (SolveFinish): the launches of iterations [0, enq_end) are in the stream; a later iteration is
+  // enqueued when the device says that it is needed (OS_NEEDS_HOST) -- see scan_match_device_loop
+  bool in_launch_finish = false;
+  int enq_end = 0;
+  SolveFinish F;
+  SolvePrep prep;
 };
+// iterations enqueued ahead of the device's verdicts in finish-in-the-Solve mode: iteration 0 almost always moves the pose
+// (so the search and the Solve of iteration 1 will run), the later ones almost never do (they run inside the launch of
+// iteration 1): launches for them would be no-ops that the frame's successor has to queue behind.
+constexpr int kEnqueueAhead = 2;
+int enqueue_ahead() {
+  static const int v = [] { const char* e = getenv("TLOAM_ENQUEUE_AHEAD"); return e ? std::max(1, atoi(e)) : kEnqueueAhead; }();
+  return v;
+}
+// finish-in-the-Solve mode: the launches of iterations [from, to): the search if the pose moved (always in the frame's
+// first), then the Solve + finish -- a launch that returns at once when an earlier one has already run its iteration
+int enqueue_iterations_in_launch_mode(tloam_ctx* c, int from, int to, const BuildParams& bp, const GridView grids[kKinds],
+                                      DeviceLoopPlan& P) {
+  GnState* st = c->state.p;
+  for (int iter = from; iter < to; ++iter) {
+    int rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, iter == 0 ? nullptr : &st->run_build, nullptr, /*prepare_in_solve=*/true);
+    if (rc != TLOAM_OK) return rc;
+    P.prep.run_build = iter == 0 ? nullptr : &st->run_build;
+    P.prep.run_refresh = iter == 0 ? nullptr : &st->run_refresh;
+    P.F.first_iter = iter;
+    P.planned[iter] = planned_sweeps_for(c, iter);
+    P.solve_start[iter] = c->batch_launches;
+    rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], &P.F.wp[iter], &P.prep, &P.F);
+    if (rc != TLOAM_OK) return rc;
+  }
+  if (to > P.enq_end) P.enq_end = to;
+  return TLOAM_OK;
+}
 // enqueue outer iterations first .. M-1.  first == 0: the frame's first iteration (always builds).  first > 0: a restart
 // behind a stand-alone finish of iteration first - 1 that has set the gates (run_build / run_refresh) on the device.
 int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildParams& bp, const GridView grids[kKinds],
@@ -1143,9 +1178,10 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   // ... and the finish of an iteration (weights, sums, loop decisions, result slot): a launch of its own / riding on the next
   // search, or the tail of the one-launch Solve, which then goes on with the next iteration itself while the pose stands still
   const bool fin_in_solve = in_solve && finish_small_path(c) && !c->no_finish_in_solve && M <= kMaxOuterInLaunch;
-  SolveFinish F;
-  memset(&F, 0, sizeof(F));
+  P.in_launch_finish = fin_in_solve;
   if (fin_in_solve) {
+    SolveFinish& F = P.F;
+    memset(&F, 0, sizeof(F));
     F.enabled = 1;
     F.have_wp = 1;
     F.n_iter = M;
@@ -1159,20 +1195,9 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
       F.hm[iter] = P.hms[iter];
       m = m * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
     }
-    for (int iter = first; iter < M; ++iter) {
-      // iteration `iter`: the search if the pose moved (always in the frame's first), then the Solve + finish -- a launch
-      // that returns at once when an earlier one has already run this iteration
-      rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, iter == 0 ? nullptr : run_build, nullptr, /*prepare_in_solve=*/true);
-      if (rc != TLOAM_OK) return rc;
-      prep.run_build = iter == 0 ? nullptr : run_build;
-      prep.run_refresh = iter == 0 ? nullptr : run_refresh;
-      F.first_iter = iter;
-      P.planned[iter] = planned_sweeps_for(c, iter);
-      P.solve_start[iter] = c->batch_launches;
-      rc = enqueue_solve(c, /*armed=*/true, P.planned[iter], &F.wp[iter], &prep, &F);
-      if (rc != TLOAM_OK) return rc;
-    }
-    return TLOAM_OK;
+    P.prep = prep;
+    P.enq_end = first;
+    return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + enqueue_ahead()), bp, grids, P);
   }
   for (int iter = first; iter < M; ++iter) {
     if (iter == 0) {
@@ -1224,16 +1249,24 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   DeviceLoopPlan P;
   rc = enqueue_outer_iterations(c, 0, initial_mu(c), bp, grids, P);
   if (rc != TLOAM_OK) return rc;
-  rc = wait_state(c, P.hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did
-  if (rc != TLOAM_OK) return rc;
+  if (!P.in_launch_finish) {
+    rc = wait_state(c, P.hms[M - 1], M - 1);   // the last slot is written last (stream order), whatever the frame did
+    if (rc != TLOAM_OK) return rc;
+  }
   // ---- the frame's bookkeeping, iteration by iteration, from the mirrored slots
   int topups = 0;
   for (int iter = 0; iter < M; ++iter) {
-    if (iter < M - 1) {   // (written before the last slot: already there -- this only unpacks it)
+    if (iter < M - 1 || P.in_launch_finish) {
+      // (all launches enqueued: written before the last slot, already there -- this only unpacks it.  Finish-in-the-Solve
+      //  mode: the slots are waited for in order -- the frame's result is there when its last iteration's is, and a launch
+      //  may have to be added on the way)
       rc = wait_state(c, P.hms[iter], iter);
       if (rc != TLOAM_OK) return rc;
     }
-    const GnState* S = &c->h_state[iter];
+    GnState* Sm = &c->h_state[iter];
+    const bool needs_host = (Sm->incomplete & OS_NEEDS_HOST) != 0;
+    Sm->incomplete &= ~(int)OS_NEEDS_HOST;
+    const GnState* S = Sm;
     if (S->host_seq != P.hms[iter].seq) {
       c->last_error = "device-driven loop: the result slot of an outer iteration was not written";
       return TLOAM_E_HIP;
@@ -1266,9 +1299,11 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
         rc = enqueue_outer_iterations(c, iter + 1, P.mus[iter] * exp((double)(iter + 1) * c->cfg.gnc_factor), bp, grids, P);
         if (rc != TLOAM_OK) return rc;
       }
-      rc = wait_state(c, P.hms[M - 1], M - 1);
-      if (rc != TLOAM_OK) return rc;
-      if (iter < M - 1) {
+      if (!P.in_launch_finish) {
+        rc = wait_state(c, P.hms[M - 1], M - 1);
+        if (rc != TLOAM_OK) return rc;
+      }
+      if (iter < M - 1 || P.in_launch_finish) {
         rc = wait_state(c, P.hms[iter], iter);
         if (rc != TLOAM_OK) return rc;
       }
@@ -1292,6 +1327,12 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     P.used[iter] = std::min(S->gn_sweeps - sweeps_before, P.planned[iter]);
     if (wv) *weight_violation = true;
     if (fin) break;
+    // the launch that ran this iteration has ended because the pose moved: the search and the Solve of the next one, unless
+    // they are in the stream already
+    if (P.in_launch_finish && needs_host && iter + 1 >= P.enq_end && iter + 1 < M) {
+      rc = enqueue_iterations_in_launch_mode(c, iter + 1, iter + 2, bp, grids, P);
+      if (rc != TLOAM_OK) return rc;
+    }
   }
   rc = harvest_k3_events_multi(c, M, P.solve_start, P.used);
   if (rc != TLOAM_OK) return rc;

@@ -153,7 +153,10 @@ struct HostMirror {
   unsigned long long seq;
 };
 // status of an outer iteration as the host reads it in GnState.incomplete
-enum OuterStatus : int { OS_OK = 0, OS_INCOMPLETE = 1, OS_COMM_ERROR = 3, OS_PLATEAU = 4, OS_SKIPPED = 8 };
+// OS_NEEDS_HOST (a flag on top of the status, result slot only): the launch that finished this iteration inside the Solve
+// has ended because the pose moved -- the loop goes on with a correspondence search, which the host enqueues unless it
+// already has
+enum OuterStatus : int { OS_OK = 0, OS_INCOMPLETE = 1, OS_COMM_ERROR = 3, OS_PLATEAU = 4, OS_SKIPPED = 8, OS_NEEDS_HOST = 16 };
 // device-driven loop control handed to the finish kernels (fast == 0: the host decides, as in the stepwise API)
 struct OuterCtl {
   double cost_threshold;  // registration.cpp:1108

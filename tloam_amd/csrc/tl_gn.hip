@@ -1195,20 +1195,25 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  s_ext[lane * 3 + 0] = have ? __longlong_as_double((long long)w[0]) : 0.0;
-  s_ext[lane * 3 + 1] = have ? __longlong_as_double((long long)w[1]) : 0.0;
-  s_ext[lane * 3 + 2] = have ? (double)(long long)w[2] : -1.0;   // the wave's kind
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane < 8) {
-    double t = 0.0;
-    if (lane < 4) {
-      for (int r = 1; r < nwaves; ++r) if (s_ext[r * 3 + 2] == (double)lane) t += s_ext[r * 3 + 0];
-    } else if (lane == 4) {
-      for (int r = 1; r < nwaves; ++r) t += s_ext[r * 3 + 1];
-    }
-    fin[lane] = t;
+  // per kind, one fixed shuffle tree over the waves (lane = wave): any fixed order will do -- every path that ends an
+  // outer iteration of a one-launch Solve takes its sums from here
+  const double cs = have ? __longlong_as_double((long long)w[0]) : 0.0;
+  const double bad = have ? __longlong_as_double((long long)w[1]) : 0.0;
+  const int kind = have ? (int)(long long)w[2] : -1;
+  double t[5];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = kind == k ? cs : 0.0;
+  t[4] = bad;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] += __shfl_down(t[k], off, 64);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) fin[k] = t[k];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  (void)s_ext;
   return ok_all;
 }
 
@@ -1229,7 +1234,10 @@ constexpr int kBcastWords = 16;
 // waves in between -- a wave that is slow to look (the GPU shared with other streams) would find the second message where it
 // expects the first and wait for ever: it has a place of its own.  Every other message is answered by a row of every block
 // before the next one is written.
-constexpr int kBcastSecond = 32;   // words
+#ifndef TLOAM_BCAST_SECOND
+#define TLOAM_BCAST_SECOND 32
+#endif
+constexpr int kBcastSecond = TLOAM_BCAST_SECOND;   // words
 // verdict: 1 go on with this Solve | 2 the Solve is over | 3 next outer iteration in this launch, from this pose | 4 leave |
 // 5 hand-over failed, leave
 __device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
@@ -1303,7 +1311,8 @@ __device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LD
   // the image into the device state (every word up to the development stamps), the result slot, and -- once the loop has
   // ended -- the slots of the iterations that will not run (what their gated-off finish kernels would have written)
   for (int w = lane; w < kWords; w += 64) reinterpret_cast<unsigned long long*>(st)[w] = reinterpret_cast<const unsigned long long*>(sm)[w];
-  mirror_wave(sm, F.hm[oi], lane);
+  // (the slot says whether the host has something to do: the loop goes on, but not inside this launch)
+  mirror_wave(sm, F.hm[oi], lane, (sm->stop == 0 && next == 4) ? (int)(sm->incomplete | OS_NEEDS_HOST) : -1);
   if (sm->stop != 0)
     for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(sm, F.hm[j], lane, (int)OS_SKIPPED);
   return next;
