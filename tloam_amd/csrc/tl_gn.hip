@@ -601,7 +601,9 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
       for (int g = 0; g < 8; ++g) {
         const double a = g < rows ? s_rows[g * 28 + lane] : 0.0;
         const double b = g + 8 < rows ? s_rows[(g + 8) * 28 + lane] : 0.0;
-        t += (((a + 0.0) + 0.0) + 0.0) + (((b + 0.0) + 0.0) + 0.0);
+        // (fold_rows adds fourteen zeros to these two: x + 0.0 is x except for x = -0.0, and a -0.0 -- or +0.0 -- added to
+        //  an accumulator that started at +0.0 leaves it as it is: the same bits without the fourteen additions)
+        t += a + b;
       }
     }
     s_tot[lane] = t;
@@ -1387,44 +1389,50 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
     if (s_in.done) return;            // a Solve that has already ended (uniform over the grid)
     TL_PROF(lane == 0, 0)
     unsigned long long step = 0;
+    int oi_now = oi;
+    auto comm_failed = [&](unsigned long long* where, unsigned long long tag) {
+      if (lane == 0) {
+        s_in.done = 1; s_in.comm_error = 1;
+        st->done = 1; st->comm_error = 1;
+        if (F.enabled) {
+          s_in.incomplete = OS_COMM_ERROR;
+          st->incomplete = OS_COMM_ERROR;
+          st->stop = 1; st->run_build = 0; st->run_refresh = 0;
+        }
+        *epoch = tag0 >> 8;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (F.enabled) {
+        mirror_wave(&s_in, F.hm[oi_now], lane, (int)OS_COMM_ERROR);
+        for (int j = oi_now + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
+      }
+      solve_publish_pose(where, &s_in, tag, 5, lane);
+    };
     for (;;) {   // outer iterations run by this launch (exactly one unless F.enabled)
       int verdict = 2;
       for (int it = 0;; ++it) {
         __syncthreads();   // the block's other waves have put their sums into LDS
         k3_post_row_tagged(partials, red, tag0 | step);
         TL_PROF(lane == 0, 8 + it * 8 + 0)
-        bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | step, s_rows, tot, lane);
+        const bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | step, s_rows, tot, lane);
         TL_PROF(lane == 0, 8 + it * 8 + 1)
-        if (ok) {
-          gn_consume(st, tot, lane, &s_in, s_scr);
-          TL_PROF(lane == 0, 8 + it * 8 + 2)
-          verdict = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
-          // the finish sums of this evaluation are wanted only if it was the Solve's last one
-          if (verdict == 2 && F.have_wp) ok = poll_fold_ext(partials, (int)gridDim.x * 4, tag0 | step, s_ext, s_fin, lane);
-        }
         if (!ok) {  // a block of the grid never posted: stop the Solve and report OS_COMM_ERROR
-          if (lane == 0) {
-            s_in.done = 1; s_in.comm_error = 1;
-            st->done = 1; st->comm_error = 1;
-            if (F.enabled) {
-              s_in.incomplete = OS_COMM_ERROR;
-              st->incomplete = OS_COMM_ERROR;
-              st->stop = 1; st->run_build = 0; st->run_refresh = 0;
-            }
-            *epoch = tag0 >> 8;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (F.enabled) {
-            mirror_wave(&s_in, F.hm[oi], lane, (int)OS_COMM_ERROR);
-            for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
-          }
-          solve_publish_pose(bcast, &s_in, tag0 | (step + 1ull), 5, lane);
+          comm_failed(bcast, tag0 | (step + 1ull));
           return;
         }
+        gn_consume(st, tot, lane, &s_in, s_scr);
+        TL_PROF(lane == 0, 8 + it * 8 + 2)
+        verdict = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
         solve_publish_pose(bcast, &s_in, tag0 | (step + 1ull), verdict, lane);
         TL_PROF(lane == 0, 8 + it * 8 + 3)
         step += 2ull;
         if (verdict != 1) break;
+      }
+      // the finish sums of the Solve's last evaluation (the waves' segments behind the rows of hand-over step - 2), while
+      // the other waves take in the verdict
+      if (F.have_wp && !poll_fold_ext(partials, (int)gridDim.x * 4, tag0 | (step - 2ull), s_ext, s_fin, lane)) {
+        comm_failed(bcast + kBcastSecond, tag0 | step);   // (where the other waves look next, if they look at all)
+        return;
       }
       if (!F.enabled) {
         // the launch ends with the Solve; a finish kernel that follows takes its sums from the state (fin_valid)
@@ -1443,6 +1451,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
         return;
       }
       oi += 1;
+      oi_now = oi;
     }
   }
   // =================== every other wave: one chunk of correspondences, in registers for the whole launch ===================
