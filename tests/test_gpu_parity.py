@@ -510,3 +510,35 @@ def test_concurrent_frame_streams_share_the_gpu(hip_module):
         assert worst[i] < 0.25, worst           # (a frame is ~0.25 ms; a timed-out hand-over would be 1 s)
         _assert_same_frame(alone[i], fp)
     for H in Hs: H.close()
+
+
+@pytest.mark.parametrize("knob", ["TLOAM_NO_SELF_PREPARE=1", "TLOAM_NO_FINISH_IN_SOLVE=1", "TLOAM_ENQUEUE_AHEAD=1",
+                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1"])
+def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
+    """The Solve launch of a KITTI-size frame prepares its own factor set, ends its outer iteration and runs the following ones;
+    the host enqueues launches for two iterations and adds one when the device asks.  Each piece can be switched off --
+    k_prepare_small in front of the Solve, the finish as a kernel of its own, one or all four iterations enqueued ahead, one
+    launch per GN iteration -- and nothing may change: three scenes (one with a large prediction error, whose pose keeps moving
+    in later outer iterations: the host-resumed path), two frames each, everything compared bit for bit (with one launch per
+    GN iteration the four cost sums are added in the finish kernel's order: last bits, see _assert_same_frame)."""
+    name, val = knob.split("=")
+    scenes = [synth.make_scene(seed=61, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT),
+              synth.make_scene(seed=62, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, pred_err=(0.25, -0.15, 0.05, 0.02, -0.015, 0.03)),
+              synth.make_scene(seed=63, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT)]
+    ref = []
+    for sc in scenes:
+        H = hip_module.HipRegistration()
+        H.set_frames(sc.source, sc.target)
+        ref.append([(lambda r: _frame_fingerprint(H, r[1], r[2]))(H.scan_match(sc.T_pred)) for _ in range(2)])
+        H.close()
+    monkeypatch.setenv(name, val)       # read once, when the context is created
+    moved_late = 0
+    for sc, want in zip(scenes, ref):
+        H = hip_module.HipRegistration()
+        H.set_frames(sc.source, sc.target)
+        for f in range(2):
+            rc, T, st = H.scan_match(sc.T_pred)
+            assert rc == 0
+            _assert_same_frame(want[f], _frame_fingerprint(H, T, st), cost_sum_rtol=1e-13 if name == "TLOAM_NO_PERSISTENT_SOLVE" else 0.0)
+        moved_late += st["accepted_steps"] > 1
+        H.close()

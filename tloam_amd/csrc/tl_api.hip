@@ -584,6 +584,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
+  c->enqueue_ahead = getenv("TLOAM_ENQUEUE_AHEAD") ? std::max(1, atoi(getenv("TLOAM_ENQUEUE_AHEAD"))) : 0;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1129,11 +1130,7 @@ struct DeviceLoopPlan {
 // iterations enqueued ahead of the device's verdicts in finish-in-the-Solve mode: iteration 0 almost always moves the pose
 // (so the search and the Solve of iteration 1 will run), the later ones almost never do (they run inside the launch of
 // iteration 1): launches for them would be no-ops that the frame's successor has to queue behind.
-constexpr int kEnqueueAhead = 2;
-int enqueue_ahead() {
-  static const int v = [] { const char* e = getenv("TLOAM_ENQUEUE_AHEAD"); return e ? std::max(1, atoi(e)) : kEnqueueAhead; }();
-  return v;
-}
+constexpr int kEnqueueAhead = 2;   // (TLOAM_ENQUEUE_AHEAD, read when the context is created: tloam_ctx::enqueue_ahead)
 // finish-in-the-Solve mode: the launches of iterations [from, to): the search if the pose moved (always in the frame's
 // first), then the Solve + finish -- a launch that returns at once when an earlier one has already run its iteration
 int enqueue_iterations_in_launch_mode(tloam_ctx* c, int from, int to, const BuildParams& bp, const GridView grids[kKinds],
@@ -1197,7 +1194,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
     }
     P.prep = prep;
     P.enq_end = first;
-    return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + enqueue_ahead()), bp, grids, P);
+    return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + (c->enqueue_ahead > 0 ? c->enqueue_ahead : kEnqueueAhead)), bp, grids, P);
   }
   for (int iter = first; iter < M; ++iter) {
     if (iter == 0) {

@@ -169,6 +169,7 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
+  int enqueue_ahead = 0;           // TLOAM_ENQUEUE_AHEAD: outer iterations enqueued ahead of the device's verdicts (0: the default)
   bool no_finish_in_solve = false; // TLOAM_NO_FINISH_IN_SOLVE: the finish of an outer iteration stays a launch of its own (A/B, tests)
   bool no_self_prepare = false;    // TLOAM_NO_SELF_PREPARE: k_prepare_small in front of every one-launch Solve (A/B, tests)
   bool no_fused_small = false;     // TLOAM_NO_FUSED_SMALL: KITTI-size sets keep sweep and step as two launches (A/B, tests)
