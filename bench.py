@@ -410,12 +410,13 @@ def main():
             if args.workload == "kitti":
                 bb = head["k3"]["back_to_back"]
                 roofline["headline_workload_k3"] = {
-                    "kernel": "k_sweep_step_small (sweep + ticket + 6x6 step in one launch); the sweep alone = k3_accumulate<true>",
+                    "kernel": "k_solve_small (one launch per run of outer iterations: compaction, every GN iteration -- sweep, rows, "
+                              "6x6 step --, weights and loop decisions); the sweep alone = k3_accumulate<true>",
                     "sweep_alone_back_to_back": bb,
-                    "note": "KITTI-cap sets (442 KB per sweep) are launch-latency bound, not bandwidth bound: in the frames the sweep "
-                            "runs fused with the minimiser step (no separate K3 launch to time, ~9 us per fused iteration in "
-                            "profiles/r03_bench_default_kernel_stats.csv); the figure here is the stand-alone sweep kernel on the "
-                            "frame's last correspondence set"}
+                    "note": "KITTI-cap sets (442 KB per sweep) are latency bound, not bandwidth bound: in the frames the sweep runs "
+                            "inside the persistent Solve launch with its correspondences held in registers (no K3 launch to time; "
+                            "~8.6 us per GN iteration, profiles/r03_solve_small_timeline.txt); the figure here is the stand-alone "
+                            "sweep kernel on the frame's last correspondence set"}
         out = {
             "metric": "gauss_newton_iters_per_sec", "value": round(head["gn_iters_per_sec"], 2), "unit": "GN iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
