@@ -10,7 +10,7 @@ name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
 rows = c.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
 names = [r[0].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("tl::", "") for r in rows]
 st = np.array([r[1] for r in rows], float); en = np.array([r[2] for r in rows], float)
-fi = [i for i, n in enumerate(names) if n.startswith("k_grid_count_all")]     # a frame starts with the grid build
+fi = [i for i, n in enumerate(names) if n.startswith("k_grid_count_all") or n.startswith("k_grid_build_coop")]     # a frame starts with the grid build
 fi = fi[len(fi) // 2: len(fi) // 2 + 40]
 agg = collections.OrderedDict()
 frames = []
