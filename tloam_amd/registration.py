@@ -73,12 +73,13 @@ class Stats(C.Structure):
     ]
 
     def as_dict(self):
-        return dict(outer_iterations=self.outer_iterations, gn_evaluations=self.gn_evaluations,
-                    gn_iterations=self.gn_iterations, accepted_steps=self.accepted_steps,
-                    n_corr=list(self.n_corr), converged_early=self.converged_early,
-                    bad_weights=self.weight_range_violations, kind_cost=list(self.kind_cost), mu=self.mu,
-                    solver_cost=self.solver_cost, se3=np.array(self.se3), gn_sweeps=self.gn_sweeps,
-                    host_wait_us=self.host_wait_us)
+        # (on the per-frame path of every caller: array fields as slices / a buffer view, ~2 us instead of ~4)
+        return {"outer_iterations": self.outer_iterations, "gn_evaluations": self.gn_evaluations,
+                "gn_iterations": self.gn_iterations, "accepted_steps": self.accepted_steps,
+                "n_corr": self.n_corr[:], "converged_early": self.converged_early,
+                "bad_weights": self.weight_range_violations, "kind_cost": self.kind_cost[:], "mu": self.mu,
+                "solver_cost": self.solver_cost, "se3": np.frombuffer(self.se3, dtype=np.float64).copy(),
+                "gn_sweeps": self.gn_sweeps, "host_wait_us": self.host_wait_us}
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
