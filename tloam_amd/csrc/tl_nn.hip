@@ -292,7 +292,7 @@ static int max_n(const GridSet& gs) {
 void launch_grid_count_all(const GridSet& gs, unsigned long long* cell_cnt, int* cell_of_pt, int* rank_of_pt,
                            hipStream_t s, const FrameInitHook* frame) {
   int blocks = (max_n(gs) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096) blocks = 4096;   // (1 M points: one point per thread -- every atomic / scattered store of the pass in flight at once)
   FrameInit fi;
   FrameInitBufs fb;
   memset(&fi, 0, sizeof(fi));
@@ -394,14 +394,14 @@ void launch_grid_finalize_scatter_all(const GridSet& gs, const unsigned long lon
   for (int k = 0; k < kKinds; ++k) m = std::max(m, gs.ncell[k] + 1);
   const int fin_blocks = (int)std::min<long long>((m + 255) / 256, 2048);
   int sc_blocks = (max_n(gs) + 255) / 256;
-  if (sc_blocks > 1024) sc_blocks = 1024;
+  if (sc_blocks > 4096) sc_blocks = 4096;
   hipLaunchKernelGGL(k_grid_finalize_scatter_all, dim3(fin_blocks + sc_blocks, kKinds), dim3(256), 0, s, gs, cell_scan, totals,
                      tiles, fin_blocks, cell_start, cell_cnt, cell_of_pt, rank_of_pt, gp);
 }
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
                              const int* rank_of_pt, double4* gp, hipStream_t s) {
   int blocks = (max_n(gs) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096) blocks = 4096;   // (1 M points: one point per thread -- every atomic / scattered store of the pass in flight at once)
   hipLaunchKernelGGL(k_grid_scatter_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_scan, rank_of_pt, gp);
 }
 
