@@ -367,7 +367,7 @@ def test_device_driven_loop_equals_host_driven_loop(hip_module, monkeypatch, sha
     H1.close(); H2.close()
 
 
-def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module, monkeypatch):
+def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module, monkeypatch, capfd):
     """The same comparison over 100 randomly drawn frame pairs -- noise, prediction error, outliers, binding caps, loop length,
     plateau threshold and GNC factor all vary -- so that the rarer branches of the device-side control are met: a
     plateau break after a Solve that moved the pose (the correspondence search that rode on that finish is then never
@@ -375,6 +375,8 @@ def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module,
     stepwise path).  The branch census is asserted so that the test cannot silently stop covering them."""
     rng = np.random.default_rng(2024)
     census = {"plateau": 0, "max_iter": 0, "moved_then_plateau": 0, "frames": 0}
+    monkeypatch.setenv("TLOAM_DEBUG_RESUME", "1")   # a line on stderr whenever the host adds a launch on the device's flag (OS_NEEDS_HOST)
+    capfd.readouterr()
     for case in range(100):
         over = dict(max_iterations=int(rng.integers(2, 7)), cost_threshold=float(rng.choice([1e-3, 2e-2, 0.5, 5.0, 50.0])),
                     gnc_factor=float(rng.choice([0.5, 1.0, 1.4, 2.0])))
@@ -406,7 +408,9 @@ def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module,
             elif st1["outer_iterations"] == over["max_iterations"]:
                 census["max_iter"] += 1
         H1.close(); H2.close()
+    census["host_resumed"] = capfd.readouterr().err.count("[tloam resume]")
     assert census["plateau"] >= 15 and census["max_iter"] >= 15 and census["moved_then_plateau"] >= 3, census
+    assert census["host_resumed"] >= 3, census   # the pose kept moving after the iterations that were enqueued ahead
     print("census", census)
 
 

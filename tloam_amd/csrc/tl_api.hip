@@ -1327,6 +1327,8 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     // the launch that ran this iteration has ended because the pose moved: the search and the Solve of the next one, unless
     // they are in the stream already
     if (P.in_launch_finish && needs_host && iter + 1 >= P.enq_end && iter + 1 < M) {
+      const bool trace = getenv("TLOAM_DEBUG_RESUME") != nullptr;   // development aid / test census: how often the host adds a launch
+      if (trace) fprintf(stderr, "[tloam resume] outer iteration %d enqueued by the host\n", iter + 1);
       rc = enqueue_iterations_in_launch_mode(c, iter + 1, iter + 2, bp, grids, P);
       if (rc != TLOAM_OK) return rc;
     }
