@@ -1113,8 +1113,12 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
 // registration.cpp:1108-1121 itself (plateau break, max_iterations, the next iteration's gates) and mirrors the
 // iteration's result into its own pinned slot -- and the host waits ONCE, for the last slot.  (The stepwise API keeps
 // the host in the loop: one round trip of ~12 us plus ~4 us of launch catch-up per following kernel and per outer
-// iteration on an otherwise idle GPU.)  Returns 1 when the frame has to be finished by the stepwise path (a Solve
-// ran out of its planned budget): the context is then positioned at that outer iteration.
+// iteration on an otherwise idle GPU.)  A Solve that runs out of its planned budget stops the device loop; the host tops
+// it up and re-enters the loop behind the top-up.
+// KITTI-size frames (self_prepare_path + finish in the Solve launch, DeviceLoopPlan::in_launch_finish): a frame is grid
+// build + (search + Solve launch) per RUN of outer iterations -- the Solve launch ends its iteration itself and goes on
+// with the next one while the pose stands still.  Only the launches of the first kEnqueueAhead iterations are enqueued up
+// front; the host waits for the result slots IN ORDER and adds a (search, Solve) pair when a slot carries OS_NEEDS_HOST.
 namespace {
 struct DeviceLoopPlan {
   int planned[kMaxOuterFast] = {}, solve_start[kMaxOuterFast] = {}, used[kMaxOuterFast] = {};
