@@ -582,6 +582,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
+  c->no_ride_large = getenv("TLOAM_NO_RIDE_LARGE") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
   c->enqueue_ahead = getenv("TLOAM_ENQUEUE_AHEAD") ? std::max(1, atoi(getenv("TLOAM_ENQUEUE_AHEAD"))) : 0;
@@ -628,7 +629,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int r = 0; r < kMaxRanks; ++r)
     if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
   if (c->mbox_local) (void)hipFree(c->mbox_local);
-  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_bcast.release();
+  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
@@ -910,11 +911,18 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
 bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv) && !c->no_fused_small; }
 // the Solve launch that follows prepares the set itself: no k_prepare_small
 bool self_prepare_path(const tloam_ctx* c) { return c->sv.flagb != nullptr && prepare_small_path(c) && solve_small_path(c); }
+// ride: the finish of the previous outer iteration rides on this search launch (large single-rank sets, device-driven loop:
+// k_build_finish_large; the search then runs on GnState::spec_build instead of `gate`)
 int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate,
-                  const int* refresh_gate = nullptr, bool prepare_in_solve = false) {
+                  const int* refresh_gate = nullptr, bool prepare_in_solve = false, const FinishLargeArgs* ride = nullptr) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
-  launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-               c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+  if (ride && !rebin) {
+    const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off[kKinds]);
+    launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream);
+  } else {
+    launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
+                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+  }
   if (prepare_in_solve) return TLOAM_OK;
   if (prepare_small_path(c)) {
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
@@ -1165,7 +1173,12 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   // KITTI-size frames: the finish of iteration k-1 does not get a launch of its own, it rides on the correspondence
   // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
   const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
+  // ... and 1 M-class frames the same way with k_weights + k_outer_finish (k_build_finish_large)
+  const bool ride_large = !ride && c->nranks == 1 && !finish_small_path(c) && build_finish_large_fits(c->sv) && !c->no_ride_large;
+  const int wblocks_large = (int)std::min<size_t>(256, std::max<size_t>(64, total_seg_cap(c) / 2048));   // as enqueue_finish
+  if (ride_large) HIPC(c, c->fin_rows.reserve((size_t)4 * 256 * 8));
   bool pending = false;   // the finish of the previous iteration has not been enqueued yet (it rides on this search)
+  bool pending_large = false;
   WeightParams wp_prev;
   OuterCtl ctl_prev{0.0, 0, 0};
   int rc = TLOAM_OK;
@@ -1212,6 +1225,13 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
       prep.run_build = run_build;
       prep.run_refresh = run_refresh;
       pending = false;
+    } else if (pending_large) {
+      const FinishLargeArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, P.hms[iter - 1], ctl_prev, c->fin_rows.p, c->k3_ticket.p + 1,
+                                wblocks_large};
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve, &fin);
+      prep.run_build = run_build;
+      prep.run_refresh = run_refresh;
+      pending_large = false;
     } else {
       rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve);   // both alternatives, device-gated
       prep.run_build = run_build;
@@ -1230,6 +1250,10 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
       wp_prev = weight_params(c, mu, bp);
       ctl_prev = ctl;
       pending = true;
+    } else if (ride_large && iter < M - 1) {
+      wp_prev = weight_params(c, mu, bp);
+      ctl_prev = ctl;
+      pending_large = true;
     } else {
       rc = enqueue_finish(c, weight_params(c, mu, bp), P.hms[iter], ctl);
       if (rc != TLOAM_OK) return rc;

@@ -466,6 +466,22 @@ struct FinishSmallArgs {
 };
 void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
                                const FinishSmallArgs& fin, hipStream_t s);
+// large single-rank sets (thread-per-query search), device-driven loop: the same for k_weights + k_outer_finish -- the
+// first 4 * wblocks one-wave blocks of the search launch are the finish (rows: [4 * wblocks][8] doubles)
+struct FinishLargeArgs {
+  const CorrView* cv;
+  const WeightParams* wp;
+  const int* seg_n;
+  double* sums16;
+  HostMirror hm;
+  OuterCtl ctl;
+  double* rows;
+  int* ticket;
+  int wblocks;
+};
+bool build_finish_large_fits(const SlotView& sv);
+void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
+                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s);
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
                                  double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);

@@ -154,6 +154,8 @@ struct tloam_ctx {
   DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned char> flagb;   // SlotView::flagb
+  DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
+  bool no_ride_large = false;  // TLOAM_NO_RIDE_LARGE: k_weights + k_outer_finish as launches of their own (A/B, tests)
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
   GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)

@@ -288,4 +288,114 @@ __device__ __forceinline__ void weights_finish_small_ride(GnState* st, const int
   finish_small_publish(st, sums16, hm, ctl, red, sh, nseg, lane, 64);
 }
 
+// ---- large sets: the finish of outer iteration k-1 riding on the thread-per-query search of iteration k -------------------------
+// k_weights (wblocks blocks of 256 threads) + k_outer_finish (one wave) as 4 * wblocks ONE-WAVE blocks at the head of the search
+// launch: block b is wave b % 4 of k_weights' block b / 4 -- the same strided elements in the same order, the same shuffle
+// tree --, hands its five sums over with device-scope stores and takes a ticket; the last one adds the four waves of every
+// block in k_weights' order, the blocks' rows in k_outer_finish's order, and publishes.  Bit-identical to the two kernels
+// (tests/test_gpu_parity.py: the device-driven loop against the stepwise API on the 1 M-class frame).
+struct FinishRideLarge {
+  double* rows;   // [4 * wblocks][8] hand-over rows (device memory)
+  int* ticket;    // zero between launches
+  int wblocks;    // what launch_weights would have been given (<= 256)
+};
+__device__ __forceinline__ void weights_finish_large_ride(GnState* st, const int* __restrict__ seg_n, double* __restrict__ sums16,
+                                                          const HostMirror& hm, const OuterCtl& ctl, const WeightArgs& A,
+                                                          const FinishRideLarge& R, int b) {
+  __shared__ double sh[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x;
+  // the loop flags first: every block reads them before the last one may change them (the ticket)
+  const int stop0 = ctl.fast ? st->stop : 0, done0 = st->done;
+  const int g = stop0 ? 1 : (!done0 ? 2 : 0);
+  double v[5] = {0, 0, 0, 0, 0};
+  if (g == 0) {
+    double sum[kKinds] = {0, 0, 0, 0};
+    double bad = 0.0;
+    const int tid = (b >> 2) * 256 + (b & 3) * 64 + lane, stride = R.wblocks * 256;
+    double* __restrict__ w_src = A.sv.w_src;
+#pragma unroll
+    for (int k = 0; k < kKinds; ++k) {
+      const int n = seg_n[k];
+      const CorrSeg& seg = A.cv.k[k];
+      constexpr int kU = 4;
+      for (int i0 = tid; i0 < n; i0 += kU * stride) {
+        double cu[kU];
+        int iu[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int i = i0 + u * stride;
+          cu[u] = (i < n) ? seg.cost[i] : 0.0;
+          iu[u] = (i < n) ? seg.idx[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (i0 + u * stride >= n) break;
+          const double c = cu[u];
+          sum[k] += c;
+          if (!A.wp.active[k]) continue;
+          if (c == 0) continue;                          // :862
+          double w;
+          if (c >= A.wp.th1) w = 0.0;                    // :865
+          else if (c <= A.wp.th2) w = 1.0;               // :867
+          else {
+            w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+            if (!(w >= 0.0 && w <= 1.0)) bad += 1.0;     // the reference asserts here (:871)
+          }
+          w_src[A.sv.slot_off[k] + (iu[u] - A.sv.src_lo[k])] = w;
+        }
+      }
+    }
+    v[0] = sum[0]; v[1] = sum[1]; v[2] = sum[2]; v[3] = sum[3]; v[4] = bad;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) __hip_atomic_store(R.rows + (size_t)b * 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (row acknowledged, flags read -- see weights_finish_small_ride)
+  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 4 * R.wblocks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  if (lane == 0) __hip_atomic_store(R.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (g != 0) {
+    finish_gate_writes(st, ctl, g, lane);
+    mirror_to_host(st, hm, lane, 64, g == 1 ? (int)OS_SKIPPED : -1);
+    return;
+  }
+  // k_weights' block rows -- ((wave 0 + wave 1) + wave 2) + wave 3 -- added as k_outer_finish adds them: lane t takes rows
+  // t, t + 64, ..., then one shuffle tree.  (In registers: static LDS here would be charged to every block of the search.)
+  double t5[5] = {0, 0, 0, 0, 0};
+  for (int wb = lane; wb < R.wblocks; wb += 64) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const double* r = R.rows + (size_t)wb * 32 + c;
+      const double r0 = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   r1 = __hip_atomic_load(r + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   r2 = __hip_atomic_load(r + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   r3 = __hip_atomic_load(r + 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t5[c] += ((r0 + r1) + r2) + r3;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t5[c] += __shfl_down(t5[c], off, 64);
+  if (lane < 16) sh[lane] = 0.0;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sh[c] = t5[c];
+    sh[8] = t5[4];
+  }
+  if (lane >= 4 && lane < 8) sh[lane] = (double)seg_n[lane - 4];
+  __syncthreads();
+  if (lane < 16) sums16[lane] = sh[lane];
+  publish_and_rearm(sh, st, lane, ctl);
+  mirror_to_host(st, hm, lane, 64);
+}
+
 }  // namespace tl

@@ -818,11 +818,11 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
 // pass 3: the queries in TILE-SORTED order: the lanes of a wave query the same few cells, so the packed
 // candidate records they touch are shared through L1/L2 instead of being re-fetched from HBM per query
 // (the unsorted SoA version moved ~30x the algorithmic bytes as 64-byte sectors).
+// the work of (physical) block `blk` of the search launch
 template <int LPQ>
-__global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
-                                                     const unsigned long long* __restrict__ n_sorted,
-                                                     const double4* __restrict__ qrec, const int* __restrict__ gate) {
-  if (gate && *gate == 0) return;  // device-driven outer loop: the pose did not move, the set is only refreshed
+__device__ __forceinline__ void build_sorted_block(const BuildArgs& A, const GnState* __restrict__ st,
+                                                   const unsigned long long* __restrict__ n_sorted,
+                                                   const double4* __restrict__ qrec, int blk, int2* __restrict__ lds_rows) {
   // XCD-aware order: the dispatcher deals blocks round-robin to the 8 XCDs (each with a private L2), so
   // physical block b is given logical position (b % 8) * (blocks / 8) + b / 8 -- every XCD then walks one
   // CONTIGUOUS eighth of the tile-sorted queries and neighbouring tiles share target records in its L2
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
   // edge kind with its 3x3 eigen solves to XCD 6-7) and the slowest XCD sets the kernel time; instead XCD x takes
   // the chunks x, x + 8, x + 16, ... of kXcdChunk consecutive blocks (1024 tile-sorted queries: still local).
   constexpr int kXcdChunk = 16;
-  const int xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3;
+  const int xcd = blk & 7, in_xcd = blk >> 3;
   const int lb0 = ((in_xcd / kXcdChunk) * 8 + xcd) * kXcdChunk + in_xcd % kXcdChunk;  // grid: a multiple of 8 chunks
   // ... and BACK TO FRONT: the sorted list ends with the edge kind (most candidates, eigen solve per query); the
   // expensive blocks are dispatched first so that the cheap ones fill the tail (longest-processing-time first)
@@ -840,7 +840,6 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
   const int lb = nblk - 1 - lb0;
   const int t = lb * 64 + threadIdx.x;
   const int i = t / LPQ, sub = t % LPQ;
-  __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
   // slots without a tile (inactive kinds) are not in qrec.  LPQ = 1 keeps the tail lanes alive (they take
   // part in the wave-wide trip count) on a harmless duplicate of the last query; LPQ = 4 exits quad-uniformly.
   if (LPQ != 1 && i >= ns) return;
@@ -851,7 +850,30 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
   const int slot = (int)__double_as_longlong(q.w);
   query_one<LPQ>(A, slot_kind(A.sv, slot), st->T_cur, q, slot, live ? sub : 1, lds_rows);
 }
-
+template <int LPQ>
+__global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
+                                                     const unsigned long long* __restrict__ n_sorted,
+                                                     const double4* __restrict__ qrec, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;  // device-driven outer loop: the pose did not move, the set is only refreshed
+  __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
+  build_sorted_block<LPQ>(A, st, n_sorted, qrec, (int)blockIdx.x, lds_rows);
+}
+// ---- large sets, device-driven loop: the finish of outer iteration k-1 (k_weights + k_outer_finish as one-wave blocks,
+//      weights_finish_large_ride) at the head of the thread-per-query search of iteration k, which runs on the
+//      minimiser's own "ended somewhere else than x_build" (spec_build) -- see k_build_finish_small
+__global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState* st, const unsigned long long* __restrict__ n_sorted,
+                                                           const double4* __restrict__ qrec, const int* __restrict__ seg_n,
+                                                           double* __restrict__ sums16, HostMirror hm, OuterCtl ctl, WeightArgs W,
+                                                           FinishRideLarge R) {
+  const int nfin = 4 * R.wblocks;
+  if ((int)blockIdx.x < nfin) {
+    weights_finish_large_ride(st, seg_n, sums16, hm, ctl, W, R, (int)blockIdx.x);
+    return;
+  }
+  if (st->spec_build == 0 || __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  __shared__ int2 lds_rows[9 * 64];
+  build_sorted_block<1>(A, st, n_sorted, qrec, (int)blockIdx.x - nfin, lds_rows);
+}
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate) {
@@ -963,6 +985,32 @@ void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds],
   const unsigned build_blocks = (unsigned)(((16LL * n + 63) / 64 + 127) / 128 * 128);  // 8 XCDs x kXcdChunk, as launch_build
   hipLaunchKernelGGL(k_build_finish_small, dim3(kFinishBlocks + build_blocks), dim3(64), 0, s, A, st, fin.seg_n, fin.sums16,
                      fin.hm, fin.ctl, W, FinishRide{fin.rows, fin.ticket});
+}
+
+bool build_finish_large_fits(const SlotView& sv) { return sv.slot_off[kKinds] > kQuadLimit; }
+void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
+                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s) {
+  const int n = sv.slot_off[kKinds];
+  BuildArgs A;
+  A.sv = sv;
+  A.bp = bp;
+  int base = 0;
+  for (int k = 0; k < kKinds; ++k) {   // (as launch_build: the tile metadata of the sorted query order)
+    A.grid[k] = grids[k];
+    A.tm.tile_base[k] = base;
+    for (int a = 0; a < 3; ++a) A.tm.tdim[k][a] = (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
+    base += A.tm.tdim[k][0] * A.tm.tdim[k][1] * A.tm.tdim[k][2];
+  }
+  A.tm.tile_base[kKinds] = base;
+  A.tm.sub = bin_sub(n);
+  A.identity_n = 0;
+  WeightArgs W;
+  W.cv = *fin.cv;
+  W.sv = sv;
+  W.wp = *fin.wp;
+  const unsigned build_blocks = (unsigned)((((long long)n + 63) / 64 + 127) / 128 * 128);   // 8 XCDs x kXcdChunk, as launch_build
+  hipLaunchKernelGGL(k_build_finish_large, dim3(4 * fin.wblocks + build_blocks), dim3(64), 0, s, A, st, n_sorted, qrec, fin.seg_n,
+                     fin.sums16, fin.hm, fin.ctl, W, FinishRideLarge{fin.rows, fin.ticket, fin.wblocks});
 }
 
 int build_tile_count(const GridView grids[kKinds], int n_slots) {
