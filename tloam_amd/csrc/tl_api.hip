@@ -928,6 +928,15 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
     return TLOAM_OK;
   }
+  if (c->nranks == 1 && !c->no_fused_small) {
+    // single rank: the tile-local scan only -- the compaction adds the tiles' offsets itself -- and ONE launch for both
+    // alternatives of a device-gated iteration (compaction, or the refresh of the unchanged set): two launches less
+    const int tiles = scan_tiles_only(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
+    if (tiles > 0) {
+      launch_compact(c->sv, c->cv, bp, c->seg_n.p, nullptr, 0, 1, c->state.p, c->stream, gate, refresh_gate, c->scan_tmp.p, tiles);
+      return TLOAM_OK;
+    }
+  }
   launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
   const double* rank_counts = nullptr;
   if (c->nranks > 1) {

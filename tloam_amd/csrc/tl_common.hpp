@@ -287,7 +287,8 @@ void launch_grid_finalize_all(const GridSet& gs, const unsigned long long* cell_
                               unsigned long long* cell_cnt /* re-zeroed */, hipStream_t s);
 // medium-size builds: tile-local scan only (returns the tile count, 0 = not applicable), then finalize + scatter in ONE
 // launch that adds the tiles' offsets itself -- three launches per build instead of five
-int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s);
+int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s,
+                    const int* gate = nullptr);
 void launch_grid_finalize_scatter_all(const GridSet& gs, const unsigned long long* cell_scan, const unsigned long long* totals,
                                       int tiles, int* cell_start, unsigned long long* cell_cnt, const int* cell_of_pt,
                                       const int* rank_of_pt, double4* gp, hipStream_t s);
@@ -307,8 +308,11 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr);
 int build_tile_count(const GridView grids[kKinds], int n_slots);  // bins of the query counting sort (tiles, or cells of tiles)
 // cap + compaction (after the flag scan)
+// refresh_gate != null: the launch also stands for the refresh alternative (see CompactArgs); tiles > 0: `sv.scan` holds
+// tile-local scans and `totals` the tiles' totals (scan_tiles_only)
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
-                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate = nullptr);
+                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate = nullptr,
+                    const int* refresh_gate = nullptr, const unsigned long long* totals = nullptr, int tiles = 0);
 void launch_rank_counts(const SlotView& sv, double* rank_counts, int rank, int nranks, hipStream_t s);
 // same correspondences, new outer iteration: re-capture the weights, zero the side-channel slots
 void launch_refresh(const SlotView& sv, const CorrView& cv, hipStream_t s, const int* gate = nullptr);

@@ -213,10 +213,11 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 
 // first half of the medium-size scan only: tile-local exclusive scans + per-tile totals (the consumer adds the tiles'
 // offsets itself, see k_grid_finalize_scatter_all).  Returns the number of tiles; 0 = not applicable (use the full scan).
-int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s) {
+int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s,
+                    const int* gate) {
   const size_t tiles = (n + kScanTile - 1) / kScanTile;
   if (n <= (size_t)kSmallTile || tiles > 1024) return 0;
-  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals, (const int*)nullptr);
+  hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, totals, gate);
   return (int)tiles;
 }
 
@@ -1039,9 +1040,49 @@ struct CompactArgs {
   int rank, nranks;
   GnState* st;                // receives the pose the set was built at (x_build)
   const int* gate;
+  const int* refresh_gate;    // non-null: the launch stands for BOTH alternatives of a device-gated iteration -- compaction
+                              // if *gate, else the refresh of the unchanged set (k_refresh) if *refresh_gate
+  const unsigned long long* totals;   // tiles > 0: `scan` holds TILE-LOCAL scans, the tiles' totals are here (the kernel adds
+  int tiles;                          // the tile offsets itself: no k_scan_add_direct launch; <= 1024)
 };
 __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
-  if (A.gate && *A.gate == 0) return;
+  __shared__ unsigned long long toff[1024];
+  __shared__ unsigned long long wtot[4];
+  if (A.gate && *A.gate == 0) {
+    if (A.refresh_gate && *A.refresh_gate != 0) {   // the set of the previous iteration: new captured weights, zeroed slots
+      const int tid = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) {
+        const int n = A.cv.seg_n[k];
+        const CorrSeg& seg = A.cv.k[k];
+        for (int i = tid; i < n; i += stride) {
+          seg.w[i] = A.sv.w_src[A.sv.slot_off[k] + (seg.idx[i] - A.sv.src_lo[k])];
+          seg.cost[i] = 0.0;
+        }
+      }
+    }
+    return;
+  }
+  if (A.tiles > 0) {  // exclusive prefix of the tile totals (packed pairs of 32-bit counts add without carries): 4 tiles per thread
+    const int t0 = threadIdx.x * 4;
+    unsigned long long v[4], run = 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = (t0 + u < A.tiles) ? A.totals[t0 + u] : 0ull; run += v[u]; }
+    unsigned long long incl = run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long pre = incl - run;
+    for (int w = 0; w < wave; ++w) pre += wtot[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { toff[t0 + u] = pre; pre += v[u]; }
+    __syncthreads();
+  }
   if (blockIdx.x == 0 && threadIdx.x < 6 && A.st) A.st->x_build[threadIdx.x] = A.st->x[threadIdx.x];
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int n_slots = A.sv.slot_off[kKinds];
@@ -1050,9 +1091,10 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs A) {
 #pragma unroll
   for (int k = 1; k < kKinds; ++k) kind += (slot >= A.sv.slot_off[k]) ? 1 : 0;
   const unsigned long long f = A.sv.flags[slot];
-  const unsigned long long sc = A.sv.scan[slot];
-  const unsigned long long sn = A.sv.scan[slot + 1];  // the scan has n_slots + 1 entries
-  const unsigned long long sb = A.sv.scan[A.sv.slot_off[kind]];
+  auto scanned = [&](int i) { return A.sv.scan[i] + (A.tiles > 0 ? toff[i / kScanTile] : 0ull); };
+  const unsigned long long sc = scanned(slot);
+  const unsigned long long sn = scanned(slot + 1);  // the scan has n_slots + 1 entries
+  const unsigned long long sb = scanned(A.sv.slot_off[kind]);
   long long C = (long long)((sc & 0xffffffffull) - (sb & 0xffffffffull));
   long long Cn = (long long)((sn & 0xffffffffull) - (sb & 0xffffffffull));
   const int V = (int)((sc >> 32) - (sb >> 32));
@@ -1202,10 +1244,14 @@ void launch_prepare_small(const SlotView& sv, const CorrView& cv, const BuildPar
   hipLaunchKernelGGL(k_prepare_small, dim3(blocks), dim3(256), 0, s, A);
 }
 void launch_compact(const SlotView& sv, const CorrView& cv, const BuildParams& bp, int* seg_n,
-                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate) {
+                    const double* rank_counts, int rank, int nranks, GnState* st, hipStream_t s, const int* gate,
+                    const int* refresh_gate, const unsigned long long* totals, int tiles) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   CompactArgs A;
+  A.refresh_gate = refresh_gate;
+  A.totals = totals;
+  A.tiles = tiles;
   A.sv = sv;
   A.cv = cv;
   for (int k = 0; k < kKinds; ++k) A.maxnum[k] = bp.maxnum[k];
