@@ -598,9 +598,21 @@ __global__ __launch_bounds__(256) void k_query_scatter(SlotView sv, const int* _
 //   LPQ = 4 / 16: smaller frames are latency-bound (a ~35-candidate dependent chain per query), so 4 (16)
 //            adjacent lanes split the nine rows -- three (at most one) each --, walk them in parallel and merge
 //            their packed-key lists with two (four) xor-shuffle rounds; lane 0 of the group finishes the fit.
+#ifdef TLOAM_K1_PROF   // development aid (scripts/k1_prof.py): wall-clock stamps of one wave of the sixteen-lane search
+__device__ unsigned long long g_k1_prof[64];
+extern "C" void tloam_debug_k1_prof(unsigned long long* out64) { (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_k1_prof), sizeof(g_k1_prof)); }
+__device__ __forceinline__ int k1_prof_which() {   // four sampled one-wave workgroups: first, a third, two thirds, late
+  const int b = (int)blockIdx.x;
+  return b == 0 ? 0 : (b == 800 ? 1 : (b == 1600 ? 2 : (b == 2300 ? 3 : -1)));
+}
+#define TL_K1_STAMP(i) if (LPQ == 16 && (threadIdx.x & 63) == 0 && k1_prof_which() >= 0) g_k1_prof[k1_prof_which() * 16 + (i)] = wall_clock64();
+#else
+#define TL_K1_STAMP(i)
+#endif
 template <int K, int LPQ>
 __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk,
                                          int2* __restrict__ lds_rows, double radius) {
+  TL_K1_STAMP(1)
   const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
   const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
   const int cz = cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]);
@@ -640,6 +652,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
     re[i] = in ? (ib == 3 ? t.w : (ib == 2 ? t.z : t.y)) : 0;
   }
   topk_clear<K>(tk);
+  TL_K1_STAMP(2)
   if (LPQ == 1) {
     // FLATTENED walk: the lane's non-empty rows are queued in LDS ([row][lane], conflict-free) and consumed
     // as ONE candidate stream, two candidates per trip.  The wave then runs max_lanes(total candidates)/2
@@ -748,6 +761,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
           key_insert<K + 1>(L, key_pack(sqdist(pw.x, pw.y, pw.z, c[u][i].x, c[u][i].y, c[u][i].z), rs[i] + s + u, keep_mask, v));
         }
     }
+    TL_K1_STAMP(3)
     // merge across the quad: after xor-1 and xor-2 every lane holds the global list (the lanes' candidate
     // sets are disjoint, +inf entries fall through)
 #ifndef TLOAM_K1_DBG_NOMERGE  // timing experiment only: without the cross-lane merge
@@ -760,8 +774,10 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
       for (int m = 0; m < K + 1; ++m) key_insert<K + 1>(L, ok[m]);
     }
 #endif
+    TL_K1_STAMP(4)
     if (!keys_ambiguous<K + 1>(L, keep_mask)) {  // (the same verdict on all lanes of the quad)
       keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
+      TL_K1_STAMP(5)
     } else {  // redo with the exact (d, original index) order
       for (int s = 0; s < len; ++s) {
         double4 c[NR];
@@ -794,6 +810,7 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
     if (sub == 0) store_flag(A.sv, slot, (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull);
     return;
   }
+  TL_K1_STAMP(0)
   const Vec3 pw = act(T, Vec3{q.x, q.y, q.z});
   const PtsGlobal pts{g.gp};
   RawRec rec;
@@ -813,7 +830,9 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
     if (sub == 0) finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
 #endif
   }
+  TL_K1_STAMP(6)
   if (sub == 0) store_raw(A.sv, slot, rec);
+  TL_K1_STAMP(7)
 }
 
 // pass 3: the queries in TILE-SORTED order: the lanes of a wave query the same few cells, so the packed
@@ -856,6 +875,9 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
                                                      const unsigned long long* __restrict__ n_sorted,
                                                      const double4* __restrict__ qrec, const int* __restrict__ gate) {
   if (gate && *gate == 0) return;  // device-driven outer loop: the pose did not move, the set is only refreshed
+#ifdef TLOAM_K1_PROF
+  if (LPQ == 16 && threadIdx.x == 0 && blockIdx.x == 0) g_k1_prof[15] = wall_clock64();   // (about when the launch starts)
+#endif
   __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
   build_sorted_block<LPQ>(A, st, n_sorted, qrec, (int)blockIdx.x, lds_rows);
 }
