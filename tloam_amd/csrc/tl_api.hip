@@ -1385,10 +1385,18 @@ int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
   return TLOAM_OK;
 }
 
+// development aid (TLOAM_HOST_PROFILE=1, single frame stream only): where the calling thread's time goes per
+// tloam_scan_match, averaged, printed to stderr every 200 calls
+struct HostProf { double begin_us = 0, enqueue_us = 0, wait_us = 0, tail_us = 0, gap_us = 0; long n = 0; std::chrono::steady_clock::time_point last_ret; bool have_last = false; };
+static HostProf g_hp;
+static const bool g_hp_on = getenv("TLOAM_HOST_PROFILE") != nullptr;
 int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega3, double result[16],
                      double* scan_xyz, size_t n_scan, tloam_stats* stats) {
+  const auto hp_t0 = std::chrono::steady_clock::now();
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
+  const auto hp_t1 = std::chrono::steady_clock::now();
+  const double hp_wait0 = c->wait_us;
   int done = 0;
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
@@ -1412,6 +1420,18 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     launch_transform_cloud(c->misc.p, n_scan, result, c->stream);
     HIPC(c, hipMemcpyAsync(scan_xyz, c->misc.p, sizeof(double) * 3 * n_scan, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+  }
+  if (g_hp_on) {
+    const auto t2 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    g_hp.begin_us += us(hp_t0, hp_t1);
+    g_hp.wait_us += c->wait_us - hp_wait0;
+    g_hp.enqueue_us += us(hp_t1, t2) - (c->wait_us - hp_wait0);   // enqueue + bookkeeping + end, without the waits
+    if (g_hp.have_last) g_hp.gap_us += us(g_hp.last_ret, hp_t0);
+    g_hp.last_ret = t2; g_hp.have_last = true;
+    if (++g_hp.n % 200 == 0)
+      fprintf(stderr, "[tloam host] per call: sm_begin %.1f us, enqueue + bookkeeping %.1f, waiting %.1f, outside the call %.1f\n",
+              g_hp.begin_us / g_hp.n, g_hp.enqueue_us / g_hp.n, g_hp.wait_us / g_hp.n, g_hp.gap_us / g_hp.n);
   }
   return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;
 }
