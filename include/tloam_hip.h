@@ -144,7 +144,9 @@ int tloam_set_target_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const
  *   tloam_frame_stash(ctx, slot)   moves the clouds currently registered with the context (whatever tloam_set_source* /
  *                                  tloam_set_target* left there: eight clouds, their bounds) into slot `slot` (>= 0) of a frame
  *                                  store kept in HBM; the context is left without registered clouds.  A slot that was in
- *                                  use is overwritten.
+ *                                  use is overwritten.  Stashing the slot that is currently selected keeps the frame in
+ *                                  that slot (including what tloam_set_* wrote since) and makes the context's own clouds
+ *                                  the registered ones again (= select -1); with ANOTHER slot selected: TLOAM_E_NOT_READY.
  *   tloam_frame_select(ctx, slot)  makes the clouds of `slot` the registered ones (buffers are exchanged, nothing is copied or
  *                                  synchronised); slot -1 = back to the context's own.  While a slot is selected,
  *                                  tloam_set_source* / tloam_set_target* write into that slot's frame.

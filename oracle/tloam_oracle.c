@@ -296,6 +296,18 @@ void orc_eig3_sym(const double cov[9], double ev[3], double V[9]) {
   double A[9];
   memcpy(A, cov, sizeof(A));
   for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  /* entries whose squares leave the fp64 range: an exact power-of-two rescale first (tl_knn.hpp eig3_sym has the same branch) */
+  int rescale = 0;
+  {
+    double mx = 0.0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = i; j < 3; ++j) mx = fmax(mx, fabs(A[i * 3 + j]));
+    if (mx != 0.0 && mx < INFINITY && (mx < 1e-120 || mx > 1e120)) {
+      (void)frexp(mx, &rescale);
+      double f = ldexp(1.0, -rescale);
+      for (int i = 0; i < 9; ++i) A[i] *= f;
+    }
+  }
   for (int sweep = 0; sweep < 60; ++sweep) {
     double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
     double dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
@@ -314,6 +326,13 @@ void orc_eig3_sym(const double cov[9], double ev[3], double V[9]) {
         double h = sqrt(d * d + b * b);
         double u = fabs(d) + h;
         double r = sqrt(u * u + b * b);
+        if (!(r > 0.0 && r < INFINITY)) { /* d*d + b*b under-/overflowed: the rotation depends on d : b only (tl_knn.hpp has the same branch) */
+          double sc = fmax(fabs(d), fabs(b));
+          d /= sc; b /= sc;
+          h = sqrt(d * d + b * b);
+          u = fabs(d) + h;
+          r = sqrt(u * u + b * b);
+        }
         double cs = u / r, sn = fabs(b) / r;
         if (!(d == 0.0 || (d > 0.0) == (b > 0.0))) sn = -sn; /* sgn(tau), tau = +-0 counting as positive */
         /* A <- G^T A G */
@@ -335,6 +354,8 @@ void orc_eig3_sym(const double cov[9], double ev[3], double V[9]) {
       }
   }
   ev[0] = A[0]; ev[1] = A[4]; ev[2] = A[8];
+  if (rescale != 0)
+    for (int i = 0; i < 3; ++i) ev[i] = ldexp(ev[i], rescale);
   /* sort ascending (3 elements) */
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2 - i; ++j)

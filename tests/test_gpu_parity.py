@@ -463,10 +463,20 @@ def test_staged_frames_equal_direct_hand_over(hip_module):
     H.set_frames(scenes[0].source, scenes[0].target)
     rc, T, _ = H.scan_match(scenes[0].T_pred)
     assert rc == 0 and np.array_equal(T, ref[0][0])
+    # select(i) -> hand a NEW frame over (it lands in slot i) -> stash(i) -> select(i): the slot holds the new frame, and the
+    # context's own frame is the registered one in between (the slot used to end up with the context's clouds)
+    H.frame_select(2)
+    H.set_frames(scenes[1].source, scenes[1].target)
+    H.frame_stash(2)
+    rc, T, _ = H.scan_match(scenes[0].T_pred)              # the context's own frame (scene 0, handed over above)
+    assert rc == 0 and np.array_equal(T, ref[0][0])
+    H.frame_select(2)
+    rc, T, st = H.scan_match(scenes[1].T_pred)
+    assert rc == 0 and np.array_equal(T, ref[1][0]) and st["n_corr"] == ref[1][1]["n_corr"]
     H.frame_select(1)
     assert H.sm_begin(scenes[1].T_pred) == 0
     assert H.L.tloam_frame_select(H.h, 0) == -6            # TLOAM_E_NOT_READY inside a solve
-    H.close()
+    H.close()                                              # (destroyed with a slot selected and a solve open: nothing leaks, nothing is freed twice)
 
 
 def test_concurrent_frame_streams_share_the_gpu(hip_module):
@@ -546,3 +556,34 @@ def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
             _assert_same_frame(want[f], _frame_fingerprint(H, T, st), cost_sum_rtol=1e-13 if name == "TLOAM_NO_PERSISTENT_SOLVE" else 0.0)
         moved_late += st["accepted_steps"] > 1
         H.close()
+
+
+def test_hand_over_time_out_falls_back_to_one_launch_per_iteration(hip_module, monkeypatch):
+    """the one-launch Solve spin-waits between its blocks.  When a hand-over times out (a block that was never
+    scheduled beside the others -- forced here by TLOAM_DEBUG_FAIL_HANDOVER: the consumer waits for rows nobody posts) the
+    bounded wait ends the launch, the host solves the SAME frame again with one launch per GN iteration and keeps the context
+    on that path: the caller sees a slower frame, not an error, and the result is the one-launch-per-iteration result."""
+    import time
+    sc = synth.make_scene(seed=61, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
+    monkeypatch.setenv("TLOAM_NO_PERSISTENT_SOLVE", "1")
+    H = hip_module.HipRegistration()
+    H.set_frames(sc.source, sc.target)
+    rc, T, st = H.scan_match(sc.T_pred)
+    assert rc == 0
+    want = _frame_fingerprint(H, T, st)
+    H.close()
+    monkeypatch.delenv("TLOAM_NO_PERSISTENT_SOLVE")
+    monkeypatch.setenv("TLOAM_DEBUG_FAIL_HANDOVER", "1")
+    H = hip_module.HipRegistration()
+    H.set_frames(sc.source, sc.target)
+    t = time.perf_counter()
+    rc, T, st = H.scan_match(sc.T_pred)
+    dt = time.perf_counter() - t
+    assert rc == 0, H.L.tloam_last_error(H.h).decode()
+    assert 0.5 < dt < 10.0, dt            # the ~1 s bounded wait was really taken
+    _assert_same_frame(want, _frame_fingerprint(H, T, st))
+    t = time.perf_counter()
+    rc, T, st = H.scan_match(sc.T_pred)   # the context stays on the fallback path: no second time-out
+    assert rc == 0 and time.perf_counter() - t < 0.25
+    _assert_same_frame(want, _frame_fingerprint(H, T, st))
+    H.close()

@@ -95,6 +95,20 @@ def test_eig3_vs_lapack(i):
     assert np.allclose(cov @ V, V * ev, atol=1e-12 * ev_ref[-1])
 
 
+@pytest.mark.parametrize("scale", [1e-160, 1e-100, 1.0, 1e100, 1e160])
+def test_eig3_degenerate_scales(scale):
+    """Equal diagonal entries with a tiny (or huge) off-diagonal one: d*d + b*b under-/overflows in the rotation
+     -- the eigen pairs must still come out finite and right (numpy as the judge)."""
+    for cov in (np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.5]]) * scale,
+                np.array([[2.0, 1.0, 0.5], [1.0, 2.0, 0.25], [0.5, 0.25, 2.0]]) * scale):
+        ev, V = ob.eig3(cov)
+        ev_ref = np.linalg.eigvalsh(cov)
+        assert np.all(np.isfinite(ev)) and np.all(np.isfinite(V))
+        np.testing.assert_allclose(ev, ev_ref, rtol=1e-12, atol=1e-14 * abs(ev_ref).max())
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
+        assert np.allclose((cov / scale) @ V, V * (ev / scale), atol=1e-12)
+
+
 @settings(max_examples=25, deadline=None)
 @given(seed=st.integers(0, 10_000), n=st.integers(12, 400), k=st.sampled_from([1, 5]),
        radius=st.sampled_from([0.02, 0.5, 1.0, 3.0]))

@@ -154,7 +154,8 @@ int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq)
 // One 64-byte segment of a result slot (MirrorSlot: seven payload words, then the sequence number XORed with them): wait
 // until the XOR of the eight words equals `seq` -- a segment that has only partly arrived does not check -- and copy the
 // payload out.  Same return convention as wait_word.
-int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]) {
+int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long number, unsigned long long payload[7]) {
+  const unsigned long long seq = check_mix(number);   // (what the check word carries, tl_common.hpp)
   for (unsigned spins = 1;; ++spins) {
     unsigned long long w[8], x = 0ull;
     for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= w[i]; }
@@ -424,7 +425,9 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 // one ceres::Solve on the current correspondence set, device resident: 1 + 4 sweeps at most;
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
-bool solve_small_path(const tloam_ctx* c) { return c->nranks == 1 && c->k3_single && !c->no_fused_small && solve_small_fits(c->k3_grid); }
+bool solve_small_path(const tloam_ctx* c) {
+  return c->nranks == 1 && c->k3_single && !c->no_fused_small && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus);
+}
 // prep: the launch also prepares the factor set (only with solve_small_path and SlotView::flagb, see self_prepare_path)
 // finish: ... and finishes the outer iteration, possibly running the following ones too (SolveFinish; needs prep).
 // wp: the weight thresholds of the outer iteration this Solve belongs to (null: a Solve outside scanMatching) -- the
@@ -441,7 +444,8 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       memset(&F, 0, sizeof(F));
       if (wp) { F.have_wp = 1; F.wp[0] = *wp; }
     }
-    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps, prep, c->seg_n.p, &F,
+    const int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_small
+    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps | sabotage, prep, c->seg_n.p, &F,
                        c->stream);
     c->batch_launches++;
     return TLOAM_OK;
@@ -582,6 +586,13 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
+  c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
+  if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) cus = 0;
+    c->device_cus = cus;
+  }
   c->no_ride_large = getenv("TLOAM_NO_RIDE_LARGE") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
@@ -631,6 +642,9 @@ void tloam_destroy(tloam_ctx* c) {
   if (c->mbox_local) (void)hipFree(c->mbox_local);
   c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+  // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
+  //  buffer is released exactly once below)
+  if (c->frame_selected >= 0) { exchange_clouds(c, *c->frame_store[c->frame_selected]); c->frame_selected = -1; }
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
     K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
@@ -642,7 +656,6 @@ void tloam_destroy(tloam_ctx* c) {
   c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qrec.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
   c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release();
-  if (c->frame_selected >= 0) exchange_clouds(c, *c->frame_store[c->frame_selected]);
   for (auto* f : c->frame_store)
     if (f) { f->release(); delete f; }
   c->frame_store.clear();
@@ -748,7 +761,14 @@ int tloam_frame_stash(tloam_ctx* c, int slot) {
   if (c->active) return TLOAM_E_NOT_READY;
   HIPC(c, hipSetDevice(c->device));
   if ((size_t)slot >= c->frame_store.size()) c->frame_store.resize((size_t)slot + 1, nullptr);
-  if (c->frame_selected == slot) { c->frame_selected = -1; return TLOAM_OK; }   // the slot's frame is the registered one: it stays in the slot
+  if (c->frame_selected == slot) {
+    // the slot's frame is the registered one (possibly just updated through tloam_set_*): kd[] holds it, the slot holds the
+    // context's own clouds.  Exchange them back -- the frame goes into the slot, the context's own clouds become the
+    // registered ones again ("select -1") -- so that a later select(slot) finds the frame, not the context's clouds
+    exchange_clouds(c, *c->frame_store[slot]);
+    c->frame_selected = -1;
+    return TLOAM_OK;
+  }
   if (c->frame_selected >= 0) return TLOAM_E_NOT_READY;   // another slot's frame is registered: select -1 first
   if (!c->frame_store[slot]) {
     c->frame_store[slot] = new (std::nothrow) FrameClouds();
@@ -1308,6 +1328,7 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     if (S->incomplete == OS_SKIPPED) break;   // the loop had ended before this iteration
     if (S->incomplete == OS_COMM_ERROR) {
       c->last_error = "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
+      c->hand_over_timed_out = true;
       return TLOAM_E_HIP;
     }
     if (S->incomplete == OS_INCOMPLETE) {
@@ -1348,6 +1369,7 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
       }
       if (S->incomplete == OS_COMM_ERROR) {
         c->last_error = "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
+        c->hand_over_timed_out = true;
         return TLOAM_E_HIP;
       }
     }
@@ -1403,7 +1425,21 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   // iterations fit the result slots, no development knob that needs the host between iterations
   if (c->nranks == 1 && c->h_mirror_dev && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
       !c->dbg_no_build_reuse && !c->no_device_loop) {
+    const bool persistent = solve_small_path(c);
     rc = scan_match_device_loop(c, &weight_violation);
+    if (rc == TLOAM_E_HIP && persistent && c->hand_over_timed_out) {
+      // A block of the one-launch Solve was never scheduled beside the others (a device shared with long-running kernels,
+      // fewer usable CUs than the attribute says): the waits inside the launch are bounded, the frame is intact in HBM --
+      // solve it again with one launch per GN iteration, and keep this context on that path.
+      c->no_persistent_solve = true;
+      c->hand_over_timed_out = false;
+      (void)hipStreamSynchronize(c->stream);
+      c->active = false;
+      rc = tloam_sm_begin(c, predict, omega3);
+      if (rc != TLOAM_OK) return rc;
+      weight_violation = false;
+      rc = scan_match_device_loop(c, &weight_violation);
+    }
     if (rc < 0) return rc;
     done = rc == 0 ? 1 : 0;
   }

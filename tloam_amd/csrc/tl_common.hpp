@@ -148,6 +148,12 @@ static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible pre
 struct MirrorSlot {
   unsigned long long w[24];
 };
+// The check word of every 64-byte hand-over segment (result slots, block rows, pose broadcasts, finish sums, submap sizes) is
+// check_mix(number) XOR the seven payload words.  Consecutive numbers differ in a few low bits; multiplied by an odd 64-bit
+// constant they differ in about half of all bits, so a segment whose check word is still the old one and of which ONE payload
+// word has arrived can only pass if that word changed by exactly that 64-bit pattern -- not by a counter step or a
+// last-mantissa-bit change.  Zeroed memory checks for number 0 only; numbers start at 1.
+__host__ __device__ inline unsigned long long check_mix(unsigned long long number) { return number * 0x9E3779B97F4A7C15ull; }
 struct HostMirror {
   MirrorSlot* out;
   unsigned long long seq;
@@ -415,7 +421,7 @@ void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipSt
 // small sets on one rank: sweep + step in ONE launch (ticket: zero between launches)
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s);
 // sets whose sweep is a grid of a dozen blocks: a whole ceres::Solve (up to max_sweeps evaluations) in ONE launch
-bool solve_small_fits(int grid);
+bool solve_small_fits(int grid, int device_cus);
 // The factor set of an outer iteration prepared by the Solve launch itself (no k_prepare_small launch in front of it):
 // flagb == null means "already prepared" (stepwise API, topped-up Solves).
 struct SolvePrep {

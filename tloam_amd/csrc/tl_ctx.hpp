@@ -176,6 +176,11 @@ struct tloam_ctx {
   bool no_self_prepare = false;    // TLOAM_NO_SELF_PREPARE: k_prepare_small in front of every one-launch Solve (A/B, tests)
   bool no_fused_small = false;     // TLOAM_NO_FUSED_SMALL: KITTI-size sets keep sweep and step as two launches (A/B, tests)
   bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)
+  bool no_persistent_solve = false;  // TLOAM_NO_PERSISTENT_SOLVE, or set by tloam_scan_match after an in-launch hand-over timed out:
+                                     // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
+  bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
+  int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
+  int device_cus = 0;              // multiProcessorCount of the device (k_solve_small needs all its blocks resident at once)
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
   double* h_bbox_dev = nullptr;
   // bounds of the registered target clouds, taken at hand-over (set_target*: the call synchronises anyway), so that

@@ -49,7 +49,7 @@ __device__ __forceinline__ void mirror_wave(const GnState* st, const HostMirror&
   x ^= __shfl_xor(x, 1, 64);
   x ^= __shfl_xor(x, 2, 64);
   x ^= __shfl_xor(x, 4, 64);
-  if (pos == 7) w = hm.seq ^ x;
+  if (pos == 7) w = check_mix(hm.seq) ^ x;
   __hip_atomic_store(&hm.out->w[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ctl.fast: the outer loop is driven from the device (every outer iteration of the frame is already enqueued) -- the

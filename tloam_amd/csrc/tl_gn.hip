@@ -558,7 +558,7 @@ __device__ __forceinline__ void k3_post_row_tagged(double* __restrict__ partials
     const double val = pos < 7 ? ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c] : 0.0;
     unsigned long long w = (unsigned long long)__double_as_longlong(val);
     const unsigned long long x = xor8(w);
-    if (pos == 7) w = tag ^ x;
+    if (pos == 7) w = check_mix(tag) ^ x;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + (size_t)blockIdx.x * kAccStride + t, w, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -572,6 +572,7 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
                                                  double* s_rows, double* s_tot, int lane) {
   const int r = lane >> 2, sgm = lane & 3;
   const bool have = r < rows;
+  const unsigned long long mtag = check_mix(tag);
   const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + (size_t)(have ? r : 0) * kAccStride + sgm * 8;
   unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
@@ -582,7 +583,7 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
     unsigned long long x = w[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) x ^= w[i];
-    ok_all = __all((!have || x == tag) ? 1 : 0) != 0;
+    ok_all = __all((!have || x == mtag) ? 1 : 0) != 0;
     if (ok_all) break;
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock
     __builtin_amdgcn_s_sleep(1);
@@ -1173,7 +1174,7 @@ __device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, 
   else if (lane == 1) wd = (unsigned long long)__double_as_longlong(bad0);
   else if (lane == 2) wd = (unsigned long long)(long long)kind;
   const unsigned long long x = xor8(wd);
-  if (lane == 7) wd = tag ^ x;
+  if (lane == 7) wd = check_mix(tag) ^ x;
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + kExtRowBase + (size_t)gw * 8 + lane, wd, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1182,6 +1183,7 @@ __device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, 
 __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partials, int nwaves, unsigned long long tag, double* s_ext /*[64*3]*/,
                                               double* fin /*[8]*/, int lane) {
   const bool have = lane >= 1 && lane < nwaves;   // (wave 0 is this one)
+  const unsigned long long mtag = check_mix(tag);
   const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + kExtRowBase + (size_t)(have ? lane : 1) * 8;
   unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
     unsigned long long x = w[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) x ^= w[i];
-    ok_all = __all((!have || x == tag) ? 1 : 0) != 0;
+    ok_all = __all((!have || x == mtag) ? 1 : 0) != 0;
     if (ok_all) break;
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;
     __builtin_amdgcn_s_sleep(1);
@@ -1253,7 +1255,7 @@ __device__ __forceinline__ void solve_publish_pose(unsigned long long* __restric
       else if (v == 12) w = (unsigned long long)verdict;
     }
     const unsigned long long x = xor8(w);
-    if (pos == 7) w = tag ^ x;
+    if (pos == 7) w = check_mix(tag) ^ x;
     __hip_atomic_store(bcast + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1261,6 +1263,7 @@ __device__ __forceinline__ void solve_publish_pose(unsigned long long* __restric
 // Returns the control word (see solve_publish_pose), 0: timed out.
 __device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restrict__ bcast, unsigned long long tag, Rt& T) {
   unsigned long long w[kBcastWords];
+  const unsigned long long mtag = check_mix(tag);
   const unsigned long long t0 = wall_clock64();
   for (unsigned spins = 1;; ++spins) {
 #pragma unroll
@@ -1268,7 +1271,7 @@ __device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restr
     unsigned long long x0 = w[0], x1 = w[8];
 #pragma unroll
     for (int i = 1; i < 8; ++i) { x0 ^= w[i]; x1 ^= w[8 + i]; }
-    if (x0 == tag && x1 == tag) break;
+    if (x0 == mtag && x1 == mtag) break;
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) return 0;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -1337,6 +1340,11 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
   const bool consumer = gw == 0;   // (holds no chunk: single_work_of)
+  // test hook (TLOAM_DEBUG_FAIL_HANDOVER, bit 16 of the argument): the consumer waits for rows that nobody posts, i.e. the
+  // launch behaves as if one of its blocks had never been scheduled -- the bounded wait, OS_COMM_ERROR and the host's
+  // fallback to one launch per GN iteration are exercised by tests/test_gpu_parity.py
+  const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;
+  max_sweeps &= 0xffff;
   const bool self_prep = prep.sv.flagb != nullptr;
   unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
 #ifdef TLOAM_STEP_PROFILE
@@ -1414,7 +1422,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
         __syncthreads();   // the block's other waves have put their sums into LDS
         k3_post_row_tagged(partials, red, tag0 | step);
         TL_PROF(lane == 0, 8 + it * 8 + 0)
-        const bool ok = poll_fold_tagged(partials, (int)gridDim.x, tag0 | step, s_rows, tot, lane);
+        const bool ok = poll_fold_tagged(partials, (int)gridDim.x, (tag0 | step) ^ sabotage, s_rows, tot, lane);
         TL_PROF(lane == 0, 8 + it * 8 + 1)
         if (!ok) {  // a block of the grid never posted: stop the Solve and report OS_COMM_ERROR
           comm_failed(bcast, tag0 | (step + 1ull));
@@ -1552,10 +1560,10 @@ void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* 
   hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
                      cv.seg_n, partials, ticket, bcast, cv, P, seg_n, F);
 }
-bool solve_small_fits(int grid) {
-  static const bool off = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;   // A/B knob: one launch per GN iteration
-  return grid <= kTaggedRows && !off;
-}
+// The launch spin-waits between its blocks, so all of them must be resident at once: one block per CU (the consumer's step
+// wants ~400 registers: one wave per SIMD), i.e. grid <= the device's CU count -- 256 on an MI355X, fewer on a CU-masked or
+// partitioned device (then the one-launch-per-iteration kernels run instead).
+bool solve_small_fits(int grid, int device_cus) { return grid <= kTaggedRows && grid <= device_cus; }
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
 }

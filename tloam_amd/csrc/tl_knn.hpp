@@ -305,10 +305,20 @@ __device__ __forceinline__ void jacobi_rotate(Sym3& m) {
   // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), c = 1 / sqrt(1 + t^2), s = t c without tau and t (oracle: orc_eig3_sym, the
   // same operations in the same order): the dependent chain is sqrt -> sqrt -> div instead of div -> sqrt -> div -> sqrt -> div,
   // and the per-query fit of an edge is ~20 such rotations one after the other on a lane that has nothing else to do
-  const double d = aqq - app, b = 2.0 * apq;
-  const double h = sqrt(d * d + b * b);
-  const double u = fabs(d) + h;
-  const double r = sqrt(u * u + b * b);
+  double d = aqq - app, b = 2.0 * apq;
+  double h = sqrt(d * d + b * b);
+  double u = fabs(d) + h;
+  double r = sqrt(u * u + b * b);
+  if (__builtin_expect(!(r > 0.0 && r < __builtin_inf()), 0)) {
+    // d*d + b*b under- or overflowed (|d|, |b| < ~1e-154 or > ~1e154; b != 0 here): the rotation only depends on d : b,
+    // so take them relative to the larger one.  Never taken for covariances of metre-scale clouds (the sweep loop stops at
+    // off-diagonal mass < 1e-36 of the diagonal's long before); the oracle has the same branch (orc_eig3_sym).
+    const double sc = fmax(fabs(d), fabs(b));
+    d /= sc; b /= sc;
+    h = sqrt(d * d + b * b);
+    u = fabs(d) + h;
+    r = sqrt(u * u + b * b);
+  }
   const double cs = u / r;
   double sn = fabs(b) / r;
   if (!(d == 0.0 || (d > 0.0) == (b > 0.0))) sn = -sn;   // sgn(tau), tau = +-0 counting as positive
@@ -345,6 +355,25 @@ __device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) m.v[i][j] = (i == j) ? 1.0 : 0.0;
+  // Entries whose SQUARES leave the fp64 range (covariances below ~1e-120 or above ~1e120 -- not of metre-scale clouds) are
+  // brought to order 1 by a power of two first: exact, so the rotations and the eigenvectors are the same ones and the
+  // eigenvalues are scaled back exactly; in the normal range nothing is touched (orc_eig3_sym has the same branch).
+  int rescale = 0;
+  {
+    double mx = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) mx = fmax(mx, fabs(m.a[i][j]));
+    if (__builtin_expect(mx != 0.0 && mx < __builtin_inf() && (mx < 1e-120 || mx > 1e120), 0)) {
+      (void)frexp(mx, &rescale);
+      const double f = ldexp(1.0, -rescale);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m.a[i][j] *= f;
+    }
+  }
   for (int sweep = 0; sweep < 60; ++sweep) {
     const double off = m.a[0][1] * m.a[0][1] + m.a[0][2] * m.a[0][2] + m.a[1][2] * m.a[1][2];
     const double dia = m.a[0][0] * m.a[0][0] + m.a[1][1] * m.a[1][1] + m.a[2][2] * m.a[2][2];
@@ -354,6 +383,10 @@ __device__ __forceinline__ void eig3_sym(Sym3& m, double ev[3]) {
     jacobi_rotate<1, 2>(m);
   }
   ev[0] = m.a[0][0]; ev[1] = m.a[1][1]; ev[2] = m.a[2][2];
+  if (__builtin_expect(rescale != 0, 0)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ev[i] = ldexp(ev[i], rescale);
+  }
   sort_swap<0>(ev, m);
   sort_swap<1>(ev, m);
   sort_swap<0>(ev, m);

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, VoxelWork W)
     x ^= __shfl_xor(x, 1, 64);
     x ^= __shfl_xor(x, 2, 64);
     x ^= __shfl_xor(x, 4, 64);
-    if (i == 7) w = W.host_seq ^ x;
+    if (i == 7) w = check_mix(W.host_seq) ^ x;
     __hip_atomic_store(&W.host_seg[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (i >= J.n) return;
