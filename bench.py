@@ -58,10 +58,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per K3 launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
 # THIS command, summarised by scripts/pmc_summary.py with the gfx950 x2 FETCH_SIZE correction).  PMC counters
 # cannot be read from inside the process, so the line quotes the committed summary and says so.
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt.json"),
-                                os.path.join(ROOT, "profiles", "r02_pmc_k3_prebuilt.json")) if os.path.exists(p)),
-                   os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt.json"))
-PMC_SUMMARY_COLD = os.path.join(ROOT, "profiles", "r03_pmc_k3_prebuilt_cold.json")
+def _first_existing(*names):
+    paths = [os.path.join(ROOT, "profiles", n) for n in names]
+    return next((p for p in paths if os.path.exists(p)), paths[0])
+
+
+PMC_SUMMARY = _first_existing("r04_pmc_k3_prebuilt.json", "r03_pmc_k3_prebuilt.json", "r02_pmc_k3_prebuilt.json")
+PMC_SUMMARY_COLD = _first_existing("r04_pmc_k3_prebuilt_cold.json", "r03_pmc_k3_prebuilt_cold.json")
 
 
 def _sha16(path):
@@ -264,6 +267,7 @@ def main():
         for i in range(warmup):
             scene, T, st = step(i)
         H.k3_timer(reset=True)
+        H.k3_span(reset=True)
         barrier()
         t0 = time.perf_counter()
         gn_iters = 0      # executed GN iterations: residual/Jacobian sweep + 6x6 step (tloam_stats.gn_sweeps)
@@ -303,6 +307,7 @@ def main():
             repeated = {"workload": "frame 105 of the sequence, the same pair 100 times (not part of value)",
                         "ms_per_frame": round(dtr / 100 * 1e3, 4), "gn_iters_per_sec": round(itr / dtr, 1),
                         "gn_iters_per_frame": itr / 100}
+        span_us, span_n = H.k3_span()                    # one-launch GN iterations: streaming span of the working sweeps (device clock)
         k3_us, k3_n, _ = H.k3_timer()                    # working sweeps
         k3_all_us, k3_all_n = H.k3_timer_all()            # every sampled K3 launch incl. no-ops after a tolerance exit
         # cross-check without per-launch event overhead: ONE event pair around 60 consecutive launches of the same
@@ -330,6 +335,14 @@ def main():
                                "frac": round(alg / (bb_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                "note": "one HIP event pair around 60 consecutive launches on the last correspondence "
                                        "set, after the timed region (no per-launch event overhead; launch gaps included)"}}
+        if span_n:
+            sp = span_us / span_n
+            k3["stream_phase"] = {"launches": int(span_n), "avg_us": round(sp, 3), "algorithmic_bytes_per_launch": alg,
+                                  "achieved": round(alg / (sp * 1e-6) / 1e9, 1), "frac": round(alg / (sp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "note": "a GN iteration of a large set is ONE launch (k3_sweep_step: sweep, row fold, minimiser step): "
+                                          "the dispatch duration above includes the serial tail (~5 us of one wave); this is the "
+                                          "STREAMING span of the same launches -- block 0's first instruction to the last block's row "
+                                          "at the coherence point, device wall clock (100 MHz), every working sweep of the timed frames"}
         if k3_all_n == 0:   # fused sweep + step launches carry no event pair (tloam_k3_timer covers k3_accumulate dispatches only)
             k3.update({"sampled": False, "achieved": None, "frac": None, "avg_launch_us": None,
                        "launch_sampling": "not sampled: KITTI-size sets run sweep + minimiser step as ONE launch "
@@ -356,9 +369,10 @@ def main():
         if side is not None:
             in_frame = dict(side["k3"])
             in_frame.update({"workload": side["workload"],
-                             "note": "the same kernel inside the timed 1 M frames (%d frames): every launch follows the one-block "
-                                     "minimiser step, i.e. starts on an idle chip; per-launch HIP event pairs read 1.2-2.5 us "
-                                     "more than the dispatch timestamps (DESIGN.md section 7)" %
+                             "note": "the same sweep inside the timed 1 M frames (%d frames), where a GN iteration is one launch "
+                                     "(k3_sweep_step = sweep + row fold + minimiser step): avg_launch_us / frac are per-launch HIP event "
+                                     "pairs around the WHOLE dispatch (serial tail included; event pairs read 1.2-2.5 us more than "
+                                     "dispatch timestamps, DESIGN.md section 7); stream_phase is the sweep alone" %
                                      (args.steps if args.workload == "m1" else args.m1_steps)})
             roofline = None
             if not multi and not args.no_side:
@@ -396,13 +410,27 @@ def main():
                                                       "stale": dc.get("kernel_source_sha16") != _sha16(os.path.join(ROOT, "tloam_amd", "csrc", "tl_gn.hip"))}
                         except Exception:  # noqa: BLE001
                             pass
-                    roofline["cold"] = cold
+                    # the headline fields are the HBM figure: every byte of every launch from HBM (the 4x set); the contract's own
+                    # 74.88 MB set, which lives in the Infinity Cache across launches, moves to `l3_resident`
+                    l3 = {k: roofline[k] for k in ("achieved", "frac", "traffic", "traffic_detail", "avg_launch_us", "launches",
+                                                   "algorithmic_bytes_per_launch", "workload", "working_set", "launch_timing", "note",
+                                                   "frac_of_measured_copy")}
+                    roofline = {"bound": "hbm", "achieved": cold["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cold["frac"],
+                                "traffic": cold.get("traffic"), "traffic_detail": cold.get("traffic_detail"),
+                                "kernel": "k3_accumulate<false, false>", "avg_launch_us": cold["avg_launch_us"], "launches": cold["launches"],
+                                "algorithmic_bytes_per_launch": cold["algorithmic_bytes_per_launch"], "workload": cold["workload"],
+                                "working_set": cold["working_set"], "launch_timing": cold["launch_timing"],
+                                "measured_copy_GBps": roofline["measured_copy_GBps"], "frac_of_measured_copy": cold["frac_of_measured_copy"],
+                                "note": "headline = the HBM figure (cold working set); the contract's 74.88 MB set (SURVEY 8(d) config 3: "
+                                        ">= 70 %% <=> <= 13.4 us) is Infinity-Cache resident across launches and is reported as l3_resident",
+                                "l3_resident": l3}
                 except Exception as e:  # noqa: BLE001  (side measurements never take the line down)
                     roofline = None
                     in_frame["side_measurements_error"] = repr(e)[:200]
             if roofline is None:   # N > 1 / --no-side: the in-frame figure stands in
                 roofline = dict(in_frame)
-                roofline.update({"kernel": "k3_accumulate<false, false>", "traffic": traffic, "traffic_detail": traffic_detail})
+                roofline.update({"kernel": "k3_sweep_step<false> (sweep + row fold + minimiser step in one dispatch)", "traffic": traffic,
+                                 "traffic_detail": traffic_detail})
             else:
                 roofline["in_frame"] = in_frame
             if side.get("k1"):

@@ -37,11 +37,12 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 5  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+#define TLOAM_ABI_VERSION 6  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
                                * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us
                                * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
                                *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned
-                               * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve) */
+                               * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve)
+                               * 6: tloam_k3_span */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -232,6 +233,11 @@ int tloam_k3_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* launche
 /* the same over EVERY K3 launch, including the no-op launches enqueued after a solver tolerance exit
  * (the population a kernel trace averages over) */
 int tloam_k3_timer_all(tloam_ctx* ctx, double* total_us, int64_t* launches);
+/* One-launch GN iterations of large sets (k3_sweep_step: sweep + row fold + minimiser step in one dispatch): the STREAMING
+ * span of those launches -- first wave in to last block row out, by the device's 100 MHz wall clock, without the serial
+ * tail -- accumulated on the device since the last reset; synchronises the stream.  launches counts working sweeps only
+ * (a launch that finds the Solve finished returns before the span is taken). */
+int tloam_k3_span(tloam_ctx* ctx, int reset, double* total_us, int64_t* launches);
 /* Test aid: the DEVICE SE(3) arithmetic the minimiser step uses (vendored-Sophus restatements sophus/so3.hpp:583-619,
  * se3.hpp:761-785 exp; so3.hpp:247-290, se3.hpp:223-256 log; registration.cpp:162-173 Plus), n items.  out26 per item:
  * [0..6] exp(delta) as (qw qx qy qz tx ty tz), [7..12] log(exp(x)), [13..18] Plus(x, delta), [19..25] exp(x) (shared form). */

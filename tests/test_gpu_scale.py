@@ -160,3 +160,58 @@ def test_quad_builder_mid_size_index_parity(hip_module):
     dt, dr = pose_delta(Th, To)
     assert dt < 1e-9 and dr < 1e-9
     H.close()
+
+
+def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m, monkeypatch):
+    """Round 4: a GN iteration of a LARGE set is one launch -- the streaming sweep's last block folds the rows and advances
+    the minimiser (k3_sweep_step) -- instead of k3_accumulate + k_reduce_and_step (TLOAM_NO_FUSED_LARGE).  Same sweep, same
+    fold tree, same step: the pre-built 1 M Solve and a 100 k-point frame (thread-per-query search, riding finish, learned
+    sweep budgets over three frames) must come out bit for bit the same; the streaming span the fused launches report about
+    themselves (tloam_k3_span) counts exactly the executed sweeps."""
+    sets, x_true, x_eval = prebuilt_1m
+    big = 1 << 30
+    sc = synth.make_scene(seed=1, n_src=(50000, 26000, 20000, 4000), n_tgt=(50000, 26000, 20000, 4000))
+    over = dict(planar_maxnum=big, ground_maxnum=big, edge_maxnum=big, sphere_maxnum=big)
+
+    def run(H):
+        for rt in range(3):
+            H.set_correspondences(rt, *sets[rt])
+        x, st = H.solve(x_eval)
+        out = [(x.copy(), {k: st[k] for k in ("gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "solver_cost")},
+                [H.get_costs(rt).copy() for rt in range(3)])]
+        Hn, gn, cn = H.get_normal_equations()
+        out.append((Hn.copy(), gn.copy(), cn))
+        return out
+
+    H1 = hip_module.HipRegistration()
+    a = run(H1)
+    us, n = H1.k3_span(reset=True)
+    assert n == a[0][1]["gn_sweeps"] and 5.0 < us / n < 200.0, (us, n)     # ~12 us per sweep of 74.88 MB
+    monkeypatch.setenv("TLOAM_NO_FUSED_LARGE", "1")                        # read once, when the context is created
+    H2 = hip_module.HipRegistration()
+    b = run(H2)
+    assert H2.k3_span()[1] == 0
+    assert np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1]
+    for ca, cb in zip(a[0][2], b[0][2]):
+        assert np.array_equal(ca, cb)
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and a[1][2] == b[1][2]
+    H1.close(); H2.close()
+    monkeypatch.delenv("TLOAM_NO_FUSED_LARGE")
+    F1 = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.setenv("TLOAM_NO_FUSED_LARGE", "1")
+    F2 = hip_module.HipRegistration(hip_module.default_config(**over))
+    for F in (F1, F2):
+        F.set_frames(sc.source, sc.target)
+    for frame in range(3):
+        rc1, T1, st1 = F1.scan_match(sc.T_pred)
+        rc2, T2, st2 = F2.scan_match(sc.T_pred)
+        assert rc1 == rc2 == 0 and np.array_equal(T1, T2)
+        for k in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "outer_iterations", "kind_cost", "se3"):
+            assert np.array_equal(np.asarray(st1[k]), np.asarray(st2[k])), k
+        for k in range(4):
+            c1 = F1.get_correspondences(k, capacity=len(sc.source.cloud(k)))
+            c2 = F2.get_correspondences(k, capacity=len(sc.source.cloud(k)))
+            for f in ("idx", "w", "cost"):
+                assert np.array_equal(c1[f], c2[f]), (k, f)
+            assert np.array_equal(F1.get_weights(k), F2.get_weights(k))
+    F1.close(); F2.close()

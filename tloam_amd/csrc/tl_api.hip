@@ -357,6 +357,27 @@ int launch_k3_timed(tloam_ctx* c, bool force) {
   }
   return TLOAM_OK;
 }
+// the same for the one-launch GN iteration (k3_sweep_step): the pair then brackets sweep + fold + step; the streaming part
+// alone is what the kernel's own span counter measures (K3Step::span, read by tloam_k3_timer_span)
+int launch_k3_step_timed(tloam_ctx* c) {
+  const bool sample = c->k3_timing && (c->k3_seq++ % kK3SampleStride) == 0;
+  const int idx = c->batch_launches++;
+  const MboxView* mb = (c->nranks > 1 && c->comm == COMM_MAILBOX) ? &c->mbox : nullptr;
+  if (sample) {
+    if (c->ev_used + 2 > c->ev_pool.size()) {
+      const size_t old = c->ev_pool.size();
+      c->ev_pool.resize(old + 256);
+      for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
+    }
+    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream,
+                   c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1]);
+    c->ev_used += 2;
+    c->ev_batch_idx.push_back(idx);
+  } else {
+    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream);
+  }
+  return TLOAM_OK;
+}
 // fold the recorded event pairs into the accumulated timers (stream must be idle).  The launches of the batch belong
 // to `nsolve` Solves starting at batch positions start[i]; of each, the first working[i] launches did a sweep, the
 // later ones were no-op launches after `done`.
@@ -450,7 +471,16 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
     c->batch_launches++;
     return TLOAM_OK;
   }
+  // One GN iteration = ONE launch whatever the size of the set (round 4): the streaming sweep's last block folds the rows and
+  // advances the minimiser (k3_sweep_step); with a mailbox it also posts, gathers and advances -- sweep + exchange + step.
+  // RCCL / callback contexts keep sweep | collective | step: the collective is enqueued by the host between two launches.
+  const bool one_launch = !c->no_fused_large && (c->nranks == 1 ? !(c->k3_single && !c->no_fused_small) : c->comm == COMM_MAILBOX);
   for (int sweep = 0; sweep < sweeps; ++sweep) {
+    if (one_launch) {
+      const int rc = launch_k3_step_timed(c);
+      if (rc != TLOAM_OK) return rc;
+      continue;
+    }
     if (c->nranks > 1) {
       // sharded GN iteration = 2 launches (+ the collective): the sweep, whose last block folds the rows into the
       // 48-double buffer (the 42 normal-equation scalars + cost) and -- with the mailbox -- stores it straight into
@@ -493,6 +523,8 @@ int ensure_common(tloam_ctx* c) {
   if (!c->k3_ticket.p) {
     HIPC(c, c->k3_ticket.reserve(4));
     HIPC(c, hipMemsetAsync(c->k3_ticket.p, 0, 4 * sizeof(int), c->stream));
+    HIPC(c, c->k3_span.reserve(4));     // K3Step::span
+    HIPC(c, hipMemsetAsync(c->k3_span.p, 0, 4 * sizeof(unsigned long long), c->stream));
     HIPC(c, c->k3_bcast.reserve(64));   // two messages of 16 words, a cache line apart each (k_solve_small: poses / end-of-iteration verdicts)
     HIPC(c, hipMemsetAsync(c->k3_bcast.p, 0, 64 * sizeof(unsigned long long), c->stream));
   }
@@ -594,6 +626,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     c->device_cus = cus;
   }
   c->no_ride_large = getenv("TLOAM_NO_RIDE_LARGE") != nullptr;
+  c->no_fused_large = getenv("TLOAM_NO_FUSED_LARGE") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
   c->enqueue_ahead = getenv("TLOAM_ENQUEUE_AHEAD") ? std::max(1, atoi(getenv("TLOAM_ENQUEUE_AHEAD"))) : 0;
@@ -640,7 +673,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int r = 0; r < kMaxRanks; ++r)
     if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
   if (c->mbox_local) (void)hipFree(c->mbox_local);
-  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
+  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_span.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)
@@ -1900,6 +1933,20 @@ int tloam_k3_timer_all(tloam_ctx* c, double* total_us, int64_t* launches) {
   if (!c) return TLOAM_E_INVALID;
   if (total_us) *total_us = c->k3_all_us;
   if (launches) *launches = c->k3_all_launches;
+  return TLOAM_OK;
+}
+
+int tloam_k3_span(tloam_ctx* c, int reset, double* total_us, int64_t* launches) {
+  if (!c) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (c->k3_span.p) {
+    HIPC(c, hipMemcpyAsync(h, c->k3_span.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (reset) HIPC(c, hipMemsetAsync(c->k3_span.p, 0, sizeof(h), c->stream));
+  }
+  if (total_us) *total_us = (double)h[1] * 0.01;   // 100 MHz wall clock
+  if (launches) *launches = (int64_t)h[2];
   return TLOAM_OK;
 }
 

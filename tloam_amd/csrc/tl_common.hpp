@@ -410,6 +410,10 @@ struct K3Fuse {
 };
 void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
                      const K3Fuse& fuse, hipStream_t s);
+// one GN iteration in ONE launch, whatever the size of the set: the sweep whose last block folds the rows and advances the
+// minimiser (mailbox contexts: posts, gathers and advances) -- k3_sweep_step, tl_gn.hip.  span: see K3Step (may be null)
+void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
+                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s);   // gather (rank order) + consume
 void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream_t s);  // buf <- sum over ranks
 void launch_mbox_gather_only(double* out48, const MboxView& mb, hipStream_t s);

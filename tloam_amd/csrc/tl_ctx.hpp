@@ -155,6 +155,7 @@ struct tloam_ctx {
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
+  bool no_fused_large = false; // TLOAM_NO_FUSED_LARGE: large sets keep sweep and step as two launches, sharded ones sweep | step (A/B, tests)
   bool no_ride_large = false;  // TLOAM_NO_RIDE_LARGE: k_weights + k_outer_finish as launches of their own (A/B, tests)
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
@@ -210,6 +211,7 @@ struct tloam_ctx {
   tl::MboxView mbox{};
   DBuf<unsigned long long> mbox_ctr;
   DBuf<int> k3_ticket;
+  DBuf<unsigned long long> k3_span;    // K3Step::span: streaming span of the one-launch GN iterations (100 MHz ticks, launches)
   DBuf<unsigned long long> k3_bcast;   // candidate-pose broadcast of the one-launch Solve (k_solve_small)
   // scanMatching host state
   bool active = false;

@@ -898,6 +898,107 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
 }
+// ---- one GN iteration of a LARGE set in ONE launch (round 4) -------------------------------------------------------
+// The streaming sweep whose LAST block (ticket) folds the rows and -- on its first wave -- advances the minimiser:
+// registration.cpp:1036-1047 is one Solve, and a GN iteration of it is one launch here whatever the size of the set.
+// Against k3_accumulate + k_reduce_and_step this removes, per GN iteration, a kernel boundary, the dispatch of a one-block
+// kernel and its row / state loads from the dependent chain (the state is requested into LDS by every block in its first
+// instructions: which block will be last is not known).  Sharded contexts with a mailbox: the last block posts the folded
+// row to every rank, then GATHERS the ranks' rows itself and runs the step -- sweep + exchange + step is one launch there
+// too (RCCL / callback contexts keep k3_accumulate<*, true> + collective + k_gn_step: the collective is a host-enqueued
+// operation between two launches).
+// Registers: the grid is two blocks per CU (k3_grid_for), i.e. two waves per SIMD, which leaves each wave 256 of the
+// SIMD's 512 registers -- the sweep needs ~118, the step ~285 when unconstrained: the step's overflow goes to scratch,
+// touched by one wave of one block per launch.
+// span (development / bench aid, may be null): [0] block 0 stores the wall clock (100 MHz) in its first instructions, the
+// last block adds (its clock at the ticket - [0]) to [1] and one to [2]: the STREAMING span of the launch, first wave in to
+// last row out, without the serial tail -- what the roofline fraction of the sweep inside a frame is computed from, now that
+// the dispatch duration includes fold + step.
+struct K3Step {
+  int* ticket;                 // zero between launches
+  unsigned long long* span;    // [4] or null
+  MboxView mb;                 // mb.nranks == 0: one rank
+};
+template <bool SINGLE>
+__global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict__ seg0, int stride0, int cap0, int unused,
+                                                        GnState* __restrict__ st, const int* __restrict__ seg_n,
+                                                        double* __restrict__ partials, CorrView cv, K3Step fs) {
+  __shared__ double red[4][32];
+  __shared__ double s_grp[8 * 33];
+  __shared__ double tot[kMboxSlot];
+  __shared__ GnState s_in;
+  (void)unused;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  ChunkData pre;
+  SingleWork wk{-1, 0};
+  const bool spec = !SINGLE && (gw + 1) * kChunk <= cap0;
+  if (SINGLE) {
+    wk = single_work_of(cv, cap0, gw, lane);
+    single_fetch(cv, seg0, stride0, wk, pre);
+  } else if (spec) {
+    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
+  }
+  if (fs.span && blockIdx.x == 0 && threadIdx.x == 0) fs.span[0] = wall_clock64();
+  {
+    constexpr int kWords = (int)(sizeof(GnState) / 8);
+    static_assert(kWords <= 256, "one word per thread");
+    if (threadIdx.x < kWords)
+      reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
+  }
+  if (st->done) return;            // after a tolerance exit the remaining launches are no-ops (uniform over the grid and the ranks)
+  const Rt T = st->Rt_eval;
+  Acc a;
+  if (SINGLE) sweep_single(cv, seg_n, T, wk, pre, a);
+  else sweep_all(cv, seg_n, T, gw, gridDim.x * 4, lane, a, pre, spec);
+  const double wtot = wave_reduce_acc(a, lane);
+  if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
+  __syncthreads();                 // (also publishes s_in)
+  if (!k3_take_ticket(partials, red, fs.ticket)) return;
+  // ---- the last block: every row has reached the coherence point
+  if (fs.span && threadIdx.x == 0) {
+    const unsigned long long t1 = wall_clock64();
+    const unsigned long long t0 = __hip_atomic_load(fs.span, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fs.span[1] += t1 - t0;
+    fs.span[2] += 1ull;
+  }
+  fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
+  if (threadIdx.x == 0) __hip_atomic_store(fs.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (threadIdx.x >= 64) return;
+  if (fs.mb.nranks > 0) {
+    // exchange: this rank's totals to every rank, every rank's totals from the local mailbox, added in rank order
+    const unsigned long long id = __hip_atomic_load(fs.mb.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    mbox_post(fs.mb, id, tot, kReduceBuf, (int)threadIdx.x);
+    const bool ok = mbox_gather(fs.mb, id, tot, kReduceBuf, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+      fs.mb.ctr[0] = id;
+      if (!ok) fs.mb.ctr[1] = 1ull;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS stores are in order
+    if (!ok) {  // a peer never posted: stop the minimiser, the host reports TLOAM_E_RCCL
+      if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
+      return;
+    }
+  }
+  gn_consume(st, tot, (int)threadIdx.x, &s_in, s_grp /* free again: the fold is over */);
+}
+void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
+                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  auto kern = single ? k3_sweep_step<true> : k3_sweep_step<false>;
+  K3Step fs;
+  memset(&fs, 0, sizeof(fs));
+  fs.ticket = ticket;
+  fs.span = span;
+  if (mb_or_null) fs.mb = *mb_or_null;
+  if (ev_start && ev_stop) {
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
+                          cv.k[0].cap, 0, st, cv.seg_n, partials, cv, fs);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, 0, st, cv.seg_n,
+                       partials, cv, fs);
+  }
+}
+
 // ---- one GN iteration of a KITTI-size set in ONE launch ----------------------------------------------------------
 // The sweep (one wave per chunk, as k3_accumulate<true, *>) and the minimiser step: every block hands its row over
 // with device-scope stores and takes a ticket (k3_take_ticket: no cache-wide fence), the LAST block folds the rows

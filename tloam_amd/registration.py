@@ -136,6 +136,7 @@ def load_library():
         "tloam_time_build": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64)]),
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
+        "tloam_k3_span": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
         "tloam_debug_se3": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
@@ -170,7 +171,7 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
-    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
+    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_k3_span", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
@@ -507,6 +508,12 @@ class HipRegistration:
     def k3_timer_all(self):
         us = C.c_double(0); n = C.c_int64(0)
         self._check(self.L.tloam_k3_timer_all(self.h, C.byref(us), C.byref(n)), "tloam_k3_timer_all")
+        return us.value, n.value
+
+    def k3_span(self, reset=False):
+        """(total us, launches) of the streaming span of the one-launch GN iterations (tloam_k3_span)."""
+        us = C.c_double(0); n = C.c_int64(0)
+        self._check(self.L.tloam_k3_span(self.h, int(bool(reset)), C.byref(us), C.byref(n)), "tloam_k3_span")
         return us.value, n.value
 
     # ---- multi-GPU ---------------------------------------------------------------------------
