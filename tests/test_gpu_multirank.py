@@ -44,7 +44,7 @@ def _make_allreduce():
 def init_comm(H, mode, rank, world):
     """callback: sum all-reduce through host memory + gloo.  mailbox: the one-shot peer exchange -- every rank exports
     its buffer (HIP IPC), the handles are all-gathered (here through gloo), every rank maps its peers."""
-    if mode == "mailbox":
+    if mode in ("mailbox", "mailbox_fused"):
         handles = [None] * world
         dist.all_gather_object(handles, H.comm_mailbox_export())
         H.comm_init_mailbox(rank, world, handles)
@@ -55,6 +55,8 @@ def init_comm(H, mode, rank, world):
 def _worker(rank, world, port, q, caps, mode="callback"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "mailbox_fused":   # sweep + exchange + step of a sharded GN iteration in ONE launch (k3_sweep_step); read at create
+        os.environ["TLOAM_FUSED_LARGE"] = "1"
     try:
         from tloam_amd import registration as reg
         sc = synth.make_scene(seed=31)
@@ -80,7 +82,7 @@ def _worker(rank, world, port, q, caps, mode="callback"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["callback", "mailbox"])
+@pytest.mark.parametrize("mode", ["callback", "mailbox", "mailbox_fused"])
 @pytest.mark.parametrize("caps", [{}, dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)],
                          ids=["default_caps", "caps_bind_across_ranks"])
 def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps, mode):
@@ -135,6 +137,8 @@ def _worker_timeout(rank, world, port, q):
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "mailbox_fused":   # sweep + exchange + step of a sharded GN iteration in ONE launch (k3_sweep_step); read at create
+        os.environ["TLOAM_FUSED_LARGE"] = "1"
     try:
         from tloam_amd import registration as reg
         sc = synth.make_scene(seed=31)

@@ -163,8 +163,8 @@ def test_quad_builder_mid_size_index_parity(hip_module):
 
 
 def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m, monkeypatch):
-    """Round 4: a GN iteration of a LARGE set is one launch -- the streaming sweep's last block folds the rows and advances
-    the minimiser (k3_sweep_step) -- instead of k3_accumulate + k_reduce_and_step (TLOAM_NO_FUSED_LARGE).  Same sweep, same
+    """Round 4: a GN iteration of a LARGE set as one launch (TLOAM_FUSED_LARGE) -- the streaming sweep's last block folds the
+    rows and advances the minimiser (k3_sweep_step) -- instead of k3_accumulate + k_reduce_and_step.  Same sweep, same
     fold tree, same step: the pre-built 1 M Solve and a 100 k-point frame (thread-per-query search, riding finish, learned
     sweep budgets over three frames) must come out bit for bit the same; the streaming span the fused launches report about
     themselves (tloam_k3_span) counts exactly the executed sweeps."""
@@ -183,11 +183,12 @@ def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m,
         out.append((Hn.copy(), gn.copy(), cn))
         return out
 
+    monkeypatch.setenv("TLOAM_FUSED_LARGE", "1")                           # read once, when the context is created
     H1 = hip_module.HipRegistration()
     a = run(H1)
     us, n = H1.k3_span(reset=True)
     assert n == a[0][1]["gn_sweeps"] and 5.0 < us / n < 200.0, (us, n)     # ~12 us per sweep of 74.88 MB
-    monkeypatch.setenv("TLOAM_NO_FUSED_LARGE", "1")                        # read once, when the context is created
+    monkeypatch.delenv("TLOAM_FUSED_LARGE")
     H2 = hip_module.HipRegistration()
     b = run(H2)
     assert H2.k3_span()[1] == 0
@@ -196,9 +197,9 @@ def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m,
         assert np.array_equal(ca, cb)
     assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1]) and a[1][2] == b[1][2]
     H1.close(); H2.close()
-    monkeypatch.delenv("TLOAM_NO_FUSED_LARGE")
+    monkeypatch.setenv("TLOAM_FUSED_LARGE", "1")
     F1 = hip_module.HipRegistration(hip_module.default_config(**over))
-    monkeypatch.setenv("TLOAM_NO_FUSED_LARGE", "1")
+    monkeypatch.delenv("TLOAM_FUSED_LARGE")
     F2 = hip_module.HipRegistration(hip_module.default_config(**over))
     for F in (F1, F2):
         F.set_frames(sc.source, sc.target)

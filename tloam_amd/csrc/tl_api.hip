@@ -474,7 +474,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
   // One GN iteration = ONE launch whatever the size of the set (round 4): the streaming sweep's last block folds the rows and
   // advances the minimiser (k3_sweep_step); with a mailbox it also posts, gathers and advances -- sweep + exchange + step.
   // RCCL / callback contexts keep sweep | collective | step: the collective is enqueued by the host between two launches.
-  const bool one_launch = !c->no_fused_large && (c->nranks == 1 ? !(c->k3_single && !c->no_fused_small) : c->comm == COMM_MAILBOX);
+  const bool one_launch = c->fused_large && (c->nranks == 1 ? !(c->k3_single && !c->no_fused_small) : c->comm == COMM_MAILBOX);
   for (int sweep = 0; sweep < sweeps; ++sweep) {
     if (one_launch) {
       const int rc = launch_k3_step_timed(c);
@@ -626,7 +626,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     c->device_cus = cus;
   }
   c->no_ride_large = getenv("TLOAM_NO_RIDE_LARGE") != nullptr;
-  c->no_fused_large = getenv("TLOAM_NO_FUSED_LARGE") != nullptr;
+  c->fused_large = getenv("TLOAM_FUSED_LARGE") != nullptr;
   c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
   c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
   c->enqueue_ahead = getenv("TLOAM_ENQUEUE_AHEAD") ? std::max(1, atoi(getenv("TLOAM_ENQUEUE_AHEAD"))) : 0;

@@ -155,7 +155,8 @@ struct tloam_ctx {
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
-  bool no_fused_large = false; // TLOAM_NO_FUSED_LARGE: large sets keep sweep and step as two launches, sharded ones sweep | step (A/B, tests)
+  bool fused_large = false;    // TLOAM_FUSED_LARGE: a GN iteration of a large set as ONE launch (k3_sweep_step; sharded + mailbox: sweep, exchange
+                               // and step).  Measured slower than sweep + step as two launches: off by default
   bool no_ride_large = false;  // TLOAM_NO_RIDE_LARGE: k_weights + k_outer_finish as launches of their own (A/B, tests)
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)

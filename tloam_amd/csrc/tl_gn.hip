@@ -939,7 +939,8 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
   } else if (spec) {
     fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
   }
-  if (fs.span && blockIdx.x == 0 && threadIdx.x == 0) fs.span[0] = wall_clock64();
+  if (fs.span && blockIdx.x == 0 && threadIdx.x == 0)   // (device-scope: read by the last block, on another XCD)
+    __hip_atomic_store(fs.span, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
     static_assert(kWords <= 256, "one word per thread");
