@@ -1268,7 +1268,7 @@ __device__ __forceinline__ bool weight_out_of_range(const WeightParams& wp, int 
 constexpr int kExtRowBase = 512;   // the waves' extra segments: words kExtRowBase + 8 wave .. of the row buffer (wave = 4 block + wave in block)
 // lanes 0..7 of the wave: (cost sum, count, kind, 0, 0, 0, 0, tag ^ xor) -- cs / bad: the wave totals (lane 0's are used)
 __device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, int gw, double cs, double bad, int kind, unsigned long long tag,
-                                                 int lane) {
+                                                 int lane, int base_word = kExtRowBase) {
   if (lane >= 8) return;
   unsigned long long wd = 0ull;
   const double cs0 = rdlane(cs, 0), bad0 = rdlane(bad, 0);
@@ -1277,16 +1277,16 @@ __device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, 
   else if (lane == 2) wd = (unsigned long long)(long long)kind;
   const unsigned long long x = xor8(wd);
   if (lane == 7) wd = check_mix(tag) ^ x;
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + kExtRowBase + (size_t)gw * 8 + lane, wd, __ATOMIC_RELAXED,
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + base_word + (size_t)gw * 8 + lane, wd, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 // the consumer wave: waits for the extra segment of every other wave of the grid (stored right behind the rows it folded a
 // step ago) and adds them per kind in wave order -> fin[0..4] in LDS.  false: timed out.  nwaves <= 64.
 __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partials, int nwaves, unsigned long long tag, double* s_ext /*[64*3]*/,
-                                              double* fin /*[8]*/, int lane) {
-  const bool have = lane >= 1 && lane < nwaves;   // (wave 0 is this one)
+                                              double* fin /*[8]*/, int lane, int base_word = kExtRowBase) {
+  const bool have = lane >= 1 && lane < nwaves;   // (wave 0 of the grid holds no chunk)
   const unsigned long long mtag = check_mix(tag);
-  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + kExtRowBase + (size_t)(have ? lane : 1) * 8;
+  const unsigned long long* p = reinterpret_cast<const unsigned long long*>(partials) + base_word + (size_t)(have ? lane : 1) * 8;
   unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
   bool ok_all;
@@ -1389,8 +1389,10 @@ __device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restr
 // fin[0..3]: the kinds' cost sums of the Solve's last evaluation, fin[4]: weights out of range (poll_fold_ext); nseg: the set.
 // Returns 3: the loop goes on with an unchanged pose -- this launch runs the next outer iteration too | 4: leave (the loop
 // has ended, or the pose moved and the correspondence search has to run first).  One wave.
+// lead == false (k_solve_all: every block runs the consumer on its own image of the state): nothing leaves the block.
 __device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LDS image, current */, const SolveFinish& F, int oi,
-                                                  const double* fin, const int nseg[kKinds], double* sh /* LDS [16] */, int lane) {
+                                                  const double* fin, const int nseg[kKinds], double* sh /* LDS [16] */, int lane,
+                                                  bool lead = true) {
   constexpr int kWords = (int)(offsetof(GnState, dbg) / 8);
   const OuterCtl ctl{F.cost_threshold, 1, oi == F.n_iter - 1 ? 1 : 0};
   int next = 4;
@@ -1407,7 +1409,7 @@ __device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LD
       else if (lane < 8) v = (double)(lane == 4 ? nseg[0] : (lane == 5 ? nseg[1] : (lane == 6 ? nseg[2] : nseg[3])));   // (no indexed array: registers)
       else if (lane == 8) v = fin[4];
       sh[lane] = v;
-      F.sums16[lane] = v;
+      if (lead) F.sums16[lane] = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     publish_and_rearm(sh, sm, lane, ctl);
@@ -1417,6 +1419,7 @@ __device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LD
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // the image into the device state (every word up to the development stamps), the result slot, and -- once the loop has
   // ended -- the slots of the iterations that will not run (what their gated-off finish kernels would have written)
+  if (!lead) return next;
   for (int w = lane; w < kWords; w += 64) reinterpret_cast<unsigned long long*>(st)[w] = reinterpret_cast<const unsigned long long*>(sm)[w];
   // (the slot says whether the host has something to do: the loop goes on, but not inside this launch)
   mirror_wave(sm, F.hm[oi], lane, (sm->stop == 0 && next == 4) ? (int)(sm->incomplete | OS_NEEDS_HOST) : -1);
@@ -1651,6 +1654,249 @@ __global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict
     oi += 1;
   }
 }
+// ---- the same Solve with EVERY block consuming (round 4) --------------------------------------------------------------------
+// k_solve_small pays two cross-CU hand-overs per GN iteration: rows -> the consumer wave (~1.9 us), candidate pose -> the other
+// waves (~1.1-1.5 us).  Here every block is its own consumer: every block posts its row, wave 0 of EVERY block polls all the
+// rows, folds them in the same order and runs the same step on its own LDS image of the state -- bit-identical in all blocks,
+// the inputs are -- and hands the candidate pose to its block's other waves through LDS and a barrier.  One cross-CU exchange
+// per GN iteration instead of two; the minimiser's step is executed sixteen times side by side, which costs nothing (the
+// other waves of those CUs would be waiting for it anyway).  Block 0 ("lead") alone writes the device state, the compact set's
+// sizes and the result slots.
+// Rows are double-buffered by the parity of the hand-over number h: block A may post row h + 1 while block B is still reading
+// the rows of h; it cannot post h + 2 before B has posted h + 1, which B does only after it has read every row of h.  The waves'
+// finish-sum segments likewise.  Layout of `partials` (64-bit words): rows [2][kTaggedRows][32] at 0, segments [2][64][8] at 1024.
+// Wave 0 of block b >= 1 holds a chunk like the other waves (the chunk -> wave mapping, hence every sum, is k_solve_small's).
+constexpr int kAllRowsParity = kTaggedRows * kAccStride;   // 512 words
+constexpr int kAllExtBase = 2 * kAllRowsParity;            // 1024
+constexpr int kAllExtParity = 64 * 8;                      // 512 words
+__global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
+                                                      GnState* __restrict__ st, const int* __restrict__ seg_n,
+                                                      double* __restrict__ partials, int* __restrict__ ticket, CorrView cv, SolvePrep prep,
+                                                      int* __restrict__ seg_n_out, SolveFinish F) {
+  __shared__ double red[4][32];
+  __shared__ double s_scr[32];
+  __shared__ double s_rows[kTaggedRows * 28];
+  __shared__ double s_ext[64 * 3];
+  __shared__ double s_fin[8];
+  __shared__ double s_sh[16];
+  __shared__ double tot[kReduceBuf];
+  __shared__ double s_msg[16];    // [0..8] R, [9..11] t of the pose to evaluate next, [12] the verdict (as an integer value)
+  __shared__ GnState s_in;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;
+  const bool stepper = wave == 0;            // the block's consumer: polls the rows, folds them, takes the minimiser's step
+  const bool lead = blockIdx.x == 0;         // the block whose image of the state is the one written out
+  const bool self_prep = prep.sv.flagb != nullptr;
+  const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;   // test hook, see k_solve_small
+  max_sweeps &= 0xffff;
+  unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
+#ifdef TLOAM_STEP_PROFILE
+  unsigned long long* const prof = reinterpret_cast<unsigned long long*>(partials) + 2048;
+  const bool prof_c = lead && stepper && lane == 0;
+  const bool prof_p = (int)blockIdx.x == (int)gridDim.x / 2 && wave == 1 && lane == 0;
+#undef TL_PROF
+#define TL_PROF(cond, slot) if (cond) prof[(slot)] = wall_clock64();
+#endif
+  // ---- this wave's chunk, requested in its first instructions (speculatively with SolvePrep, see k_solve_small)
+  ChunkData pre;
+  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
+  single_fetch(cv, seg0, stride0, wk, pre);
+  FlagBytes fbytes;
+  if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
+  if (stepper) {
+    constexpr int kWords = (int)(sizeof(GnState) / 8);
+    for (int w = lane; w < kWords; w += 64)
+      reinterpret_cast<unsigned long long*>(&s_in)[w] = reinterpret_cast<const unsigned long long*>(st)[w];
+  }
+  // (every block reads the launch counter, the loop control and the gates before any block can change them: the lead writes
+  //  them only after it has seen a row of every block, and a block posts its first row after these reads)
+  const unsigned long long tag0 = (*epoch + 1ull) << 8;
+  int oi = F.first_iter;
+  if (F.enabled && (st->stop != 0 || st->next_outer != oi)) return;
+  const bool build = self_prep && (!prep.run_build || *prep.run_build != 0);
+  const bool refresh = self_prep && !build && prep.run_refresh && *prep.run_refresh != 0;
+  const bool done_at_entry = st->done != 0;
+  Rt T = st->Rt_eval;
+  // ---- the factor set of this outer iteration (SolvePrep)
+  int n_mine = 0;
+  int slot[2] = {0, 0};
+  int nseg[kKinds] = {0, 0, 0, 0};   // (the lead's stepper: the sizes of the whole set, for the state and the host)
+  if (lead && stepper) {
+    if (build) {
+      FlagBytes fb[kKinds];
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) load_flag_bytes(prep.sv.flagb, k, lane, fb[k]);
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) nseg[k] = kind_set_of(prep, cv, k, lane, fb[k]).total;
+      if (lane < kKinds) seg_n_out[lane] = lane == 0 ? nseg[0] : (lane == 1 ? nseg[1] : (lane == 2 ? nseg[2] : nseg[3]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
+    }
+  }
+  if (wk.kind >= 0) {
+    if (build) {
+      n_mine = self_compact(prep, cv, wk, lane, fbytes, pre, slot);
+    } else {
+      n_mine = seg_n[wk.kind];
+      if (self_prep) {
+        slots_of_chunk(prep, cv, wk, n_mine, slot);
+        if (refresh) self_refresh(prep, cv, wk, n_mine, slot, pre);
+      }
+    }
+  }
+  if (stepper) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the image is in LDS
+    if (build && lane < 6) {   // the set is built at this pose (k_prepare_small's x_build = x)
+      s_in.x_build[lane] = s_in.x[lane];
+      if (lead) st->x_build[lane] = s_in.x[lane];
+    }
+  }
+  if (done_at_entry) return;          // a Solve that has already ended (uniform over the grid)
+  TL_PROF(prof_c, 0)
+  unsigned long long h = 0;           // hand-over number: rows of GN evaluation h carry tag0 | h, parity h & 1
+  for (;;) {   // outer iterations run by this launch (exactly one unless F.enabled)
+    int verdict = 2;
+    double2 last_cost = double2{0.0, 0.0};
+    for (int it = 0;; ++it) {
+      Acc a;
+      last_cost = double2{0.0, 0.0};
+      sweep_single_n(cv, n_mine, T, wk, pre, a, &last_cost);
+      TL_PROF(prof_p, 64 + it * 8 + 1)
+      const double wtot = wave_reduce_acc(a, lane);
+      if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
+      __syncthreads();
+      double* const rows = partials + (size_t)(h & 1ull) * kAllRowsParity;
+      const int ext_base = kAllExtBase + (int)(h & 1ull) * kAllExtParity;
+      k3_post_row_tagged(rows, red, tag0 | h);     // (the first 32 threads of the block)
+      TL_PROF(prof_c, 8 + it * 8 + 0)
+      if (F.have_wp) {   // this chunk's part of the finish sums, behind the row (see post_ext_segment)
+        double cs = last_cost.x + last_cost.y;   // (a lane without a second / any factor holds 0 there)
+        double bad = 0.0;
+        if (wk.kind >= 0) {
+          const bool two = single_chunk_of(wk.kind) == kChunk;
+          if (wk.j < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.x)) bad += 1.0;
+          if (two && wk.j + 1 < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.y)) bad += 1.0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          cs += __shfl_down(cs, off, 64);
+          bad += __shfl_down(bad, off, 64);
+        }
+        post_ext_segment(partials, gw, cs, bad, wk.kind, tag0 | h, lane, ext_base);
+      }
+      TL_PROF(prof_p, 64 + it * 8 + 2)
+      if (stepper) {
+        const bool ok = poll_fold_tagged(rows, (int)gridDim.x, (tag0 | h) ^ sabotage, s_rows, tot, lane);
+        TL_PROF(prof_c, 8 + it * 8 + 1)
+        int vd = 5;
+        if (ok) {
+          gn_consume(st, tot, lane, &s_in, s_scr, lead);
+          vd = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
+        }
+        TL_PROF(prof_c, 8 + it * 8 + 2)
+        if (lane < 9) s_msg[lane] = s_in.Rt_eval.r[lane];
+        else if (lane < 12) s_msg[lane] = s_in.Rt_eval.t[lane - 9];
+        else if (lane == 12) s_msg[12] = (double)vd;
+      }
+      __syncthreads();
+      verdict = (int)s_msg[12];
+#pragma unroll
+      for (int v = 0; v < 9; ++v) T.r[v] = s_msg[v];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) T.t[v] = s_msg[9 + v];
+      TL_PROF(prof_c, 8 + it * 8 + 3)
+      TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
+      h += 1ull;
+      if (verdict != 1) break;
+    }
+    if (verdict == 5) {   // a block of the grid never posted (every block finds out in the same poll): stop, the lead reports
+      if (lead && stepper) {
+        if (lane == 0) {
+          st->done = 1; st->comm_error = 1;
+          s_in.done = 1; s_in.comm_error = 1;
+          if (F.enabled) {
+            s_in.incomplete = OS_COMM_ERROR;
+            st->incomplete = OS_COMM_ERROR;
+            st->stop = 1; st->run_build = 0; st->run_refresh = 0;
+          }
+          *epoch = tag0 >> 8;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (F.enabled) {
+          mirror_wave(&s_in, F.hm[oi], lane, (int)OS_COMM_ERROR);
+          for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
+        }
+      }
+      return;
+    }
+    // ---- the Solve is over.  The finish sums of its last evaluation (hand-over h - 1): every stepper collects the waves'
+    //      segments; meanwhile every wave works out the new GNC weights of the factors it holds (updateWeight, :858-876)
+    double2 w_new = pre.w;
+    if (F.enabled && wk.kind >= 0) {
+      const bool two = single_chunk_of(wk.kind) == kChunk;
+      if (wk.j < n_mine) w_new.x = refreshed_weight(F.wp[oi], wk.kind, last_cost.x, pre.w.x, prep.sv.w_src, slot[0]);
+      if (two && wk.j + 1 < n_mine) w_new.y = refreshed_weight(F.wp[oi], wk.kind, last_cost.y, pre.w.y, prep.sv.w_src, slot[1]);
+    }
+    if (stepper) {
+      int next = 4;
+      bool ok = true;
+      if (F.have_wp)
+        ok = poll_fold_ext(partials, (int)gridDim.x * 4, tag0 | (h - 1ull), s_ext, s_fin, lane, kAllExtBase + (int)((h - 1ull) & 1ull) * kAllExtParity);
+      if (!ok) {
+        next = 5;
+      } else if (!F.enabled) {
+        // the launch ends with the Solve; a finish kernel that follows takes its sums from the state (fin_valid)
+        if (lead) {
+          if (F.have_wp && lane < 5) {
+            const double v = s_fin[lane];
+            if (lane < 4) st->fin_sum[lane] = v; else st->fin_bad = v;
+          }
+          if (lane == 0) { st->fin_valid = F.have_wp ? 1 : 0; *epoch = tag0 >> 8; }   // (plain stores: read by the next launch)
+        }
+      } else {
+        next = finish_by_consumer(st, &s_in, F, oi, s_fin, nseg, s_sh, lane, lead);
+      }
+      if (lane < 9) s_msg[lane] = s_in.Rt_eval.r[lane];          // (the pose the re-armed minimiser starts from: exp(x))
+      else if (lane < 12) s_msg[lane] = s_in.Rt_eval.t[lane - 9];
+      else if (lane == 12) s_msg[12] = (double)next;
+    }
+    if (!F.enabled) return;
+    __syncthreads();
+    const int next = (int)s_msg[12];
+#pragma unroll
+    for (int v = 0; v < 9; ++v) T.r[v] = s_msg[v];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) T.t[v] = s_msg[9 + v];
+    if (next == 5) {   // the waves' segments never arrived: as above
+      if (lead && stepper) {
+        if (lane == 0) {
+          st->done = 1; st->comm_error = 1; s_in.done = 1; s_in.comm_error = 1;
+          s_in.incomplete = OS_COMM_ERROR; st->incomplete = OS_COMM_ERROR;
+          st->stop = 1; st->run_build = 0; st->run_refresh = 0;
+          *epoch = tag0 >> 8;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mirror_wave(&s_in, F.hm[oi], lane, (int)OS_COMM_ERROR);
+        for (int j = oi + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
+      }
+      return;
+    }
+    if (next != 3) {
+      if (lead && stepper && lane == 0) *epoch = tag0 >> 8;
+      return;
+    }
+    // ---- the next outer iteration on the same correspondences: new captured weights, zeroed side-channel slots (k_refresh)
+    if (wk.kind >= 0) {
+      const CorrSeg& seg = cv.k[wk.kind];
+      const bool two = single_chunk_of(wk.kind) == kChunk;
+      pre.w = w_new;
+      if (wk.j < n_mine) { seg.w[wk.j] = w_new.x; seg.cost[wk.j] = 0.0; }
+      if (two && wk.j + 1 < n_mine) { seg.w[wk.j + 1] = w_new.y; seg.cost[wk.j + 1] = 0.0; }
+    }
+    oi += 1;
+  }
+}
 void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
                         const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s) {
   SolvePrep P;
@@ -1659,8 +1905,13 @@ void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* 
   SolveFinish F;
   if (finish_or_null) F = *finish_or_null;
   else memset(&F, 0, sizeof(F));
-  hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
-                     cv.seg_n, partials, ticket, bcast, cv, P, seg_n, F);
+  static const bool v1 = getenv("TLOAM_SOLVE_V1") != nullptr;   // A/B knob: one consumer wave for the whole grid (round 3's k_solve_small)
+  if (v1)
+    hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
+                       cv.seg_n, partials, ticket, bcast, cv, P, seg_n, F);
+  else
+    hipLaunchKernelGGL(k_solve_all, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
+                       cv.seg_n, partials, ticket, cv, P, seg_n, F);
 }
 // The launch spin-waits between its blocks, so all of them must be resident at once: one block per CU (the consumer's step
 // wants ~400 registers: one wave per SIMD), i.e. grid <= the device's CU count -- 256 on an MI355X, fewer on a CU-masked or

@@ -437,8 +437,10 @@ __device__ __forceinline__ bool step_can_continue(StepVars& v) {
   return true;
 }
 
+// WRITE_GLOBAL = false (k_solve_all: every block advances its own LDS image of the state, one of them writes it out): the
+// device state `st` is not touched (wave-uniform run-time flag: ONE inlined copy of the step per kernel).
 __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS */, int lane, GnState* sm /* LDS */,
-                                           double* scr /* LDS */) {
+                                           double* scr /* LDS */, const bool WRITE_GLOBAL = true) {
   TL_STAMP(1)
   constexpr double function_tolerance = 1e-6, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
   StepVars v;
@@ -548,14 +550,19 @@ __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS
   {
     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sm);
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(st);
+    if (WRITE_GLOBAL) {
 #pragma unroll
-    for (int w = lane; w < kStepWords; w += 64) dst[w] = src[w];
+      for (int w = lane; w < kStepWords; w += 64) dst[w] = src[w];
+    }
     // has this Solve ended somewhere else than where the factor set was built?  (what publish_and_rearm will find when it
     // compares x with x_build -- known here already, so the next search need not wait for the finish kernel)
     bool moved = false;
 #pragma unroll
     for (int i = 0; i < 6; ++i) moved = moved || (sm->x[i] != sm->x_build[i]);
-    if (lane == 0) sm->spec_build = st->spec_build = (v.done && moved) ? 1 : 0;
+    if (lane == 0) {
+      sm->spec_build = (v.done && moved) ? 1 : 0;
+      if (WRITE_GLOBAL) st->spec_build = sm->spec_build;
+    }
   }
 }
 
