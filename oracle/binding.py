@@ -253,6 +253,23 @@ class Oracle:
         assert rc == 0, rc
         return x, st.as_dict()
 
+    TRACE_FIELDS = ("solve", "iteration", "cost", "cost_change", "step_ok", "radius", "step_norm", "relative_decrease",
+                    "gradient_max_norm", "exit_kind")
+
+    def get_trace(self):
+        """The minimiser's per-iteration trace since the last sm_begin / solve (orc_get_trace): a list of dicts with the
+        TRACE_FIELDS and "x" (the state after the iteration) -- what ceres::IterationSummary + the parameter block show."""
+        self.L.orc_get_trace.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        self.L.orc_get_trace.restype = C.c_int
+        buf = np.zeros((256, 16))
+        n = self.L.orc_get_trace(self.h, _dp(buf), 256)
+        out = []
+        for r in buf[:min(n, 256)]:
+            d = {k: (int(r[i]) if k in ("solve", "iteration", "step_ok", "exit_kind") else float(r[i])) for i, k in enumerate(self.TRACE_FIELDS)}
+            d["x"] = r[10:16].copy()
+            out.append(d)
+        return out
+
 
 # thin wrappers for the free functions
 def se3_exp(a):

@@ -7,6 +7,7 @@
 // yaml-cpp and the ROS logging macros (registration.hpp:17-31), none of which exist here; the CMakeLists.txt beside
 // this file finds the real packages and fails at configure time without them (no stand-ins).  On a machine that has
 // them:   cmake -S oracle/ref_harness -B oracle/_ref/build -DTLOAM_REFERENCE_DIR=/path/to/tloam && cmake --build oracle/_ref/build
+//         (or, with docker and a network, ONE command: oracle/ref_harness/run.sh -- see the Dockerfile beside this file)
 //         python tests/golden_ref_tools/export_ref_inputs.py          # tests/golden/case_*.npz -> oracle/_ref/in/*.bin
 //         oracle/_ref/build/ref_dump oracle/_ref/in tests/golden_ref  # -> tests/golden_ref/case_*.ref.txt
 //         python -m pytest tests/test_golden_ref.py
@@ -27,7 +28,9 @@
 // this file DEFINES ceres::Solve(options, problem, summary).  The reference's object file binds to that definition (an
 // executable's own symbols come first), which forwards to the real one in libceres (dlsym RTLD_NEXT on the mangled name)
 // and then writes the Summary: one "s" line per Solve call, one "i" line per minimiser iteration (cost, cost change, step
-// accepted or rejected, trust-region radius).  libceres must be linked SHARED for this (the CMake recipe checks).
+// accepted or rejected, trust-region radius, step norm, step quality, gradient max norm), and -- through an IterationCallback the
+// interposer adds to a COPY of the options -- one "x" line per iteration with the state the minimiser is at (StateDump below).
+// libceres must be linked SHARED for this (the CMake recipe checks).
 #include <dlfcn.h>
 
 #include <cstdint>
@@ -35,6 +38,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <yaml-cpp/yaml.h>
@@ -48,20 +52,54 @@ std::FILE* g_solve_log = nullptr;   // where the interposed ceres::Solve writes 
 int g_run = 0, g_call = 0;          // max_iterations of the current run, index of the Solve call inside it
 }  // namespace
 
+namespace {
+// The state the minimiser is at after every iteration (the accepted iterate: a rejected candidate leaves it unchanged), one
+// "x" line per iteration: run, Solve call, iteration, the parameter block(s), step quality and gradient max norm.  With it the
+// reject-four-times dynamics of SURVEY Appendix A.13 are compared STATE BY STATE, not only through the Summary's counters.
+// Needs Solver::Options::update_state_every_iteration (a copy-out after each iteration: no effect on the iterates) -- set on
+// a COPY of the reference's options inside the interposed Solve; the reference's source stays untouched.
+class StateDump : public ceres::IterationCallback {
+ public:
+  StateDump(std::vector<double*> blocks, std::vector<int> sizes) : blocks_(std::move(blocks)), sizes_(std::move(sizes)) {}
+  ceres::CallbackReturnType operator()(const ceres::IterationSummary& s) override {
+    if (g_solve_log) {
+      std::fprintf(g_solve_log, "x %d %d %d", g_run, g_call, s.iteration);
+      for (size_t b = 0; b < blocks_.size(); ++b)
+        for (int i = 0; i < sizes_[b]; ++i) std::fprintf(g_solve_log, " %.17g", blocks_[b][i]);
+      std::fprintf(g_solve_log, " rel %.17g gmax %.17g\n", s.relative_decrease, s.gradient_max_norm);
+    }
+    return ceres::SOLVER_CONTINUE;
+  }
+
+ private:
+  std::vector<double*> blocks_;
+  std::vector<int> sizes_;
+};
+}  // namespace
+
 namespace ceres {
 // interposed: see the header comment.  Same signature as ceres/solver.h declares.
 void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
   using Fn = void (*)(const Solver::Options&, Problem*, Solver::Summary*);
   static Fn real = reinterpret_cast<Fn>(dlsym(RTLD_NEXT, "_ZN5ceres5SolveERKNS_6Solver7OptionsEPNS_7ProblemEPNS0_7SummaryE"));
   if (!real) { std::fprintf(stderr, "ref_dump: the real ceres::Solve was not found behind this one (static libceres?)\n"); std::abort(); }
-  real(options, problem, summary);
+  std::vector<double*> blocks;
+  problem->GetParameterBlocks(&blocks);                   // the reference has one: `parameters`, 6 doubles (registration.cpp:972-974)
+  std::vector<int> sizes;
+  for (double* b : blocks) sizes.push_back(problem->ParameterBlockSize(b));
+  StateDump dump(blocks, sizes);
+  Solver::Options with_dump = options;
+  with_dump.update_state_every_iteration = true;
+  with_dump.callbacks.push_back(&dump);
+  real(with_dump, problem, summary);
   if (g_solve_log) {
     std::fprintf(g_solve_log, "s %d %d initial_cost %.17g final_cost %.17g successful %d unsuccessful %d termination %d\n", g_run,
                  g_call, summary->initial_cost, summary->final_cost, summary->num_successful_steps,
                  summary->num_unsuccessful_steps, static_cast<int>(summary->termination_type));
     for (const IterationSummary& it : summary->iterations)
-      std::fprintf(g_solve_log, "i %d %d %d cost %.17g change %.17g step_ok %d radius %.17g step_norm %.17g\n", g_run, g_call,
-                   it.iteration, it.cost, it.cost_change, it.step_is_successful ? 1 : 0, it.trust_region_radius, it.step_norm);
+      std::fprintf(g_solve_log, "i %d %d %d cost %.17g change %.17g step_ok %d radius %.17g step_norm %.17g rel %.17g gmax %.17g valid %d\n",
+                   g_run, g_call, it.iteration, it.cost, it.cost_change, it.step_is_successful ? 1 : 0, it.trust_region_radius,
+                   it.step_norm, it.relative_decrease, it.gradient_max_norm, it.step_is_valid ? 1 : 0);
   }
   ++g_call;
 }

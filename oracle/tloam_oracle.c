@@ -542,6 +542,10 @@ struct orc_ctx {
   tloam_stats stats;
   int bad_weights;
   double last_H[36], last_g[6], last_cost;
+  /* per-minimiser-iteration trace of every Solve since sm_begin / orc_solve (orc_get_trace): what a ceres::IterationSummary
+   * + the state after the iteration would show -- held against the REFERENCE's own Solves when tests/golden_ref/ exists */
+  double trace[ORC_TRACE_ROWS][ORC_TRACE_COLS];
+  int ntrace, nsolve;
   void* eval_part; /* orc_normal[eval_part_n]: per-thread partial sums of the threaded evaluator */
   int eval_part_n; /* normal equations at the accepted iterate when the last Solve returned */
 };
@@ -1059,6 +1063,25 @@ static double grad_max_norm(const double x[6], const double g[6]) {
   return m;
 }
 
+/* one row of the trace: [0] Solve index, [1] minimiser iteration, [2] cost after the iteration (x_cost), [3] cost change
+ * (x_cost - candidate cost), [4] step accepted, [5] trust-region radius after the iteration, [6] |x - x_candidate|,
+ * [7] step quality (relative decrease), [8] gradient max norm at x, [9] 0 regular | 1 ended by the parameter tolerance |
+ * 2 by the function tolerance | 3 invalid step, [10..15] x after the iteration */
+static void trace_push(orc_ctx* c, int iteration, double cost, double change, int ok, double radius, double step_norm, double rel,
+                       double gmax, int kind, const double x[6]) {
+  if (c->ntrace >= ORC_TRACE_ROWS) return;
+  double* r = c->trace[c->ntrace++];
+  r[0] = c->nsolve; r[1] = iteration; r[2] = cost; r[3] = change; r[4] = ok; r[5] = radius; r[6] = step_norm; r[7] = rel;
+  r[8] = gmax; r[9] = kind;
+  memcpy(r + 10, x, sizeof(double) * 6);
+}
+int orc_get_trace(orc_ctx* c, double* out, int cap_rows) {
+  if (!c) return TLOAM_E_INVALID;
+  int n = c->ntrace < cap_rows ? c->ntrace : cap_rows;
+  if (out && n > 0) memcpy(out, c->trace, sizeof(double) * ORC_TRACE_COLS * (size_t)n);
+  return c->ntrace;
+}
+
 static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_trust_region_radius = 1e-32;
@@ -1079,6 +1102,7 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
   int step_successful = 1;
   double gmax = grad_max_norm(x, cur.g);
   int iteration = 0, invalid = 0;
+  trace_push(c, 0, x_cost, 0.0, 1, dl.radius, 0.0, 0.0, gmax, 0, x);
   for (;;) {
     /* FinalizeIterationAndCheckIfMinimizerCanContinue */
     if (iteration >= max_num_iterations) break;
@@ -1106,6 +1130,7 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
     }
     if (!valid) {
       /* HandleInvalidStep -> StepIsInvalid */
+      trace_push(c, iteration, x_cost, 0.0, 0, dl.radius, 0.0, 0.0, gmax, 3, x);
       if (++invalid >= max_consecutive_invalid) break;
       dl.mu *= 10.0;
       dl.reuse = 0;
@@ -1125,11 +1150,18 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
     /* ParameterToleranceReached */
     double dx[6];
     for (int i = 0; i < 6; ++i) dx[i] = x[i] - x_cand[i];
-    if (vnorm(dx, 6) <= parameter_tolerance * (x_norm + parameter_tolerance)) break;
+    if (vnorm(dx, 6) <= parameter_tolerance * (x_norm + parameter_tolerance)) {
+      trace_push(c, iteration, x_cost, x_cost - candidate_cost, 0, dl.radius, vnorm(dx, 6), 0.0, gmax, 1, x);
+      break;
+    }
     /* FunctionToleranceReached */
-    if (fabs(x_cost - candidate_cost) <= function_tolerance * x_cost) break;
+    if (fabs(x_cost - candidate_cost) <= function_tolerance * x_cost) {
+      trace_push(c, iteration, x_cost, x_cost - candidate_cost, 0, dl.radius, vnorm(dx, 6), 0.0, gmax, 2, x);
+      break;
+    }
     /* IsStepSuccessful */
     double rel = (x_cost - candidate_cost) / model_cost_change;
+    const double cost_change = x_cost - candidate_cost, step_norm_x = vnorm(dx, 6);
     if (rel > min_relative_decrease) {
       /* HandleSuccessfulStep: x = candidate; re-evaluate the same point WITH Jacobians */
       memcpy(x, x_cand, sizeof(double) * 6);
@@ -1145,13 +1177,16 @@ static void ceres_solve(orc_ctx* c, double x[6], tloam_stats* st) {
       dl.mu = 2.0 * dl.mu / 10.0;
       if (dl.mu < 1e-8) dl.mu = 1e-8;
       dl.reuse = 0;
+      trace_push(c, iteration, x_cost, cost_change, 1, dl.radius, step_norm_x, rel, gmax, 0, x);
     } else {
       /* HandleUnsuccessfulStep -> StepRejected */
       step_successful = 0;
       dl.radius *= 0.5;
       dl.reuse = 1;
+      trace_push(c, iteration, x_cost, cost_change, 0, dl.radius, step_norm_x, rel, gmax, 0, x);
     }
   }
+  c->nsolve++;
   st->solver_cost = x_cost;
   memcpy(c->last_H, cur.H, sizeof(cur.H));
   memcpy(c->last_g, cur.g, sizeof(cur.g));
@@ -1169,6 +1204,7 @@ int orc_sm_begin(orc_ctx* c, const double predict[16], const double* omega3) {
   int rc = orc_se3_from_matrix(predict, q, t);
   if (rc != TLOAM_OK) return rc;
   orc_se3_log(q, t, c->x); /* :881 */
+  c->ntrace = 0; c->nsolve = 0;
   double on = sqrt(c->x[3] * c->x[3] + c->x[4] * c->x[4] + c->x[5] * c->x[5]);
   if (on < 1e-2) { /* :884-886; Random().normalized() replaced by an explicit input */
     double u[3] = {0.0, 0.0, 1.0};
@@ -1458,6 +1494,7 @@ int orc_solve(orc_ctx* c, double se3[6], tloam_stats* stats) {
   if (!c || !se3) return TLOAM_E_INVALID;
   tloam_stats st;
   memset(&st, 0, sizeof(st));
+  c->ntrace = 0; c->nsolve = 0;
   ceres_solve(c, se3, &st);
   memcpy(st.se3, se3, sizeof(double) * 6);
   if (stats) *stats = st;

@@ -74,6 +74,12 @@ int orc_accumulate(orc_ctx* c, const double se3[6], double H[36], double g[6], d
 int orc_get_costs(orc_ctx* c, int res_type, size_t capacity, size_t* n, double* cost);
 int orc_get_normal_equations(orc_ctx* c, double H[36], double g[6], double* cost);
 int orc_solve(orc_ctx* c, double se3_inout[6], tloam_stats* stats);
+/* the minimiser's trace since the last orc_sm_begin / orc_solve: rows of ORC_TRACE_COLS doubles (layout at trace_push in
+ * tloam_oracle.c: Solve index, iteration, cost, cost change, accepted, radius, |dx|, step quality, gradient max norm, exit kind,
+ * x[6]); copies min(rows, cap_rows) rows, returns the number of rows recorded */
+#define ORC_TRACE_ROWS 256
+#define ORC_TRACE_COLS 16
+int orc_get_trace(orc_ctx* c, double* out_rows, int cap_rows);
 
 #ifdef __cplusplus
 }

@@ -137,8 +137,6 @@ def _worker_timeout(rank, world, port, q):
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    if mode == "mailbox_fused":   # sweep + exchange + step of a sharded GN iteration in ONE launch (k3_sweep_step); read at create
-        os.environ["TLOAM_FUSED_LARGE"] = "1"
     try:
         from tloam_amd import registration as reg
         sc = synth.make_scene(seed=31)
