@@ -66,6 +66,10 @@ def test_scan_match_stepwise_parity(hip_module, seed):
     H, O = _make_pair(hip_module, sc)
     assert H.sm_begin(sc.T_pred) == 0
     assert O.sm_begin(sc.T_pred) == 0
+    cfg = hip_module.default_config()
+    nb2 = cfg.noise_bound * cfg.noise_bound
+    mu = 1e-10                                             # registration.cpp:1027-1033 with every residual slot still 0
+    w_prev = [np.ones(len(sc.source.cloud(k))) for k in range(4)]   # :931-949
     for it in range(4):
         rc_h, done_h, st_h = H.sm_outer()
         rc_o, done_o, st_o = O.sm_outer()
@@ -73,6 +77,21 @@ def test_scan_match_stepwise_parity(hip_module, seed):
         assert st_h["n_corr"] == st_o["n_corr"], (it, st_h["n_corr"], st_o["n_corr"])
         for kind in range(4):
             ch, co = H.get_correspondences(kind), O.get_correspondences(kind)
+            # updateWeight (registration.cpp:858-876) EXACTLY, on the HIP path's OWN side-channel costs: the cross-check against
+            # the oracle's weights below is loose from iteration 1 on (conditioning, see there) -- this one is not, so a wrong
+            # weight formula cannot hide behind it.  <= 2 ulp: one correctly rounded division, square root and subtraction.
+            th1, th2 = (mu + 1) / mu * nb2, mu / (mu + 1) * nb2
+            c = ch["cost"]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mid = np.sqrt(nb2 * mu * (mu + 1) / c) - mu
+            w_fac = np.where(c >= th1, 0.0, np.where(c <= th2, 1.0, mid))
+            want = w_prev[kind].copy()
+            upd = c != 0                                   # :862 a slot whose cost is 0 keeps its weight
+            want[ch["idx"][upd]] = w_fac[upd]
+            got = H.get_weights(kind)
+            assert np.all(np.abs(got - want) <= 2 * np.spacing(np.maximum(np.abs(want), mu))), (it, kind, np.abs(got - want).max())
+            assert np.array_equal(got[want == 0.0], want[want == 0.0]) and np.array_equal(got[want == 1.0], want[want == 1.0])
+            w_prev[kind] = got
             assert np.array_equal(ch["idx"], co["idx"]), (it, kind)
             np.testing.assert_allclose(ch["a"], co["a"], rtol=0, atol=1e-9)
             if kind == 2:   # the edge line's second endpoint (registration.cpp:484)
@@ -104,6 +123,7 @@ def test_scan_match_stepwise_parity(hip_module, seed):
         assert done_h == done_o
         if done_h:
             break
+        mu = mu * np.exp((it + 1) * cfg.gnc_factor)        # :1089
     _, T_h, st_h = H.sm_end()
     _, T_o, st_o = O.sm_end()
     dt, dr = pose_delta(T_h, T_o)
@@ -527,14 +547,17 @@ def test_concurrent_frame_streams_share_the_gpu(hip_module):
 
 
 @pytest.mark.parametrize("knob", ["TLOAM_NO_SELF_PREPARE=1", "TLOAM_NO_FINISH_IN_SOLVE=1", "TLOAM_ENQUEUE_AHEAD=1",
-                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1"])
+                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_SOLVE_V1=1", "TLOAM_NO_COOP_STEP=1"])
 def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     """The Solve launch of a KITTI-size frame prepares its own factor set, ends its outer iteration and runs the following ones;
     the host enqueues launches for two iterations and adds one when the device asks.  Each piece can be switched off --
     k_prepare_small in front of the Solve, the finish as a kernel of its own, one or all four iterations enqueued ahead, one
     launch per GN iteration -- and nothing may change: three scenes (one with a large prediction error, whose pose keeps moving
     in later outer iterations: the host-resumed path), two frames each, everything compared bit for bit (with one launch per
-    GN iteration the four cost sums are added in the finish kernel's order: last bits, see _assert_same_frame)."""
+    GN iteration the four cost sums are added in the finish kernel's order: last bits, see _assert_same_frame).
+    Round 4: the default Solve launch is k_solve_all -- every block consumes the rows, the minimiser's step shared out over
+    three waves of each block; TLOAM_SOLVE_V1 = round 3's single consumer wave (k_solve_small), TLOAM_NO_COOP_STEP = the step
+    on one wave: the same frames, bit for bit."""
     name, val = knob.split("=")
     scenes = [synth.make_scene(seed=61, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT),
               synth.make_scene(seed=62, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, pred_err=(0.25, -0.15, 0.05, 0.02, -0.015, 0.03)),

@@ -455,7 +455,7 @@ struct SolveFinish {
   HostMirror hm[kMaxOuterInLaunch];
 };
 void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s);
+                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s, bool v1 = false);
 // (gated on st->done: see k_weights)
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
                     int blocks, const GnState* st, hipStream_t s);
