@@ -131,7 +131,11 @@ const char* tloam_last_error(const tloam_ctx* ctx);
 /* ---- inputs: RegistrationInterface::setInputSource / setInputTarget -------------------
  * (registration.cpp:232-248).  The reference keeps shared_ptrs; here the cloud is copied
  * to HBM (AoS -> SoA on device).  In a sharded context (tloam_comm_*) every rank passes
- * the FULL cloud and the context keeps its contiguous index block. */
+ * the FULL cloud and the context keeps its contiguous index block.
+ * Non-finite coordinates (NaN, +-inf) are taken as they are, like the reference takes them (it hands every point to nanoflann,
+ * whose result set never admits a NaN / inf distance): such a SOURCE point is never matched -- it keeps its index and its
+ * weight of 1 --, such a TARGET point is never anybody's neighbour and does not extend the search grid.  No status is raised;
+ * the result is the reference's (tests/test_gpu_parity.py::test_non_finite_points_are_never_matched). */
 int tloam_set_source(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
 int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
 /* The same for the four clouds of a tloam::Frame at once (registration_interface.hpp:19-38; setInputSource /

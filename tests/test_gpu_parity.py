@@ -353,6 +353,54 @@ def test_nan_targets_are_never_neighbours(hip_module, n_src, n_tgt):
     H.close()
 
 
+@pytest.mark.parametrize("n_src,n_tgt,over", [(synth.SMALL_SRC, synth.SMALL_TGT, {}),
+                                               (synth.SMALL_SRC, synth.SMALL_TGT, dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)),
+                                               ((40_000, 50_000, 35_000, 8_000), (30_000, 30_000, 20_000, 5_000), {})],
+                         ids=["small", "small_caps_bind", "thread_per_query"])
+def test_non_finite_points_are_never_matched(hip_module, n_src, n_tgt, over):
+    """Review item 7c.  The reference hands every source point to nanoflann as it is (registration.cpp:444/:535/:588/:731): a NaN
+    or infinite coordinate gives NaN / inf distances, the result set's `<` never admits them, SearchHybrid returns 0 and the
+    builder moves on -- such a point is simply never matched (it still counts as a source index and, for the sphere builder,
+    in sphere_sum, :551).  Same here, for SOURCE rows (NaN, +-inf, 1e300) spliced into the clouds and for infinite TARGET rows:
+    status 0, the index lists of the clean frame shifted by the spliced rows, the same pose -- against the oracle bit for bit
+    in the lists, and no garbage (finite pose, weights in [0, 1])."""
+    sc = synth.make_scene(seed=43, n_src=n_src, n_tgt=n_tgt)
+    bad = np.array([[np.nan, 0.0, 0.0], [1.0, np.inf, 2.0], [-np.inf, 0.0, 0.0], [np.nan, np.nan, np.nan], [1e300, -1e300, 1e300],
+                    [np.inf, np.inf, -np.inf]])
+    at = 50
+    src = [np.ascontiguousarray(np.vstack([sc.source.cloud(k)[:at], bad, sc.source.cloud(k)[at:]])) for k in range(4)]
+    tgt = [np.ascontiguousarray(np.vstack([sc.target.cloud(k), bad[[1, 2, 5]]])) for k in range(4)]   # (infinite rows only: no 1e300 box)
+    cfg = hip_module.default_config(**over)
+    Hc = hip_module.HipRegistration(cfg)
+    Hc.set_frames(sc.source, sc.target)
+    rc0, T0, st0 = Hc.scan_match(sc.T_pred)
+    assert rc0 == 0
+    H = hip_module.HipRegistration(cfg)
+    O = ob.Oracle(ob.make_config(**over))
+    for k in range(4):
+        H.set_source(k, src[k]); H.set_target(k, tgt[k])
+        O.set_source(k, src[k]); O.set_target(k, tgt[k])
+    rc, T, st = H.scan_match(sc.T_pred)
+    rco, To, sto = O.scan_match(sc.T_pred)
+    assert rc == 0 and rco == 0
+    assert np.all(np.isfinite(T)) and st["n_corr"] == sto["n_corr"]
+    assert (st["gn_iterations"], st["accepted_steps"], st["gn_evaluations"]) == (sto["gn_iterations"], sto["accepted_steps"], sto["gn_evaluations"])
+    dt, dr = pose_delta(T, To)
+    assert dt < 1e-9 and dr < 1e-9
+    for k in range(4):
+        ih = H.get_correspondences(k, capacity=len(src[k]))["idx"]
+        assert np.array_equal(ih, O.get_correspondences(k)["idx"]), k
+        assert not np.any((ih >= at) & (ih < at + len(bad))), k          # a spliced row is never a factor
+        w = H.get_weights(k)
+        assert np.all((w >= 0) & (w <= 1)) and np.all(w[at:at + len(bad)] == 1.0)
+        if not over:   # (with binding caps the spliced rows shift which points the sphere builder ever looks at, :538/:551)
+            clean = Hc.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"]
+            assert np.array_equal(np.where(ih >= at + len(bad), ih - len(bad), ih), clean), k
+    if not over:
+        assert np.array_equal(T, T0)
+    H.close(); Hc.close()
+
+
 @pytest.mark.parametrize("shape", ["small", "kitti", "caps", "noise_free", "m1"])
 def test_device_driven_loop_equals_host_driven_loop(hip_module, monkeypatch, shape):
     """tloam_scan_match enqueues every outer GNC iteration at once -- builders / refresh gated on device flags, the
@@ -547,7 +595,7 @@ def test_concurrent_frame_streams_share_the_gpu(hip_module):
 
 
 @pytest.mark.parametrize("knob", ["TLOAM_NO_SELF_PREPARE=1", "TLOAM_NO_FINISH_IN_SOLVE=1", "TLOAM_ENQUEUE_AHEAD=1",
-                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_SOLVE_V1=1", "TLOAM_NO_COOP_STEP=1"])
+                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_SOLVE_V1=1"])
 def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     """The Solve launch of a KITTI-size frame prepares its own factor set, ends its outer iteration and runs the following ones;
     the host enqueues launches for two iterations and adds one when the device asks.  Each piece can be switched off --
@@ -555,9 +603,8 @@ def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     launch per GN iteration -- and nothing may change: three scenes (one with a large prediction error, whose pose keeps moving
     in later outer iterations: the host-resumed path), two frames each, everything compared bit for bit (with one launch per
     GN iteration the four cost sums are added in the finish kernel's order: last bits, see _assert_same_frame).
-    Round 4: the default Solve launch is k_solve_all -- every block consumes the rows, the minimiser's step shared out over
-    three waves of each block; TLOAM_SOLVE_V1 = round 3's single consumer wave (k_solve_small), TLOAM_NO_COOP_STEP = the step
-    on one wave: the same frames, bit for bit."""
+    Round 4: the default Solve launch is k_solve_all -- every block consumes the rows and takes the step on its own image of
+    the state; TLOAM_SOLVE_V1 = round 3's single consumer wave for the whole grid (k_solve_small): the same frames, bit for bit."""
     name, val = knob.split("=")
     scenes = [synth.make_scene(seed=61, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT),
               synth.make_scene(seed=62, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, pred_err=(0.25, -0.15, 0.05, 0.02, -0.015, 0.03)),

@@ -465,8 +465,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       memset(&F, 0, sizeof(F));
       if (wp) { F.have_wp = 1; F.wp[0] = *wp; }
     }
-    int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_small
-    if (c->no_coop_step) sabotage |= 1 << 17;   // (A/B knob of k_solve_all, same argument)
+    const int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_small
     launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps | sabotage, prep, c->seg_n.p, &F,
                        c->stream, c->solve_v1);
     c->batch_launches++;
@@ -620,7 +619,6 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
-  c->no_coop_step = getenv("TLOAM_NO_COOP_STEP") != nullptr;
   c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {

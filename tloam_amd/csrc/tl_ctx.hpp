@@ -181,7 +181,6 @@ struct tloam_ctx {
   bool no_persistent_solve = false;  // TLOAM_NO_PERSISTENT_SOLVE, or set by tloam_scan_match after an in-launch hand-over timed out:
                                      // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
   bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
-  bool no_coop_step = false;       // TLOAM_NO_COOP_STEP: k_solve_all's stepper wave takes the whole minimiser step itself (A/B, tests)
   bool solve_v1 = false;           // TLOAM_SOLVE_V1: round 3's one-launch Solve (k_solve_small: ONE consumer wave for the grid) instead of k_solve_all
   int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
   int device_cus = 0;              // multiProcessorCount of the device (k_solve_small needs all its blocks resident at once)

@@ -1682,20 +1682,12 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
   __shared__ double tot[kReduceBuf];
   __shared__ double s_msg[16];    // [0..8] R, [9..11] t of the pose to evaluate next, [12] the verdict (as an integer value)
   __shared__ GnState s_in;
-  __shared__ CoopB s_cb;          // the step shared out over three waves (tl_step.hpp): wave 1's and wave 2's results
-  __shared__ CoopC s_cc;
-  __shared__ int s_fail;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
   const bool stepper = wave == 0;            // the block's consumer: polls the rows, folds them, takes the minimiser's step
   const bool lead = blockIdx.x == 0;         // the block whose image of the state is the one written out
   const bool self_prep = prep.sv.flagb != nullptr;
   const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;   // test hook, see k_solve_small
-#ifdef TLOAM_COOP_COMPILED_OUT   // (tuning builds: the kernel without the three-wave step in its code at all)
-  const bool coop = false;
-#else
-  const bool coop = ((max_sweeps >> 17) & 1) == 0;   // (bit 17, TLOAM_NO_COOP_STEP: the stepper wave takes the whole step itself -- A/B, tests)
-#endif
   max_sweeps &= 0xffff;
   unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
 #ifdef TLOAM_STEP_PROFILE
@@ -1795,36 +1787,17 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
       }
       TL_PROF(prof_p, 64 + it * 8 + 2)
       if (stepper) {
-        if (lane == 0) { s_cb.status = 0; s_cc.ready = 0; }
         const bool ok = poll_fold_tagged(rows, (int)gridDim.x, (tag0 | h) ^ sabotage, s_rows, tot, lane);
-        if (lane == 0) s_fail = ok ? 0 : 1;
         TL_PROF(prof_c, 8 + it * 8 + 1)
-      }
-      __syncthreads();   // the totals are in LDS
-      const bool failed = s_fail != 0;
-      // the decision, by every wave that acts on it; waves 1 and 2 take what they need of the image into registers ...
-      StepDecision dec{false, false, false, 0.0};
-      CoopBIn bin;
-      CoopCIn cin;
-      if (coop && !failed) {
-        dec = step_decide(&s_in, tot[27]);
-        if (wave == 1) bin = coop_candidate_inputs(&s_in, tot, dec);
-        else if (wave == 2) cin = coop_gradient_inputs(&s_in, tot, dec);
-      }
-      __syncthreads();   // ... before the stepper rewrites it
-      if (stepper) {
         int vd = 5;
-        if (!failed) {
-          gn_consume<true>(st, tot, lane, &s_in, s_scr, lead, coop ? &s_cb : nullptr, coop ? &s_cc : nullptr, coop ? &dec : nullptr);
+        if (ok) {
+          gn_consume(st, tot, lane, &s_in, s_scr, lead);
           vd = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
         }
         TL_PROF(prof_c, 8 + it * 8 + 2)
         if (lane < 9) s_msg[lane] = s_in.Rt_eval.r[lane];
         else if (lane < 12) s_msg[lane] = s_in.Rt_eval.t[lane - 9];
         else if (lane == 12) s_msg[12] = (double)vd;
-      } else if (coop && !failed) {
-        if (wave == 1) coop_candidate(bin, tot, &s_cb, lane);
-        else if (wave == 2) coop_gradient(cin, &s_cc, lane);
       }
       __syncthreads();
       verdict = (int)s_msg[12];

@@ -235,7 +235,13 @@ __global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict
   const int n = gs.n[k];
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const double a = x[i], b = y[i], c = z[i];
+    // only FINITE coordinates extend the box: fmin / fmax already pass over a NaN, an infinite one would make the box -- and
+    // with it the cell size -- infinite.  Such a point still gets a (boundary) cell and is simply never anybody's neighbour:
+    // its distance to every query is inf or NaN, as in the reference's kd-tree (tests/test_gpu_parity.py).
+    double a = x[i], b = y[i], c = z[i];
+    if (!(fabs(a) < __builtin_inf())) a = __builtin_nan("");
+    if (!(fabs(b) < __builtin_inf())) b = __builtin_nan("");
+    if (!(fabs(c) < __builtin_inf())) c = __builtin_nan("");
     lo[0] = fmin(lo[0], a); hi[0] = fmax(hi[0], a);
     lo[1] = fmin(lo[1], b); hi[1] = fmax(hi[1], b);
     lo[2] = fmin(lo[2], c); hi[2] = fmax(hi[2], c);

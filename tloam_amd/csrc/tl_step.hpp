@@ -425,8 +425,7 @@ __device__ __forceinline__ StepResult step_compute(StepVars& v, GnState* st, con
 
 // ---- the decision a reduced sweep allows, before anything is computed: tolerances, then the step quality --------------------
 // (ParameterToleranceReached / FunctionToleranceReached / IsStepSuccessful, trust_region_minimizer.cc).  Pure function of the LDS
-// image and the sweep's cost: gn_consume and the waves that work beside it (coop_candidate / coop_gradient) all evaluate it and
-// agree bit for bit.
+// image and the sweep's cost.
 struct StepDecision {
   bool iter0;      // the sweep was the first evaluation of the Solve (IterationZero)
   bool done_tol;   // a tolerance exit: the candidate is NOT applied
@@ -450,148 +449,6 @@ __device__ __forceinline__ StepDecision step_decide(const GnState* sm, double co
   return d;
 }
 
-// ---- the step shared out over three waves of a block (k_solve_all) ----------------------------------------------------------
-// After IterationZero or an accepted step the minimiser computes, from the totals (H, g) of the sweep just folded, (a) a fresh
-// dogleg step -- Jacobi scaling, Cholesky of Hs + mu D^2, model cost change -- and the candidate Plus(x, delta), and (b) the
-// projected-gradient point Plus(x, -g) for the gradient tolerance: ~4 us of dependent fp64 on one wave, while the block's other
-// waves wait for the pose.  Here the STEPPER wave keeps the minimiser's bookkeeping (gn_consume), wave B computes (a) and wave
-// C computes (b), all three starting from the same StepDecision; the stepper merges B's and C's results where the serial code
-// would have computed them.  Same operations on the same inputs in the same order per value: bit-identical to the serial step
-// (tests/test_gpu_parity.py compares k_solve_all with the one-launch-per-iteration kernels, which run the serial step).  Anything
-// off the straight path -- linear solver failure, a Gauss-Newton step that leaves the trust region, an invalid step -- is left
-// to the serial code: B reports status 2 and the stepper computes the step itself, as before.
-struct CoopB {   // LDS; written by lane 0 of wave B, `status` last
-  double D2[6], stp[6], xc[6];
-  Pose C;
-  Rt R;
-  double mu, gn_norm, mcc;
-  int status;    // 0 not there yet | 1 candidate ready | 2 off the straight path: the serial step takes over | 3 not asked for
-};
-struct CoopC {   // LDS; written by lane 0 of wave C, `ready` last
-  double gmax;
-  int ready;     // 0 not there yet | 1 gmax is there | 3 not asked for
-};
-// will the minimiser, after this decision, compute a FRESH step from the totals of the sweep?  (gn_consume: take && !reuse && the
-// loop goes on -- FinalizeIterationAndCheckIfMinimizerCanContinue with the gradient test deferred)
-__device__ __forceinline__ bool coop_go(const GnState* sm, const StepDecision& d, double* radius_out, double* mu_out) {
-  double radius = sm->radius, mu = sm->mu;
-  if (!d.iter0) {
-    if (d.done_tol || !d.accepted) return false;
-    if (d.rel < 0.25) radius *= 0.5;                      // DoglegStrategy::StepAccepted, as gn_consume
-    if (d.rel > 0.75) radius = fmax(radius, 3.0 * sm->step_norm);
-    mu = fmax(1e-8, 2.0 * mu / 10.0);
-  } else if (sm->reuse) {
-    return false;   // (cannot happen: a Solve is armed with reuse = 0)
-  }
-  *radius_out = radius;
-  *mu_out = mu;
-  return sm->iteration < 4 && !(radius <= 1e-32);          // max_num_iterations, min_trust_region_radius
-}
-// wave B.  Inputs are read into registers BEFORE the block's barrier (the stepper rewrites x / T_cur / H / g of the image
-// after it): call coop_candidate_inputs first, the barrier, then coop_candidate.
-struct CoopBIn { double Sv[6], mu, radius; Pose T; bool go; };
-__device__ __forceinline__ CoopBIn coop_candidate_inputs(const GnState* sm, const double* tot, const StepDecision& d) {
-  CoopBIn in;
-  in.go = coop_go(sm, d, &in.radius, &in.mu);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) in.Sv[i] = d.iter0 ? fast_rcp(1.0 + fsqrt(tot[ut(i, i)])) : sm->S[i];   // jacobi_scaling (gn_consume)
-  in.T = d.iter0 ? sm->T_cur : sm->T_eval;   // exp(accepted point)
-  return in;
-}
-__device__ __forceinline__ void coop_candidate(const CoopBIn& in, const double* tot, CoopB* out, int lane) {
-  if (!in.go) {
-    if (lane == 0) __hip_atomic_store(&out->status, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return;
-  }
-  int status = 1;
-  double gs[6], Hs[21];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    gs[i] = in.Sv[i] * tot[21 + i];
-#pragma unroll
-    for (int j = i; j < 6; ++j) Hs[ut(i, j)] = in.Sv[i] * tot[ut(i, j)] * in.Sv[j];
-  }
-  double D2[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) D2[i] = fmin(fmax(Hs[ut(i, i)], 1e-6), 1e32);
-  double mu = in.mu;
-  bool ok = false;
-  double y[6] = {0, 0, 0, 0, 0, 0};
-  while (mu < 1.0) {
-    double A[21];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) A[i] = Hs[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) A[ut(i, i)] = __builtin_fma(mu, D2[i], A[ut(i, i)]);
-    if (chol6_uniform(A, gs, y)) { ok = true; break; }
-    mu *= 10.0;
-  }
-  double stp[6] = {0, 0, 0, 0, 0, 0};
-  double gn_norm = 0.0, mcc = 0.0;
-  if (!ok) {
-    status = 2;
-  } else {
-    double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { stp[i] = -y[i]; q = __builtin_fma(D2[i] * stp[i], stp[i], q); }
-    gn_norm = fsqrt(q);
-    if (gn_norm == 0.0 && dot6(gs, gs) == 0.0) status = 2;   // rank-0 subspace
-    else if (!(gn_norm <= in.radius)) status = 2;             // leaves the trust region: subspace dogleg (serial code)
-    else {
-      mcc = __builtin_fma(-0.5, quad6(stp, Hs, stp), -dot6(stp, gs));
-      if (!(mcc > 0.0)) status = 2;                           // invalid step
-    }
-  }
-  Pose C{};
-  double xc[6] = {0, 0, 0, 0, 0, 0};
-  if (status == 1) {
-    double din[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) din[i] = stp[i] * in.Sv[i];
-    C = compose_fast2(exp_fast2(din), in.T);   // exp(delta) * exp(x)   registration.cpp:162-173
-    log_fast2(C, xc);
-  }
-  if (lane == 0) {
-    if (status == 1) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { out->D2[i] = D2[i]; out->stp[i] = stp[i]; out->xc[i] = xc[i]; }
-      out->C = C;
-      out->R = to_rt(C);
-      out->mu = mu; out->gn_norm = gn_norm; out->mcc = mcc;
-    }
-    __hip_atomic_store(&out->status, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-// wave C: || x - Plus(x, -g) ||_inf at the accepted point
-struct CoopCIn { double x[6], g[6]; Pose T; bool go; };
-__device__ __forceinline__ CoopCIn coop_gradient_inputs(const GnState* sm, const double* tot, const StepDecision& d) {
-  CoopCIn in;
-  double r, m;
-  in.go = coop_go(sm, d, &r, &m);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { in.x[i] = d.iter0 ? sm->x[i] : sm->x_cand[i]; in.g[i] = tot[21 + i]; }
-  in.T = d.iter0 ? sm->T_cur : sm->T_eval;
-  return in;
-}
-__device__ __forceinline__ void coop_gradient(const CoopCIn& in, CoopC* out, int lane) {
-  if (!in.go) {
-    if (lane == 0) __hip_atomic_store(&out->ready, 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return;
-  }
-  double din[6], o[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) din[i] = -in.g[i];
-  const Pose C = compose_fast2(exp_fast2(din), in.T);
-  log_fast2(C, o);
-  double m = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) m = fmax(m, fabs(in.x[i] - o[i]));
-  if (lane == 0) {
-    out->gmax = m;
-    __hip_atomic_store(&out->ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-
 // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test is deferred while need_gmax): true = go on
 __device__ __forceinline__ bool step_can_continue(StepVars& v) {
   constexpr double min_trust_region_radius = 1e-32;
@@ -608,15 +465,8 @@ __device__ __forceinline__ bool step_can_continue(StepVars& v) {
 
 // WRITE_GLOBAL = false (k_solve_all: every block advances its own LDS image of the state, one of them writes it out): the
 // device state `st` is not touched (wave-uniform run-time flag: ONE inlined copy of the step per kernel).
-// cb / cc != null (k_solve_all): waves B and C of the block compute the fresh step and the gradient point beside this wave
-// (coop_candidate / coop_gradient, started from the same StepDecision `dec`); their results are merged where the serial code
-// would have computed them.
-// COMPACT (k_solve_all, where the serial step is the rare path): ONE inlined copy of step_compute inside the retry loop instead
-// of the straight-line copy + the loop's copy -- half the registers of the step's largest piece.
-template <bool COMPACT = false>
 __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS */, int lane, GnState* sm /* LDS */,
-                                           double* scr /* LDS */, const bool WRITE_GLOBAL = true, CoopB* cb = nullptr,
-                                           CoopC* cc = nullptr, const StepDecision* dec = nullptr) {
+                                           double* scr /* LDS */, const bool WRITE_GLOBAL = true) {
   TL_STAMP(1)
   StepVars v;
   v.phase = sm->phase; v.iteration = sm->iteration; v.invalid = sm->invalid; v.step_successful = sm->step_successful;
@@ -647,7 +497,7 @@ __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS
       for (int i = 0; i < 6; ++i) sm->S[i] = S[i];
     }
   } else {
-    const StepDecision d = dec ? *dec : step_decide(sm, cost);
+    const StepDecision d = step_decide(sm, cost);
     if (d.done_tol) v.done = 1;                     // ParameterToleranceReached / FunctionToleranceReached
     else {
       const double rel = d.rel;                     // TrustRegionStepEvaluator::StepQuality
@@ -703,52 +553,11 @@ __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS
   }
   // ---- then at most one step computation on the straight-line path; an invalid step (rare) goes round a loop of its own
   if (compute) {
-    bool merged = false;
-    if (cb && v.take && !v.reuse && v.need_gmax) {
-      // the fresh step from this sweep's totals: waves B and C have been at it since the decision (see CoopB)
-      int sb, sc;
-      while ((sb = __hip_atomic_load(&cb->status, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(0);
-      while ((sc = __hip_atomic_load(&cc->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(0);
-      if (sb == 1 && sc == 1) {
-        merged = true;
-        // what step_compute leaves behind on its straight path (fresh dogleg data, Gauss-Newton step inside the region)
-        v.reuse = 1;
-        v.mu = cb->mu;
-        v.gn_norm = cb->gn_norm;
-        v.subspace_1d = -1;
-        v.step_norm = cb->gn_norm;
-        v.cand_gn = 1;
-        v.mcc = cb->mcc;
-        if (lane < 6) { sm->D[lane] = cb->D2[lane]; sm->gn[lane] = cb->stp[lane]; }
-        v.need_gmax = false;
-        v.gmax = cc->gmax;
-        if (v.gmax <= kGradientTolerance) {   // the accepted point was already converged: roll back
-          v.iteration--;
-          v.iters--;
-          v.done = 1;
-        } else {
-          if (lane < 6) sm->x_cand[lane] = cb->xc[lane];
-          if (lane < 7) reinterpret_cast<double*>(&sm->T_eval)[lane] = reinterpret_cast<const double*>(&cb->C)[lane];
-          if (lane < 12) reinterpret_cast<double*>(&sm->Rt_eval)[lane] = reinterpret_cast<const double*>(&cb->R)[lane];
-          v.invalid = 0;
-          v.phase = PH_CAND;
-        }
-      }
-    }
-    if (!merged) {
-      if (COMPACT) {
-        for (;;) {
-          const StepResult r = step_compute(v, st, tot, lane, sm, scr);
-          if (r != SR_RETRY || !step_can_continue(v)) break;
-        }
-      } else {
-        StepResult r = step_compute(v, st, tot, lane, sm, scr);
-        if (__builtin_expect(r == SR_RETRY, 0)) {
-          while (step_can_continue(v)) {
-            r = step_compute(v, st, tot, lane, sm, scr);
-            if (r != SR_RETRY) break;
-          }
-        }
+    StepResult r = step_compute(v, st, tot, lane, sm, scr);
+    if (__builtin_expect(r == SR_RETRY, 0)) {
+      while (step_can_continue(v)) {
+        r = step_compute(v, st, tot, lane, sm, scr);
+        if (r != SR_RETRY) break;
       }
     }
   }
