@@ -42,7 +42,7 @@ extern "C" {
                                * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
                                *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned
                                * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve)
-                               * 6: tloam_k3_span */
+                               * 6: tloam_k3_span, tloam_shard_ranges_frame */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -340,6 +340,10 @@ int tloam_comm_mailbox_export(tloam_ctx* ctx, void* handle64_out);
 int tloam_comm_init_mailbox(tloam_ctx* ctx, int rank, int nranks, const void* handles64_by_rank);
 /* contiguous index block [*lo,*hi) of n items owned by `rank` of `nranks` (pure function) */
 void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi);
+/* The blocks of a whole Frame (what tloam_set_source_frame keeps in a sharded context): the four clouds laid end to end, the
+ * line cut into nranks equal pieces.  Per kind still contiguous index blocks in rank order; every rank the same number of
+ * source points; a rank touches one or two kinds and builds only those kinds' search grids. */
+void tloam_shard_ranges_frame(const size_t n[4], int rank, int nranks, size_t lo[4], size_t hi[4]);
 
 /* ---- SE(3) helpers (host; the ~150 lines of vendored Sophus the path uses) -------------
  * se3.hpp:761-785 (exp), :223-256 (log), :497-504 (from matrix), registration.cpp:162-173 */

@@ -425,7 +425,7 @@ static void grid_free(orc_grid* g) {
 }
 static inline int grid_coord(const orc_grid* g, double v, int ax) {
   double f = floor((v - g->org[ax]) / g->cell);
-  if (f < -2.0) f = -2.0;
+  if (!(f >= -2.0)) f = -2.0; /* (also a NaN coordinate: some cell, never a neighbour) */
   if (f > (double)g->dim[ax] + 1.0) f = (double)g->dim[ax] + 1.0;
   return (int)f;
 }
@@ -438,9 +438,13 @@ static void grid_build(orc_grid* g, const double* pts, int n, double radius) {
   for (int i = 0; i < n; ++i)
     for (int a = 0; a < 3; ++a) {
       double v = pts[3 * i + a];
+      if (!(fabs(v) < INFINITY)) continue; /* only finite coordinates extend the box (as k_bbox_all): a point with a NaN or
+                                            * infinite coordinate still gets a cell and is never anybody's neighbour */
       if (v < lo[a]) lo[a] = v;
       if (v > hi[a]) hi[a] = v;
     }
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] > hi[a]) lo[a] = hi[a] = 0.0; /* no finite coordinate on this axis */
   double cell = radius * (1.0 + 1e-6);
   for (;;) {
     double cells = 1.0;

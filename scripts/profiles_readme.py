@@ -1,0 +1,49 @@
+"""Writes the section of profiles/README.md for one round's files FROM the files (so the README cannot drift from what is
+there): usage  profiles_readme.py <tag> <dir>  -> markdown on stdout.  Called by scripts/gpu_profile_r0N.sh."""
+import csv, glob, json, os, sys
+tag, d = sys.argv[1], sys.argv[2]
+WHAT = {
+    "bench_default.json": "the line `python bench.py` printed (no profiler attached)",
+    "bench_default_under_rocprof.json": "the bench line of the profiled run (host launch rate limited by the profiler: frame times inflated)",
+    "bench_default_kernel_stats.csv": "`rocprofv3 --kernel-trace --stats` of the same command, per kernel (`scripts/rocpd_stats.py`) -- ALL workloads of the bench mixed; the roofline kernel alone is in the two files below",
+    "k3_prebuilt_kernel_stats.csv": "`rocprofv3 --kernel-trace --stats -- python scripts/k3_only.py 50 1`: K3 (`k3_accumulate<false, false>`) ALONE on the contract's pre-built 760k:200k:40k set (74.88 MB per sweep, Infinity-Cache resident across launches) -- `roofline.l3_resident` is recomputed from this row: 74 880 000 B / avg duration / 8 TB/s",
+    "k3_cold_kernel_stats.csv": "the same with `k3_only.py 50 4`: four times the set (299.52 MB per sweep > 256 MiB Infinity Cache, every byte from HBM) -- the headline `roofline.frac`: 299 520 000 B / avg duration / 8 TB/s",
+    "pmc_k3_prebuilt.json": "separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the scale-1 run (`scripts/pmc_summary.py`, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); quoted by the bench line as `roofline.l3_resident.traffic`",
+    "pmc_k3_cold.json": "the same for the cold set; quoted as `roofline.traffic`",
+    "kitti_frame_timeline.txt": "`scripts/frame_timeline.py` on a kernel trace of `bench.py --workload kitti`: the launches of a KITTI-density frame in order, median duration and gap before each",
+    "m1_frame_timeline.txt": "the same for the 1 M frame (`bench.py --workload m1`)",
+    "solve_all_timeline.txt": "`scripts/solve_profile2.py` on a `-DTLOAM_STEP_PROFILE` build: wall-clock stamps (10 ns) inside the one-launch Solve `k_solve_all` per GN iteration -- lead block's stepper wave and one other wave",
+    "solve_small_timeline.txt": "the same with `TLOAM_SOLVE_V1=1` (round 3's `k_solve_small`: one consumer wave for the whole grid)",
+}
+print("## Round %s\n" % tag[1:].lstrip("0"))
+print("Written by `scripts/gpu_profile_%s.sh` (this section by `scripts/profiles_readme.py` from the files themselves).\n" % tag)
+print("| file | what |\n|---|---|")
+for p in sorted(glob.glob(os.path.join(d, tag + "_*"))):
+    name = os.path.basename(p)
+    print("| `%s` | %s |" % (name, WHAT.get(name[len(tag) + 1:], "(see the script)")))
+def k3_row(path):
+    try:
+        for row in csv.DictReader(open(path)):
+            nm = row.get("name") or row.get("Name") or ""
+            if nm.startswith("k3_accumulate<false, false>") or "k3_accumulate<false, false>" in nm:
+                return row
+    except OSError:
+        pass
+    return None
+print()
+for name, alg in (("k3_prebuilt_kernel_stats.csv", 74880000.0), ("k3_cold_kernel_stats.csv", 299520000.0)):
+    row = k3_row(os.path.join(d, "%s_%s" % (tag, name)))
+    if row:
+        try:
+            avg_us = float(row["AverageNs"]) / 1e3
+            print("`%s_%s`: `k3_accumulate<false, false>` avg %.3f us over %s dispatches -> %.0f B / %.3f us / 8 TB/s = **%.3f**"
+                  % (tag, name, avg_us, row.get("calls") or row.get("Calls") or "?", alg, avg_us, alg / (avg_us * 1e-6) / 8e12))
+        except (ValueError, KeyError):
+            print("`%s_%s`: %s" % (tag, name, row))
+try:
+    b = json.loads(open(os.path.join(d, tag + "_bench_default.json")).read().strip().splitlines()[-1])
+    r = b["roofline"]
+    print("\nBench line of the same run: value %.1f GN iter/s, ms_per_step %.4f; roofline.frac %.4f (avg %.3f us), l3_resident %.4f (avg %.3f us)."
+          % (b["value"], b["ms_per_step"], r["frac"], r["avg_launch_us"], r["l3_resident"]["frac"], r["l3_resident"]["avg_launch_us"]))
+except Exception as e:  # noqa: BLE001
+    print("\n(bench line not readable: %r)" % (e,))

@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the multi-rank decomposition of the path.
+"""CPU, world_size 2 / 4 / 8, gloo: the multi-rank decomposition of the path.
 
-The product shards SOURCE points in contiguous index blocks (tloam_shard_range), replicates the
-targets, and sums per-rank normal equations with one all-reduce per sweep.  Without a GPU the per-shard
+The product shards SOURCE points in contiguous index blocks (tloam_shard_range; a whole Frame: tloam_shard_ranges_frame -- the
+four clouds end to end, cut into equal pieces), replicates the targets, and sums per-rank normal equations with one all-reduce
+per sweep.  Without a GPU the per-shard
 arithmetic is supplied by the oracle (test infrastructure); what is under test is the decomposition:
   * shard ranges (the product's tloam_shard_range, a host function of the C ABI),
   * sum over ranks of per-shard (H, g, cost) == the unsharded sweep,
@@ -57,22 +58,53 @@ def _worker(rank, world, port, q):
         added = [int(i) for j, i in enumerate(local_valid) if offset + j < cap]
         gathered = [None] * world
         dist.all_gather_object(gathered, added)
+        # ---- a whole Frame over the ranks (tloam_shard_ranges_frame), binding caps on ALL FOUR kinds: every rank keeps the
+        #      intersection of its piece of the concatenated clouds with each kind, the cap prefix runs over the lower ranks'
+        #      counts per kind -- the merged lists must be the single-rank lists
+        caps = dict(planar_maxnum=60, ground_maxnum=45, edge_maxnum=25, sphere_maxnum=12)
+        big = {k: 1 << 30 for k in caps}
+        G = ob.Oracle(ob.make_config(**big)); G.set_frames(sc.source, sc.target)
+        G.sm_begin(sc.T_pred); G.sm_outer()
+        n4 = [len(sc.source.cloud(k)) for k in range(4)]
+        ranges = reg.shard_ranges_frame(n4, rank, world)
+        capv = [caps["planar_maxnum"], caps["ground_maxnum"], caps["edge_maxnum"], caps["sphere_maxnum"]]
+        cnt4 = torch.zeros(world, 4, dtype=torch.float64)
+        local = []
+        for k in range(4):
+            # (planar / ground / edge: the cap counts ADDED factors, i.e. valid slots; the sphere builder counts every source
+            #  point it looks at, :551 -- the product's `counted` flag; here: indices below the cap are the ones ever looked at)
+            vk = G.get_correspondences(k)["idx"]
+            lo, hi = ranges[k]
+            lv = vk[(vk >= lo) & (vk < hi)]
+            local.append(lv)
+            cnt4[rank, k] = (hi - lo) if k == 3 else len(lv)
+        dist.all_reduce(cnt4)                                 # the 4 x nranks zero-padded sum the product exchanges
+        added4 = []
+        for k in range(4):
+            off = int(cnt4[:rank, k].sum())
+            if k == 3:   # counted = every source point: position in the cloud, added iff valid and counted-before < cap
+                lo, hi = ranges[k]
+                added4.append([int(i) for i in local[k] if off + (int(i) - lo) < capv[k]])
+            else:
+                added4.append([int(i) for j, i in enumerate(local[k]) if off + j < capv[k]])
+        gathered4 = [None] * world
+        dist.all_gather_object(gathered4, (added4, ranges))
         if rank == 0:
-            q.put((buf.numpy().copy(), sum(gathered, [])))
+            q.put((buf.numpy().copy(), sum(gathered, []), gathered4))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_decomposition_equals_single_rank():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multi_rank_decomposition_equals_single_rank(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
-    buf, added = q.get(timeout=120)
+    buf, added, frame4 = q.get(timeout=240)
     for p in procs:
-        p.join(timeout=60); assert p.exitcode == 0
+        p.join(timeout=120); assert p.exitcode == 0
     # single-rank references
     sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=3001, n_line=777, n_point=130, weights="timing")
     O = ob.Oracle()
@@ -88,3 +120,18 @@ def test_two_rank_decomposition_equals_single_rank():
     S = ob.Oracle(ob.make_config(planar_maxnum=60)); S.set_frames(sc.source, sc.target)
     S.sm_begin(sc.T_pred); S.sm_outer()
     assert added == list(S.get_correspondences(0)["idx"])     # capped list == concatenation of per-rank lists
+    # the whole Frame over the ranks: blocks tile every cloud in rank order, the pieces are equal, and with binding caps on all
+    # four kinds the merged per-rank lists are the single-rank lists
+    n4 = [len(sc.source.cloud(k)) for k in range(4)]
+    for k in range(4):
+        edges = [frame4[r][1][k] for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == n4[k] and all(edges[r][1] == edges[r + 1][0] for r in range(world - 1)), (k, edges)
+    sizes = [sum(hi - lo for lo, hi in frame4[r][1]) for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == sum(n4)
+    if world >= 4:
+        assert max(sum(1 for lo, hi in frame4[r][1] if hi > lo) for r in range(world)) <= 2   # a rank touches at most two kinds (here)
+    C4 = ob.Oracle(ob.make_config(planar_maxnum=60, ground_maxnum=45, edge_maxnum=25, sphere_maxnum=12)); C4.set_frames(sc.source, sc.target)
+    C4.sm_begin(sc.T_pred); C4.sm_outer()
+    for k in range(4):
+        merged = sum((frame4[r][0][k] for r in range(world)), [])
+        assert merged == list(C4.get_correspondences(k)["idx"]), k

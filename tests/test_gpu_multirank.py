@@ -132,8 +132,10 @@ def test_native_rccl_single_rank(hip_module):
     assert np.array_equal(xa, xb)
 
 
-def _worker_timeout(rank, world, port, q):
-    """rank 1 sets the mailbox up and then never enters the solve: rank 0's exchanges must give up after their bounded wait"""
+def _worker_timeout(rank, world, port, q, frames_before_silence=0):
+    """rank 1 sets the mailbox up, solves `frames_before_silence` frames with rank 0 and then never enters the next solve: rank
+    0's exchanges must give up after their bounded wait (the peer's buffer stays mapped: a peer whose process is GONE would take
+    its memory with it, and a store into it is a GPU page fault -- not something to provoke on a shared box)"""
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,6 +145,9 @@ def _worker_timeout(rank, world, port, q):
         H = reg.HipRegistration()
         init_comm(H, "mailbox", rank, world)
         H.set_frames(sc.source, sc.target)
+        for _ in range(frames_before_silence):
+            rc, T, st = H.scan_match(sc.T_pred)
+            assert rc == 0
         if rank == 0:
             t0 = time.perf_counter()
             rc, T, st = H.scan_match(sc.T_pred)
@@ -154,14 +159,16 @@ def _worker_timeout(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module):
-    """The bounded wait of the peer mailbox: a rank whose peer never posts does not hang -- every
-    exchange gives up after ~2 s, the Solve is stopped and scan_match returns TLOAM_E_RCCL with a message that says why."""
+@pytest.mark.parametrize("frames_before_silence", [0, 2], ids=["from_the_start", "after_two_frames"])
+def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module, frames_before_silence):
+    """The bounded wait of the peer mailbox: a rank whose peer never posts -- from the start, or after
+    two frames solved together (exchange counters and parities in mid-stream) -- does not hang: every exchange gives up after
+    ~2 s, the Solve is stopped and scan_match returns TLOAM_E_RCCL with a message that says why."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_timeout, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_timeout, args=(r, world, port, q, frames_before_silence)) for r in range(world)]
     for p in procs: p.start()
     res = q.get(timeout=120)
     for p in procs:
@@ -169,6 +176,68 @@ def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module):
     assert res["rc"] == -5, res                                  # TLOAM_E_RCCL
     assert "timed out" in res["msg"] and "peer" in res["msg"], res
     assert 1.5 < res["seconds"] < 40.0, res                      # bounded: a few exchanges of ~2 s each, not forever
+
+
+def _worker_peer_dies(rank, world, port, q):
+    """callback contexts: rank 1's process EXITS inside its 6th all-reduce (no clean-up, no goodbye); the collective layer of the
+    survivor notices (gloo: connection closed by peer), its callback reports failure, and the library hands TLOAM_E_RCCL to the
+    caller instead of a result."""
+    import time
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=20))
+    from tloam_amd import registration as reg
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    calls = [0]
+
+    def allreduce(dev_ptr, count, stream):
+        calls[0] += 1
+        if rank == 1 and calls[0] == 6:
+            os._exit(0)                                   # dies inside the exchange
+        try:
+            assert hip.hipStreamSynchronize(stream) == 0
+            host = np.zeros(count)
+            assert hip.hipMemcpy(host.ctypes.data, dev_ptr, 8 * count, 2) == 0
+            t = torch.from_numpy(host)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            assert hip.hipMemcpy(dev_ptr, host.ctypes.data, 8 * count, 1) == 0
+            return 0
+        except Exception:                                 # noqa: BLE001 -- the peer is gone: report, never raise through the C ABI
+            return 1
+
+    sc = synth.make_scene(seed=31)
+    H = reg.HipRegistration()
+    H.comm_init_callback(rank, world, allreduce)
+    H.set_frames(sc.source, sc.target)
+    t0 = time.perf_counter()
+    rc, T, st = H.scan_match(sc.T_pred)
+    dt = time.perf_counter() - t0
+    msg = H.L.tloam_last_error(H.h).decode()
+    H.close()
+    # the survivor is still in working order: a fresh single-rank context solves the frame
+    S = reg.HipRegistration(); S.set_frames(sc.source, sc.target)
+    rc2, T2, st2 = S.scan_match(sc.T_pred)
+    S.close()
+    q.put(dict(rc=rc, seconds=dt, msg=msg, calls=calls[0], rc_after=rc2))
+    os._exit(0)                                           # (the process group lost a member: no orderly shutdown to wait for)
+
+
+def test_callback_exchange_reports_a_peer_that_dies_inside_it(hip_module):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_peer_dies, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+    assert res["rc"] == -5, res                                  # TLOAM_E_RCCL
+    assert "allreduce callback failed" in res["msg"], res
+    assert res["calls"] >= 6 and res["seconds"] < 60.0, res
+    assert res["rc_after"] == 0, res
 
 
 def test_bench_n_gpus_path_runs_on_one_device(hip_module):

@@ -548,12 +548,14 @@ void exchange_clouds(tloam_ctx* c, FrameClouds& F) {
     std::swap(K.n_src_full, F.n_src_full[k]); std::swap(K.src_lo, F.src_lo[k]); std::swap(K.n_src, F.n_src[k]);
     std::swap(K.n_tgt, F.n_tgt[k]);
     std::swap(K.src_aos, F.src_aos[k]); std::swap(K.tgt_aos, F.tgt_aos[k]);
+    std::swap(K.src_ptr, F.src_ptr[k]);
     std::swap(K.tx, F.tx[k]); std::swap(K.ty, F.ty[k]); std::swap(K.tz, F.tz[k]);
     std::swap(K.src_set, F.src_set[k]); std::swap(K.tgt_set, F.tgt_set[k]);
     for (int a = 0; a < 6; ++a) std::swap(c->tgt_box[k][a], F.tgt_box[k][a]);
     std::swap(c->tgt_box_valid[k], F.tgt_box_valid[k]);
     K.grid_valid = false;   // the search grids belong to the frame they were built over
   }
+  std::swap(c->src_pack, F.src_pack);
   c->have_build = false;
 }
 }  // namespace
@@ -620,6 +622,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
   c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
+  c->sync_set_source = getenv("TLOAM_SYNC_SET_SOURCE") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;
@@ -684,6 +687,11 @@ void tloam_destroy(tloam_ctx* c) {
     K.src_aos.release(); K.tgt_aos.release(); K.tx.release(); K.ty.release(); K.tz.release();
     K.c_idx.release(); K.c_buf.release();
   }
+  c->src_pack.release();
+  for (int h = 0; h < 2; ++h) {
+    if (c->h_stage[h]) (void)hipHostFree(c->h_stage[h]);
+    if (c->stage_ev[h]) (void)hipEventDestroy(c->stage_ev[h]);
+  }
   c->sx.release(); c->sy.release(); c->sz.release(); c->w_src.release();
   c->fit_x.release(); c->fit_y.release(); c->fit_z.release();
   c->raw.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
@@ -716,20 +724,93 @@ void tloam_shard_range(size_t n, int rank, int nranks, size_t* lo, size_t* hi) {
   if (hi) *hi = b;
 }
 
+// A whole Frame over the ranks: the four source clouds laid end to end (planar | ground | edge | sphere), the line cut into
+// nranks equal pieces, every rank the intersection of its piece with each cloud.  Per kind that is still contiguous index
+// blocks in rank order (so the cap prefix over the lower ranks' counts, registration.cpp:448/:538/:592/:735, holds as it
+// is), every rank gets the same number of queries whatever the mix, and a rank touches one or two kinds instead of four:
+// it builds only THOSE kinds' search grids (tloam_sm_begin) -- the target-grid build is what a sharded frame replicates.
+void tloam_shard_ranges_frame(const size_t n[4], int rank, int nranks, size_t lo[4], size_t hi[4]) {
+  if (nranks < 1) nranks = 1;
+  if (rank < 0) rank = 0;
+  if (rank >= nranks) rank = nranks - 1;
+  unsigned __int128 total = 0;
+  for (int k = 0; k < kKinds; ++k) total += n[k];
+  const size_t a = (size_t)((total * (unsigned)rank) / (unsigned)nranks), b = (size_t)((total * (unsigned)(rank + 1)) / (unsigned)nranks);
+  size_t base = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    const size_t l = std::min(std::max(a, base), base + n[k]), h = std::min(std::max(b, base), base + n[k]);
+    lo[k] = l - base;
+    hi[k] = h - base;
+    base += n[k];
+  }
+}
+
 // ---- setInputSource / setInputTarget (registration.cpp:232-248) --------------------------------
 namespace {
-int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+// range: this rank's block when the cloud is handed over as part of a Frame (tloam_shard_ranges_frame); null: the cloud alone
+int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n, const size_t* range = nullptr) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   size_t lo = 0, hi = n;
-  tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
+  if (range) { lo = range[0]; hi = range[1]; }
+  else tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
   K.n_src_full = n;
   K.src_lo = lo;
   K.n_src = hi - lo;
   HIPC(c, K.src_aos.reserve(3 * std::max<size_t>(K.n_src, 1)));
   if (K.n_src > 0)
     HIPC(c, hipMemcpyAsync(K.src_aos.p, xyz + 3 * lo, sizeof(double) * 3 * K.n_src, hipMemcpyHostToDevice, c->stream));
+  K.src_ptr = K.src_aos.p;
   K.src_set = true;
+  return TLOAM_OK;
+}
+// setInputSource(const Frame&): the four clouds through pinned staging and ONE asynchronous copy, no host synchronisation
+// (front_end.cpp:314 is followed at once by scanMatching, :321: the wait moves to that call's first wait for the device)
+int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
+  size_t off[kKinds + 1] = {0, 0, 0, 0, 0};
+  size_t lo4[kKinds], hi4[kKinds];
+  tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
+  for (int k = 0; k < kKinds; ++k) {
+    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
+    KindData& K = c->kd[k];
+    K.n_src_full = n[k];
+    K.src_lo = lo4[k];
+    K.n_src = hi4[k] - lo4[k];
+    off[k + 1] = off[k] + 3 * K.n_src;
+  }
+  const size_t total = std::max<size_t>(off[kKinds], 3);
+  const int h = c->stage_next;
+  c->stage_next ^= 1;
+  if (c->stage_busy[h]) {   // the copy that last read this half: long done in the reference's call pattern, waited for otherwise
+    HIPC(c, hipEventSynchronize(c->stage_ev[h]));
+    c->stage_busy[h] = false;
+  }
+  if (total > c->h_stage_cap[h]) {
+    if (c->h_stage[h]) (void)hipHostFree(c->h_stage[h]);
+    c->h_stage[h] = nullptr;
+    c->h_stage_cap[h] = 0;
+    const size_t want = total + total / 2;
+    HIPC(c, hipHostMalloc((void**)&c->h_stage[h], want * sizeof(double), hipHostMallocDefault));
+    c->h_stage_cap[h] = want;
+  }
+  if (!c->stage_ev[h]) HIPC(c, hipEventCreateWithFlags(&c->stage_ev[h], hipEventDisableTiming));
+  if (total > c->src_pack.cap) {
+    // (a kernel of an earlier frame may still read the old block: nothing of this context is in flight in the reference's
+    //  call pattern, but a growing buffer is rare enough to afford the certainty)
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, c->src_pack.reserve(total));
+  }
+  for (int k = 0; k < kKinds; ++k) {
+    KindData& K = c->kd[k];
+    if (K.n_src > 0) memcpy(c->h_stage[h] + off[k], xyz[k] + 3 * K.src_lo, sizeof(double) * 3 * K.n_src);
+    K.src_ptr = c->src_pack.p + off[k];
+    K.src_set = true;
+  }
+  if (off[kKinds] > 0) {
+    HIPC(c, hipMemcpyAsync(c->src_pack.p, c->h_stage[h], sizeof(double) * off[kKinds], hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipEventRecord(c->stage_ev[h], c->stream));
+    c->stage_busy[h] = true;
+  }
   return TLOAM_OK;
 }
 int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
@@ -772,10 +853,18 @@ int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
 int tloam_set_source_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
-  int rc = TLOAM_OK;
-  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_source_async(c, k, xyz[k], n[k]);
-  HIPC(c, hipStreamSynchronize(c->stream));  // the host buffers are only borrowed for the call
-  return rc;
+  if (c->sync_set_source) {   // TLOAM_SYNC_SET_SOURCE (A/B): four pageable copies and a stream synchronisation, as round 3
+    int rc = TLOAM_OK;
+    size_t lo4[kKinds], hi4[kKinds];
+    tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
+    for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) {
+      const size_t range[2] = {lo4[k], hi4[k]};
+      rc = set_source_async(c, k, xyz[k], n[k], range);
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));  // the host buffers are only borrowed for the call
+    return rc;
+  }
+  return set_source_frame_packed(c, xyz, n);   // (the host buffers have been copied out when this returns)
 }
 
 int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
@@ -894,7 +983,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   //      first launch of the grid build
   FrameInitHook hook;
   memset(&hook, 0, sizeof(hook));
-  for (int k = 0; k < kKinds; ++k) { hook.fi.src_aos[k] = c->kd[k].src_aos.p; hook.fi.slot_off[k] = c->sv.slot_off[k]; }
+  for (int k = 0; k < kKinds; ++k) { hook.fi.src_aos[k] = c->kd[k].src_ptr; hook.fi.slot_off[k] = c->sv.slot_off[k]; }
   hook.fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
   for (int i = 0; i < 6; ++i) hook.fi.x[i] = x[i];
   hook.fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
@@ -905,6 +994,10 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     double radius[kKinds];
     GridView views[kKinds];
     for (int k = 0; k < kKinds; ++k) radius[k] = kind_radius(c->cfg, k);
+    // a sharded rank searches only the kinds it holds source points of (tloam_shard_ranges_frame): the other grids are not built
+    if (c->nranks > 1)
+      for (int k = 0; k < kKinds; ++k)
+        if (c->kd[k].n_src == 0) radius[k] = 0.0;
     rc = build_grids(c, c->grids, radius, views, &hook);
     if (rc != TLOAM_OK) return rc;
     for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
@@ -1526,7 +1619,7 @@ int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
     // raw scan-frame source points (:271): this kind's AoS block as SoA, in scratch of its own (the slot arrays
     // sx/sy/sz belong to scan_match: SlotView holds their addresses)
     HIPC(c, c->fit_x.reserve(K.n_src)); HIPC(c, c->fit_y.reserve(K.n_src)); HIPC(c, c->fit_z.reserve(K.n_src));
-    launch_aos_to_soa(K.src_aos.p, K.n_src, c->fit_x.p, c->fit_y.p, c->fit_z.p, c->stream);
+    launch_aos_to_soa(K.src_ptr, K.n_src, c->fit_x.p, c->fit_y.p, c->fit_z.p, c->stream);
     launch_fitness(K.gv, c->fit_x.p, c->fit_y.p, c->fit_z.p, (int)K.n_src, c->cfg.fitness_thres, c->misc.p, blocks, c->stream);
     HIPC(c, hipMemcpyAsync(c->h_small, c->misc.p, sizeof(double) * blocks * 2, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));

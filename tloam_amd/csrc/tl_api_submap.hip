@@ -24,7 +24,10 @@ int submap_reserve_work(tloam_ctx* c, size_t n) {
   SubmapState& S = c->submap;
   const size_t m = std::max<size_t>(n, 1), cap = voxel_table_size(m);
   HIPC(c, S.min_partial.reserve(256 * 6)); HIPC(c, S.vmin.reserve(8)); HIPC(c, S.counts.reserve(8));
-  HIPC(c, S.overflow.reserve(8));
+  if (!S.overflow.p) {   // [0] overflow flag, [1] the ticket of k_vox_min2: zero between launches, so zero before the first
+    HIPC(c, S.overflow.reserve(8));
+    HIPC(c, hipMemsetAsync(S.overflow.p, 0, 8 * sizeof(int), c->stream));
+  }
   HIPC(c, S.keys.reserve(cap + 1)); HIPC(c, S.cnt.reserve(cap + 1)); HIPC(c, S.off.reserve(cap + 1));
   HIPC(c, S.slot_of_pt.reserve(m)); HIPC(c, S.urank.reserve(m)); HIPC(c, S.members.reserve(m)); HIPC(c, S.sorted.reserve(m));
   HIPC(c, S.leader.reserve(m + 1)); HIPC(c, S.leader_scan.reserve(m + 1));

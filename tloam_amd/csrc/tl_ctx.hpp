@@ -51,7 +51,8 @@ struct DBuf {
 struct KindData {
   // source (this rank's block)
   size_t n_src_full = 0, src_lo = 0, n_src = 0;
-  DBuf<double> src_aos;
+  DBuf<double> src_aos;          // storage when the cloud came through tloam_set_source (one kind at a time)
+  const double* src_ptr = nullptr;   // this rank's block of the cloud, AoS: src_aos.p, or inside the frame's src_pack (tloam_set_source_frame)
   bool src_set = false;
   // target as given by set_target
   size_t n_tgt = 0;
@@ -75,11 +76,14 @@ struct KindData {
 struct FrameClouds {
   size_t n_src_full[tl::kKinds] = {}, src_lo[tl::kKinds] = {}, n_src[tl::kKinds] = {}, n_tgt[tl::kKinds] = {};
   DBuf<double> src_aos[tl::kKinds], tgt_aos[tl::kKinds], tx[tl::kKinds], ty[tl::kKinds], tz[tl::kKinds];
+  DBuf<double> src_pack;                       // the four source clouds of a Frame handed over in one piece (tloam_set_source_frame)
+  const double* src_ptr[tl::kKinds] = {};
   bool src_set[tl::kKinds] = {}, tgt_set[tl::kKinds] = {};
   double tgt_box[tl::kKinds][6] = {};
   bool tgt_box_valid[tl::kKinds] = {};
   void release() {
-    for (int k = 0; k < tl::kKinds; ++k) { src_aos[k].release(); tgt_aos[k].release(); tx[k].release(); ty[k].release(); tz[k].release(); }
+    for (int k = 0; k < tl::kKinds; ++k) { src_aos[k].release(); tgt_aos[k].release(); tx[k].release(); ty[k].release(); tz[k].release(); src_ptr[k] = nullptr; }
+    src_pack.release();
   }
 };
 
@@ -182,6 +186,7 @@ struct tloam_ctx {
                                      // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
   bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
   bool solve_v1 = false;           // TLOAM_SOLVE_V1: round 3's one-launch Solve (k_solve_small: ONE consumer wave for the grid) instead of k_solve_all
+  bool sync_set_source = false;    // TLOAM_SYNC_SET_SOURCE: tloam_set_source_frame as four pageable copies + a stream synchronisation (A/B)
   int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
   int device_cus = 0;              // multiProcessorCount of the device (k_solve_small needs all its blocks resident at once)
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
@@ -195,6 +200,15 @@ struct tloam_ctx {
   tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
   tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;
+  DBuf<double> src_pack;                        // the registered Frame's four source clouds in one piece (tloam_set_source_frame)
+  // pinned staging of tloam_set_source_frame: the borrowed host clouds are copied here (two halves, used alternately; an
+  // event per half says when the device has read it) and go to HBM with ONE asynchronous copy -- the call returns without
+  // waiting for the device, the frame's first kernel is ordered behind the copy by the stream
+  double* h_stage[2] = {nullptr, nullptr};
+  size_t h_stage_cap[2] = {0, 0};               // doubles
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_busy[2] = {false, false};
+  int stage_next = 0;
   std::vector<tlh::FrameClouds*> frame_store;   // tloam_frame_stash / tloam_frame_select
   int frame_selected = -1;                      // slot whose clouds are the registered ones (-1: the context's own)
   int dbg_planned_sweeps = 0;      // TLOAM_PLANNED_SWEEPS: force the sweep budget per Solve (exercises the top-up)

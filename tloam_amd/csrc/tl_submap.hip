@@ -110,17 +110,34 @@ __device__ __forceinline__ bool in_box(const VoxelJob& J, int seg, double x, dou
          z <= J.hi[seg][2];
 }
 
-// GetMinBound() of the cropped clouds (one per segment), block partials
-__global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict__ partial /*[blocks][6]*/,
-                                                 unsigned long long* __restrict__ keys,
-                                                 unsigned long long* __restrict__ cnt, int* __restrict__ overflow) {
+// ---- Crop + VoxelDownSample in THREE launches (round 4; eleven before: min, min-final, insert, a three-launch scan of the hash
+// table, scatter, order, a three-launch scan of the leader flags, accumulate -- a chain of launch-latency-bound kernels) --------
+//   k_vox_min2     GetMinBound() of the cropped clouds: block partials, the LAST block (ticket) finishes voxel_min_bound; the
+//                  same launch empties the hash table and the control words of the job
+//   k_vox_insert2  voxel of every in-box point -> hash slot, and the point is pushed on its voxel's member LIST (one atomic
+//                  exchange on the slot's head) -- no counting, no offsets, hence no scan over the table
+//   k_vox_emit     per point: walk the voxel's list -- the smallest index is the voxel's leader; the leader orders the members
+//                  by index (in LDS: the order AddPoint is called in, :379-385), accumulates and averages; its output position
+//                  -- the number of leaders in front, i.e. first-occurrence order -- comes from a single-pass scan over the
+//                  blocks inside the same launch (a block publishes its count, then looks back over its predecessors' words)
+// Same voxels, same member order, same sums, same output order as the eleven-launch form: tests/test_gpu_submap.py compares with
+// the oracle bit for bit.
+constexpr unsigned long long kNoHead = ~0ull;
+constexpr int kVoxLocal = 32;           // members a leader orders in LDS; a fuller voxel is ordered in global scratch (heap sort)
+constexpr unsigned long long kCntMask = (1ull << 30) - 1ull;   // look-back word: [0..29] leaders of segment 0, [32..61] of segment 1, [62..63] status
+// VoxelWork::leader_scan, the control words of a job: [0] blocks of k_vox_emit started so far, [1] cursor of the sort scratch
+// VoxelWork::overflow: [0] voxel index out of range, [1] ticket of k_vox_min2 (zero between launches)
+// VoxelWork::cnt[h] = head of slot h's member list, VoxelWork::urank[i] = next member after point i (-1: none)
+// VoxelWork::leader[b] = look-back word of block b of k_vox_emit
+__global__ __launch_bounds__(256) void k_vox_min2(VoxelJob J, VoxelWork W, int emit_blocks) {
   __shared__ double sm[6][256];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;  // (set by k_vox_insert, the launch after the next)
-  // the same launch empties the hash table of this job (keys = empty, cnt = 0 incl. the scan terminator)
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= J.mask + 1; i += (size_t)gridDim.x * 256) {
-    if (i <= J.mask) keys[i] = kEmpty;
-    cnt[i] = 0ull;
+  __shared__ int s_last;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { W.overflow[0] = 0; W.leader_scan[0] = 0ull; W.leader_scan[1] = 0ull; }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= J.mask; i += (size_t)gridDim.x * 256) {
+    W.keys[i] = kEmpty;
+    W.cnt[i] = kNoHead;
   }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= (size_t)emit_blocks; i += (size_t)gridDim.x * 256) W.leader[i] = 0ull;
   double m[6];
 #pragma unroll
   for (int a = 0; a < 6; ++a) m[a] = __builtin_inf();
@@ -141,40 +158,44 @@ __global__ __launch_bounds__(256) void k_vox_min(VoxelJob J, double* __restrict_
       for (int a = 0; a < 6; ++a) sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x < 6) partial[blockIdx.x * 6 + threadIdx.x] = sm[threadIdx.x][0];
-}
-// voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); an empty cloud has min bound (0, 0, 0)
-__global__ __launch_bounds__(384) void k_vox_min_final(const double* __restrict__ partial, int blocks, double voxel0,
-                                                       double voxel1, double* __restrict__ vmin) {
-  // one wave per (segment, axis), the rows spread over its lanes (min is exact in any order); a 3-thread serial
-  // loop over the 256 rows was a 26 us chain of dependent loads -- a quarter of the submap update
-  const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double m = __builtin_inf();
-  for (int b = lane; b < blocks; b += 64) m = fmin(m, partial[b * 6 + a]);
+  // the row is handed over with device-scope stores, their completion is waited for, then the ticket (k3_take_ticket, tl_gn.hip)
+  if (threadIdx.x < 6)
+    __hip_atomic_store(W.min_partial + blockIdx.x * 6 + threadIdx.x, sm[threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = (__hip_atomic_fetch_add(W.overflow + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  // voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); an empty cloud has min bound (0, 0, 0).  One wave per
+  // (segment, axis): min is exact in any order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int a = wave; a < 6; a += 4) {
+    double v = __builtin_inf();
+    for (int b = lane; b < (int)gridDim.x; b += 64)
+      v = fmin(v, __hip_atomic_load(W.min_partial + b * 6 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
-  if (!(m < __builtin_inf())) m = 0.0;
-  if (lane == 0) vmin[a] = m - (a < 3 ? voxel0 : voxel1) * 0.5;
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    if (!(v < __builtin_inf())) v = 0.0;
+    if (lane == 0) W.vmin[a] = v - J.voxel[a < 3 ? 0 : 1] * 0.5;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(W.overflow + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
 }
 
-// voxel of every in-box point -> hash slot; the counting atomic also hands out an (arbitrary) member rank
-__global__ __launch_bounds__(256) void k_vox_insert(VoxelJob J, const double* __restrict__ vmin,
-                                                    unsigned long long* __restrict__ keys,
-                                                    unsigned long long* __restrict__ cnt, int* __restrict__ slot_of_pt,
-                                                    int* __restrict__ urank, int* __restrict__ overflow) {
+__global__ __launch_bounds__(256) void k_vox_insert2(VoxelJob J, VoxelWork W) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= J.n) return;
   const double x = J.x[i], y = J.y[i], z = J.z[i];
   const int seg = i >= J.n0 ? 1 : 0;
-  if (!in_box(J, seg, x, y, z)) { slot_of_pt[i] = -1; return; }
+  if (!in_box(J, seg, x, y, z)) { W.slot_of_pt[i] = -1; return; }
   // ref_coord = (p - voxel_min_bound) / voxel_size; index = int(floor(ref_coord))   (:380-383)
   const double voxel = J.voxel[seg];
-  const long long ix = (long long)floor((x - vmin[3 * seg + 0]) / voxel);
-  const long long iy = (long long)floor((y - vmin[3 * seg + 1]) / voxel);
-  const long long iz = (long long)floor((z - vmin[3 * seg + 2]) / voxel);
+  const long long ix = (long long)floor((x - W.vmin[3 * seg + 0]) / voxel);
+  const long long iy = (long long)floor((y - W.vmin[3 * seg + 1]) / voxel);
+  const long long iz = (long long)floor((z - W.vmin[3 * seg + 2]) / voxel);
   if (ix < 0 || iy < 0 || iz < 0 || ix >= (1ll << 21) || iy >= (1ll << 21) || iz >= (1ll << 21)) {
-    *overflow = 1;  // "[VoxelDownSample] voxel_size is too small." (:370-372)
-    slot_of_pt[i] = -1;
+    W.overflow[0] = 1;  // "[VoxelDownSample] voxel_size is too small." (:370-372)
+    W.slot_of_pt[i] = -1;
     return;
   }
   // 3 x 21 bits of voxel coordinates, bit 63 = segment.  The all-ones key (segment 1, all three indices 2^21 - 1)
@@ -182,85 +203,145 @@ __global__ __launch_bounds__(256) void k_vox_insert(VoxelJob J, const double* __
   const unsigned long long key = (unsigned long long)ix | ((unsigned long long)iy << 21) | ((unsigned long long)iz << 42) |
                                  ((unsigned long long)seg << 63);
   if (key == kEmpty) {
-    *overflow = 1;
-    slot_of_pt[i] = -1;
+    W.overflow[0] = 1;
+    W.slot_of_pt[i] = -1;
     return;
   }
   unsigned long long h = mix64(key) & J.mask;
   for (;;) {
-    const unsigned long long prev = atomicCAS(&keys[h], kEmpty, key);
+    const unsigned long long prev = atomicCAS(&W.keys[h], kEmpty, key);
     if (prev == kEmpty || prev == key) break;
     h = (h + 1) & J.mask;
   }
-  slot_of_pt[i] = (int)h;
-  urank[i] = (int)atomicAdd(&cnt[h], 1ull);
+  W.slot_of_pt[i] = (int)h;
+  W.urank[i] = (int)atomicExch(&W.cnt[h], (unsigned long long)i);   // next[i] = the old head (-1: none), head = i
 }
 
-__global__ __launch_bounds__(256) void k_vox_scatter(size_t n, const int* __restrict__ slot_of_pt,
-                                                     const int* __restrict__ urank,
-                                                     const unsigned long long* __restrict__ off, int* __restrict__ members) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int h = slot_of_pt[i];
-  if (h < 0) return;
-  members[off[h] + (unsigned long long)urank[i]] = (int)i;
-}
-
-// rank of every point among its voxel's members in INDEX order (the order AddPoint is called in, :379-385);
-// the first member is the voxel's leader
-__global__ __launch_bounds__(256) void k_vox_order(size_t n, const int* __restrict__ slot_of_pt,
-                                                   const unsigned long long* __restrict__ off,
-                                                   const unsigned long long* __restrict__ cnt,
-                                                   const int* __restrict__ members, int* __restrict__ sorted,
-                                                   unsigned long long* __restrict__ leader) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i > n) return;
-  if (i == n) { leader[n] = 0ull; return; }  // scan terminator
-  const int h = slot_of_pt[i];
-  if (h < 0) { leader[i] = 0ull; return; }
-  const unsigned long long o = off[h];
-  const int m = (int)cnt[h];
-  int r = 0;
-  for (int q = 0; q < m; ++q) r += (members[o + q] < (int)i) ? 1 : 0;
-  sorted[o + r] = (int)i;
-  leader[i] = (r == 0) ? 1ull : 0ull;
-}
-
-// AccumulatedPoint: point_ += p in index order, GetAveragePoint = point_ / double(num) (:253-272); the voxels of
-// segment 0 come first in first-occurrence order, so segment 1's positions are rebased by their count
-__global__ __launch_bounds__(256) void k_vox_accumulate(VoxelJob J, VoxelWork W) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long base1 = W.leader_scan[J.n0];
-  if (i == 0) {  // numbers of voxels = sizes of the down-sampled clouds
-    W.n_out[0] = base1;
-    W.n_out[1] = W.leader_scan[J.n] - base1;
+__device__ __forceinline__ void heap_sift(int* a, int start, int end) {   // max-heap on a[0 .. end]
+  int root = start;
+  for (;;) {
+    int child = 2 * root + 1;
+    if (child > end) break;
+    if (child + 1 <= end && a[child] < a[child + 1]) ++child;
+    if (a[root] >= a[child]) break;
+    const int t = a[root]; a[root] = a[child]; a[child] = t;
+    root = child;
   }
-  if (W.host_seg && i < 8) {  // ... and straight to the host (stream order: everything the host waits for precedes this kernel)
-    unsigned long long w = i == 0 ? base1 : i == 1 ? W.leader_scan[J.n] - base1 : i == 2 ? (unsigned long long)W.overflow[0] : 0ull;
-    // word 7 = sequence number XOR the payload words (tlh::wait_segment: a torn segment reads as "not there yet")
-    unsigned long long x = w;
-    x ^= __shfl_xor(x, 1, 64);
-    x ^= __shfl_xor(x, 2, 64);
-    x ^= __shfl_xor(x, 4, 64);
-    if (i == 7) w = check_mix(W.host_seq) ^ x;
-    __hip_atomic_store(&W.host_seg[i], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (i >= J.n) return;
-  const int h = W.slot_of_pt[i];
-  if (h < 0) return;
-  const unsigned long long pos = W.leader_scan[i];
-  if (W.leader_scan[i + 1] == pos) return;  // not a leader
+}
+__global__ __launch_bounds__(256) void k_vox_emit(VoxelJob J, VoxelWork W, int nblocks) {
+  __shared__ int s_mem[kVoxLocal * 256];    // s_mem[k * 256 + t]: member k of thread t's voxel (conflict-free columns)
+  __shared__ unsigned long long s_wave[4];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_bid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // blocks take their place in the scan in the order they START: a block only ever waits for blocks that started before it
+  if (tid == 0) s_bid = (int)atomicAdd(&W.leader_scan[0], 1ull);
+  __syncthreads();
+  const int bid = s_bid;
+  const size_t i = (size_t)bid * 256 + tid;
+  const int h = i < J.n ? W.slot_of_pt[i] : -1;
   const int seg = i >= J.n0 ? 1 : 0;
-  const unsigned long long o = W.off[h];
-  const int m = (int)W.cnt[h];
-  double sx = 0.0, sy = 0.0, sz = 0.0;
-  for (int q = 0; q < m; ++q) {
-    const int j = W.sorted[o + q];
-    sx += J.x[j]; sy += J.y[j]; sz += J.z[j];
+  int m = 0;
+  bool leader = false;
+  if (h >= 0) {
+    int first = 0x7fffffff;
+    for (int j = (int)W.cnt[h]; j >= 0; j = W.urank[j]) {
+      if (m < kVoxLocal) s_mem[m * 256 + tid] = j;
+      first = j < first ? j : first;
+      ++m;
+    }
+    leader = first == (int)i;
   }
-  const double dn = (double)m;
-  const unsigned long long p = pos - (seg ? base1 : 0ull);
-  W.out[seg][0][p] = sx / dn; W.out[seg][1][p] = sy / dn; W.out[seg][2][p] = sz / dn;
+  // AccumulatedPoint: point_ += p in index order, GetAveragePoint = point_ / double(num) (:253-272)
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  if (leader) {
+    if (m <= kVoxLocal) {
+      for (int a = 1; a < m; ++a) {   // insertion sort of this thread's column
+        const int key = s_mem[a * 256 + tid];
+        int b = a - 1;
+        while (b >= 0 && s_mem[b * 256 + tid] > key) { s_mem[(b + 1) * 256 + tid] = s_mem[b * 256 + tid]; --b; }
+        s_mem[(b + 1) * 256 + tid] = key;
+      }
+      for (int q = 0; q < m; ++q) {
+        const int j = s_mem[q * 256 + tid];
+        sx += J.x[j]; sy += J.y[j]; sz += J.z[j];
+      }
+    } else {
+      // a crowded voxel: its members into a piece of the global scratch (only this thread ever touches it), heap sort, sum
+      int* buf = W.members + atomicAdd(&W.leader_scan[1], (unsigned long long)m);
+      int k = 0;
+      for (int j = (int)W.cnt[h]; j >= 0; j = W.urank[j]) buf[k++] = j;
+      for (int st = (m - 2) / 2; st >= 0; --st) heap_sift(buf, st, m - 1);
+      for (int end = m - 1; end > 0; --end) {
+        const int t = buf[0]; buf[0] = buf[end]; buf[end] = t;
+        heap_sift(buf, 0, end - 1);
+      }
+      for (int q = 0; q < m; ++q) {
+        const int j = buf[q];
+        sx += J.x[j]; sy += J.y[j]; sz += J.z[j];
+      }
+    }
+    const double dn = (double)m;
+    sx /= dn; sy /= dn; sz /= dn;
+  }
+  // ---- the leader's output position: leaders of its segment in front of it.  Block-exclusive scan of the packed flags ...
+  const unsigned long long flag = leader ? (seg ? (1ull << 32) : 1ull) : 0ull;
+  unsigned long long incl = flag;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long wave_base = 0ull, block_total = 0ull;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) wave_base += s_wave[w];
+    block_total += s_wave[w];
+  }
+  // ... and the blocks in front: publish this block's count, then look back (status 1: the block's own count, 2: the count of
+  // everything up to and including the block)
+  if (tid == 0) {
+    unsigned long long prefix = 0ull;
+    if (bid == 0) {
+      __hip_atomic_store(&W.leader[0], (2ull << 62) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(&W.leader[bid], (1ull << 62) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int p = bid - 1;;) {
+        const unsigned long long w = __hip_atomic_load(&W.leader[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned st = (unsigned)(w >> 62);
+        if (st == 0u) { __builtin_amdgcn_s_sleep(1); continue; }
+        prefix += w & ~(3ull << 62);
+        if (st == 2u) break;
+        --p;
+      }
+      __hip_atomic_store(&W.leader[bid], (2ull << 62) | (prefix + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_prefix = prefix;
+  }
+  __syncthreads();
+  const unsigned long long before = s_prefix + wave_base + (incl - flag);
+  if (leader) {
+    const unsigned long long p = seg ? ((before >> 32) & kCntMask) : (before & kCntMask);
+    W.out[seg][0][p] = sx; W.out[seg][1][p] = sy; W.out[seg][2][p] = sz;
+  }
+  if (bid == nblocks - 1 && tid < 8) {   // the block that holds the last point: the totals = the sizes of the down-sampled clouds
+    const unsigned long long total = s_prefix + block_total;
+    const unsigned long long n0_out = total & kCntMask, n1_out = (total >> 32) & kCntMask;
+    if (tid == 0) { W.n_out[0] = n0_out; W.n_out[1] = n1_out; }
+    if (W.host_seg) {  // ... and straight to the host: every leader's stores precede this block's in no particular order, so the
+                       // host reads the clouds only through the stream (it waits for this word, then enqueues behind the launch)
+      unsigned long long w = tid == 0 ? n0_out : tid == 1 ? n1_out : tid == 2 ? (unsigned long long)W.overflow[0] : 0ull;
+      // word 7 = check_mix(sequence number) XOR the payload words (tlh::wait_segment: a torn segment reads as "not there yet")
+      unsigned long long x = w;
+      x ^= __shfl_xor(x, 1, 64);
+      x ^= __shfl_xor(x, 2, 64);
+      x ^= __shfl_xor(x, 4, 64);
+      if (tid == 7) w = check_mix(W.host_seq) ^ x;
+      __hip_atomic_store(&W.host_seg[tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -342,19 +423,10 @@ size_t voxel_table_size(size_t n) {
 void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s) {
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
-  hipLaunchKernelGGL(k_vox_min, dim3(kMinBlocks), dim3(256), 0, s, J, W.min_partial, W.keys, W.cnt, W.overflow);
-  hipLaunchKernelGGL(k_vox_min_final, dim3(1), dim3(384), 0, s, W.min_partial, kMinBlocks, J.voxel[0], J.voxel[1], W.vmin);
-  const size_t cap = (size_t)J.mask + 1;
-  if (n > 0)
-    hipLaunchKernelGGL(k_vox_insert, dim3(blocks_for(n)), dim3(256), 0, s, J, W.vmin, W.keys, W.cnt, W.slot_of_pt,
-                       W.urank, W.overflow);
-  launch_exclusive_scan_u64(W.cnt, W.off, cap + 1, W.scan_tmp, s);
-  if (n > 0)
-    hipLaunchKernelGGL(k_vox_scatter, dim3(blocks_for(n)), dim3(256), 0, s, n, W.slot_of_pt, W.urank, W.off, W.members);
-  hipLaunchKernelGGL(k_vox_order, dim3(blocks_for(n + 1)), dim3(256), 0, s, n, W.slot_of_pt, W.off, W.cnt, W.members,
-                     W.sorted, W.leader);
-  launch_exclusive_scan_u64(W.leader, W.leader_scan, n + 1, W.scan_tmp, s);
-  hipLaunchKernelGGL(k_vox_accumulate, dim3(blocks_for(n + 1)), dim3(256), 0, s, J, W);
+  const int emit_blocks = (int)blocks_for(n + 1);   // (n + 1: an empty job still has a block that reports sizes of 0)
+  hipLaunchKernelGGL(k_vox_min2, dim3(kMinBlocks), dim3(256), 0, s, J, W, emit_blocks);
+  if (n > 0) hipLaunchKernelGGL(k_vox_insert2, dim3(blocks_for(n)), dim3(256), 0, s, J, W);
+  hipLaunchKernelGGL(k_vox_emit, dim3(emit_blocks), dim3(256), 0, s, J, W, emit_blocks);
 }
 
 }  // namespace tl

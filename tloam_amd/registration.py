@@ -152,6 +152,7 @@ def load_library():
         "tloam_comm_init_rccl": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "tloam_comm_init_callback": (C.c_int, [vp, C.c_int, C.c_int, ALLREDUCE_FN, vp]),
         "tloam_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
+        "tloam_shard_ranges_frame": (None, [C.POINTER(sz), C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
         "tloam_se3_exp": (C.c_int, [dp, dp]),
         "tloam_se3_log": (C.c_int, [dp, dp]),
         "tloam_se3_plus": (C.c_int, [dp, dp, dp]),
@@ -175,7 +176,7 @@ EXPORTED_SYMBOLS = (
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
-    "tloam_comm_init_callback", "tloam_shard_range", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
+    "tloam_comm_init_callback", "tloam_shard_range", "tloam_shard_ranges_frame", "tloam_se3_exp", "tloam_se3_log", "tloam_se3_plus",
 )
 
 
@@ -209,6 +210,14 @@ def shard_range(n, rank, nranks):
     lo, hi = C.c_size_t(0), C.c_size_t(0)
     load_library().tloam_shard_range(C.c_size_t(n), int(rank), int(nranks), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def shard_ranges_frame(n4, rank, nranks):
+    """[(lo, hi)] x 4: the blocks of a whole Frame a sharded context keeps (tloam_shard_ranges_frame)."""
+    n = (C.c_size_t * 4)(*[int(v) for v in n4])
+    lo, hi = (C.c_size_t * 4)(), (C.c_size_t * 4)()
+    load_library().tloam_shard_ranges_frame(n, int(rank), int(nranks), lo, hi)
+    return [(int(lo[k]), int(hi[k])) for k in range(4)]
 
 
 def se3_exp(x):
