@@ -369,10 +369,10 @@ def main():
         if side is not None:
             in_frame = dict(side["k3"])
             in_frame.update({"workload": side["workload"],
-                             "note": "the same sweep inside the timed 1 M frames (%d frames), where a GN iteration is one launch "
-                                     "(k3_sweep_step = sweep + row fold + minimiser step): avg_launch_us / frac are per-launch HIP event "
-                                     "pairs around the WHOLE dispatch (serial tail included; event pairs read 1.2-2.5 us more than "
-                                     "dispatch timestamps, DESIGN.md section 7); stream_phase is the sweep alone" %
+                             "note": "the same kernel inside the timed 1 M frames (%d frames): every launch follows the one-block "
+                                     "minimiser step, i.e. starts on an idle chip; per-launch HIP event pairs read 1.2-2.5 us "
+                                     "more than the dispatch timestamps (DESIGN.md section 7).  With TLOAM_FUSED_LARGE (sweep + fold + "
+                                     "step in one dispatch, measured slower, off by default) a stream_phase entry reports the sweep alone" %
                                      (args.steps if args.workload == "m1" else args.m1_steps)})
             roofline = None
             if not multi and not args.no_side:
@@ -422,15 +422,14 @@ def main():
                                 "working_set": cold["working_set"], "launch_timing": cold["launch_timing"],
                                 "measured_copy_GBps": roofline["measured_copy_GBps"], "frac_of_measured_copy": cold["frac_of_measured_copy"],
                                 "note": "headline = the HBM figure (cold working set); the contract's 74.88 MB set (SURVEY 8(d) config 3: "
-                                        ">= 70 %% <=> <= 13.4 us) is Infinity-Cache resident across launches and is reported as l3_resident",
+                                        ">= 70 % <=> <= 13.4 us) is Infinity-Cache resident across launches and is reported as l3_resident",
                                 "l3_resident": l3}
                 except Exception as e:  # noqa: BLE001  (side measurements never take the line down)
                     roofline = None
                     in_frame["side_measurements_error"] = repr(e)[:200]
             if roofline is None:   # N > 1 / --no-side: the in-frame figure stands in
                 roofline = dict(in_frame)
-                roofline.update({"kernel": "k3_sweep_step<false> (sweep + row fold + minimiser step in one dispatch)", "traffic": traffic,
-                                 "traffic_detail": traffic_detail})
+                roofline.update({"kernel": "k3_accumulate<false, false>", "traffic": traffic, "traffic_detail": traffic_detail})
             else:
                 roofline["in_frame"] = in_frame
             if side.get("k1"):

@@ -178,14 +178,15 @@ def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module, frames_b
     assert 1.5 < res["seconds"] < 40.0, res                      # bounded: a few exchanges of ~2 s each, not forever
 
 
-def _worker_peer_dies(rank, world, port, q):
-    """callback contexts: rank 1's process EXITS inside its 6th all-reduce (no clean-up, no goodbye); the collective layer of the
-    survivor notices (gloo: connection closed by peer), its callback reports failure, and the library hands TLOAM_E_RCCL to the
-    caller instead of a result."""
+def _worker_peer_dies(rank, world, port, q, alive, entered):
+    """callback contexts: rank 1's process EXITS at its 6th all-reduce (no clean-up, no goodbye).  What a collective layer does
+    with a dead peer is its own business (gloo may abort the survivor, RCCL may hang): the caller's all-reduce here has the
+    failure detector a production one needs -- a heartbeat (`alive`, `entered`: shared words) consulted before it commits to the
+    collective -- and reports failure to the library, which hands TLOAM_E_RCCL to its caller instead of a result."""
     import time
     import torch
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=20))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     from tloam_amd import registration as reg
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -195,7 +196,14 @@ def _worker_peer_dies(rank, world, port, q):
     def allreduce(dev_ptr, count, stream):
         calls[0] += 1
         if rank == 1 and calls[0] == 6:
-            os._exit(0)                                   # dies inside the exchange
+            alive.value = 0
+            os._exit(0)                                   # dies at the exchange
+        entered[rank] = calls[0]
+        t0 = time.perf_counter()
+        while entered[1 - rank] < calls[0]:               # the peer has not arrived at this exchange yet
+            if not alive.value or time.perf_counter() - t0 > 30.0:
+                return 1                                  # ... and never will
+            time.sleep(0.0005)
         try:
             assert hip.hipStreamSynchronize(stream) == 0
             host = np.zeros(count)
@@ -204,7 +212,7 @@ def _worker_peer_dies(rank, world, port, q):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             assert hip.hipMemcpy(dev_ptr, host.ctypes.data, 8 * count, 1) == 0
             return 0
-        except Exception:                                 # noqa: BLE001 -- the peer is gone: report, never raise through the C ABI
+        except Exception:                                 # noqa: BLE001 -- report, never raise through the C ABI
             return 1
 
     sc = synth.make_scene(seed=31)
@@ -228,8 +236,10 @@ def test_callback_exchange_reports_a_peer_that_dies_inside_it(hip_module):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    alive = ctx.Value("i", 1)
+    entered = ctx.Array("i", [0, 0])
     port = _free_port()
-    procs = [ctx.Process(target=_worker_peer_dies, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_peer_dies, args=(r, world, port, q, alive, entered)) for r in range(world)]
     for p in procs: p.start()
     res = q.get(timeout=180)
     for p in procs:

@@ -393,10 +393,12 @@ def test_non_finite_points_are_never_matched(hip_module, n_src, n_tgt, over):
         assert not np.any((ih >= at) & (ih < at + len(bad))), k          # a spliced row is never a factor
         w = H.get_weights(k)
         assert np.all((w >= 0) & (w <= 1)) and np.all(w[at:at + len(bad)] == 1.0)
-        if not over:   # (with binding caps the spliced rows shift which points the sphere builder ever looks at, :538/:551)
+        # (the sphere builder counts every source point it LOOKS at, :538/:551: where that cap binds, the spliced rows shift which
+        #  points it ever gets to -- the lists then differ legitimately, HIP and oracle alike)
+        if not over and not (k == 3 and len(src[3]) > cfg.sphere_maxnum):
             clean = Hc.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"]
             assert np.array_equal(np.where(ih >= at + len(bad), ih - len(bad), ih), clean), k
-    if not over:
+    if not over and len(src[3]) <= cfg.sphere_maxnum:
         assert np.array_equal(T, T0)
     H.close(); Hc.close()
 
