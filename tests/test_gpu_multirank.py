@@ -229,6 +229,7 @@ def _worker_peer_dies(rank, world, port, q, alive, entered):
     rc2, T2, st2 = S.scan_match(sc.T_pred)
     S.close()
     q.put(dict(rc=rc, seconds=dt, msg=msg, calls=calls[0], rc_after=rc2))
+    q.close(); q.join_thread()                            # (the queue's feeder thread has written the message out)
     os._exit(0)                                           # (the process group lost a member: no orderly shutdown to wait for)
 
 

@@ -177,6 +177,38 @@ int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long
     __builtin_ia32_pause();
   }
 }
+// Borrowed host arrays -> device, without waiting for the device: the pieces are copied end to end into a pinned staging half
+// (two halves used alternately; an event per half says when the device has read it -- long ago in the reference's call pattern,
+// waited for otherwise) and go to `dev_dst` with ONE asynchronous copy on the context's stream.  counts in doubles.
+int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst) {
+  size_t total = 0;
+  for (int i = 0; i < nparts; ++i) total += counts[i];
+  if (total == 0) return TLOAM_OK;
+  const int h = c->stage_next;
+  c->stage_next ^= 1;
+  if (c->stage_busy[h]) {
+    HIPC(c, hipEventSynchronize(c->stage_ev[h]));
+    c->stage_busy[h] = false;
+  }
+  if (total > c->h_stage_cap[h]) {
+    if (c->h_stage[h]) (void)hipHostFree(c->h_stage[h]);
+    c->h_stage[h] = nullptr;
+    c->h_stage_cap[h] = 0;
+    const size_t want = total + total / 2;
+    HIPC(c, hipHostMalloc((void**)&c->h_stage[h], want * sizeof(double), hipHostMallocDefault));
+    c->h_stage_cap[h] = want;
+  }
+  if (!c->stage_ev[h]) HIPC(c, hipEventCreateWithFlags(&c->stage_ev[h], hipEventDisableTiming));
+  size_t off = 0;
+  for (int i = 0; i < nparts; ++i) {
+    if (counts[i] > 0) memcpy(c->h_stage[h] + off, parts[i], sizeof(double) * counts[i]);
+    off += counts[i];
+  }
+  HIPC(c, hipMemcpyAsync(dev_dst, c->h_stage[h], sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  HIPC(c, hipEventRecord(c->stage_ev[h], c->stream));
+  c->stage_busy[h] = true;
+  return TLOAM_OK;
+}
 // The four search grids share one set of buffers (points and cell tables concatenated), so that every
 // phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
 // scatter.  `GridBuffers` owns the storage; ctx->grids is the set built by scanMatching, tloam_knn uses a
@@ -779,39 +811,22 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
     off[k + 1] = off[k] + 3 * K.n_src;
   }
   const size_t total = std::max<size_t>(off[kKinds], 3);
-  const int h = c->stage_next;
-  c->stage_next ^= 1;
-  if (c->stage_busy[h]) {   // the copy that last read this half: long done in the reference's call pattern, waited for otherwise
-    HIPC(c, hipEventSynchronize(c->stage_ev[h]));
-    c->stage_busy[h] = false;
-  }
-  if (total > c->h_stage_cap[h]) {
-    if (c->h_stage[h]) (void)hipHostFree(c->h_stage[h]);
-    c->h_stage[h] = nullptr;
-    c->h_stage_cap[h] = 0;
-    const size_t want = total + total / 2;
-    HIPC(c, hipHostMalloc((void**)&c->h_stage[h], want * sizeof(double), hipHostMallocDefault));
-    c->h_stage_cap[h] = want;
-  }
-  if (!c->stage_ev[h]) HIPC(c, hipEventCreateWithFlags(&c->stage_ev[h], hipEventDisableTiming));
   if (total > c->src_pack.cap) {
     // (a kernel of an earlier frame may still read the old block: nothing of this context is in flight in the reference's
     //  call pattern, but a growing buffer is rare enough to afford the certainty)
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, c->src_pack.reserve(total));
   }
+  const double* parts[kKinds];
+  size_t counts[kKinds];
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
-    if (K.n_src > 0) memcpy(c->h_stage[h] + off[k], xyz[k] + 3 * K.src_lo, sizeof(double) * 3 * K.n_src);
+    parts[k] = K.n_src > 0 ? xyz[k] + 3 * K.src_lo : nullptr;
+    counts[k] = 3 * K.n_src;
     K.src_ptr = c->src_pack.p + off[k];
     K.src_set = true;
   }
-  if (off[kKinds] > 0) {
-    HIPC(c, hipMemcpyAsync(c->src_pack.p, c->h_stage[h], sizeof(double) * off[kKinds], hipMemcpyHostToDevice, c->stream));
-    HIPC(c, hipEventRecord(c->stage_ev[h], c->stream));
-    c->stage_busy[h] = true;
-  }
-  return TLOAM_OK;
+  return tlh::stage_and_upload(c, parts, counts, kKinds, c->src_pack.p);
 }
 int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;

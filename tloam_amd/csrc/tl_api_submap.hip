@@ -175,6 +175,10 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   (void)sphere;
   for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = false;  // the targets are about to be rebuilt on the device
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
+  // The three clouds the device needs (planar, edge, ground) go up in ONE piece -- pinned staging, one asynchronous copy
+  // (tlh::stage_and_upload) -- into the planar ring frame's buffer: the planar cloud stays there for the frames it is
+  // buffered, the edge and ground clouds behind it are read by this update's assemble launch only.  (Three pageable
+  // copies cost ~25 us each of the calling thread's time: more than the update's kernels.)
   auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep, bool upload) -> int {
     RingFrame* f = nullptr;
     if ((int)ring.size() >= keep) {  // recycle the frame that falls out
@@ -188,9 +192,12 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     f->n = n;
     memcpy(f->pose, pose, sizeof(double) * 16);
     if (!upload) return TLOAM_OK;
-    HIPC(c, f->aos.reserve(3 * std::max<size_t>(n, 1)));
-    if (n > 0) HIPC(c, hipMemcpyAsync(f->aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    return TLOAM_OK;
+    const size_t all = 3 * (n + n_edge + n_ground);
+    if (f->aos.cap < std::max<size_t>(all, 3)) HIPC(c, hipStreamSynchronize(c->stream));   // regrowth: nothing may be in flight
+    HIPC(c, f->aos.reserve(std::max<size_t>(all, 3)));
+    const double* parts[3] = {xyz, edge, ground};
+    const size_t counts[3] = {3 * n, 3 * n_edge, 3 * n_ground};
+    return tlh::stage_and_upload(c, parts, counts, 3, f->aos.p);
   };
   // The sphere buffer is kept for its bookkeeping only (sizes, poses, frame count): nothing ever reads its points --
   // the sphere submap is rebuilt from the PLANAR buffer (front_end.cpp:221) -- so they are not uploaded.
@@ -239,14 +246,10 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
      // only then -- in steady state the capacities suffice and the update runs without a host wait
     const size_t m = std::max<size_t>(n_all, 1);
-    bool grow = S.wx.cap < m || S.in_aos.cap < 3 * std::max<size_t>(accs[0].n, 1) ||
-                S.in_aos2.cap < 3 * std::max<size_t>(accs[1].n, 1) || S.slot_of_pt.cap < m ||
-                S.keys.cap < voxel_table_size(m) + 1 || S.leader.cap < m + 1;
+    bool grow = S.wx.cap < m || S.slot_of_pt.cap < m || S.keys.cap < voxel_table_size(m) + 1 || S.leader.cap < m + 1;
     for (int s = 0; s < 2; ++s) grow = grow || c->kd[accs[s].kind].tx.cap < std::max<size_t>(n_in[s], 1);
     if (grow) HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
-    HIPC(c, S.in_aos.reserve(3 * std::max<size_t>(accs[0].n, 1)));
-    HIPC(c, S.in_aos2.reserve(3 * std::max<size_t>(accs[1].n, 1)));
   }
   double lo[2][3], hi[2][3];
   {
@@ -255,8 +258,8 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     for (int s = 0; s < 2; ++s) {
       const Acc& a = accs[s];
       KindData& K = c->kd[a.kind];
-      double* stage = s == 0 ? S.in_aos.p : S.in_aos2.p;
-      if (a.n > 0) HIPC(c, hipMemcpyAsync(stage, a.xyz, sizeof(double) * 3 * a.n, hipMemcpyHostToDevice, c->stream));
+      // (uploaded with the planar cloud, behind it in the newest ring frame's buffer)
+      const double* stage = S.planar_ring.back()->aos.p + 3 * (n_planar + (s == 0 ? 0 : n_edge));
       A.ox[s] = K.tx.p; A.oy[s] = K.ty.p; A.oz[s] = K.tz.p;
       A.aos[s] = stage;
       A.n_old[s] = n_old[s]; A.n_new[s] = a.n; A.base[s] = base;

@@ -112,14 +112,14 @@ struct SubmapState {
   unsigned long long pending_seq = 0ull;  // sequence number the last kernel of the update in flight stores into the host slot
   tloam_submap_config cfg;
   std::vector<RingFrame*> planar_ring, sphere_ring;  // oldest first (std::deque in the reference)
-  DBuf<double> in_aos, in_aos2, wx, wy, wz, min_partial, vmin;
+  DBuf<double> in_aos, wx, wy, wz, min_partial, vmin;
   DBuf<unsigned long long> keys, cnt, off, leader, leader_scan, scan_tmp, counts;
   DBuf<int> slot_of_pt, urank, members, sorted, overflow;
   void release() {
     for (auto* f : planar_ring) { f->aos.release(); delete f; }
     for (auto* f : sphere_ring) { f->aos.release(); delete f; }
     planar_ring.clear(); sphere_ring.clear();
-    in_aos.release(); in_aos2.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
+    in_aos.release(); wx.release(); wy.release(); wz.release(); min_partial.release(); vmin.release();
     keys.release(); cnt.release(); off.release(); leader.release(); leader_scan.release(); scan_tmp.release();
     counts.release(); slot_of_pt.release(); urank.release(); members.release(); sorted.release(); overflow.release();
     inited = false;
@@ -267,6 +267,7 @@ namespace tlh {
 // tl_api.hip
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
 int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]);
+int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst);
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
                      tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr,
                      tl::FrameInitHook* frame = nullptr);
