@@ -17,8 +17,9 @@ for S in 1 4; do
   (cd $R && python scripts/rocpd_stats.py $(find $O/k3trace_$S -name "*.db" | head -1) $P/${TAG}_k3_${N}_kernel_stats.csv > /dev/null)
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$S -o p -- python $R/scripts/k3_only.py 50 $S > /dev/null 2> $O/pmc_fetch_$S.err
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$S -o p -- python $R/scripts/k3_only.py 50 $S > /dev/null 2> $O/pmc_write_$S.err
-  (cd $R && python scripts/pmc_summary.py "k3_accumulate<false" $P/${TAG}_pmc_k3_${N}.json $(find $O/pmc_fetch_$S -name "*.db" | head -1) $(find $O/pmc_write_$S -name "*.db" | head -1) > /dev/null)
-  cp $P/${TAG}_pmc_k3_${N}.json $R/profiles/   # (the bench line below quotes the counters collected on the kernel it times)
+  M=$([ $S = 1 ] && echo prebuilt || echo prebuilt_cold)
+  (cd $R && python scripts/pmc_summary.py "k3_accumulate<false" $P/${TAG}_pmc_k3_${M}.json $(find $O/pmc_fetch_$S -name "*.db" | head -1) $(find $O/pmc_write_$S -name "*.db" | head -1) > /dev/null)
+  cp $P/${TAG}_pmc_k3_${M}.json $R/profiles/   # (the bench line below quotes the counters collected on the kernel it times)
   rm -rf $O/k3trace_$S $O/pmc_fetch_$S $O/pmc_write_$S
 done
 cd $R

@@ -9,7 +9,7 @@ WHAT = {
     "k3_prebuilt_kernel_stats.csv": "`rocprofv3 --kernel-trace --stats -- python scripts/k3_only.py 50 1`: K3 (`k3_accumulate<false, false>`) ALONE on the contract's pre-built 760k:200k:40k set (74.88 MB per sweep, Infinity-Cache resident across launches) -- `roofline.l3_resident` is recomputed from this row: 74 880 000 B / avg duration / 8 TB/s",
     "k3_cold_kernel_stats.csv": "the same with `k3_only.py 50 4`: four times the set (299.52 MB per sweep > 256 MiB Infinity Cache, every byte from HBM) -- the headline `roofline.frac`: 299 520 000 B / avg duration / 8 TB/s",
     "pmc_k3_prebuilt.json": "separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the scale-1 run (`scripts/pmc_summary.py`, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); quoted by the bench line as `roofline.l3_resident.traffic`",
-    "pmc_k3_cold.json": "the same for the cold set; quoted as `roofline.traffic`",
+    "pmc_k3_prebuilt_cold.json": "the same for the cold set; quoted as `roofline.traffic`",
     "kitti_frame_timeline.txt": "`scripts/frame_timeline.py` on a kernel trace of `bench.py --workload kitti`: the launches of a KITTI-density frame in order, median duration and gap before each",
     "m1_frame_timeline.txt": "the same for the 1 M frame (`bench.py --workload m1`)",
     "solve_all_timeline.txt": "`scripts/solve_profile2.py` on a `-DTLOAM_STEP_PROFILE` build: wall-clock stamps (10 ns) inside the one-launch Solve `k_solve_all` per GN iteration -- lead block's stepper wave and one other wave",

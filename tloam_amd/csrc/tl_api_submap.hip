@@ -38,7 +38,7 @@ int submap_reserve_work(tloam_ctx* c, size_t n) {
 // [s ? n0 : 0, s ? n : n0) -> target[kind[s]] = VoxelDownSample(Crop(segment, box[s]), voxel[s]); sizes to counts[s].
 // A single cloud: n0 == n, kind[1] ignored.
 struct CropVoxelSeg { int kind; size_t n; const double* lo; const double* hi; double voxel; };
-int submap_crop_voxel(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg) {
+int submap_job(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg, VoxelJob* Jout, VoxelWork* Wout) {
   SubmapState& S = c->submap;
   const size_t n0 = seg[0].n, n = n0 + (nseg > 1 ? seg[1].n : 0);
   int rc = submap_reserve_work(c, n);
@@ -69,6 +69,15 @@ int submap_crop_voxel(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg) {
   W.host_seg = (c->h_mirror_dev && !c->no_host_mirror) ? &c->h_mirror_dev[kMirrorSlots - 1].w[0] : nullptr;
   W.host_seq = W.host_seg ? ++c->mirror_seq : 0ull;
   S.pending_seq = W.host_seq;
+  *Jout = J;
+  *Wout = W;
+  return TLOAM_OK;
+}
+int submap_crop_voxel(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg) {
+  VoxelJob J;
+  VoxelWork W;
+  const int rc = submap_job(c, seg, nseg, &J, &W);
+  if (rc != TLOAM_OK) return rc;
   launch_crop_voxel(J, W, c->stream);
   return TLOAM_OK;
 }
@@ -173,6 +182,7 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
                               const double* ground, size_t n_ground) {
   SubmapState& S = c->submap;
   (void)sphere;
+  bool fused_front = false;
   for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = false;  // the targets are about to be rebuilt on the device
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
   // The three clouds the device needs (planar, edge, ground) go up in ONE piece -- pinned staging, one asynchronous copy
@@ -214,11 +224,9 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     if (P.tx.cap < m || Q.tx.cap < m) HIPC(c, hipStreamSynchronize(c->stream));  // regrowth: nothing may be in flight
     HIPC(c, P.tx.reserve(m)); HIPC(c, P.ty.reserve(m)); HIPC(c, P.tz.reserve(m));
     HIPC(c, Q.tx.reserve(m)); HIPC(c, Q.ty.reserve(m)); HIPC(c, Q.tz.reserve(m));
-    if ((int)S.planar_ring.size() <= transform_ring_max()) {  // all buffered frames, both submaps: ONE launch
-      const double* aos[16]; size_t nn[16]; const double* poses[16];
-      int cnt = 0;
-      for (auto* f : S.planar_ring) { aos[cnt] = f->aos.p; nn[cnt] = f->n; poses[cnt] = f->pose; ++cnt; }
-      launch_transform_ring(cnt, aos, nn, poses, P.tx.p, P.ty.p, P.tz.p, Q.tx.p, Q.ty.p, Q.tz.p, c->stream);
+    if ((int)S.planar_ring.size() <= transform_ring_max()) {
+      // all buffered frames, both submaps: part of the update's front launch below (k_submap_front)
+      fused_front = true;
     } else {
       size_t off = 0;
       for (auto* f : S.planar_ring) {  // one launch per buffered frame writes both submaps
@@ -267,13 +275,31 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
       base += n_in[s];
     }
     for (int i = 0; i < 16; ++i) A.M[i] = pose[i];
-    launch_assemble(A, S.wx.p, S.wy.p, S.wz.p, c->stream);  // [old | Transform(new)] of both clouds, one launch
-  }
-  {
     const CropVoxelSeg seg[2] = {{accs[0].kind, n_in[0], lo[0], hi[0], accs[0].voxel},
                                  {accs[1].kind, n_in[1], lo[1], hi[1], accs[1].voxel}};
-    rc = submap_crop_voxel(c, seg, 2);
-    if (rc != TLOAM_OK) return rc;
+    if (fused_front) {
+      // ONE launch for the planar ring, the assembly of both clouds and the head of the crop + voxel job (table emptied, min
+      // bound): the update is front | insert | emit
+      size_t ring_max = 0;
+      const double* aos[16]; size_t nn[16]; const double* poses[16];
+      int cnt = 0;
+      for (auto* f : S.planar_ring) { aos[cnt] = f->aos.p; nn[cnt] = f->n; poses[cnt] = f->pose; ring_max = std::max(ring_max, f->n); ++cnt; }
+      const size_t rows = submap_front_rows(ring_max, std::max(n_in[0], n_in[1]));
+      if (S.min_partial.cap < rows * 6) HIPC(c, hipStreamSynchronize(c->stream));   // regrowth: nothing may be in flight
+      HIPC(c, S.min_partial.reserve(rows * 6));
+      VoxelJob J;
+      VoxelWork W;
+      rc = submap_job(c, seg, 2, &J, &W);
+      if (rc != TLOAM_OK) return rc;
+      KindData& P = c->kd[TLOAM_KIND_PLANAR];
+      KindData& Q = c->kd[TLOAM_KIND_SPHERE];
+      launch_submap_front(cnt, aos, nn, poses, A, J, W, P.tx.p, P.ty.p, P.tz.p, Q.tx.p, Q.ty.p, Q.tz.p, S.wx.p, S.wy.p, S.wz.p, c->stream);
+      launch_crop_voxel(J, W, c->stream, /*front_done=*/true);
+    } else {
+      launch_assemble(A, S.wx.p, S.wy.p, S.wz.p, c->stream);  // [old | Transform(new)] of both clouds, one launch
+      rc = submap_crop_voxel(c, seg, 2);
+      if (rc != TLOAM_OK) return rc;
+    }
   }
   size_t ne = 0, ng = 0;
   rc = submap_finish(c, &ne, &ng);

@@ -19,6 +19,7 @@
 // (ix | iy << 21 | iz << 42); per-voxel member lists are ordered by index with a rank-by-counting pass so the
 // floating-point accumulation order is the reference's (ascending index).  Compiled with -ffp-contract=off.
 #include <algorithm>
+#include <string.h>
 
 #include "tl_common.hpp"
 
@@ -386,6 +387,113 @@ void launch_assemble(const AssembleArgs& A, double* wx, double* wy, double* wz, 
   if (nmax == 0) return;
   hipLaunchKernelGGL(k_assemble, dim3(blocks_for(nmax), 2), dim3(256), 0, s, A, wx, wy, wz);
 }
+// ---- the front of a submap update in ONE launch: the planar ring (blockIdx.y < ring frames: k_transform_ring's work), the
+// assembly of [old submap | Transform(new scan)] of the edge and the ground cloud (the next two rows of blocks: k_assemble's
+// work) and, by those same blocks on the points they have just written, what k_vox_min2 would do next: the hash table of the
+// crop + voxel job emptied, the min bound of the cropped clouds as block partials, voxel_min_bound finished by the last block
+// (ticket).  launch_crop_voxel then starts at the insert pass: an update is front | insert | emit.
+__global__ __launch_bounds__(256) void k_submap_front(RingArgs R, int ring_count, AssembleArgs A, VoxelJob J, VoxelWork W, int emit_blocks,
+                                                      double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
+                                                      double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz,
+                                                      double* __restrict__ wx, double* __restrict__ wy, double* __restrict__ wz) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.y < ring_count) {   // ---- planar / sphere submaps from the ring buffer (front_end.cpp:220-243)
+    const int f = blockIdx.y;
+    if (i >= R.n[f]) return;
+    const double* __restrict__ aos = R.aos[f];
+    const Mat16& M = R.M[f];
+    const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+    double r[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) r[a] = ((M.m[a] * x + M.m[4 + a] * y) + M.m[8 + a] * z) + M.m[12 + a] * 1.0;
+    const double vx = r[0] / r[3], vy = r[1] / r[3], vz = r[2] / r[3];
+    const size_t o = R.off[f] + i;
+    px[o] = vx; py[o] = vy; pz[o] = vz;
+    qx[o] = vx; qy[o] = vy; qz[o] = vz;
+    return;
+  }
+  __shared__ double sm[3][256];
+  __shared__ int s_last;
+  const int s = (int)blockIdx.y - ring_count;            // segment: 0 edge, 1 ground
+  const int lb = s * (int)gridDim.x + (int)blockIdx.x, nlb = 2 * (int)gridDim.x;   // this block among the assembling ones
+  if (lb == 0 && threadIdx.x == 0) { W.overflow[0] = 0; W.leader_scan[0] = 0ull; W.leader_scan[1] = 0ull; }
+  for (size_t t = (size_t)lb * 256 + threadIdx.x; t <= J.mask; t += (size_t)nlb * 256) {
+    W.keys[t] = kEmpty;
+    W.cnt[t] = kNoHead;
+  }
+  for (size_t t = (size_t)lb * 256 + threadIdx.x; t <= (size_t)emit_blocks; t += (size_t)nlb * 256) W.leader[t] = 0ull;
+  double m[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+  const size_t n_old = A.n_old[s], n_new = A.n_new[s];
+  if (i < n_old + n_new) {
+    const size_t o = A.base[s] + i;
+    double x, y, z;
+    if (i < n_old) {  // *submap (kept as is)
+      x = A.ox[s][i]; y = A.oy[s][i]; z = A.oz[s][i];
+    } else {          // += scan->Transform(pose)
+      const size_t k = i - n_old;
+      const double* __restrict__ aos = A.aos[s];
+      const double ax = aos[3 * k], ay = aos[3 * k + 1], az = aos[3 * k + 2];
+      double r[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) r[a] = ((A.M[a] * ax + A.M[4 + a] * ay) + A.M[8 + a] * az) + A.M[12 + a] * 1.0;
+      x = r[0] / r[3]; y = r[1] / r[3]; z = r[2] / r[3];
+    }
+    wx[o] = x; wy[o] = y; wz[o] = z;
+    if (in_box(J, s, x, y, z)) { m[0] = x; m[1] = y; m[2] = z; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = m[a];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sm[a][threadIdx.x] = fmin(sm[a][threadIdx.x], sm[a][threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) {   // this block's row: its segment's three columns, +inf in the other segment's
+    const int a = threadIdx.x;
+    const double v = (a / 3 == s) ? sm[a % 3][0] : __builtin_inf();
+    __hip_atomic_store(W.min_partial + (size_t)lb * 6 + a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = (__hip_atomic_fetch_add(W.overflow + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nlb - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int a = wave; a < 6; a += 4) {   // voxel_min_bound = GetMinBound() - voxel_size * 0.5 (:366); empty cloud: (0, 0, 0)
+    double v = __builtin_inf();
+    for (int b = lane; b < nlb; b += 64)
+      v = fmin(v, __hip_atomic_load(W.min_partial + (size_t)b * 6 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    if (!(v < __builtin_inf())) v = 0.0;
+    if (lane == 0) W.vmin[a] = v - J.voxel[a < 3 ? 0 : 1] * 0.5;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(W.overflow + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+}
+// rows of VoxelWork::min_partial the front launch needs (6 doubles each)
+size_t submap_front_rows(size_t n_ring_max, size_t n_seg_max) { return 2 * (size_t)blocks_for(std::max<size_t>(std::max(n_ring_max, n_seg_max), 1)); }
+void launch_submap_front(int count, const double* const aos[], const size_t n[], const double* const poses[], const AssembleArgs& A,
+                         const VoxelJob& J, const VoxelWork& W, double* px, double* py, double* pz, double* qx, double* qy, double* qz,
+                         double* wx, double* wy, double* wz, hipStream_t s) {
+  RingArgs R;
+  memset(&R, 0, sizeof(R));
+  size_t off = 0, nmax = 1;
+  for (int f = 0; f < count; ++f) {
+    R.aos[f] = aos[f];
+    R.n[f] = n[f];
+    R.off[f] = off;
+    for (int i = 0; i < 16; ++i) R.M[f].m[i] = poses[f][i];
+    off += n[f];
+    nmax = std::max(nmax, n[f]);
+  }
+  nmax = std::max(nmax, std::max(A.n_old[0] + A.n_new[0], A.n_old[1] + A.n_new[1]));
+  const int emit_blocks = (int)blocks_for(J.n + 1);
+  hipLaunchKernelGGL(k_submap_front, dim3(blocks_for(nmax), count + 2), dim3(256), 0, s, R, count, A, J, W, emit_blocks, px, py, pz, qx, qy,
+                     qz, wx, wy, wz);
+}
 int transform_ring_max() { return kRingMax; }
 void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
                            double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s) {
@@ -420,11 +528,12 @@ size_t voxel_table_size(size_t n) {
 
 // Crop(box) -> VoxelDownSample(voxel) of the one or two SoA clouds in J, written to W.out; the output sizes land in
 // W.n_out[0..1] (device).  No host synchronisation.
-void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s) {
+// front_done: the table has been emptied and voxel_min_bound finished by k_submap_front
+void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s, bool front_done) {
   const size_t n = J.n;
   constexpr int kMinBlocks = 256;
   const int emit_blocks = (int)blocks_for(n + 1);   // (n + 1: an empty job still has a block that reports sizes of 0)
-  hipLaunchKernelGGL(k_vox_min2, dim3(kMinBlocks), dim3(256), 0, s, J, W, emit_blocks);
+  if (!front_done) hipLaunchKernelGGL(k_vox_min2, dim3(kMinBlocks), dim3(256), 0, s, J, W, emit_blocks);
   if (n > 0) hipLaunchKernelGGL(k_vox_insert2, dim3(blocks_for(n)), dim3(256), 0, s, J, W);
   hipLaunchKernelGGL(k_vox_emit, dim3(emit_blocks), dim3(256), 0, s, J, W, emit_blocks);
 }
