@@ -1,0 +1,13 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4i; mkdir -p $O; cd $R
+timeout 900 python -X faulthandler -m pytest -m gpu -q --timeout 300 -o faulthandler_timeout=200 tests/test_gpu_scale.py tests/test_gpu_feature.py tests/test_gpu_configs.py 2>&1 | tail -8
+for rep in 1 2; do
+for knob in "TLOAM_X=1" "TLOAM_NO_SCAN_1P=1"; do
+echo "== m1 knob=[$knob]"
+env $knob timeout 300 python bench.py --workload m1 --steps 30 --warmup 3 --no-cpu-baseline --no-kitti --no-side 2>$O/err_$rep.txt | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('ms/frame', d['ms_per_step'], 'GN it/s', d['value'])"
+done
+done
+bash scripts/gpu_timeline_m1.sh r4i_tl > /dev/null 2>&1; head -20 $R/gpurun_out/r4i_tl/timeline.txt

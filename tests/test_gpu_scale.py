@@ -216,3 +216,30 @@ def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m,
                 assert np.array_equal(c1[f], c2[f]), (k, f)
             assert np.array_equal(F1.get_weights(k), F2.get_weights(k))
     F1.close(); F2.close()
+
+
+def test_single_pass_scans_of_the_large_tables_are_exact(hip_module, monkeypatch):
+    """Round 4: the two ~3 M-entry histograms of a 1 M-class frame (cells of the target grids, bins of the query sort) are
+    scanned by ONE single-pass look-back launch each -- the grid's also writes cell_start and re-zeroes the histogram --
+    instead of tile scan + scan of the totals + add (+ finalize); TLOAM_NO_SCAN_1P keeps the multi-launch form.  Integer
+    work: the frame must come out identical, twice in a row (epochs, re-armed counters), and a 1 M-point kNN as well."""
+    sc = synth.make_scene(seed=0, n_src=synth.M1_SRC, n_tgt=synth.M1_TGT)
+    cfg = hip_module.default_config(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+    H1 = hip_module.HipRegistration(cfg)
+    monkeypatch.setenv("TLOAM_NO_SCAN_1P", "1")            # read once, when the context is created
+    H2 = hip_module.HipRegistration(cfg)
+    for H in (H1, H2):
+        H.set_frames(sc.source, sc.target)
+    for rep in range(2):
+        rc1, T1, st1 = H1.scan_match(sc.T_pred)
+        rc2, T2, st2 = H2.scan_match(sc.T_pred)
+        assert rc1 == rc2 == 0 and np.array_equal(T1, T2)
+        for k in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "outer_iterations", "kind_cost", "se3"):
+            assert np.array_equal(np.asarray(st1[k]), np.asarray(st2[k])), k
+        for k in range(4):
+            n = len(sc.source.cloud(k))
+            assert np.array_equal(H1.get_correspondences(k, capacity=n)["idx"], H2.get_correspondences(k, capacity=n)["idx"]), k
+    q = sc.source.planar[:2000] @ sc.T_pred[:3, :3].T + sc.T_pred[:3, 3]
+    a, b = H1.knn(0, q, 0.5, 5), H2.knn(0, q, 0.5, 5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    H1.close(); H2.close()

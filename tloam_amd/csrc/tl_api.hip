@@ -323,6 +323,16 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     frame->consumed = true;
   }
   launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream, frame);
+  if (!c->no_scan_1p && scan_1p_applies(nc + 1)) {
+    // 1 M-class tables: count | scan + finalize in ONE single-pass launch | scatter (three launches and one pass over the table
+    // less than tile scan + scan of the totals + add + finalize)
+    const size_t before = G.scan1p.cap;
+    HIPC(c, G.scan1p.reserve(scan_1p_ctl_elems(nc_res + 1)));
+    if (G.scan1p.cap != before) HIPC(c, hipMemsetAsync(G.scan1p.p, 0, G.scan1p.cap * sizeof(unsigned long long), c->stream));
+    launch_grid_scan_finalize_scatter_1p(gs, G.cell_cnt.p, nc + 1, G.cell_start.p, G.scan1p.p, G.cell_of_pt.p, G.rank_of_pt.p, G.gp.p,
+                                         c->stream);
+    return TLOAM_OK;
+  }
   const int tiles = scan_tiles_only(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
   if (tiles > 0) {
     launch_grid_finalize_scatter_all(gs, G.cell_scan.p, G.scan_tmp.p, tiles, G.cell_start.p, G.cell_cnt.p, G.cell_of_pt.p,
@@ -655,6 +665,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
   c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
   c->sync_set_source = getenv("TLOAM_SYNC_SET_SOURCE") != nullptr;
+  c->no_scan_1p = getenv("TLOAM_NO_SCAN_1P") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;
@@ -709,7 +720,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int r = 0; r < kMaxRanks; ++r)
     if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
   if (c->mbox_local) (void)hipFree(c->mbox_local);
-  c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_span.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
+  c->scan1p_q.release(); c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_span.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)
@@ -1065,6 +1076,11 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)nt_res, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
   HIPC(c, c->qrec.reserve(n_slots + 1));
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(nt_res + 1, n_slots + 1))));
+  if (!c->no_scan_1p && scan_1p_applies(ntiles + 1)) {
+    const size_t before = c->scan1p_q.cap;
+    HIPC(c, c->scan1p_q.reserve(scan_1p_ctl_elems(nt_res + 1)));
+    if (c->scan1p_q.cap != before) HIPC(c, hipMemsetAsync(c->scan1p_q.p, 0, c->scan1p_q.cap * sizeof(unsigned long long), c->stream));
+  }
   return TLOAM_OK;
 }
 // :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
@@ -1083,7 +1099,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
     launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream);
   } else {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate);
+                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->no_scan_1p ? nullptr : c->scan1p_q.p);
   }
   if (prepare_in_solve) return TLOAM_OK;
   if (prepare_small_path(c)) {

@@ -300,6 +300,14 @@ void launch_grid_finalize_scatter_all(const GridSet& gs, const unsigned long lon
                                       const int* rank_of_pt, double4* gp, hipStream_t s);
 void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const unsigned long long* cell_scan,
                              const int* rank_of_pt, double4* gp, hipStream_t s);
+// large tables (more than 1024 scan tiles: the 1 M-class frames): ONE single-pass launch scans the histogram, writes cell_start
+// and re-zeroes the histogram (no scan array), then the scatter -- count | scan + finalize | scatter.  ctl: scan_1p_ctl_elems(n)
+// words, zero when allocated (k_scan_1p, tl_nn.hip)
+size_t scan_1p_ctl_elems(size_t n);
+bool scan_1p_applies(size_t n);
+void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s);
+void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
+                                          unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s);
 
 struct BuildParams {
   double radius[kKinds];
@@ -309,9 +317,11 @@ struct BuildParams {
 };
 // start-of-frame initialisation, one launch
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
+// scan1p_ctl: control words of the single-pass scan of the query-sort histogram (large frames), or null: the multi-launch scan
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr);
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr,
+                  unsigned long long* scan1p_ctl = nullptr);
 int build_tile_count(const GridView grids[kKinds], int n_slots);  // bins of the query counting sort (tiles, or cells of tiles)
 // cap + compaction (after the flag scan)
 // refresh_gate != null: the launch also stands for the refresh alternative (see CompactArgs); tiles > 0: `sv.scan` holds

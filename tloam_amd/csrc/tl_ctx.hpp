@@ -91,10 +91,11 @@ struct GridBuffers {
   DBuf<double4> gp;
   DBuf<int> cell_start, cell_of_pt, rank_of_pt;
   DBuf<unsigned long long> cell_cnt, cell_scan, scan_tmp;
+  DBuf<unsigned long long> scan1p;   // control words of the single-pass scan (large tables), zero when allocated
   DBuf<double> bbox;
   void release() {
     gp.release(); cell_start.release(); cell_of_pt.release(); rank_of_pt.release();
-    cell_cnt.release(); cell_scan.release(); scan_tmp.release(); bbox.release();
+    cell_cnt.release(); cell_scan.release(); scan_tmp.release(); scan1p.release(); bbox.release();
   }
 };
 
@@ -157,6 +158,8 @@ struct tloam_ctx {
   DBuf<double> sx, sy, sz, w_src, raw;
   DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
+  DBuf<unsigned long long> scan1p_q;   // control words of the single-pass scan of the query-sort histogram, zero when allocated
+  bool no_scan_1p = false;     // TLOAM_NO_SCAN_1P: the multi-launch scans for the large tables too (A/B, tests)
   DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
   bool fused_large = false;    // TLOAM_FUSED_LARGE: a GN iteration of a large set as ONE launch (k3_sweep_step; sharded + mailbox: sweep, exchange

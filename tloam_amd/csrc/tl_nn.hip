@@ -211,6 +211,145 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
   }
 }
 
+// ---- single-pass scan of large COUNT arrays (round 4) --------------------------------------------------------------------------
+// The 1 M-class frames scan two histograms of ~3 M entries per frame (cells of the target grids, bins of the query sort): tile
+// scan + scan of the tile totals + add = three launches and two passes over the array.  Here ONE launch, one pass: a block
+// scans its tile, publishes the tile's total in a status word, looks back over the words of the blocks in front of it (a wave
+// reads 64 of them at a time) until it meets one that already carries its inclusive prefix, publishes its own, and emits its
+// elements with the prefix added.  Blocks take their place in the ORDER THEY START (an atomic counter; the last one to take
+// a number re-arms it), so a block only ever waits for blocks that are resident or done.  Status word: [63:62] 0 nothing |
+// 1 the tile's own total | 2 inclusive prefix, [61:32] the launch's epoch -- a word of an earlier launch reads as "nothing",
+// so the array is never cleared (it is zeroed when it is allocated) --, [31:0] the value: totals below 2^32, i.e. counts.
+struct Scan1p {
+  unsigned long long* status;   // [tiles]
+  unsigned long long* counter;  // zero between launches
+  unsigned epoch;               // 1 .. 2^30 - 1, different from the previous launch's on the same status array
+};
+// returns the block's place (tile index); ex / a as wave_scan_rows leaves them, *base = sum of everything in front of this wave
+__device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict__ in, size_t n, const Scan1p& C,
+                                           unsigned long long (&ex)[kScanRows], unsigned long long (&a)[kScanRows][kScanPer],
+                                           unsigned long long* base, size_t* wbase_out) {
+  __shared__ unsigned long long wave_tot[kScanThreads / 64];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_bid;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    const int b = (int)atomicAdd(C.counter, 1ull);
+    if (b == (int)gridDim.x - 1) *C.counter = 0ull;   // every block has its number: re-armed for the next launch
+    s_bid = b;
+  }
+  __syncthreads();
+  const int bid = s_bid;
+  const size_t wbase = (size_t)bid * kScanTile + (size_t)wave * (kScanRows * kScanRowElems);
+  const unsigned long long tot = wave_scan_rows<kScanRows>(in, n, wbase, lane, ex, a);
+  if (lane == 0) wave_tot[wave] = tot;
+  __syncthreads();
+  unsigned long long wave_off = 0, block_total = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    if (w < wave) wave_off += wave_tot[w];
+    block_total += wave_tot[w];
+  }
+  const unsigned long long tag = (unsigned long long)C.epoch << 32;
+  if (wave == 0) {
+    unsigned long long prefix = 0ull;
+    if (bid == 0) {
+      if (lane == 0) __hip_atomic_store(&C.status[0], (2ull << 62) | tag | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&C.status[bid], (1ull << 62) | tag | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int top = bid - 1;;) {   // lanes look at blocks top, top - 1, ..., top - 63
+        const int p = top - lane;
+        unsigned long long w = 0ull;
+        if (p >= 0) w = __hip_atomic_load(&C.status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = p >= 0 && ((w >> 32) & 0x3fffffffull) == (unsigned long long)C.epoch;
+        const unsigned st = mine ? (unsigned)(w >> 62) : 0u;
+        const unsigned long long have = __ballot(p < 0 || st != 0u);          // (lanes past block 0 count as ready, value 0)
+        const unsigned long long full = __ballot(p >= 0 && st == 2u);
+        // the nearest block that carries an inclusive prefix, provided every block nearer than it has published its total
+        const int first_full = full ? __ffsll((long long)full) - 1 : 64;
+        const unsigned long long need = first_full >= 63 ? ~0ull : ((2ull << first_full) - 1ull);
+        if ((have & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }   // somebody in the window is not there yet
+        unsigned long long v = (p >= 0 && lane <= first_full) ? (w & 0xffffffffull) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        prefix += __shfl(v, 0, 64);
+        if (first_full < 64 || top - 64 < 0) break;
+        top -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&C.status[bid], (2ull << 62) | tag | (prefix + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  *base = s_prefix + wave_off;
+  *wbase_out = wbase;
+  return bid;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_1p(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
+                                                          size_t n, Scan1p C) {
+  unsigned long long ex[kScanRows], a[kScanRows][kScanPer], base;
+  size_t wbase;
+  (void)scan1p_tile(in, n, C, ex, a, &base, &wbase);
+  wave_store_rows<kScanRows>(out, n, wbase, threadIdx.x & 63, base, ex, a);
+}
+// the scan of the concatenated cell histogram AND what k_grid_finalize_all does with it: cell_start of every kind (relative to the
+// kind's own point block, with its terminator), the histogram left empty for the next build.  No cell_scan array is written.
+__global__ __launch_bounds__(kScanThreads) void k_grid_scan_finalize_1p(GridSet gs, unsigned long long* __restrict__ cell_cnt, size_t n,
+                                                                        int* __restrict__ cell_start, Scan1p C) {
+  unsigned long long ex[kScanRows], a[kScanRows][kScanPer], base;
+  size_t wbase;
+  const int bid = scan1p_tile(cell_cnt, n, C, ex, a, &base, &wbase);
+  const int lane = threadIdx.x & 63;
+  if (bid == 0 && threadIdx.x < kKinds && gs.ncell[threadIdx.x] == 0)   // a kind without a grid: just its terminator
+    cell_start[gs.cell_base[threadIdx.x] + threadIdx.x] = gs.n[threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanRows; ++i) {
+    unsigned long long run = base + ex[i];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+      const long long e = (long long)(wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j);
+      if ((size_t)e < n) {
+#pragma unroll
+        for (int k = 0; k < kKinds; ++k) {
+          const long long c = e - gs.cell_base[k];
+          if (c >= 0 && c < gs.ncell[k]) {
+            cell_start[e + k] = (int)(run - (unsigned long long)gs.tgt_off[k]);
+            if (c == gs.ncell[k] - 1) cell_start[e + k + 1] = gs.n[k];
+          }
+        }
+        cell_cnt[e] = 0ull;
+      }
+      run += a[i][j];
+    }
+  }
+}
+// scatter of the one-pass build: the cell's first position comes from cell_start (what the scan wrote), not from a scan array
+__global__ void k_grid_scatter_start_all(GridSet gs, const int* __restrict__ cell_of_pt, const int* __restrict__ cell_start,
+                                         const int* __restrict__ rank_of_pt, double4* __restrict__ gp) {
+  const int k = blockIdx.y;
+  const int n = gs.n[k];
+  const long long base = gs.cell_base[k] + k;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = cell_of_pt[gs.tgt_off[k] + i];
+    const int pos = cell_start[base + c] + rank_of_pt[gs.tgt_off[k] + i];
+    gp[gs.tgt_off[k] + pos] =
+        double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
+  }
+}
+static unsigned next_scan_epoch() {   // process-wide: any two launches on the same status array differ
+  static unsigned e = 0;
+  e = (e % 0x3ffffffeu) + 1u;
+  return e;
+}
+size_t scan_1p_ctl_elems(size_t n) { return (n + kScanTile - 1) / kScanTile + 8; }
+bool scan_1p_applies(size_t n) { return (n + kScanTile - 1) / kScanTile > 1024; }   // (smaller arrays: the fused / two-launch forms)
+void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s) {
+  const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
+  hipLaunchKernelGGL(k_scan_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, C);
+}
+
 // first half of the medium-size scan only: tile-local exclusive scans + per-tile totals (the consumer adds the tiles'
 // offsets itself, see k_grid_finalize_scatter_all).  Returns the number of tiles; 0 = not applicable (use the full scan).
 int scan_tiles_only(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* totals, hipStream_t s,
@@ -903,9 +1042,19 @@ __global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState*
   __shared__ int2 lds_rows[9 * 64];
   build_sorted_block<1>(A, st, n_sorted, qrec, (int)blockIdx.x - nfin, lds_rows);
 }
+void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
+                                          unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s) {
+  const size_t tiles = (ncells_plus_1 + kScanTile - 1) / kScanTile;
+  Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
+  hipLaunchKernelGGL(k_grid_scan_finalize_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, gs, cell_cnt, ncells_plus_1, cell_start, C);
+  int blocks = (max_n(gs) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_grid_scatter_start_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_start, rank_of_pt, gp);
+}
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
-                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate) {
+                  double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate,
+                  unsigned long long* scan1p_ctl) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -931,7 +1080,8 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     // the pose moves by centimetres.
     // (tile_cnt[0 .. ntiles] was zeroed by k_frame_init -- one launch less at the start of every frame)
     hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
-    launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
+    if (scan1p_ctl && scan_1p_applies((size_t)ntiles + 1)) launch_scan_counts_1p(tile_cnt, tile_scan, (size_t)ntiles + 1, scan1p_ctl, s);
+    else launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
     hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
                        tile_fill, qrec);
   }
