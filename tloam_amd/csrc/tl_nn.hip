@@ -220,6 +220,11 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 // a number re-arms it), so a block only ever waits for blocks that are resident or done.  Status word: [63:62] 0 nothing |
 // 1 the tile's own total | 2 inclusive prefix, [61:32] the launch's epoch -- a word of an earlier launch reads as "nothing",
 // so the array is never cleared (it is zeroed when it is allocated) --, [31:0] the value: totals below 2^32, i.e. counts.
+// Tiles of 16 Ki elements (64 per thread, in registers): ~200 blocks for 3.2 M entries, all resident at once, so that the
+// look-back is three or four reads of 64 status words -- with 2 Ki tiles (1563 blocks, not all resident) the prefix crept from
+// block to block at a coherence-point round trip per hop and the launch took 52-57 us, longer than the three launches it replaced.
+constexpr int kRows1p = 16;                                                  // rows of 256 elements per wave
+constexpr int kTile1p = (kScanThreads / 64) * kRows1p * kScanRowElems;       // 16384 elements per block
 struct Scan1p {
   unsigned long long* status;   // [tiles]
   unsigned long long* counter;  // zero between launches
@@ -227,7 +232,7 @@ struct Scan1p {
 };
 // returns the block's place (tile index); ex / a as wave_scan_rows leaves them, *base = sum of everything in front of this wave
 __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict__ in, size_t n, const Scan1p& C,
-                                           unsigned long long (&ex)[kScanRows], unsigned long long (&a)[kScanRows][kScanPer],
+                                           unsigned long long (&ex)[kRows1p], unsigned long long (&a)[kRows1p][kScanPer],
                                            unsigned long long* base, size_t* wbase_out) {
   __shared__ unsigned long long wave_tot[kScanThreads / 64];
   __shared__ unsigned long long s_prefix;
@@ -240,8 +245,8 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
   }
   __syncthreads();
   const int bid = s_bid;
-  const size_t wbase = (size_t)bid * kScanTile + (size_t)wave * (kScanRows * kScanRowElems);
-  const unsigned long long tot = wave_scan_rows<kScanRows>(in, n, wbase, lane, ex, a);
+  const size_t wbase = (size_t)bid * kTile1p + (size_t)wave * (kRows1p * kScanRowElems);
+  const unsigned long long tot = wave_scan_rows<kRows1p>(in, n, wbase, lane, ex, a);
   if (lane == 0) wave_tot[wave] = tot;
   __syncthreads();
   unsigned long long wave_off = 0, block_total = 0;
@@ -288,23 +293,23 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
 }
 __global__ __launch_bounds__(kScanThreads) void k_scan_1p(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                                           size_t n, Scan1p C) {
-  unsigned long long ex[kScanRows], a[kScanRows][kScanPer], base;
+  unsigned long long ex[kRows1p], a[kRows1p][kScanPer], base;
   size_t wbase;
   (void)scan1p_tile(in, n, C, ex, a, &base, &wbase);
-  wave_store_rows<kScanRows>(out, n, wbase, threadIdx.x & 63, base, ex, a);
+  wave_store_rows<kRows1p>(out, n, wbase, threadIdx.x & 63, base, ex, a);
 }
 // the scan of the concatenated cell histogram AND what k_grid_finalize_all does with it: cell_start of every kind (relative to the
 // kind's own point block, with its terminator), the histogram left empty for the next build.  No cell_scan array is written.
 __global__ __launch_bounds__(kScanThreads) void k_grid_scan_finalize_1p(GridSet gs, unsigned long long* __restrict__ cell_cnt, size_t n,
                                                                         int* __restrict__ cell_start, Scan1p C) {
-  unsigned long long ex[kScanRows], a[kScanRows][kScanPer], base;
+  unsigned long long ex[kRows1p], a[kRows1p][kScanPer], base;
   size_t wbase;
   const int bid = scan1p_tile(cell_cnt, n, C, ex, a, &base, &wbase);
   const int lane = threadIdx.x & 63;
   if (bid == 0 && threadIdx.x < kKinds && gs.ncell[threadIdx.x] == 0)   // a kind without a grid: just its terminator
     cell_start[gs.cell_base[threadIdx.x] + threadIdx.x] = gs.n[threadIdx.x];
 #pragma unroll
-  for (int i = 0; i < kScanRows; ++i) {
+  for (int i = 0; i < kRows1p; ++i) {
     unsigned long long run = base + ex[i];
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
@@ -342,10 +347,10 @@ static unsigned next_scan_epoch() {   // process-wide: any two launches on the s
   e = (e % 0x3ffffffeu) + 1u;
   return e;
 }
-size_t scan_1p_ctl_elems(size_t n) { return (n + kScanTile - 1) / kScanTile + 8; }
+size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
 bool scan_1p_applies(size_t n) { return (n + kScanTile - 1) / kScanTile > 1024; }   // (smaller arrays: the fused / two-launch forms)
 void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s) {
-  const size_t tiles = (n + kScanTile - 1) / kScanTile;
+  const size_t tiles = (n + kTile1p - 1) / kTile1p;
   Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
   hipLaunchKernelGGL(k_scan_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, C);
 }
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState*
 }
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
                                           unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s) {
-  const size_t tiles = (ncells_plus_1 + kScanTile - 1) / kScanTile;
+  const size_t tiles = (ncells_plus_1 + kTile1p - 1) / kTile1p;
   Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
   hipLaunchKernelGGL(k_grid_scan_finalize_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, gs, cell_cnt, ncells_plus_1, cell_start, C);
   int blocks = (max_n(gs) + 255) / 256;
