@@ -577,7 +577,9 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
   unsigned long long w[8];
   const unsigned long long t0 = wall_clock64();
   bool ok_all;
-#ifdef TLOAM_POLL_ONE_IN_FLIGHT   // (tuning builds: read - check - sleep, one look per memory round trip -- round 3's form)
+  // (read - check - sleep: one look per round trip to the coherence point.  Two looks in flight -- the next one issued before
+  //  this one is checked -- measured 1 % SLOWER on the headline frame, three interleaved pairs on one box: 0.1749 against
+  //  0.1729 ms; the extra reads of sixteen pollers compete with the row stores they wait for.  Round 4, not kept.)
   for (unsigned spins = 1;; ++spins) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -589,35 +591,6 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock
     __builtin_amdgcn_s_sleep(1);
   }
-#else
-  // TWO looks in flight: a look costs a round trip to the coherence point (~0.7 us), and a row that lands just after a look
-  // was issued is only seen by the next one -- issued a whole round trip later when the loop is read - check - sleep.  With the
-  // next look already on its way while this one is checked, the rows are seen within half a round trip of landing.
-  unsigned long long v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (unsigned spins = 1;; ++spins) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long x = w[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) x ^= w[i];
-    ok_all = __all((!have || x == mtag) ? 1 : 0) != 0;
-    if (ok_all) break;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    x = v[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) x ^= v[i];
-    ok_all = __all((!have || x == mtag) ? 1 : 0) != 0;
-    if (ok_all) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = v[i];
-      break;
-    }
-    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;   // ~1 s of the 100 MHz wall clock
-  }
-#endif
   if (have) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) s_rows[r * 28 + sgm * 7 + i] = __longlong_as_double((long long)w[i]);

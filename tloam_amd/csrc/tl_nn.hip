@@ -216,8 +216,8 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 // scan + scan of the tile totals + add = three launches and two passes over the array.  Here ONE launch, one pass: a block
 // scans its tile, publishes the tile's total in a status word, looks back over the words of the blocks in front of it (a wave
 // reads 64 of them at a time) until it meets one that already carries its inclusive prefix, publishes its own, and emits its
-// elements with the prefix added.  Blocks take their place in the ORDER THEY START (an atomic counter; the last one to take
-// a number re-arms it), so a block only ever waits for blocks that are resident or done.  Status word: [63:62] 0 nothing |
+// elements with the prefix added.  At most one block per CU (scan_1p_applies), so every block is resident at once and a
+// block only ever waits for blocks that are running.  Status word: [63:62] 0 nothing |
 // 1 the tile's own total | 2 inclusive prefix, [61:32] the launch's epoch -- a word of an earlier launch reads as "nothing",
 // so the array is never cleared (it is zeroed when it is allocated) --, [31:0] the value: totals below 2^32, i.e. counts.
 // Tiles of 16 Ki elements (64 per thread, in registers): ~200 blocks for 3.2 M entries, all resident at once, so that the
@@ -227,7 +227,6 @@ constexpr int kRows1p = 16;                                                  // 
 constexpr int kTile1p = (kScanThreads / 64) * kRows1p * kScanRowElems;       // 16384 elements per block
 struct Scan1p {
   unsigned long long* status;   // [tiles]
-  unsigned long long* counter;  // zero between launches
   unsigned epoch;               // 1 .. 2^30 - 1, different from the previous launch's on the same status array
 };
 // returns the block's place (tile index); ex / a as wave_scan_rows leaves them, *base = sum of everything in front of this wave
@@ -236,15 +235,12 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
                                            unsigned long long* base, size_t* wbase_out) {
   __shared__ unsigned long long wave_tot[kScanThreads / 64];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_bid;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) {
-    const int b = (int)atomicAdd(C.counter, 1ull);
-    if (b == (int)gridDim.x - 1) *C.counter = 0ull;   // every block has its number: re-armed for the next launch
-    s_bid = b;
-  }
-  __syncthreads();
-  const int bid = s_bid;
+  // The block's place is its index: the launcher only uses this kernel when the grid is at most one block per CU
+  // (scan_1p_applies), so every block is resident as soon as the device has room for it and nobody waits for a block that
+  // cannot start.  (Places handed out by an atomic counter -- the usual guard -- cost ~10 us here: ~200 returning atomics on
+  // one address are served one after the other at the memory side, ~50 ns each.)
+  const int bid = (int)blockIdx.x;
   const size_t wbase = (size_t)bid * kTile1p + (size_t)wave * (kRows1p * kScanRowElems);
   const unsigned long long tot = wave_scan_rows<kRows1p>(in, n, wbase, lane, ex, a);
   if (lane == 0) wave_tot[wave] = tot;
@@ -348,10 +344,12 @@ static unsigned next_scan_epoch() {   // process-wide: any two launches on the s
   return e;
 }
 size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
-bool scan_1p_applies(size_t n) { return (n + kScanTile - 1) / kScanTile > 1024; }   // (smaller arrays: the fused / two-launch forms)
+// arrays of more than 1024 small tiles (the 1 M-class frames; smaller ones use the fused / two-launch forms) whose 16 Ki tiles
+// number at most 240 -- one block per CU with room to spare on a 256-CU part: every block resident at once (see scan1p_tile)
+bool scan_1p_applies(size_t n) { return (n + kScanTile - 1) / kScanTile > 1024 && (n + kTile1p - 1) / kTile1p <= 240; }
 void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s) {
   const size_t tiles = (n + kTile1p - 1) / kTile1p;
-  Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
+  Scan1p C{ctl, next_scan_epoch()};
   hipLaunchKernelGGL(k_scan_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, C);
 }
 
@@ -1050,7 +1048,7 @@ __global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState*
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
                                           unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s) {
   const size_t tiles = (ncells_plus_1 + kTile1p - 1) / kTile1p;
-  Scan1p C{ctl, ctl + tiles, next_scan_epoch()};
+  Scan1p C{ctl, next_scan_epoch()};
   hipLaunchKernelGGL(k_grid_scan_finalize_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, gs, cell_cnt, ncells_plus_1, cell_start, C);
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
