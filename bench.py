@@ -902,6 +902,9 @@ def cpu_baseline(head, side, args, kitti_seq=None):
     res = {"value": sweep[best]["value"], "unit": "GN iter/s", "cores": best, "host_cores": cores, "kind": "port",
            "build": "oracle/tloam_oracle.c, gcc -O3 -march=native -fopenmp (the cpu_baseline build; parity uses -ffp-contract=off)",
            "ms_per_frame": sweep[best]["ms_per_frame"], "workload": head["workload"],
+           "note": "value = the BEST of the thread sweep (its thread count in `cores`), not the reference's own thread shape -- at "
+                   "hardware_concurrency()/2 evaluator threads (`reference_thread_shape`) the port's OpenMP evaluator is far slower "
+                   "on this frame size; a reported baseline, not a target: the GPU/CPU ratio says nothing about kernel quality",
            "single_thread": sweep[1], "thread_sweep": {str(t): sweep[t] for t in sweep},
            "sample": "scan_match of the headline frame pair x10 per thread count (1..32 evaluator threads, min(4, t) builder "
                      "threads) + one 1M frame + the first 8 frames of the KITTI-density sequence"}

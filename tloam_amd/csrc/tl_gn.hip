@@ -1794,7 +1794,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
         TL_PROF(prof_c, 8 + it * 8 + 1)
         int vd = 5;
         if (ok) {
-          gn_consume(st, tot, lane, &s_in, s_scr, lead);
+          gn_consume(st, tot, lane, &s_in, s_scr, /*WRITE_GLOBAL=*/false);
           vd = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
         }
         TL_PROF(prof_c, 8 + it * 8 + 2)
@@ -1803,6 +1803,8 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
         else if (lane == 12) s_msg[12] = (double)vd;
       }
       __syncthreads();
+      // (the lead's image of the state goes out to the device state now, beside the other waves' evaluation)
+      if (lead && stepper && (int)s_msg[12] != 5) gn_write_back(st, &s_in, lane);
       verdict = (int)s_msg[12];
 #pragma unroll
       for (int v = 0; v < 9; ++v) T.r[v] = s_msg[v];

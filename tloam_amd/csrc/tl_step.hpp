@@ -590,5 +590,15 @@ __device__ __forceinline__ void gn_consume(GnState* st, const double* tot /* LDS
     }
   }
 }
+// what gn_consume(WRITE_GLOBAL = true) writes to the device state, as a step of its own: k_solve_all's lead block hands the
+// candidate pose to its waves FIRST and copies the image out while they evaluate (its stepper wave holds no chunk) -- the copy
+// (~0.3 us) was on the path every block's next row waits on
+__device__ __forceinline__ void gn_write_back(GnState* st, const GnState* sm /* LDS */, int lane) {
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(sm);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(st);
+#pragma unroll
+  for (int w = lane; w < kStepWords; w += 64) dst[w] = src[w];
+  if (lane == 0) st->spec_build = sm->spec_build;
+}
 
 }  // namespace tl
