@@ -20,6 +20,7 @@
 // the device only where it flips on the host.
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 
 #include "tl_common.hpp"
 #include "tl_knn.hpp"
@@ -338,10 +339,9 @@ __global__ void k_grid_scatter_start_all(GridSet gs, const int* __restrict__ cel
         double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
   }
 }
-static unsigned next_scan_epoch() {   // process-wide: any two launches on the same status array differ
-  static unsigned e = 0;
-  e = (e % 0x3ffffffeu) + 1u;
-  return e;
+static unsigned next_scan_epoch() {   // process-wide (contexts on different host threads share it): any two launches differ
+  static std::atomic<unsigned> e{0};
+  return e.fetch_add(1u, std::memory_order_relaxed) % 0x3ffffffeu + 1u;
 }
 size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
 // arrays of more than 1024 small tiles (the 1 M-class frames; smaller ones use the fused / two-launch forms) whose 16 Ki tiles
