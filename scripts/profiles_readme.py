@@ -13,6 +13,7 @@ WHAT = {
     "kitti_frame_timeline.txt": "`scripts/frame_timeline.py` on a kernel trace of `bench.py --workload kitti`: the launches of a KITTI-density frame in order, median duration and gap before each",
     "m1_frame_timeline.txt": "the same for the 1 M frame (`bench.py --workload m1`)",
     "solve_all_timeline.txt": "`scripts/solve_profile2.py` on a `-DTLOAM_STEP_PROFILE` build: wall-clock stamps (10 ns) inside the one-launch Solve `k_solve_all` per GN iteration -- lead block's stepper wave and one other wave",
+    "kitti_sequence_4540.json": "`python bench.py --kitti-frames 4540 --no-m1 --no-cpu-baseline` (`scripts/gpu_seq4540.sh`): the KITTI-density sequence over the WHOLE published KITTI-00 trajectory of the reference (SURVEY 8(d) config 2); numbers below",
     "solve_small_timeline.txt": "the same with `TLOAM_SOLVE_V1=1` (round 3's `k_solve_small`: one consumer wave for the whole grid)",
 }
 print("## Round %s\n" % tag[1:].lstrip("0"))
@@ -47,3 +48,12 @@ try:
           % (b["value"], b["ms_per_step"], r["frac"], r["avg_launch_us"], r["l3_resident"]["frac"], r["l3_resident"]["avg_launch_us"]))
 except Exception as e:  # noqa: BLE001
     print("\n(bench line not readable: %r)" % (e,))
+try:
+    q = json.loads(open(os.path.join(d, tag + "_kitti_sequence_4540.json")).read().strip().splitlines()[-1])["kitti_sequence"]
+    print("\n`%s_kitti_sequence_4540.json`: %d frames, %.4f ms/frame mean / %.4f p50 / %.4f p99, %.1f GN iter/s, %.2f GN iterations per frame; "
+          "set_source + scan_match %.4f ms, set_target %.4f ms; pose error against the generator %.2f mm mean / %.2f mm max."
+          % (tag, q["frames"], q["ms_per_frame"], q["ms_per_frame_p50"], q["ms_per_frame_p99"], q["gn_iters_per_sec"], q["gn_iters_per_frame"],
+             q["per_call"]["set_source_plus_scan_match_ms"], q["per_call"]["set_target_ms"], q["pose_err_vs_truth_m"]["mean"] * 1e3,
+             q["pose_err_vs_truth_m"]["max"] * 1e3))
+except Exception:  # noqa: BLE001
+    pass
