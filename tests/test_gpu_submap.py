@@ -33,8 +33,11 @@ def test_hip_replays_golden_bit_exact(hip_module):
     replay_golden(lambda cfg: _HipSubmap(hip_module, cfg), lambda S, k: S.get(k))
 
 
+@pytest.mark.parametrize("copy", [False, True], ids=["staging_read_in_place", "TLOAM_SUBMAP_COPY"])
 @pytest.mark.parametrize("seed,crop", [(0, 100.0), (1, 30.0), (2, 12.0)])
-def test_hip_vs_oracle_sequences(hip_module, seed, crop):
+def test_hip_vs_oracle_sequences(hip_module, monkeypatch, seed, crop, copy):
+    if copy:   # the new scan's clouds uploaded with a copy instead of read in the pinned staging (read when the context is created)
+        monkeypatch.setenv("TLOAM_SUBMAP_COPY", "1")
     cfg = dict(edge_crop_box_length=crop, ground_crop_box_length=crop * 0.8, planar_frame_size=2 + seed)
     A = _HipSubmap(hip_module, cfg)
     B = ob.OracleSubmap(ob.make_submap_config(**cfg))
@@ -68,6 +71,26 @@ def test_crowded_voxels_and_duplicates(hip_module):
     A.update(T, planar, sphere, edge, ground); B.update(T, planar, sphere, edge, ground)
     for k in range(4):
         assert np.array_equal(A.get(k), B.get(k)), k
+
+
+@pytest.mark.parametrize("copy", [False, True], ids=["staging_read_in_place", "TLOAM_SUBMAP_COPY"])
+def test_odd_cloud_sizes_and_one_point_clouds(hip_module, monkeypatch, copy):
+    """The staged clouds start on 16-byte boundaries and are read in 16-byte steps: odd point counts (a padding double behind
+    the cloud), clouds of one point, clouds that end inside a block's first pair."""
+    if copy:
+        monkeypatch.setenv("TLOAM_SUBMAP_COPY", "1")
+    A = _HipSubmap(hip_module, {}); B = ob.OracleSubmap()
+    sizes = [(51, 21, 101, 103), (1, 1, 1, 1), (257, 3, 513, 255), (255, 7, 1, 769), (3, 5, 771, 1)]
+    for f, n in enumerate(sizes):
+        cl = ss.frame_clouds(11, f, n=n)
+        if f == 0:
+            A.init(*cl); B.init(*cl)
+        else:
+            T = ss.frame_pose(f, step=1.0, yaw_rate=0.02)
+            A.update(T, *cl); B.update(T, *cl)
+        for k in range(4):
+            a, b = A.get(k), B.get(k)
+            assert a.shape == b.shape and np.array_equal(a, b), (f, k)
 
 
 def test_empty_and_everything_cropped(hip_module):

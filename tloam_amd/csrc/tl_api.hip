@@ -177,12 +177,22 @@ int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long
     __builtin_ia32_pause();
   }
 }
-// Borrowed host arrays -> device, without waiting for the device: the pieces are copied end to end into a pinned staging half
-// (two halves used alternately; an event per half says when the device has read it -- long ago in the reference's call pattern,
-// waited for otherwise) and go to `dev_dst` with ONE asynchronous copy on the context's stream.  counts in doubles.
-int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst) {
+// Borrowed host arrays -> device, without waiting for the device: the pieces are copied into a pinned staging half (two halves
+// used alternately; an event per half says when the device has read it -- long ago in the reference's call pattern, waited for
+// otherwise), every piece on a 16-byte boundary (offs[i], in doubles; `total` out), and either
+//   stage_and_upload: go to `dev_dst` with ONE asynchronous copy on the context's stream (same layout there), or
+//   stage_in_place:   stay where they are for the caller's kernels to read across PCIe (*dev_view = the half as the device sees
+//                     it); the caller reports the end of that use with stage_release.
+// counts in doubles.
+static int stage_fill(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, size_t offs[], size_t* total_out,
+                      int* half_out) {
   size_t total = 0;
-  for (int i = 0; i < nparts; ++i) total += counts[i];
+  for (int i = 0; i < nparts; ++i) {
+    offs[i] = total;
+    total += counts[i] + (counts[i] & 1u);   // the next piece starts on an even double
+  }
+  *total_out = total;
+  *half_out = -1;
   if (total == 0) return TLOAM_OK;
   const int h = c->stage_next;
   c->stage_next ^= 1;
@@ -190,24 +200,61 @@ int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t cou
     HIPC(c, hipEventSynchronize(c->stage_ev[h]));
     c->stage_busy[h] = false;
   }
-  if (total > c->h_stage_cap[h]) {
+  if (total + 2 > c->h_stage_cap[h]) {   // (+ 2: a kernel reading a piece in 16-byte steps may touch one double past its end)
     if (c->h_stage[h]) (void)hipHostFree(c->h_stage[h]);
     c->h_stage[h] = nullptr;
+    c->h_stage_dev[h] = nullptr;
     c->h_stage_cap[h] = 0;
-    const size_t want = total + total / 2;
-    HIPC(c, hipHostMalloc((void**)&c->h_stage[h], want * sizeof(double), hipHostMallocDefault));
+    const size_t want = total + total / 2 + 2;
+    HIPC(c, hipHostMalloc((void**)&c->h_stage[h], want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     c->h_stage_cap[h] = want;
+    c->h_stage[h][want - 1] = c->h_stage[h][want - 2] = 0.0;
+    if (hipHostGetDevicePointer((void**)&c->h_stage_dev[h], c->h_stage[h], 0) != hipSuccess) c->h_stage_dev[h] = nullptr;
   }
   if (!c->stage_ev[h]) HIPC(c, hipEventCreateWithFlags(&c->stage_ev[h], hipEventDisableTiming));
-  size_t off = 0;
   for (int i = 0; i < nparts; ++i) {
-    if (counts[i] > 0) memcpy(c->h_stage[h] + off, parts[i], sizeof(double) * counts[i]);
-    off += counts[i];
+    if (counts[i] > 0) memcpy(c->h_stage[h] + offs[i], parts[i], sizeof(double) * counts[i]);
+    if (counts[i] & 1u) c->h_stage[h][offs[i] + counts[i]] = 0.0;   // the padding double is defined
   }
-  HIPC(c, hipMemcpyAsync(dev_dst, c->h_stage[h], sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  *half_out = h;
+  return TLOAM_OK;
+}
+int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst, size_t offs[]) {
+  size_t total = 0;
+  int h = -1;
+  const int rc = stage_fill(c, parts, counts, nparts, offs, &total, &h);
+  if (rc != TLOAM_OK || h < 0) return rc;
+  // up to a few MB a kernel that reads the pinned block in place does the copy (TLOAM_STAGE_MEMCPY: always the copy command)
+  if (c->h_stage_dev[h] && !c->stage_memcpy && total <= (size_t)1 << 19)
+    launch_blit_doubles(c->h_stage_dev[h], dev_dst, total, c->stream);
+  else
+    HIPC(c, hipMemcpyAsync(dev_dst, c->h_stage[h], sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
   HIPC(c, hipEventRecord(c->stage_ev[h], c->stream));
   c->stage_busy[h] = true;
   return TLOAM_OK;
+}
+int stage_in_place(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, size_t offs[], const double** dev_view,
+                   int* half) {
+  size_t total = 0;
+  *dev_view = nullptr;
+  const int rc = stage_fill(c, parts, counts, nparts, offs, &total, half);
+  if (rc != TLOAM_OK || *half < 0) return rc;
+  if (!c->h_stage_dev[*half]) return TLOAM_E_NOT_READY;   // (the caller looked at stage_in_place_ok first)
+  *dev_view = c->h_stage_dev[*half];
+  return TLOAM_OK;
+}
+// completed: the caller has waited for the kernels that read the half; otherwise an event behind them is recorded
+int stage_release(tloam_ctx* c, int half, bool completed) {
+  if (half < 0) return TLOAM_OK;
+  if (completed) { c->stage_busy[half] = false; return TLOAM_OK; }
+  HIPC(c, hipEventRecord(c->stage_ev[half], c->stream));
+  c->stage_busy[half] = true;
+  return TLOAM_OK;
+}
+size_t staged_size(const size_t counts[], int nparts) {   // doubles the pieces take up, padding included
+  size_t total = 0;
+  for (int i = 0; i < nparts; ++i) total += counts[i] + (counts[i] & 1u);
+  return total;
 }
 // The four search grids share one set of buffers (points and cell tables concatenated), so that every
 // phase of the build is ONE launch for all kinds: bbox -> (host: dims) -> histogram -> scan -> finalize ->
@@ -666,6 +713,8 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
   c->sync_set_source = getenv("TLOAM_SYNC_SET_SOURCE") != nullptr;
   c->no_scan_1p = getenv("TLOAM_NO_SCAN_1P") != nullptr;
+  c->submap_copy = getenv("TLOAM_SUBMAP_COPY") != nullptr;
+  c->stage_memcpy = getenv("TLOAM_STAGE_MEMCPY") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;
@@ -810,8 +859,8 @@ int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n, const 
 // setInputSource(const Frame&): the four clouds through pinned staging and ONE asynchronous copy, no host synchronisation
 // (front_end.cpp:314 is followed at once by scanMatching, :321: the wait moves to that call's first wait for the device)
 int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
-  size_t off[kKinds + 1] = {0, 0, 0, 0, 0};
-  size_t lo4[kKinds], hi4[kKinds];
+  size_t off[kKinds] = {0, 0, 0, 0};
+  size_t lo4[kKinds], hi4[kKinds], cnt4[kKinds];
   tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
   for (int k = 0; k < kKinds; ++k) {
     if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
@@ -819,9 +868,9 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
     K.n_src_full = n[k];
     K.src_lo = lo4[k];
     K.n_src = hi4[k] - lo4[k];
-    off[k + 1] = off[k] + 3 * K.n_src;
+    cnt4[k] = 3 * K.n_src;
   }
-  const size_t total = std::max<size_t>(off[kKinds], 3);
+  const size_t total = std::max<size_t>(tlh::staged_size(cnt4, kKinds), 3);
   if (total > c->src_pack.cap) {
     // (a kernel of an earlier frame may still read the old block: nothing of this context is in flight in the reference's
     //  call pattern, but a growing buffer is rare enough to afford the certainty)
@@ -829,15 +878,13 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
     HIPC(c, c->src_pack.reserve(total));
   }
   const double* parts[kKinds];
-  size_t counts[kKinds];
+  for (int k = 0; k < kKinds; ++k) parts[k] = c->kd[k].n_src > 0 ? xyz[k] + 3 * c->kd[k].src_lo : nullptr;
+  const int rc = tlh::stage_and_upload(c, parts, cnt4, kKinds, c->src_pack.p, off);
   for (int k = 0; k < kKinds; ++k) {
-    KindData& K = c->kd[k];
-    parts[k] = K.n_src > 0 ? xyz[k] + 3 * K.src_lo : nullptr;
-    counts[k] = 3 * K.n_src;
-    K.src_ptr = c->src_pack.p + off[k];
-    K.src_set = true;
+    c->kd[k].src_ptr = c->src_pack.p + off[k];
+    c->kd[k].src_set = true;
   }
-  return tlh::stage_and_upload(c, parts, counts, kKinds, c->src_pack.p);
+  return rc;
 }
 int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;

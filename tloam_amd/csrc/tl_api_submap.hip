@@ -185,10 +185,16 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   bool fused_front = false;
   for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = false;  // the targets are about to be rebuilt on the device
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
-  // The three clouds the device needs (planar, edge, ground) go up in ONE piece -- pinned staging, one asynchronous copy
-  // (tlh::stage_and_upload) -- into the planar ring frame's buffer: the planar cloud stays there for the frames it is
-  // buffered, the edge and ground clouds behind it are read by this update's assemble launch only.  (Three pageable
-  // copies cost ~25 us each of the calling thread's time: more than the update's kernels.)
+  // The three clouds the device needs (planar, edge, ground) are copied end to end into pinned staging (every cloud on a 16-byte
+  // boundary) and the update's front launch reads them THERE, across PCIe, through LDS: the planar cloud is copied to the newest
+  // ring frame's device buffer on the way (it is read again by the next planar_frame_size - 1 updates), the edge and ground clouds
+  // are needed by this launch only.  No copy command: a hipMemcpyAsync costs the calling thread ~10 us and the copy engine about
+  // as much before the first kernel can start, more than the update's kernels take.  (Three pageable copies: ~25 us each.)
+  // TLOAM_SUBMAP_COPY / more ring frames than one front launch takes: ONE asynchronous copy into the ring frame's buffer instead.
+  const bool in_place = !c->submap_copy && S.cfg.planar_frame_size <= transform_ring_max();
+  const double* stage_view = nullptr;   // the staging half as the device sees it (in_place)
+  size_t stage_off[3] = {0, 0, 0};      // first double of planar | edge | ground in the staged block
+  int stage_half = -1;
   auto push = [&](std::vector<RingFrame*>& ring, const double* xyz, size_t n, int keep, bool upload) -> int {
     RingFrame* f = nullptr;
     if ((int)ring.size() >= keep) {  // recycle the frame that falls out
@@ -202,12 +208,19 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     f->n = n;
     memcpy(f->pose, pose, sizeof(double) * 16);
     if (!upload) return TLOAM_OK;
-    const size_t all = 3 * (n + n_edge + n_ground);
-    if (f->aos.cap < std::max<size_t>(all, 3)) HIPC(c, hipStreamSynchronize(c->stream));   // regrowth: nothing may be in flight
-    HIPC(c, f->aos.reserve(std::max<size_t>(all, 3)));
     const double* parts[3] = {xyz, edge, ground};
     const size_t counts[3] = {3 * n, 3 * n_edge, 3 * n_ground};
-    return tlh::stage_and_upload(c, parts, counts, 3, f->aos.p);
+    const size_t all = std::max<size_t>(tlh::staged_size(counts, 3), 2) + 2;   // (+ 2: read / written in 16-byte steps)
+    if (f->aos.cap < all) HIPC(c, hipStreamSynchronize(c->stream));   // regrowth: nothing may be in flight
+    HIPC(c, f->aos.reserve(all));
+    if (in_place) {
+      const int rc = tlh::stage_in_place(c, parts, counts, 3, stage_off, &stage_view, &stage_half);
+      if (rc != TLOAM_E_NOT_READY) return rc;
+      stage_view = nullptr;   // no device view of the pinned block on this system: the pieces are staged, copy them
+      HIPC(c, hipMemcpyAsync(f->aos.p, c->h_stage[stage_half], sizeof(double) * tlh::staged_size(counts, 3), hipMemcpyHostToDevice, c->stream));
+      return tlh::stage_release(c, stage_half, /*completed=*/false);
+    }
+    return tlh::stage_and_upload(c, parts, counts, 3, f->aos.p, stage_off);
   };
   // The sphere buffer is kept for its bookkeeping only (sizes, poses, frame count): nothing ever reads its points --
   // the sphere submap is rebuilt from the PLANAR buffer (front_end.cpp:221) -- so they are not uploaded.
@@ -266,8 +279,8 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     for (int s = 0; s < 2; ++s) {
       const Acc& a = accs[s];
       KindData& K = c->kd[a.kind];
-      // (uploaded with the planar cloud, behind it in the newest ring frame's buffer)
-      const double* stage = S.planar_ring.back()->aos.p + 3 * (n_planar + (s == 0 ? 0 : n_edge));
+      // (staged with the planar cloud, behind it: in the pinned block itself, or uploaded to the newest ring frame's buffer)
+      const double* stage = (stage_view ? stage_view : S.planar_ring.back()->aos.p) + stage_off[1 + s];
       A.ox[s] = K.tx.p; A.oy[s] = K.ty.p; A.oz[s] = K.tz.p;
       A.aos[s] = stage;
       A.n_old[s] = n_old[s]; A.n_new[s] = a.n; A.base[s] = base;
@@ -284,6 +297,7 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
       const double* aos[16]; size_t nn[16]; const double* poses[16];
       int cnt = 0;
       for (auto* f : S.planar_ring) { aos[cnt] = f->aos.p; nn[cnt] = f->n; poses[cnt] = f->pose; ring_max = std::max(ring_max, f->n); ++cnt; }
+      if (stage_view) aos[cnt - 1] = stage_view + stage_off[0];   // the newest frame: read in the staging, copied to f->aos on the way
       const size_t rows = submap_front_rows(ring_max, std::max(n_in[0], n_in[1]));
       if (S.min_partial.cap < rows * 6) HIPC(c, hipStreamSynchronize(c->stream));   // regrowth: nothing may be in flight
       HIPC(c, S.min_partial.reserve(rows * 6));
@@ -293,7 +307,8 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
       if (rc != TLOAM_OK) return rc;
       KindData& P = c->kd[TLOAM_KIND_PLANAR];
       KindData& Q = c->kd[TLOAM_KIND_SPHERE];
-      launch_submap_front(cnt, aos, nn, poses, A, J, W, P.tx.p, P.ty.p, P.tz.p, Q.tx.p, Q.ty.p, Q.tz.p, S.wx.p, S.wy.p, S.wz.p, c->stream);
+      launch_submap_front(cnt, aos, nn, poses, A, J, W, P.tx.p, P.ty.p, P.tz.p, Q.tx.p, Q.ty.p, Q.tz.p, S.wx.p, S.wy.p, S.wz.p, c->stream,
+                          cnt - 1, stage_view ? S.planar_ring.back()->aos.p : nullptr);
       launch_crop_voxel(J, W, c->stream, /*front_done=*/true);
     } else {
       launch_assemble(A, S.wx.p, S.wy.p, S.wz.p, c->stream);  // [old | Transform(new)] of both clouds, one launch
@@ -303,6 +318,8 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   }
   size_t ne = 0, ng = 0;
   rc = submap_finish(c, &ne, &ng);
+  // (the update's last kernel has completed, or -- on an error -- the caller drains the stream: the staging half is free)
+  if (stage_view) (void)tlh::stage_release(c, stage_half, /*completed=*/true);
   if (rc != TLOAM_OK) return rc;
   c->kd[TLOAM_KIND_EDGE].n_tgt = ne;
   c->kd[TLOAM_KIND_GROUND].n_tgt = ng;

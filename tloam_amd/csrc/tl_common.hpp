@@ -388,13 +388,16 @@ void launch_transform_ring(int count, const double* const aos[], const size_t n[
 void launch_copy3(const double* ax, const double* ay, const double* az, size_t n, double* ox, double* oy, double* oz,
                   hipStream_t s);
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s);
+void launch_blit_doubles(const double* src_host_view, double* dst, size_t n, hipStream_t s);   // pinned host -> device by a kernel
 void launch_crop_voxel(const VoxelJob& J, const VoxelWork& W, hipStream_t s, bool front_done = false);
 // the front of a submap update in one launch (k_submap_front): planar ring transform + assembly of the edge / ground clouds +
 // the crop + voxel job's table clear and min bound; launch_crop_voxel(front_done = true) follows
 size_t submap_front_rows(size_t n_ring_max, size_t n_seg_max);
 void launch_submap_front(int count, const double* const aos[], const size_t n[], const double* const poses[], const AssembleArgs& A,
                          const VoxelJob& J, const VoxelWork& W, double* px, double* py, double* pz, double* qx, double* qy, double* qz,
-                         double* wx, double* wy, double* wz, hipStream_t s);
+                         double* wx, double* wy, double* wz, hipStream_t s, int copy_frame = -1, double* copy_dst = nullptr);
+// (copy_dst: frame `copy_frame`'s cloud is read from pinned host memory and copied to this device buffer on the way; every
+//  AoS cloud the launch reads must start on a 16-byte boundary and may be read up to one double past its end)
 
 // ---- PCA feature extraction (tl_feature.hip; feature_extract.cpp:47-197) -----------------------
 struct FeatArgs {

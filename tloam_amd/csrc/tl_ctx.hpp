@@ -189,6 +189,8 @@ struct tloam_ctx {
                                      // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
   bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
   bool solve_v1 = false;           // TLOAM_SOLVE_V1: round 3's one-launch Solve (k_solve_small: ONE consumer wave for the grid) instead of k_solve_all
+  bool stage_memcpy = false;       // TLOAM_STAGE_MEMCPY: staged host clouds go up with hipMemcpyAsync, never with the copy kernel (A/B, tests)
+  bool submap_copy = false;        // TLOAM_SUBMAP_COPY: tloam_submap_update uploads the new scan's clouds with a copy instead of reading the pinned staging in place (A/B, tests)
   bool sync_set_source = false;    // TLOAM_SYNC_SET_SOURCE: tloam_set_source_frame as four pageable copies + a stream synchronisation (A/B)
   int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
   int device_cus = 0;              // multiProcessorCount of the device (k_solve_small needs all its blocks resident at once)
@@ -208,6 +210,7 @@ struct tloam_ctx {
   // event per half says when the device has read it) and go to HBM with ONE asynchronous copy -- the call returns without
   // waiting for the device, the frame's first kernel is ordered behind the copy by the stream
   double* h_stage[2] = {nullptr, nullptr};
+  double* h_stage_dev[2] = {nullptr, nullptr};  // the halves as the device addresses them (kernels that read the staging in place)
   size_t h_stage_cap[2] = {0, 0};               // doubles
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
   bool stage_busy[2] = {false, false};
@@ -270,7 +273,11 @@ namespace tlh {
 // tl_api.hip
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
 int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]);
-int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst);
+int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst, size_t offs[]);
+int stage_in_place(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, size_t offs[], const double** dev_view,
+                   int* half);
+int stage_release(tloam_ctx* c, int half, bool completed);
+size_t staged_size(const size_t counts[], int nparts);
 int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], const CloudRef clouds[tl::kKinds],
                      tl::GridView out[tl::kKinds], const double (*known_boxes)[6] = nullptr,
                      tl::FrameInitHook* frame = nullptr);

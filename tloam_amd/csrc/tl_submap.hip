@@ -73,6 +73,8 @@ struct RingArgs {
   const double* aos[kRingMax];
   size_t n[kRingMax], off[kRingMax];
   Mat16 M[kRingMax];
+  int copy_frame;      // k_submap_front: the frame whose cloud is read from pinned HOST memory and kept in ...
+  double* copy_dst;    // ... this device buffer for the updates to come (-1 / null: every frame is on the device already)
 };
 __global__ void k_transform_ring(RingArgs R, double* __restrict__ ax, double* __restrict__ ay, double* __restrict__ az,
                                  double* __restrict__ bx, double* __restrict__ by, double* __restrict__ bz) {
@@ -387,6 +389,18 @@ void launch_assemble(const AssembleArgs& A, double* wx, double* wy, double* wz, 
   if (nmax == 0) return;
   hipLaunchKernelGGL(k_assemble, dim3(blocks_for(nmax), 2), dim3(256), 0, s, A, wx, wy, wz);
 }
+// doubles [d0, d1) of `src` -> LDS, dst[d - (d0 & ~1)] = src[d]: one coalesced 16-byte load per lane and pass (src 16-byte
+// aligned; up to one double in front of d0 and one behind d1 come along).  The new scan's clouds are read where the host left
+// them -- pinned staging, across PCIe -- so every byte has to cross once: three 8-byte loads per lane at a 24-byte stride would
+// fetch every line three times from memory the GPU does not cache.
+__device__ __forceinline__ void stage_doubles(const double* __restrict__ src, size_t d0, size_t d1, double* __restrict__ dst) {
+  const size_t p0 = d0 >> 1, p1 = (d1 + 1) >> 1;
+  for (size_t p = p0 + threadIdx.x; p < p1; p += 256) {
+    const double2 v = *reinterpret_cast<const double2*>(src + 2 * p);
+    dst[2 * (p - p0)] = v.x;
+    dst[2 * (p - p0) + 1] = v.y;
+  }
+}
 // ---- the front of a submap update in ONE launch: the planar ring (blockIdx.y < ring frames: k_transform_ring's work), the
 // assembly of [old submap | Transform(new scan)] of the edge and the ground cloud (the next two rows of blocks: k_assemble's
 // work) and, by those same blocks on the points they have just written, what k_vox_min2 would do next: the hash table of the
@@ -397,12 +411,22 @@ __global__ __launch_bounds__(256) void k_submap_front(RingArgs R, int ring_count
                                                       double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz,
                                                       double* __restrict__ wx, double* __restrict__ wy, double* __restrict__ wz) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ double s_stage[3 * 256 + 4];
   if ((int)blockIdx.y < ring_count) {   // ---- planar / sphere submaps from the ring buffer (front_end.cpp:220-243)
     const int f = blockIdx.y;
-    if (i >= R.n[f]) return;
-    const double* __restrict__ aos = R.aos[f];
+    const size_t b0 = (size_t)blockIdx.x * 256, nf = R.n[f];
+    if (b0 >= nf) return;   // (block-uniform)
+    const size_t b1 = b0 + 256 < nf ? b0 + 256 : nf;
+    stage_doubles(R.aos[f], 3 * b0, 3 * b1, s_stage);   // (3 * b0 is even: the block's first double is s_stage[0])
+    __syncthreads();
+    if (f == R.copy_frame) {   // the newest frame arrives in host memory: its cloud stays on the device for the frames it is buffered
+      const size_t nd = 3 * (b1 - b0);
+      for (size_t p = threadIdx.x; 2 * p < nd; p += 256)
+        *reinterpret_cast<double2*>(R.copy_dst + 3 * b0 + 2 * p) = double2{s_stage[2 * p], s_stage[2 * p + 1]};
+    }
+    if (i >= nf) return;
     const Mat16& M = R.M[f];
-    const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+    const double x = s_stage[3 * threadIdx.x], y = s_stage[3 * threadIdx.x + 1], z = s_stage[3 * threadIdx.x + 2];
     double r[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) r[a] = ((M.m[a] * x + M.m[4 + a] * y) + M.m[8 + a] * z) + M.m[12 + a] * 1.0;
@@ -424,6 +448,11 @@ __global__ __launch_bounds__(256) void k_submap_front(RingArgs R, int ring_count
   for (size_t t = (size_t)lb * 256 + threadIdx.x; t <= (size_t)emit_blocks; t += (size_t)nlb * 256) W.leader[t] = 0ull;
   double m[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
   const size_t n_old = A.n_old[s], n_new = A.n_new[s];
+  // the points of the new scan this block transforms: [k0, k1) of the segment's scan cloud, through LDS
+  const size_t blk0 = (size_t)blockIdx.x * 256, blk1 = blk0 + 256 < n_old + n_new ? blk0 + 256 : n_old + n_new;
+  const size_t k0 = blk0 > n_old ? blk0 - n_old : 0, k1 = blk1 > n_old ? blk1 - n_old : 0;
+  if (k1 > k0) stage_doubles(A.aos[s], 3 * k0, 3 * k1, s_stage);
+  __syncthreads();
   if (i < n_old + n_new) {
     const size_t o = A.base[s] + i;
     double x, y, z;
@@ -431,8 +460,8 @@ __global__ __launch_bounds__(256) void k_submap_front(RingArgs R, int ring_count
       x = A.ox[s][i]; y = A.oy[s][i]; z = A.oz[s][i];
     } else {          // += scan->Transform(pose)
       const size_t k = i - n_old;
-      const double* __restrict__ aos = A.aos[s];
-      const double ax = aos[3 * k], ay = aos[3 * k + 1], az = aos[3 * k + 2];
+      const double* a = s_stage + (3 * k - ((3 * k0) & ~(size_t)1));
+      const double ax = a[0], ay = a[1], az = a[2];
       double r[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) r[a] = ((A.M[a] * ax + A.M[4 + a] * ay) + A.M[8 + a] * az) + A.M[12 + a] * 1.0;
@@ -477,9 +506,11 @@ __global__ __launch_bounds__(256) void k_submap_front(RingArgs R, int ring_count
 size_t submap_front_rows(size_t n_ring_max, size_t n_seg_max) { return 2 * (size_t)blocks_for(std::max<size_t>(std::max(n_ring_max, n_seg_max), 1)); }
 void launch_submap_front(int count, const double* const aos[], const size_t n[], const double* const poses[], const AssembleArgs& A,
                          const VoxelJob& J, const VoxelWork& W, double* px, double* py, double* pz, double* qx, double* qy, double* qz,
-                         double* wx, double* wy, double* wz, hipStream_t s) {
+                         double* wx, double* wy, double* wz, hipStream_t s, int copy_frame, double* copy_dst) {
   RingArgs R;
   memset(&R, 0, sizeof(R));
+  R.copy_frame = copy_dst ? copy_frame : -1;
+  R.copy_dst = copy_dst;
   size_t off = 0, nmax = 1;
   for (int f = 0; f < count; ++f) {
     R.aos[f] = aos[f];
@@ -498,6 +529,8 @@ int transform_ring_max() { return kRingMax; }
 void launch_transform_ring(int count, const double* const aos[], const size_t n[], const double* const poses[],
                            double* ax, double* ay, double* az, double* bx, double* by, double* bz, hipStream_t s) {
   RingArgs R;
+  memset(&R, 0, sizeof(R));
+  R.copy_frame = -1;
   size_t off = 0, nmax = 0;
   for (int f = 0; f < count; ++f) {
     R.aos[f] = aos[f];
@@ -514,6 +547,19 @@ void launch_copy3(const double* ax, const double* ay, const double* az, size_t n
                   hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_copy3, dim3(blocks_for(n)), dim3(256), 0, s, ax, ay, az, n, ox, oy, oz);
+}
+// n doubles (n even, both ends 16-byte aligned) from pinned host memory the device can address to device memory: what a
+// hipMemcpyAsync would do, as a kernel -- for a few hundred KB the copy command costs the calling thread and the copy engine
+// more than a launch that reads across PCIe with every load in flight at once
+__global__ __launch_bounds__(256) void k_blit_pairs(const double2* __restrict__ src, double2* __restrict__ dst, size_t pairs) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pairs; p += (size_t)gridDim.x * 256) dst[p] = src[p];
+}
+void launch_blit_doubles(const double* src_host_view, double* dst, size_t n, hipStream_t s) {
+  const size_t pairs = (n + 1) / 2;
+  if (pairs == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((pairs + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_blit_pairs, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const double2*>(src_host_view),
+                     reinterpret_cast<double2*>(dst), pairs);
 }
 void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t n, double* aos, hipStream_t s) {
   if (n == 0) return;
