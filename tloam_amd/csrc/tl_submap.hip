@@ -237,10 +237,20 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxelJob J, VoxelWork W, int n
   __shared__ unsigned long long s_prefix;
   __shared__ int s_bid;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TLOAM_VOX_TICKET
   // blocks take their place in the scan in the order they START: a block only ever waits for blocks that started before it
   if (tid == 0) s_bid = (int)atomicAdd(&W.leader_scan[0], 1ull);
   __syncthreads();
   const int bid = s_bid;
+#else
+  // A block only ever waits for blocks of LOWER index, and those have started before it: every XCD's dispatcher hands out its
+  // share of the grid (blockIdx mod 8) in ascending order, so whatever occupies the slots a lower block is waiting for is a block
+  // of still lower index of this launch -- which waits for nothing that has not started -- or another launch's.  (A ticket
+  // taken at the start of every block -- ~500 returning atomics on one word, served one after the other -- was a quarter of
+  // the launch; -DTLOAM_VOX_TICKET brings it back.)
+  const int bid = (int)blockIdx.x;
+  (void)s_bid;
+#endif
   const size_t i = (size_t)bid * 256 + tid;
   const int h = i < J.n ? W.slot_of_pt[i] : -1;
   const int seg = i >= J.n0 ? 1 : 0;
