@@ -722,7 +722,7 @@ def kitti_sequence(args, reg, synth, torch, device):
              "set_source_plus_scan_match_ms": round(float(np.mean(np.array(t_src) + np.array(t_sm))), 4),
              "note": "reference call order, no caller-side synchronisation between the calls: set_target (4 submap clouds, 83.5k "
                      "points, H2D + bounds, synchronises) | set_source (4 scan clouds, 9.4k points: pinned staging + ONE "
-                     "asynchronous copy, returns without waiting for the device) | scan_match (waits for the copy through the "
+                     "copy kernel reading it in place, returns without waiting for the device) | scan_match (waits for the copy through the "
                      "stream).  Only set_source + scan_match sit between front_end.cpp:314 and :322"}
     rep = {"workload": "synthetic KITTI-density sequence (9.4k src / 83.5k tgt pts per frame, reference caps 2500/2000/1200/200)",
            "frames": nf, "ms_per_frame": round(float(ms.mean()), 4), "ms_per_frame_p50": round(float(np.median(ms)), 4),
