@@ -579,7 +579,9 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
   bool ok_all;
   // (read - check - sleep: one look per round trip to the coherence point.  Two looks in flight -- the next one issued before
   //  this one is checked -- measured 1 % SLOWER on the headline frame, three interleaved pairs on one box: 0.1749 against
-  //  0.1729 ms; the extra reads of sixteen pollers compete with the row stores they wait for.  Round 4, not kept.)
+  //  0.1729 ms; the extra reads of sixteen pollers compete with the row stores they wait for.  Nor does it pay to hold the FIRST
+  //  look back until the late blocks have posted: 4 / 8 / 16 / 32 s_sleep units in front of it measured 0.1735-0.1747 /
+  //  0.1731-0.1748 / 0.1743-0.1774 / 0.1790-0.1792 against 0.1711-0.1721 ms, three interleaved rounds.  Round 4, not kept.)
   for (unsigned spins = 1;; ++spins) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
