@@ -42,6 +42,30 @@ def test_index_lists_bit_exact(hip_module, seed, cfg):
     H.close()
 
 
+def test_ranking_with_exact_ties_and_many_candidates(hip_module):
+    """The ranking (std::sort descending by flatness, ties by ascending index) works bucket by bucket on the device.  A cloud and
+    its point reflection have bit-identical PCA values -- every candidate ties with its mirror image --, and 16 k points give
+    lists of several blocks: the four index lists as the oracle's, a cloud whose candidates all share ONE flatness value too."""
+    p = ss.feature_cloud(4, n=8000)
+    cloud = np.ascontiguousarray(np.concatenate([p, -p]))
+    H = hip_module.HipRegistration()
+    for cfg in ({}, dict(planar_num=50, sphere_num=10, planar_submap_thres=0.3, cvr_submap=0.05)):
+        g = H.extract_planar_sphere(cloud, hip_module.default_feature_config(**cfg))
+        o = ob.extract_planar_sphere(cloud, ob.make_feature_config(**cfg))
+        assert len(o[1]) > 2000 and len(o[1]) % 2 == 0
+        for i, name in enumerate(("planar_scan", "planar_submap", "sphere_scan", "sphere_submap")):
+            assert _same(g[i], o[i]), (name, len(g[i]), len(o[i]))
+    # a lattice: every interior point has the same neighbourhood up to translation by exactly representable steps
+    a = np.arange(24) * 0.0625
+    lat = np.ascontiguousarray(np.array([(x, y, 0.0) for x in a for y in a]))
+    g, o = H.extract_planar_sphere(lat, hip_module.default_feature_config(planar_vertic_thres=2.0, planar_submap_thres=-1.0)), \
+        ob.extract_planar_sphere(lat, ob.make_feature_config(planar_vertic_thres=2.0, planar_submap_thres=-1.0))
+    assert len(o[1]) > 300
+    for a_, b_ in zip(g, o):
+        assert _same(a_, b_)
+    H.close()
+
+
 def test_hip_against_golden(hip_module):
     from test_feature_oracle import check_against_golden
     H = hip_module.HipRegistration()

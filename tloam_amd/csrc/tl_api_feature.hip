@@ -24,6 +24,8 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
   HIPC(c, F.flatness.reserve(m)); HIPC(c, F.cvr.reserve(m)); HIPC(c, F.sphericity.reserve(m)); HIPC(c, F.normal.reserve(3 * m));
   HIPC(c, F.num_sum.reserve(m)); HIPC(c, F.neigh.reserve(m * (size_t)cfg.K));
   if (n > 0) {
+    // (the borrowed cloud straight through the copy command: for 2.4 MB that beats pinned staging + copy kernel, 0.425 against
+    //  0.478 ms per call, three interleaved rounds -- the staging pays below ~1 MB, where the command's fixed cost dominates)
     HIPC(c, hipMemcpyAsync(F.aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     launch_aos_to_soa(F.aos.p, n, F.x.p, F.y.p, F.z.p, c->stream);
   }
@@ -79,39 +81,40 @@ int tloam_extract_planar_sphere(tloam_ctx* c, const tloam_feature_config* cfg, c
   FeatBuffers& F = c->feat;
   FeatArgs A;
   int rc = feature_pca(c, *cfg, xyz, n, F, &A);
-  std::vector<double> pf, sf;
-  std::vector<int> pidx, sidx;
+  std::vector<double> blob;   // the ranked lists as k_rank_final packs them: flatness planar | sphere, then the indices
+  size_t np = 0, ns = 0;
   unsigned long long total = 0;
   if (rc == TLOAM_OK) {
     hipError_t e = hipSuccess;
     if ((e = F.flags.reserve(n + 1)) == hipSuccess && (e = F.scan.reserve(n + 1)) == hipSuccess &&
-        (e = F.scan_tmp.reserve(scan_tmp_elems(n + 1))) == hipSuccess && (e = F.pf.reserve(n)) == hipSuccess &&
-        (e = F.sf.reserve(n)) == hipSuccess && (e = F.pfs.reserve(n)) == hipSuccess && (e = F.sfs.reserve(n)) == hipSuccess &&
-        (e = F.pidx.reserve(n)) == hipSuccess && (e = F.sidx.reserve(n)) == hipSuccess &&
-        (e = F.pidxs.reserve(n)) == hipSuccess && (e = F.sidxs.reserve(n)) == hipSuccess &&
-        (e = F.rank.reserve(2 * n)) == hipSuccess) {
+        (e = F.scan_tmp.reserve(scan_tmp_elems(n + 1))) == hipSuccess && (e = F.f2.reserve(2 * n)) == hipSuccess &&
+        (e = F.gf.reserve(2 * n)) == hipSuccess && (e = F.out.reserve(3 * n + 2)) == hipSuccess &&
+        (e = F.idx2.reserve(2 * n)) == hipSuccess && (e = F.gi.reserve(2 * n)) == hipSuccess &&
+        (e = F.bkt.reserve(2 * n)) == hipSuccess && (e = F.pos.reserve(2 * n)) == hipSuccess &&
+        (e = F.rank_ctl.reserve(1)) == hipSuccess) {
       const FeatSelect S{cfg->cvr_submap, cfg->planar_submap_thres, cfg->planar_vertic_thres};
-      launch_feat_select(A, S, F.flags.p, F.scan.p, F.scan_tmp.p, F.pf.p, F.pidx.p, F.sf.p, F.sidx.p, F.pfs.p, F.pidxs.p,
-                         F.sfs.p, F.sidxs.p, F.rank.p, c->stream);
+      launch_feat_select(A, S, F.flags.p, F.scan.p, F.scan_tmp.p, F.f2.p, F.idx2.p, F.rank_ctl.p, F.bkt.p, F.pos.p, F.gf.p, F.gi.p,
+                         F.out.p, c->stream);
       e = hipMemcpyAsync(&total, F.scan.p + n, sizeof(total), hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-      const size_t np = (size_t)(total >> 32), ns = (size_t)(total & 0xffffffffull);
-      pf.resize(np); pidx.resize(np); sf.resize(ns); sidx.resize(ns);
-      if (e == hipSuccess && np) e = hipMemcpy(pf.data(), F.pfs.p, sizeof(double) * np, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && np) e = hipMemcpy(pidx.data(), F.pidxs.p, sizeof(int) * np, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && ns) e = hipMemcpy(sf.data(), F.sfs.p, sizeof(double) * ns, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && ns) e = hipMemcpy(sidx.data(), F.sidxs.p, sizeof(int) * ns, hipMemcpyDeviceToHost);
+      np = (size_t)(total >> 32); ns = (size_t)(total & 0xffffffffull);
+      // ONE copy for both ranked lists: (np + ns) doubles, then (np + ns) ints
+      blob.resize(np + ns + (np + ns + 1) / 2);
+      if (e == hipSuccess && np + ns) e = hipMemcpy(blob.data(), F.out.p, sizeof(double) * (np + ns) + sizeof(int) * (np + ns), hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) { c->last_error = hipGetErrorString(e); rc = TLOAM_E_HIP; }
   }
   (void)hipStreamSynchronize(c->stream);
   if (rc != TLOAM_OK) return rc;
   // :178-190 on the ranked lists
-  for (size_t id = 0; id < pf.size(); ++id) {
+  const double* pf = blob.data();
+  const double* sf = pf + np;
+  const int* pidx = reinterpret_cast<const int*>(blob.data() + np + ns);
+  for (size_t id = 0; id < np; ++id) {
     if (id < (size_t)std::max(cfg->planar_num, 0) || pf[id] > cfg->planar_scan_thres) planar_scan[(*n_ps)++] = pidx[id];
     planar_submap[(*n_pm)++] = pidx[id];
   }
-  for (size_t id = 0; id < sf.size(); ++id) {  // the RANK is stored, not the point index (:186, :188)
+  for (size_t id = 0; id < ns; ++id) {  // the RANK is stored, not the point index (:186, :188)
     if (id < (size_t)std::max(cfg->sphere_num, 0) || sf[id] > cfg->cvr_scan) sphere_scan[(*n_ss)++] = (int32_t)id;
     sphere_submap[(*n_sm)++] = (int32_t)id;
   }

@@ -411,9 +411,13 @@ struct FeatArgs {
 };
 struct FeatSelect { double cvr_submap, planar_submap_thres, planar_vertic_thres; };
 void launch_pca_info(const FeatArgs& A, hipStream_t s);
+struct FeatRankCtl {   // control block of the ranking (tl_feature.hip): two lists, 0 planar, 1 sphere
+  unsigned long long kmin[2], kmax[2];   // order-preserving keys of the smallest / largest flatness of a list
+  int hist[2][4096 + 1];                 // bucket sizes, then bucket starts (+ the list's length)
+};
 void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long long* flags, unsigned long long* scan,
-                        unsigned long long* scan_tmp, double* pf, int* pidx, double* sf, int* sidx, double* pf_sorted,
-                        int* pidx_sorted, double* sf_sorted, int* sidx_sorted, int* rank, hipStream_t s);
+                        unsigned long long* scan_tmp, double* f2, int* idx2, FeatRankCtl* ctl, int* bkt, int* pos, double* gf, int* gi,
+                        double* out, hipStream_t s);
 
 // K3 and the minimiser
 int k3_grid_for(int total_cap);

@@ -129,15 +129,17 @@ struct SubmapState {
 
 // scratch of the PCA feature path (grow-only, kept across calls)
 struct FeatBuffers {
-  DBuf<double> aos, x, y, z, flatness, cvr, sphericity, normal, pf, sf, pfs, sfs;
-  DBuf<int> num_sum, neigh, pidx, sidx, pidxs, sidxs, rank;
+  DBuf<double> aos, x, y, z, flatness, cvr, sphericity, normal;
+  DBuf<double> f2, gf, out;        // candidate flatness of both lists ([0, n) planar, [n, 2n) sphere), grouped by bucket, ranked + packed
+  DBuf<int> num_sum, neigh, idx2, gi, bkt, pos;
   DBuf<unsigned long long> flags, scan, scan_tmp;
+  DBuf<tl::FeatRankCtl> rank_ctl;
   GridBuffers grid;
   void release() {
     aos.release(); x.release(); y.release(); z.release(); flatness.release(); cvr.release(); sphericity.release();
-    normal.release(); pf.release(); sf.release(); pfs.release(); sfs.release(); num_sum.release(); neigh.release();
-    pidx.release(); sidx.release(); pidxs.release(); sidxs.release(); rank.release(); flags.release(); scan.release();
-    scan_tmp.release(); grid.release();
+    normal.release(); f2.release(); gf.release(); out.release(); num_sum.release(); neigh.release();
+    idx2.release(); gi.release(); bkt.release(); pos.release(); flags.release(); scan.release();
+    scan_tmp.release(); rank_ctl.release(); grid.release();
   }
 };
 
