@@ -15,14 +15,25 @@ namespace tl {
 namespace {
 constexpr int kFeatK = 20;  // feature.yaml: K
 
-// calculatePCAInfo (:61-119), one thread per point
+// calculatePCAInfo (:61-119), one thread per point.  The points are taken in the GRID's order (cell by cell: thread j owns
+// the j-th record of the cell-sorted array, which carries the point's own index): the 64 queries of a wave then sit in a few
+// neighbouring cells, walk the same rows of cells and share the candidates' cache lines -- what the query sort does for the
+// 1 M-query search of the registration path, here for free, the queries being the grid's own points.  Every point's result is
+// the same whichever thread computes it.  (TLOAM_PCA_INDEX_ORDER: thread i owns point i, as until round 4.)
 __global__ __launch_bounds__(64) void k_pca_info(FeatArgs A) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= A.n) return;
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= A.n) return;
   // value-initialised PCAInfo (pca_info_.resize, :59)
   double flat = 0.0, cvr = 0.0, sph = 0.0, nx = 0.0, ny = 0.0, nz = 0.0;
   int num = 0;
+#ifdef TLOAM_PCA_INDEX_ORDER
+  const int i = j;
   const double qx = A.x[i], qy = A.y[i], qz = A.z[i];
+#else
+  const double4 self = A.g.gp[j];
+  const int i = (int)__double_as_longlong(self.w);
+  const double qx = self.x, qy = self.y, qz = self.z;
+#endif
   TopK<kFeatK> tk;
   knn_grid_fast<kFeatK>(A.g, qx, qy, qz, tk);
   // SearchHybrid(cur_pt, r, K): the K nearest (K <= 20: a prefix of the sorted list), then the radius cut (:71)
