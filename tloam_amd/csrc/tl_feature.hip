@@ -9,6 +9,7 @@
 // list -- K = 20 here, walked with packed keys (tl_knn.hpp) -- and the cyclic-Jacobi 3x3 eigen solve.  Compiled with -ffp-contract=off.
 #include "tl_common.hpp"
 #include "tl_knn.hpp"
+#include "tl_walk.hpp"
 
 namespace tl {
 
@@ -35,7 +36,15 @@ __global__ __launch_bounds__(64) void k_pca_info(FeatArgs A) {
   const double qx = self.x, qy = self.y, qz = self.z;
 #endif
   TopK<kFeatK> tk;
+#ifdef TLOAM_PCA_PLAIN_WALK
   knn_grid_fast<kFeatK>(A.g, qx, qy, qz, tk);
+#else
+  // the walk of the registration path's 1 M-query search (tl_walk.hpp, one lane per query): only the cells the search ball can
+  // reach, the lane's rows as ONE candidate stream, four records per trip with the next trip's records requested ahead.  Entries
+  // at or beyond the radius may differ from the unclipped walk's; they are cut below (SearchHybrid: K nearest, THEN the radius)
+  __shared__ int2 s_rows[9 * 64];
+  knn_rows<kFeatK, 1>(A.g, PtsGlobal{A.g.gp}, Vec3{qx, qy, qz}, 0, tk, s_rows, A.radius);
+#endif
   // SearchHybrid(cur_pt, r, K): the K nearest (K <= 20: a prefix of the sorted list), then the radius cut (:71)
   const double r2 = A.radius * A.radius;
   int cnt = 0;
