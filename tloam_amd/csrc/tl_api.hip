@@ -886,7 +886,7 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
   }
   return rc;
 }
-int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
+int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n, bool convert = true) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   K.n_tgt = n;
@@ -896,7 +896,7 @@ int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
   if (n > 0) {
     HIPC(c, hipMemcpyAsync(K.tgt_aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    launch_aos_to_soa(K.tgt_aos.p, n, K.tx.p, K.ty.p, K.tz.p, c->stream);  // AoS -> SoA on the device
+    if (convert) launch_aos_to_soa(K.tgt_aos.p, n, K.tx.p, K.ty.p, K.tz.p, c->stream);  // AoS -> SoA on the device
   }
   K.tgt_set = true;
   return TLOAM_OK;
@@ -944,8 +944,20 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   int rc = TLOAM_OK;
-  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k]);
-  if (rc == TLOAM_OK) rc = enqueue_target_bounds(c);
+  // with pinned box rows: four copies, then ONE launch that converts all four clouds and takes their bounds
+  const bool fused = c->h_bbox_dev != nullptr;
+  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k], /*convert=*/!fused);
+  if (rc == TLOAM_OK && fused) {
+    IngestArgs A;
+    for (int k = 0; k < kKinds; ++k) {
+      KindData& K = c->kd[k];
+      A.aos[k] = K.tgt_aos.p; A.x[k] = K.tx.p; A.y[k] = K.ty.p; A.z[k] = K.tz.p;
+      A.n[k] = (int)K.n_tgt;
+    }
+    launch_ingest_targets(A, c->h_bbox_dev, c->stream);
+  } else if (rc == TLOAM_OK) {
+    rc = enqueue_target_bounds(c);
+  }
   HIPC(c, hipStreamSynchronize(c->stream));
   if (rc == TLOAM_OK) finish_target_bounds(c);
   return rc;

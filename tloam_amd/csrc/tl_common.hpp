@@ -212,6 +212,12 @@ struct GridSet {
   double inv_cell[kKinds];
   int dim[kKinds][3];
 };
+struct IngestArgs {   // k_ingest_targets: the four target clouds as uploaded (AoS) and where their SoA copies go
+  const double* aos[kKinds];
+  double *x[kKinds], *y[kKinds], *z[kKinds];
+  int n[kKinds];
+};
+void launch_ingest_targets(const IngestArgs& A, double* bbox_rows /*[kind][64][6]*/, hipStream_t s);
 struct FrameInit {
   const double* src_aos[kKinds];
   int slot_off[kKinds + 1];

@@ -408,6 +408,50 @@ __global__ __launch_bounds__(256) void k_bbox_all(GridSet gs, double* __restrict
     out[((size_t)k * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;
   }
 }
+// setInputTarget of a whole Frame: AoS -> SoA of the four clouds AND their bounding-box rows in ONE launch (four conversion
+// launches and k_bbox_all otherwise).  Same rows as k_bbox_all: 64 per kind, finite coordinates only.
+__global__ __launch_bounds__(256) void k_ingest_targets(IngestArgs A, double* __restrict__ out) {
+  __shared__ double red[4][6];
+  const int k = blockIdx.y;
+  const double* __restrict__ aos = A.aos[k];
+  double* __restrict__ x = A.x[k];
+  double* __restrict__ y = A.y[k];
+  double* __restrict__ z = A.z[k];
+  const int n = A.n[k];
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    double a = aos[3 * (size_t)i], b = aos[3 * (size_t)i + 1], c = aos[3 * (size_t)i + 2];
+    x[i] = a; y[i] = b; z[i] = c;
+    if (!(fabs(a) < __builtin_inf())) a = __builtin_nan("");
+    if (!(fabs(b) < __builtin_inf())) b = __builtin_nan("");
+    if (!(fabs(c) < __builtin_inf())) c = __builtin_nan("");
+    lo[0] = fmin(lo[0], a); hi[0] = fmax(hi[0], a);
+    lo[1] = fmin(lo[1], b); hi[1] = fmax(hi[1], b);
+    lo[2] = fmin(lo[2], c); hi[2] = fmax(hi[2], c);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmax(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = (threadIdx.x < 3) ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+    out[((size_t)k * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = v;
+  }
+}
+void launch_ingest_targets(const IngestArgs& A, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_ingest_targets, dim3(64, kKinds), dim3(256), 0, s, A, out);
+}
 void launch_bbox_all(const GridSet& gs, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_bbox_all, dim3(64, kKinds), dim3(256), 0, s, gs, out);
 }
