@@ -63,6 +63,14 @@ def test_ranking_with_exact_ties_and_many_candidates(hip_module):
     assert len(o[1]) > 300
     for a_, b_ in zip(g, o):
         assert _same(a_, b_)
+    # 3 000 collinear points: every flatness is exactly 0 -- ONE crowded bucket, the blocks count through LDS over all of it
+    x = np.arange(3000) * 2.0 ** -7
+    line = np.ascontiguousarray(np.column_stack([x, np.zeros_like(x), np.zeros_like(x)]))
+    cfg = dict(planar_vertic_thres=2.0, planar_submap_thres=-1.0, planar_num=10)
+    g, o = H.extract_planar_sphere(line, hip_module.default_feature_config(**cfg)), ob.extract_planar_sphere(line, ob.make_feature_config(**cfg))
+    assert len(o[1]) == 3000 and list(o[1][:5]) == [0, 1, 2, 3, 4]
+    for a_, b_ in zip(g, o):
+        assert _same(a_, b_)
     H.close()
 
 
