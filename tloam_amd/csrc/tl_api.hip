@@ -262,7 +262,7 @@ size_t staged_size(const size_t counts[], int nparts) {   // doubles the pieces 
 // temporary one.
 // radius[k] <= 0: kind not rebuilt (its view is left empty).  One host synchronisation (bounding boxes).
 // rows of launch_bbox_all ([kind][64][6]) -> (lo[3], hi[3]) per kind
-static void reduce_box_rows(const double* box_rows, double boxes[kKinds][6]) {
+void reduce_box_rows(const double* box_rows, double boxes[kKinds][6]) {
   for (int k = 0; k < kKinds; ++k) {
     double* b = boxes[k];
     b[0] = b[1] = b[2] = 1e300;

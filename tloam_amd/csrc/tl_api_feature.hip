@@ -27,13 +27,27 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
     // (the borrowed cloud straight through the copy command: for 2.4 MB that beats pinned staging + copy kernel, 0.425 against
     //  0.478 ms per call, three interleaved rounds -- the staging pays below ~1 MB, where the command's fixed cost dominates)
     HIPC(c, hipMemcpyAsync(F.aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    launch_aos_to_soa(F.aos.p, n, F.x.p, F.y.p, F.z.p, c->stream);
   }
   GridView views[kKinds];
   double radii[kKinds] = {cfg.radius, 0, 0, 0};
   CloudRef clouds[kKinds] = {{F.x.p, F.y.p, F.z.p, n}, {nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0},
                              {nullptr, nullptr, nullptr, 0}};
-  int rc = build_grids_over(c, F.grid, radii, clouds, views);  // KDTreeFlann::SetGeometry(cloud) :57
+  double boxes[kKinds][6];
+  const double (*known)[6] = nullptr;
+  if (n > 0 && c->h_bbox_dev) {
+    // AoS -> SoA and the cloud's bounds in ONE launch, the rows straight into pinned memory (k_ingest_targets, as
+    // tloam_set_target_frame): the grid is sized without a bounds launch of its own
+    IngestArgs I;
+    memset(&I, 0, sizeof(I));
+    I.aos[0] = F.aos.p; I.x[0] = F.x.p; I.y[0] = F.y.p; I.z[0] = F.z.p; I.n[0] = (int)n;
+    launch_ingest_targets(I, c->h_bbox_dev, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    tlh::reduce_box_rows(c->h_bbox, boxes);
+    known = boxes;
+  } else if (n > 0) {
+    launch_aos_to_soa(F.aos.p, n, F.x.p, F.y.p, F.z.p, c->stream);
+  }
+  int rc = build_grids_over(c, F.grid, radii, clouds, views, known);  // KDTreeFlann::SetGeometry(cloud) :57
   if (rc != TLOAM_OK) return rc;
   FeatArgs A;
   A.g = views[0];

@@ -285,6 +285,7 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKind
                      tl::FrameInitHook* frame = nullptr);
 int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[tl::kKinds], tl::GridView out[tl::kKinds],
                 tl::FrameInitHook* frame = nullptr);
+void reduce_box_rows(const double* box_rows, double boxes[tl::kKinds][6]);   // rows of k_bbox_all / k_ingest_targets -> (lo, hi) per kind
 int enqueue_target_bounds(tloam_ctx* c);
 void finish_target_bounds(tloam_ctx* c);
 }  // namespace tlh

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void k_feat_select(FeatArgs A, FeatSelect S, u
 // ---- std::sort descending by flatness (:168-174), made total: ties by ascending index ------------------------------------
 // Round 3 ranked by counting over the WHOLE list (O(m^2): 59 + 98 us for the 10 k + 20 k candidates of a 100 k-point scan,
 // more than the PCA pass).  Now the counting is confined to a neighbourhood of the element's own value:
-//   k_feat_compact  also takes the smallest / largest flatness of either list (one atomic pair per wave, order-preserving keys)
+//   k_feat_compact  also takes the smallest / largest flatness of either list per block (order-preserving keys); k_rank_range
+//                   folds the blocks' rows and empties the histograms
 //   k_rank_hist     bucket of every candidate -- kRankBuckets equal slices of [min, max], bucket 0 the LARGEST values -- and its
 //                   place inside the bucket (the histogram's returning atomic: arbitrary, only used to group)
 //   k_rank_scan     bucket starts (one block per list)
@@ -144,10 +145,6 @@ __device__ __forceinline__ int rank_bucket(double f, const RankRange& r) {   // 
   int b = (int)t;
   b = b < 0 ? 0 : (b > kRankBuckets - 1 ? kRankBuckets - 1 : b);
   return kRankBuckets - 1 - b;
-}
-__global__ __launch_bounds__(256) void k_rank_init(FeatRankCtl* ctl) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 2 * (kRankBuckets + 1)) (&ctl->hist[0][0])[i] = 0;
 }
 __global__ __launch_bounds__(256) void k_feat_compact(FeatArgs A, const unsigned long long* __restrict__ flags,
                                                       const unsigned long long* __restrict__ scan, double* __restrict__ pf,
@@ -180,9 +177,12 @@ __global__ __launch_bounds__(256) void k_feat_compact(FeatArgs A, const unsigned
     part[(size_t)blockIdx.x * 4 + a] = r;
   }
 }
-// the lists' value ranges from the blocks' partials (one block; min / max are exact in any order)
+// the lists' value ranges from the blocks' partials (block 0; min / max are exact in any order); every block of the launch also
+// empties its share of the two histograms
 __global__ __launch_bounds__(256) void k_rank_range(const unsigned long long* __restrict__ part, int blocks, FeatRankCtl* __restrict__ ctl) {
   __shared__ unsigned long long s_red[4][4];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * (kRankBuckets + 1); i += gridDim.x * 256) (&ctl->hist[0][0])[i] = 0;
+  if (blockIdx.x != 0) return;
   unsigned long long v[4] = {~0ull, 0ull, ~0ull, 0ull};
   for (int b = threadIdx.x; b < blocks; b += 256) {
 #pragma unroll
@@ -324,7 +324,6 @@ void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long lo
                         double* out, hipStream_t s) {
   const int n = A.n;
   hipLaunchKernelGGL(k_feat_select, dim3((n + 1 + 255) / 256), dim3(256), 0, s, A, S, flags);
-  hipLaunchKernelGGL(k_rank_init, dim3((2 * (kRankBuckets + 1) + 255) / 256), dim3(256), 0, s, ctl);
   launch_exclusive_scan_u64(flags, scan, (size_t)n + 1, scan_tmp, s);
   if (n <= 0) return;
   // (the blocks' value ranges go through the front of the work array `pos`: 4 x 8 bytes per block of 256 points, read by
@@ -332,7 +331,7 @@ void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long lo
   unsigned long long* part = reinterpret_cast<unsigned long long*>(pos);
   const int cblocks = (n + 255) / 256;
   hipLaunchKernelGGL(k_feat_compact, dim3(cblocks), dim3(256), 0, s, A, flags, scan, f2, idx2, f2 + n, idx2 + n, part);
-  hipLaunchKernelGGL(k_rank_range, dim3(1), dim3(256), 0, s, part, cblocks, ctl);
+  hipLaunchKernelGGL(k_rank_range, dim3(8), dim3(256), 0, s, part, cblocks, ctl);
   // the candidate counts are only known on the device: the rank kernels cover n and bound themselves
   const dim3 g2((n + 255) / 256, 2);
   hipLaunchKernelGGL(k_rank_hist, g2, dim3(256), 0, s, f2, scan + n, n, ctl, bkt, pos);
