@@ -721,10 +721,13 @@ def kitti_sequence(args, reg, synth, torch, device):
              "scan_match_ms": round(float(np.mean(t_sm)), 4),
              "set_source_plus_scan_match_ms": round(float(np.mean(np.array(t_src) + np.array(t_sm))), 4),
              "note": "reference call order, no caller-side synchronisation between the calls: set_target (4 submap clouds, 83.5k "
-                     "points, H2D + bounds, synchronises) | set_source (4 scan clouds, 9.4k points: pinned staging + ONE "
+                     "points, H2D + bounds, synchronises; then ENQUEUES the four search-grid builds behind it without waiting -- the ~24 us of launches the "
+                     "headline's scan_match contains are outside this block's scan_match; TLOAM_NO_GRID_AHEAD=1 puts them back) | set_source (4 scan clouds, 9.4k points: pinned staging + ONE "
                      "copy kernel reading it in place, returns without waiting for the device) | scan_match (waits for the copy through the "
                      "stream).  Only set_source + scan_match sit between front_end.cpp:314 and :322"}
     rep = {"workload": "synthetic KITTI-density sequence (9.4k src / 83.5k tgt pts per frame, reference caps 2500/2000/1200/200)",
+           "grids": "built at target hand-over (tloam_set_target_frame), not inside scan_match -- unlike the headline, whose frames "
+                    "are staged in HBM and selected, and whose scan_match builds its four grids itself",
            "frames": nf, "ms_per_frame": round(float(ms.mean()), 4), "ms_per_frame_p50": round(float(np.median(ms)), 4),
            "ms_per_frame_p99": round(float(np.percentile(ms, 99)), 4),
            "gn_iters_per_sec": round(it / (ms.sum() * 1e-3), 1), "gn_iters_per_frame": round(it / nf, 2),

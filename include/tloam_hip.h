@@ -140,7 +140,9 @@ int tloam_set_source(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
 int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
 /* The same for the four clouds of a tloam::Frame at once (registration_interface.hpp:19-38; setInputSource /
  * setInputTarget take a Frame, registration.cpp:232-248), indexed by TLOAM_KIND_*.  xyz_aos[k] may be NULL when n[k] == 0.
- * tloam_set_target_frame synchronises once per frame instead of once per cloud.  tloam_set_source_frame does not wait for the
+ * tloam_set_target_frame synchronises once per frame instead of once per cloud, then enqueues the build of the four search
+ * grids over the new targets without waiting for it (the next tloam_scan_match / tloam_sm_begin uses them; until then the
+ * context's search structures -- what tloam_fitness sees -- remain those of the last scanMatching).  tloam_set_source_frame does not wait for the
  * device at all: it returns when the borrowed buffers have been copied OUT (into pinned staging; one copy is enqueued on the
  * context's stream behind it), so they may be reused at once and the next call on the context is ordered behind the copy. */
 int tloam_set_source_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);

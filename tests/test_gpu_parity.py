@@ -598,7 +598,7 @@ def test_concurrent_frame_streams_share_the_gpu(hip_module):
 
 @pytest.mark.parametrize("knob", ["TLOAM_NO_SELF_PREPARE=1", "TLOAM_NO_FINISH_IN_SOLVE=1", "TLOAM_ENQUEUE_AHEAD=1",
                                   "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_SOLVE_V1=1",
-                                  "TLOAM_STAGE_MEMCPY=1", "TLOAM_SYNC_SET_SOURCE=1"])
+                                  "TLOAM_STAGE_MEMCPY=1", "TLOAM_SYNC_SET_SOURCE=1", "TLOAM_NO_GRID_AHEAD=1"])
 def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     """The Solve launch of a KITTI-size frame prepares its own factor set, ends its outer iteration and runs the following ones;
     the host enqueues launches for two iterations and adds one when the device asks.  Each piece can be switched off --
@@ -609,7 +609,8 @@ def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     Round 4: the default Solve launch is k_solve_all -- every block consumes the rows and takes the step on its own image of
     the state; TLOAM_SOLVE_V1 = round 3's single consumer wave for the whole grid (k_solve_small): the same frames, bit for bit.
     The scan's clouds reach the device through pinned staging and a copy KERNEL that reads it in place; TLOAM_STAGE_MEMCPY = the
-    copy command instead, TLOAM_SYNC_SET_SOURCE = four pageable copies and a synchronisation: the same clouds."""
+    copy command instead, TLOAM_SYNC_SET_SOURCE = four pageable copies and a synchronisation: the same clouds.  The search grids are
+    built when the targets are handed over (tloam_set_target_frame); TLOAM_NO_GRID_AHEAD builds them inside scanMatching: the same grids."""
     name, val = knob.split("=")
     scenes = [synth.make_scene(seed=61, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT),
               synth.make_scene(seed=62, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, pred_err=(0.25, -0.15, 0.05, 0.02, -0.015, 0.03)),

@@ -644,6 +644,7 @@ void exchange_clouds(tloam_ctx* c, FrameClouds& F) {
     std::swap(c->tgt_box_valid[k], F.tgt_box_valid[k]);
     K.grid_valid = false;   // the search grids belong to the frame they were built over
   }
+  c->grids_ahead = false;
   std::swap(c->src_pack, F.src_pack);
   c->have_build = false;
 }
@@ -713,6 +714,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
   c->sync_set_source = getenv("TLOAM_SYNC_SET_SOURCE") != nullptr;
   c->no_scan_1p = getenv("TLOAM_NO_SCAN_1P") != nullptr;
+  c->no_grid_ahead = getenv("TLOAM_NO_GRID_AHEAD") != nullptr;
   c->submap_copy = getenv("TLOAM_SUBMAP_COPY") != nullptr;
   c->stage_memcpy = getenv("TLOAM_STAGE_MEMCPY") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
@@ -789,7 +791,7 @@ void tloam_destroy(tloam_ctx* c) {
   c->raw.release(); c->flags.release(); c->scan.release(); c->scan_tmp.release(); c->seg_n.release();
   c->tile_cnt.release(); c->tile_scan.release(); c->tile_of_slot.release(); c->tile_fill.release(); c->qrec.release();
   c->partials.release(); c->red48.release(); c->sums16.release(); c->wpart.release(); c->rank_counts.release();
-  c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release();
+  c->se3_dev.release(); c->bbox_dev.release(); c->misc.release(); c->state.release(); c->grids.release(); c->grids_next.release();
   for (auto* f : c->frame_store)
     if (f) { f->release(); delete f; }
   c->frame_store.clear();
@@ -891,6 +893,7 @@ int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n, bool c
   KindData& K = c->kd[kind];
   K.n_tgt = n;
   c->tgt_box_valid[kind] = false;
+  c->grids_ahead = false;
   const size_t m = std::max<size_t>(n, 1);
   HIPC(c, K.tgt_aos.reserve(3 * m));
   HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
@@ -960,6 +963,25 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   }
   HIPC(c, hipStreamSynchronize(c->stream));
   if (rc == TLOAM_OK) finish_target_bounds(c);
+  // The four search grids (registration.cpp:889-915 builds its kd-trees at the top of scanMatching) are enqueued HERE, behind the
+  // hand-over's own synchronisation and not waited for: the targets are final once setInputTarget returns, the next scan is a
+  // sensor period away, and the ~24 us of launches leave the bracket around scanMatching (front_end.cpp:320-322).  The grids
+  // stay valid until a target changes; a frame brought in by tloam_frame_select is built over inside scanMatching as before.
+  if (rc == TLOAM_OK && c->nranks == 1 && !c->no_grid_ahead) {
+    double radius[kKinds];
+    GridView views[kKinds];
+    bool all = true;
+    for (int k = 0; k < kKinds; ++k) { radius[k] = kind_radius(c->cfg, k); all = all && c->tgt_box_valid[k]; }
+    if (all) {
+      // (into a second set of buffers: until the next scanMatching the context's search structures are those of the LAST one,
+      //  as the reference's kd-trees are -- getFitnessScore in between sees them, :257-296)
+      rc = build_grids(c, c->grids_next, radius, views, nullptr);
+      if (rc == TLOAM_OK) {
+        for (int k = 0; k < kKinds; ++k) c->gv_next[k] = views[k];
+        c->grids_ahead = true;
+      }
+    }
+  }
   return rc;
 }
 
@@ -1083,15 +1105,23 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     if (c->nranks > 1)
       for (int k = 0; k < kKinds; ++k)
         if (c->kd[k].n_src == 0) radius[k] = 0.0;
-    rc = build_grids(c, c->grids, radius, views, &hook);
-    if (rc != TLOAM_OK) return rc;
-    for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
+    if (c->grids_ahead && c->nranks == 1) {
+      // built when the targets were handed over (tloam_set_target_frame): they become the context's search structures now;
+      // the frame's start is a launch of its own, below.  Used once: a second scanMatching over the same targets builds its own
+      std::swap(c->grids, c->grids_next);
+      for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = c->gv_next[k]; c->kd[k].grid_valid = true; }
+      c->grids_ahead = false;
+    } else {
+      rc = build_grids(c, c->grids, radius, views, &hook);
+      if (rc != TLOAM_OK) return rc;
+      for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
+    }
   }
   if (!hook.consumed) {  // (no grid launch: cannot happen with >= 10 targets per kind, kept for safety)
     GridView gviews[kKinds];
     for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
     const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off[kKinds]);
-    HIPC(c, c->tile_cnt.reserve(ntiles + 1));
+    HIPC(c, c->tile_cnt.reserve(ntiles + 1 > c->tile_cnt.cap ? 2 * ntiles + 64 : ntiles + 1));   // (room to spare, as build_grids_over)
     hook.fi.tile_cnt = c->tile_cnt.p;
     hook.fi.n_tile_cnt = (int)ntiles + 1;
     launch_frame_init(hook.fi, hook.b, c->stream);

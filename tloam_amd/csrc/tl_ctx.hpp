@@ -161,6 +161,8 @@ struct tloam_ctx {
   DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned long long> scan1p_q;   // control words of the single-pass scan of the query-sort histogram, zero when allocated
+  bool grids_ahead = false;    // the search grids in `grids` were built over the registered targets at hand-over (tloam_set_target_frame) and are still theirs
+  bool no_grid_ahead = false;  // TLOAM_NO_GRID_AHEAD: the grids are always built inside scanMatching (A/B, tests)
   bool no_scan_1p = false;     // TLOAM_NO_SCAN_1P: the multi-launch scans for the large tables too (A/B, tests)
   DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
@@ -170,6 +172,8 @@ struct tloam_ctx {
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
   GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
+  GridBuffers grids_next;      // ... and the set built AHEAD, over targets just handed over (tloam_set_target_frame); swapped in by the next sm_begin
+  tl::GridView gv_next[tl::kKinds];
   SlotView sv{};
   CorrView cv{};
   DBuf<int> seg_n;
