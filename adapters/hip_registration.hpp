@@ -24,6 +24,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -43,6 +44,10 @@ inline bool ok(int status, const char* what, const tloam_ctx* ctx) {
 // The default fits open3d::geometry::PointCloud2 (std::vector<Eigen::Vector3d> points_).
 template <class Cloud>
 struct PointsAccessor {
+  // the reinterpret_casts below read `points_` as packed xyz doubles: true of std::vector<Eigen::Vector3d> (24 bytes per
+  // point, no padding; PointCloud2.hpp:396) -- checked at compile time for whatever point type the cloud carries
+  using Point = typename std::remove_cv<typename std::remove_reference<decltype(std::declval<const Cloud&>().points_[0])>::type>::type;
+  static_assert(sizeof(Point) == 3 * sizeof(double), "points_ must be 24 bytes per point: packed double[3] (Eigen::Vector3d)");
   static const double* data(const Cloud& c) { return c.points_.empty() ? nullptr : reinterpret_cast<const double*>(c.points_.data()); }
   static double* mutable_data(Cloud& c) { return c.points_.empty() ? nullptr : reinterpret_cast<double*>(c.points_.data()); }
   static std::size_t size(const Cloud& c) { return c.points_.size(); }
@@ -191,7 +196,7 @@ class HipRegistration : public RegistrationInterface {
   // beyond the interface: the device-resident submap entry points
   tloam_hip::HipRegistrationCore<Frame, Eigen::Isometry3d>& core() { return core_; }
 
- private:
+  // the 16 keys of the `TLS:` block exactly as LocalRegistration::initConfig reads them (registration.cpp:212-230)
   static tloam_tls_config fromYaml(const YAML::Node& n) {
     tloam_tls_config c;
     tloam_default_config(&c);
@@ -213,6 +218,8 @@ class HipRegistration : public RegistrationInterface {
     c.fitness_thres = n["fitness_thres"].as<double>();
     return c;
   }
+
+ private:
   tloam_hip::HipRegistrationCore<Frame, Eigen::Isometry3d> core_;
 };
 }  // namespace tloam
