@@ -37,12 +37,13 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 6  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+#define TLOAM_ABI_VERSION 7  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
                                * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us
                                * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
                                *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned
                                * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve)
-                               * 6: tloam_k3_span, tloam_shard_ranges_frame */
+                               * 6: tloam_k3_span, tloam_shard_ranges_frame
+                               * 7: tloam_debug_raise_fault */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -255,6 +256,13 @@ int tloam_debug_state(tloam_ctx* ctx, double* out, int n_doubles);
 /* development aid: the per-block partial rows of the last K3 launch (32 doubles per block); returns the
  * number of rows.  Columns 28..31 carry in-kernel timestamps in builds with -DTLOAM_K3_PROFILE. */
 int tloam_debug_partials(tloam_ctx* ctx, double* out, int n_doubles);
+/* Test hook.  A few kernels spin on blocks of their own launch (the single-pass look-back scans of 1 M-class tables, the
+ * voxel down-sampling's look-back); the host only picks those forms where the device's CU count says every block is
+ * resident at once, their waits are bounded (~1 s) all the same, and a wait that runs out raises a word in pinned host
+ * memory: the call in progress returns TLOAM_E_HIP -- tloam_scan_match runs the frame again by itself -- and the context
+ * uses the forms that wait for nothing (multi-launch scans / start tickets) from then on.  This raises the word by hand:
+ * which = 0 look-back scan, 1 voxel down-sampling. */
+int tloam_debug_raise_fault(tloam_ctx* ctx, int which);
 
 /* ---- submap maintenance on the device ---------------------------------------
  * FrontEnd::updateSubmap (front_end.cpp:201-275) and the first-frame branch of updateLidarOdometry

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert set(reg.EXPORTED_SYMBOLS) == set(names)
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tloam_hip.h")).read()
-    assert L.tloam_abi_version() == int(re.search(r"#define\s+TLOAM_ABI_VERSION\s+(\d+)", hdr).group(1)) == 6
+    assert L.tloam_abi_version() == int(re.search(r"#define\s+TLOAM_ABI_VERSION\s+(\d+)", hdr).group(1)) == 7
 
 
 def test_struct_layout_matches_the_c_header():

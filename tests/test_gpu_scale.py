@@ -218,18 +218,22 @@ def test_one_launch_gn_iteration_of_large_sets_is_exact(hip_module, prebuilt_1m,
     F1.close(); F2.close()
 
 
-def test_single_pass_scans_of_the_large_tables_are_exact(hip_module, monkeypatch):
-    """Round 4: the two ~3 M-entry histograms of a 1 M-class frame (cells of the target grids, bins of the query sort) are
-    scanned by ONE single-pass look-back launch each -- the grid's also writes cell_start and re-zeroes the histogram --
-    instead of tile scan + scan of the totals + add (+ finalize); TLOAM_NO_SCAN_1P keeps the multi-launch form.  Integer
-    work: the frame must come out identical, twice in a row (epochs, re-armed counters), and a 1 M-point kNN as well."""
+def test_single_pass_scans_and_their_time_out_fallback_are_exact(hip_module):
+    """The two ~3 M-entry histograms of a 1 M-class frame (cells of the target grids, bins of the query sort) are scanned by
+    ONE single-pass look-back launch each -- the grid's also writes cell_start and re-zeroes the histogram -- where the
+    device's CU count says all blocks of the launch are resident at once; the look-back is bounded, and a wait that runs out
+    (a partitioned / shared device) raises a fault word: tloam_scan_match then runs the SAME frame again with
+    tile scan + scan of the totals + add (+ finalize) and the context stays there.  H2's fault word is raised by hand
+    (tloam_debug_raise_fault) before its first frame: first frame = the re-run path, second = the multi-launch scans from the
+    start.  Integer work: the frames must come out identical, twice in a row (epochs, re-armed counters), and a 1 M-point kNN
+    as well."""
     sc = synth.make_scene(seed=0, n_src=synth.M1_SRC, n_tgt=synth.M1_TGT)
     cfg = hip_module.default_config(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
     H1 = hip_module.HipRegistration(cfg)
-    monkeypatch.setenv("TLOAM_NO_SCAN_1P", "1")            # read once, when the context is created
     H2 = hip_module.HipRegistration(cfg)
     for H in (H1, H2):
         H.set_frames(sc.source, sc.target)
+    assert H2.L.tloam_debug_raise_fault(H2.h, 0) == 0
     for rep in range(2):
         rc1, T1, st1 = H1.scan_match(sc.T_pred)
         rc2, T2, st2 = H2.scan_match(sc.T_pred)

@@ -33,11 +33,8 @@ def test_hip_replays_golden_bit_exact(hip_module):
     replay_golden(lambda cfg: _HipSubmap(hip_module, cfg), lambda S, k: S.get(k))
 
 
-@pytest.mark.parametrize("copy", [False, True], ids=["staging_read_in_place", "TLOAM_SUBMAP_COPY"])
 @pytest.mark.parametrize("seed,crop", [(0, 100.0), (1, 30.0), (2, 12.0)])
-def test_hip_vs_oracle_sequences(hip_module, monkeypatch, seed, crop, copy):
-    if copy:   # the new scan's clouds uploaded with a copy instead of read in the pinned staging (read when the context is created)
-        monkeypatch.setenv("TLOAM_SUBMAP_COPY", "1")
+def test_hip_vs_oracle_sequences(hip_module, seed, crop):
     cfg = dict(edge_crop_box_length=crop, ground_crop_box_length=crop * 0.8, planar_frame_size=2 + seed)
     A = _HipSubmap(hip_module, cfg)
     B = ob.OracleSubmap(ob.make_submap_config(**cfg))
@@ -73,12 +70,9 @@ def test_crowded_voxels_and_duplicates(hip_module):
         assert np.array_equal(A.get(k), B.get(k)), k
 
 
-@pytest.mark.parametrize("copy", [False, True], ids=["staging_read_in_place", "TLOAM_SUBMAP_COPY"])
-def test_odd_cloud_sizes_and_one_point_clouds(hip_module, monkeypatch, copy):
+def test_odd_cloud_sizes_and_one_point_clouds(hip_module):
     """The staged clouds start on 16-byte boundaries and are read in 16-byte steps: odd point counts (a padding double behind
     the cloud), clouds of one point, clouds that end inside a block's first pair."""
-    if copy:
-        monkeypatch.setenv("TLOAM_SUBMAP_COPY", "1")
     A = _HipSubmap(hip_module, {}); B = ob.OracleSubmap()
     sizes = [(51, 21, 101, 103), (1, 1, 1, 1), (257, 3, 513, 255), (255, 7, 1, 769), (3, 5, 771, 1)]
     for f, n in enumerate(sizes):
@@ -141,3 +135,24 @@ def test_scan_match_on_the_device_submap(hip_module):
     assert dt < 1e-6 and dr < 1e-6        # north-star tolerance; in practice ~1e-12
     assert st_h["n_corr"] == st_o["n_corr"]
     H.close()
+
+
+def test_look_back_time_out_switches_to_start_tickets(hip_module):
+    """k_vox_emit's blocks wait for the blocks in front of them (look-back scan); they take their places from
+    blockIdx only while the whole grid is resident on the device, the wait is bounded, and one that runs out raises a fault word:
+    the update in progress reports TLOAM_E_HIP (its submap is undefined) and the context's emit blocks take start tickets from
+    then on.  The word is raised by hand here (tloam_debug_raise_fault); after a new init the ticketed form must reproduce the
+    oracle bit for bit."""
+    A = _HipSubmap(hip_module, {}); B = ob.OracleSubmap()
+    cl0 = ss.frame_clouds(5, 0)
+    A.init(*cl0); B.init(*cl0)
+    assert A.H.L.tloam_debug_raise_fault(A.H.h, 1) == 0
+    with pytest.raises(hip_module.TloamHipError):
+        A.update(ss.frame_pose(1, step=1.0, yaw_rate=0.02), *ss.frame_clouds(5, 1))
+    A.init(*cl0)
+    for f in range(1, 6):
+        T = ss.frame_pose(f, step=1.0, yaw_rate=0.02)
+        cl = ss.frame_clouds(5, f)
+        A.update(T, *cl); B.update(T, *cl)
+        for k in range(4):
+            assert np.array_equal(A.get(k), B.get(k)), (f, k)

@@ -177,6 +177,35 @@ int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long
     __builtin_ia32_pause();
   }
 }
+// After a host synchronisation: did a kernel of this context give up one of its bounded in-launch waits?  The single-pass scans
+// (tl_nn.hip scan1p_tile) and k_vox_emit's look-back (tl_submap.hip) spin on blocks of their own launch, which is only safe
+// while all of them are resident at once; the host only picks those forms where the device's CU count says they are, and
+// should that ever be wrong (a device shared with long-running kernels) the wait runs out after ~1 s, the kernel raises a word
+// in pinned memory and finishes with garbage.  Here the context is switched to the forms that wait for nothing (multi-launch
+// scans, start tickets) for good, everything derived from the garbage is invalidated, and the caller gets TLOAM_E_HIP (or, in
+// tloam_scan_match, runs the frame again).
+int check_device_faults(tloam_ctx* c) {
+  if (!c->h_fault) return TLOAM_OK;
+  int rc = TLOAM_OK;
+  if (__atomic_load_n(&c->h_fault[kFaultScan1p], __ATOMIC_ACQUIRE) != 0u) {
+    __atomic_store_n(&c->h_fault[kFaultScan1p], 0u, __ATOMIC_RELEASE);
+    c->no_scan_1p = true;
+    c->grids_ahead = false;
+    for (int k = 0; k < kKinds; ++k) c->kd[k].grid_valid = false;
+    c->have_build = false;
+    c->last_error = "a single-pass scan timed out in its look-back (its blocks were not resident together): the context now uses the multi-launch scans";
+    rc = TLOAM_E_HIP;
+  }
+  if (__atomic_load_n(&c->h_fault[kFaultVoxEmit], __ATOMIC_ACQUIRE) != 0u) {
+    __atomic_store_n(&c->h_fault[kFaultVoxEmit], 0u, __ATOMIC_RELEASE);
+    c->vox_ticket = true;
+    c->grids_ahead = false;
+    c->last_error = "the voxel down-sampling timed out in its look-back (its blocks were not resident together): the context now uses start tickets; "
+                    "the submap of this update is undefined -- initialise it again";
+    rc = TLOAM_E_HIP;
+  }
+  return rc;
+}
 // Borrowed host arrays -> device, without waiting for the device: the pieces are copied into a pinned staging half (two halves
 // used alternately; an event per half says when the device has read it -- long ago in the reference's call pattern, waited for
 // otherwise), every piece on a 16-byte boundary (offs[i], in doubles; `total` out), and either
@@ -224,8 +253,9 @@ int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t cou
   int h = -1;
   const int rc = stage_fill(c, parts, counts, nparts, offs, &total, &h);
   if (rc != TLOAM_OK || h < 0) return rc;
-  // up to a few MB a kernel that reads the pinned block in place does the copy (TLOAM_STAGE_MEMCPY: always the copy command)
-  if (c->h_stage_dev[h] && !c->stage_memcpy && total <= (size_t)1 << 19)
+  // up to a few MB a kernel that reads the pinned block in place does the copy (for 226 KB the copy command costs the calling
+  // thread and the copy engine more than a launch: 0.197 / 0.201 against 0.206 / 0.206 ms set_source + scan_match, round 4)
+  if (c->h_stage_dev[h] && total <= (size_t)1 << 19)
     launch_blit_doubles(c->h_stage_dev[h], dev_dst, total, c->stream);
   else
     HIPC(c, hipMemcpyAsync(dev_dst, c->h_stage[h], sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
@@ -286,25 +316,15 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     gs.tgt_off[k] = (int)tgt_total;
     tgt_total += (size_t)gs.n[k];
   }
-  constexpr size_t kBoxDoubles = (size_t)kKinds * 64 * 6;
   double boxes[kKinds][6];
   if (known_boxes) {
     memcpy(boxes, known_boxes, sizeof(boxes));
   } else {
-    const double* box_rows = c->h_small;
-    if (c->h_bbox_dev) {
-      // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
-      // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
-      launch_bbox_all(gs, c->h_bbox_dev, c->stream);
-      HIPC(c, hipStreamSynchronize(c->stream));
-      box_rows = c->h_bbox;
-    } else {
-      HIPC(c, G.bbox.reserve(kBoxDoubles));
-      launch_bbox_all(gs, G.bbox.p, c->stream);
-      HIPC(c, hipMemcpyAsync(c->h_small, G.bbox.p, sizeof(double) * kBoxDoubles, hipMemcpyDeviceToHost, c->stream));
-      HIPC(c, hipStreamSynchronize(c->stream));
-    }
-    reduce_box_rows(box_rows, boxes);
+    // rows straight into pinned host memory: no copy kernel.  (Publishing a completion word from the last of the
+    // 256 blocks -- system-scope fence per block -- was measured: it costs more than this synchronisation.)
+    launch_bbox_all(gs, c->h_bbox_dev, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    reduce_box_rows(c->h_bbox, boxes);
   }
   long long cell_total = 0;
   for (int k = 0; k < kKinds; ++k) {
@@ -370,14 +390,14 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     frame->consumed = true;
   }
   launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream, frame);
-  if (!c->no_scan_1p && scan_1p_applies(nc + 1)) {
+  if (!c->no_scan_1p && scan_1p_applies(nc + 1, c->device_cus)) {
     // 1 M-class tables: count | scan + finalize in ONE single-pass launch | scatter (three launches and one pass over the table
     // less than tile scan + scan of the totals + add + finalize)
     const size_t before = G.scan1p.cap;
     HIPC(c, G.scan1p.reserve(scan_1p_ctl_elems(nc_res + 1)));
     if (G.scan1p.cap != before) HIPC(c, hipMemsetAsync(G.scan1p.p, 0, G.scan1p.cap * sizeof(unsigned long long), c->stream));
-    launch_grid_scan_finalize_scatter_1p(gs, G.cell_cnt.p, nc + 1, G.cell_start.p, G.scan1p.p, G.cell_of_pt.p, G.rank_of_pt.p, G.gp.p,
-                                         c->stream);
+    launch_grid_scan_finalize_scatter_1p(gs, G.cell_cnt.p, nc + 1, G.cell_start.p, G.scan1p.p, c->h_fault_dev + kFaultScan1p, G.cell_of_pt.p,
+                                         G.rank_of_pt.p, G.gp.p, c->stream);
     return TLOAM_OK;
   }
   const int tiles = scan_tiles_only(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);
@@ -403,7 +423,6 @@ int build_grids(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], GridV
 }
 // bounds of the target clouds registered so far, taken while the hand-over call is synchronising anyway
 int enqueue_target_bounds(tloam_ctx* c) {
-  if (!c->h_bbox_dev) return TLOAM_OK;  // no pinned rows: scanMatching computes them itself
   GridSet gs;
   memset(&gs, 0, sizeof(gs));
   for (int k = 0; k < kKinds; ++k) {
@@ -415,7 +434,6 @@ int enqueue_target_bounds(tloam_ctx* c) {
   return TLOAM_OK;
 }
 void finish_target_bounds(tloam_ctx* c) {  // after the stream has been synchronised
-  if (!c->h_bbox_dev) return;
   reduce_box_rows(c->h_bbox, c->tgt_box);
   for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = c->kd[k].tgt_set && c->kd[k].n_tgt > 0;
 }
@@ -502,8 +520,8 @@ int harvest_k3_events(tloam_ctx* c, int working) {
 // stream drained without the number arriving, copy the state and synchronise.
 HostMirror next_mirror(tloam_ctx* c, int slot = 0) {
   HostMirror hm;
-  hm.out = c->h_mirror_dev ? c->h_mirror_dev + slot : nullptr;
-  hm.seq = hm.out ? ++c->mirror_seq : 0ull;
+  hm.out = c->h_mirror_dev + slot;
+  hm.seq = ++c->mirror_seq;
   return hm;
 }
 int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
@@ -546,7 +564,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
                   const SolveFinish* finish = nullptr) {
   if (!armed) launch_solve_init(c->state.p, c->stream);  // scan_match re-arms the minimiser in its finish kernel
   if (sweeps > 0 && solve_small_path(c)) {
-    // KITTI-size set: the whole Solve (up to `sweeps` evaluations) is one launch (k_solve_small)
+    // KITTI-size set: the whole Solve (up to `sweeps` evaluations) is one launch (k_solve_all)
     SolveFinish F;
     if (prep && finish) {
       F = *finish;
@@ -554,9 +572,8 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       memset(&F, 0, sizeof(F));
       if (wp) { F.have_wp = 1; F.wp[0] = *wp; }
     }
-    const int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_small
-    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_bcast.p, c->k3_grid, sweeps | sabotage, prep, c->seg_n.p, &F,
-                       c->stream, c->solve_v1);
+    const int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_all
+    launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, sweeps | sabotage, prep, c->seg_n.p, &F, c->stream);
     c->batch_launches++;
     return TLOAM_OK;
   }
@@ -614,8 +631,6 @@ int ensure_common(tloam_ctx* c) {
     HIPC(c, hipMemsetAsync(c->k3_ticket.p, 0, 4 * sizeof(int), c->stream));
     HIPC(c, c->k3_span.reserve(4));     // K3Step::span
     HIPC(c, hipMemsetAsync(c->k3_span.p, 0, 4 * sizeof(unsigned long long), c->stream));
-    HIPC(c, c->k3_bcast.reserve(64));   // two messages of 16 words, a cache line apart each (k_solve_small: poses / end-of-iteration verdicts)
-    HIPC(c, hipMemsetAsync(c->k3_bcast.p, 0, 64 * sizeof(unsigned long long), c->stream));
   }
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;
@@ -711,12 +726,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
-  c->solve_v1 = getenv("TLOAM_SOLVE_V1") != nullptr;
-  c->sync_set_source = getenv("TLOAM_SYNC_SET_SOURCE") != nullptr;
-  c->no_scan_1p = getenv("TLOAM_NO_SCAN_1P") != nullptr;
   c->no_grid_ahead = getenv("TLOAM_NO_GRID_AHEAD") != nullptr;
-  c->submap_copy = getenv("TLOAM_SUBMAP_COPY") != nullptr;
-  c->stage_memcpy = getenv("TLOAM_STAGE_MEMCPY") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;
@@ -737,23 +747,24 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     return TLOAM_E_HIP;
   }
   memset(c->h_state, 0, sizeof(GnState) * kMirrorSlots);
-  c->no_host_mirror = getenv("TLOAM_NO_HOST_MIRROR") != nullptr;
-  if (!c->no_host_mirror) {
-    if (hipHostMalloc((void**)&c->h_mirror, sizeof(MirrorSlot) * kMirrorSlots, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-      memset(c->h_mirror, 0, sizeof(MirrorSlot) * kMirrorSlots);
-      if (((uintptr_t)c->h_mirror & 63u) != 0 ||
-          hipHostGetDevicePointer((void**)&c->h_mirror_dev, c->h_mirror, 0) != hipSuccess)
-        c->h_mirror_dev = nullptr;  // no (aligned) device view of the slots: fall back to copy + synchronise
-    }
-    (void)hipGetLastError();
-  }
-  if (!c->no_host_mirror) {
+  {
+    // pinned, device-visible host memory the kernels write their results into (result slots, bounding-box rows, fault words):
+    // required -- there is no copy + synchronise variant of the paths that use them
     constexpr size_t kBoxBytes = sizeof(double) * ((size_t)kKinds * 64 * 6 + 8);
-    if (hipHostMalloc((void**)&c->h_bbox, kBoxBytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-      memset(c->h_bbox, 0, kBoxBytes);
-      if (hipHostGetDevicePointer((void**)&c->h_bbox_dev, c->h_bbox, 0) != hipSuccess) c->h_bbox_dev = nullptr;
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (hipHostMalloc((void**)&c->h_mirror, sizeof(MirrorSlot) * kMirrorSlots, flags) != hipSuccess ||
+        ((uintptr_t)c->h_mirror & 63u) != 0 || hipHostGetDevicePointer((void**)&c->h_mirror_dev, c->h_mirror, 0) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_bbox, kBoxBytes, flags) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->h_bbox_dev, c->h_bbox, 0) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_fault, sizeof(unsigned) * kFaultWords, flags) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->h_fault_dev, c->h_fault, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      tloam_destroy(c);
+      return TLOAM_E_HIP;
     }
-    (void)hipGetLastError();
+    memset(c->h_mirror, 0, sizeof(MirrorSlot) * kMirrorSlots);
+    memset(c->h_bbox, 0, kBoxBytes);
+    memset(c->h_fault, 0, sizeof(unsigned) * kFaultWords);
   }
   if (ensure_common(c) != TLOAM_OK) { tloam_destroy(c); return TLOAM_E_HIP; }
   (void)hipMemsetAsync(c->state.p, 0, sizeof(GnState), c->stream);
@@ -771,7 +782,7 @@ void tloam_destroy(tloam_ctx* c) {
   for (int r = 0; r < kMaxRanks; ++r)
     if (c->mbox_opened[r]) (void)hipIpcCloseMemHandle(c->mbox_opened[r]);
   if (c->mbox_local) (void)hipFree(c->mbox_local);
-  c->scan1p_q.release(); c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_span.release(); c->k3_bcast.release(); c->fin_rows.release(); c->flagb.release();
+  c->scan1p_q.release(); c->mbox_ctr.release(); c->k3_ticket.release(); c->k3_span.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)
@@ -801,6 +812,7 @@ void tloam_destroy(tloam_ctx* c) {
   if (c->h_mirror) (void)hipHostFree(c->h_mirror);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_bbox) (void)hipHostFree(c->h_bbox);
+  if (c->h_fault) (void)hipHostFree(c->h_fault);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -841,13 +853,11 @@ void tloam_shard_ranges_frame(const size_t n[4], int rank, int nranks, size_t lo
 
 // ---- setInputSource / setInputTarget (registration.cpp:232-248) --------------------------------
 namespace {
-// range: this rank's block when the cloud is handed over as part of a Frame (tloam_shard_ranges_frame); null: the cloud alone
-int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n, const size_t* range = nullptr) {
+int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
   if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   size_t lo = 0, hi = n;
-  if (range) { lo = range[0]; hi = range[1]; }
-  else tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
+  tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
   K.n_src_full = n;
   K.src_lo = lo;
   K.n_src = hi - lo;
@@ -883,8 +893,9 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
   for (int k = 0; k < kKinds; ++k) parts[k] = c->kd[k].n_src > 0 ? xyz[k] + 3 * c->kd[k].src_lo : nullptr;
   const int rc = tlh::stage_and_upload(c, parts, cnt4, kKinds, c->src_pack.p, off);
   for (int k = 0; k < kKinds; ++k) {
-    c->kd[k].src_ptr = c->src_pack.p + off[k];
-    c->kd[k].src_set = true;
+    // (a failed staging / upload leaves the block undefined: the sources are NOT registered, the next solve says so)
+    c->kd[k].src_ptr = rc == TLOAM_OK ? c->src_pack.p + off[k] : nullptr;
+    c->kd[k].src_set = rc == TLOAM_OK;
   }
   return rc;
 }
@@ -929,17 +940,6 @@ int tloam_set_target(tloam_ctx* c, int kind, const double* xyz, size_t n) {
 int tloam_set_source_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
-  if (c->sync_set_source) {   // TLOAM_SYNC_SET_SOURCE (A/B): four pageable copies and a stream synchronisation, as round 3
-    int rc = TLOAM_OK;
-    size_t lo4[kKinds], hi4[kKinds];
-    tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
-    for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) {
-      const size_t range[2] = {lo4[k], hi4[k]};
-      rc = set_source_async(c, k, xyz[k], n[k], range);
-    }
-    HIPC(c, hipStreamSynchronize(c->stream));  // the host buffers are only borrowed for the call
-    return rc;
-  }
   return set_source_frame_packed(c, xyz, n);   // (the host buffers have been copied out when this returns)
 }
 
@@ -947,10 +947,9 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   int rc = TLOAM_OK;
-  // with pinned box rows: four copies, then ONE launch that converts all four clouds and takes their bounds
-  const bool fused = c->h_bbox_dev != nullptr;
-  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k], /*convert=*/!fused);
-  if (rc == TLOAM_OK && fused) {
+  // four copies, then ONE launch that converts all four clouds and takes their bounds (rows into pinned memory)
+  for (int k = 0; k < kKinds && rc == TLOAM_OK; ++k) rc = set_target_async(c, k, xyz[k], n[k], /*convert=*/false);
+  if (rc == TLOAM_OK) {
     IngestArgs A;
     for (int k = 0; k < kKinds; ++k) {
       KindData& K = c->kd[k];
@@ -958,8 +957,6 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
       A.n[k] = (int)K.n_tgt;
     }
     launch_ingest_targets(A, c->h_bbox_dev, c->stream);
-  } else if (rc == TLOAM_OK) {
-    rc = enqueue_target_bounds(c);
   }
   HIPC(c, hipStreamSynchronize(c->stream));
   if (rc == TLOAM_OK) finish_target_bounds(c);
@@ -1029,6 +1026,8 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   HIPC(c, hipSetDevice(c->device));
   for (int k = 0; k < kKinds; ++k)  // the reference asserts (registration.cpp:928-929)
     if (c->kd[k].n_src_full < 10 || c->kd[k].n_tgt < 10) return TLOAM_E_TOO_FEW_POINTS;
+  for (int k = 0; k < kKinds; ++k)  // a hand-over that failed half way (staging, upload) left nothing registered
+    if (!c->kd[k].src_set || !c->kd[k].tgt_set) { c->last_error = "a source / target hand-over failed: hand the frame over again"; return TLOAM_E_NOT_READY; }
   Pose P;
   if (!pose_from_matrix(predict, &P)) return TLOAM_E_BAD_POSE;  // SOPHUS_ENSURE in the reference
   double x[6];
@@ -1165,7 +1164,8 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)nt_res, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
   HIPC(c, c->qrec.reserve(n_slots + 1));
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(nt_res + 1, n_slots + 1))));
-  if (!c->no_scan_1p && scan_1p_applies(ntiles + 1)) {
+  c->scan1p_q_use = !c->no_scan_1p && scan_1p_applies(ntiles + 1, c->device_cus);
+  if (c->scan1p_q_use) {
     const size_t before = c->scan1p_q.cap;
     HIPC(c, c->scan1p_q.reserve(scan_1p_ctl_elems(nt_res + 1)));
     if (c->scan1p_q.cap != before) HIPC(c, hipMemsetAsync(c->scan1p_q.p, 0, c->scan1p_q.cap * sizeof(unsigned long long), c->stream));
@@ -1188,7 +1188,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
     launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream);
   } else {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->no_scan_1p ? nullptr : c->scan1p_q.p);
+                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->scan1p_q_use ? c->scan1p_q.p : nullptr, c->h_fault_dev + kFaultScan1p);
   }
   if (prepare_in_solve) return TLOAM_OK;
   if (prepare_small_path(c)) {
@@ -1651,7 +1651,7 @@ int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
   pose_to_matrix(T, result);
   if (stats) *stats = c->stats;
   c->active = false;
-  return TLOAM_OK;
+  return check_device_faults(c);   // (every iteration's result has been waited for: the frame's kernels are done)
 }
 
 // development aid (TLOAM_HOST_PROFILE=1, single frame stream only): where the calling thread's time goes per
@@ -1670,7 +1670,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
   // iterations fit the result slots, no development knob that needs the host between iterations
-  if (c->nranks == 1 && c->h_mirror_dev && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
+  if (c->nranks == 1 && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
       !c->dbg_no_build_reuse && !c->no_device_loop) {
     const bool persistent = solve_small_path(c);
     rc = scan_match_device_loop(c, &weight_violation);
@@ -1696,6 +1696,12 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     if (rc != TLOAM_OK) return rc;
   }
   rc = tloam_sm_end(c, result, stats);
+  if (rc == TLOAM_E_HIP && c->no_scan_1p && !c->scan1p_retried) {
+    // a look-back scan of this frame gave up (check_device_faults): the clouds are intact in HBM and the context has been
+    // switched to the multi-launch scans -- run the frame again, once
+    c->scan1p_retried = true;
+    return tloam_scan_match(c, predict, omega3, result, scan_xyz, n_scan, stats);
+  }
   if (rc != TLOAM_OK) return rc;
   if (scan_xyz && n_scan > 0) {  // :1126-1128 out_result_.scan_cloud->Transform(curr_frame_pose)
     HIPC(c, c->misc.reserve(3 * n_scan));
@@ -1851,7 +1857,7 @@ int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius,
   e = hipStreamSynchronize(c->stream);
   cleanup();
   if (e != hipSuccess) { c->last_error = hipGetErrorString(e); return TLOAM_E_HIP; }
-  return TLOAM_OK;
+  return check_device_faults(c);
 }
 
 // ---- pre-built correspondence sets ------------------------------------------------------------------
@@ -2119,6 +2125,12 @@ int tloam_debug_se3(tloam_ctx* c, int n, const double* x, const double* delta, d
   launch_debug_se3(dx, dd, n, dout, c->stream);
   HIPC(c, hipMemcpyAsync(out26, dout, sizeof(double) * 26 * n, hipMemcpyDeviceToHost, c->stream));
   HIPC(c, hipStreamSynchronize(c->stream));
+  return TLOAM_OK;
+}
+
+int tloam_debug_raise_fault(tloam_ctx* c, int which) {
+  if (!c || which < 0 || which >= kFaultWords || !c->h_fault) return TLOAM_E_INVALID;
+  __atomic_store_n(&c->h_fault[which], 1u, __ATOMIC_RELEASE);
   return TLOAM_OK;
 }
 

@@ -34,7 +34,7 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
                              {nullptr, nullptr, nullptr, 0}};
   double boxes[kKinds][6];
   const double (*known)[6] = nullptr;
-  if (n > 0 && c->h_bbox_dev) {
+  if (n > 0) {
     // AoS -> SoA and the cloud's bounds in ONE launch, the rows straight into pinned memory (k_ingest_targets, as
     // tloam_set_target_frame): the grid is sized without a bounds launch of its own
     IngestArgs I;
@@ -44,8 +44,6 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
     HIPC(c, hipStreamSynchronize(c->stream));
     tlh::reduce_box_rows(c->h_bbox, boxes);
     known = boxes;
-  } else if (n > 0) {
-    launch_aos_to_soa(F.aos.p, n, F.x.p, F.y.p, F.z.p, c->stream);
   }
   int rc = build_grids_over(c, F.grid, radii, clouds, views, known);  // KDTreeFlann::SetGeometry(cloud) :57
   if (rc != TLOAM_OK) return rc;
@@ -81,6 +79,7 @@ int tloam_pca_info(tloam_ctx* c, const tloam_feature_config* cfg, const double* 
     if (e != hipSuccess) { c->last_error = hipGetErrorString(e); rc = TLOAM_E_HIP; }
   }
   (void)hipStreamSynchronize(c->stream);
+  if (rc == TLOAM_OK) rc = tlh::check_device_faults(c);   // (the grid build's single-pass scan: bounded look-back)
   return rc;
 }
 
@@ -119,6 +118,7 @@ int tloam_extract_planar_sphere(tloam_ctx* c, const tloam_feature_config* cfg, c
     if (e != hipSuccess) { c->last_error = hipGetErrorString(e); rc = TLOAM_E_HIP; }
   }
   (void)hipStreamSynchronize(c->stream);
+  if (rc == TLOAM_OK) rc = tlh::check_device_faults(c);
   if (rc != TLOAM_OK) return rc;
   // :178-190 on the ranked lists
   const double* pf = blob.data();

@@ -66,8 +66,10 @@ int submap_job(tloam_ctx* c, const CropVoxelSeg seg[2], int nseg, VoxelJob* Jout
   W.leader = S.leader.p; W.leader_scan = S.leader_scan.p; W.scan_tmp = S.scan_tmp.p; W.overflow = S.overflow.p;
   W.n_out = S.counts.p;
   // the last slot of the result mirror is free outside scanMatching: the sizes come back through it
-  W.host_seg = (c->h_mirror_dev && !c->no_host_mirror) ? &c->h_mirror_dev[kMirrorSlots - 1].w[0] : nullptr;
-  W.host_seq = W.host_seg ? ++c->mirror_seq : 0ull;
+  W.host_seg = &c->h_mirror_dev[kMirrorSlots - 1].w[0];
+  W.host_seq = ++c->mirror_seq;
+  W.use_ticket = (c->vox_ticket || (long long)(n + 256) / 256 > (long long)vox_emit_resident_blocks(c->device_cus)) ? 1 : 0;
+  W.fault = c->h_fault_dev + kFaultVoxEmit;
   S.pending_seq = W.host_seq;
   *Jout = J;
   *Wout = W;
@@ -105,6 +107,7 @@ int submap_finish(tloam_ctx* c, size_t* n_edge, size_t* n_ground) {  // the ONE 
     HIPC(c, hipMemcpyAsync(&ov, S.overflow.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
   }
+  if (tlh::check_device_faults(c) != TLOAM_OK) return TLOAM_E_HIP;   // (k_vox_emit's bounded look-back ran out: see there)
   if (ov) {
     c->last_error = "[VoxelDownSample] voxel_size is too small.";  // PointCloud2.cpp:370-372
     return TLOAM_E_INVALID;
@@ -192,8 +195,9 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   // ring frame's device buffer on the way (it is read again by the next planar_frame_size - 1 updates), the edge and ground clouds
   // are needed by this launch only.  No copy command: a hipMemcpyAsync costs the calling thread ~10 us and the copy engine about
   // as much before the first kernel can start, more than the update's kernels take.  (Three pageable copies: ~25 us each.)
-  // TLOAM_SUBMAP_COPY / more ring frames than one front launch takes: ONE asynchronous copy into the ring frame's buffer instead.
-  const bool in_place = !c->submap_copy && S.cfg.planar_frame_size <= transform_ring_max();
+  // (Measured against the staged upload, round 4: 0.093-0.097 against 0.102-0.106 ms per update.)  More ring frames than one front
+  // launch takes: ONE asynchronous copy into the ring frame's buffer instead.
+  const bool in_place = S.cfg.planar_frame_size <= transform_ring_max();
   const double* stage_view = nullptr;   // the staging half as the device sees it (in_place)
   size_t stage_off[3] = {0, 0, 0};      // first double of planar | edge | ground in the staged block
   int stage_half = -1;

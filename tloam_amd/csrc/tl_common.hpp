@@ -308,12 +308,15 @@ void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const uns
                              const int* rank_of_pt, double4* gp, hipStream_t s);
 // large tables (more than 1024 scan tiles: the 1 M-class frames): ONE single-pass launch scans the histogram, writes cell_start
 // and re-zeroes the histogram (no scan array), then the scatter -- count | scan + finalize | scatter.  ctl: scan_1p_ctl_elems(n)
-// words, zero when allocated (k_scan_1p, tl_nn.hip)
+// words, zero when allocated (k_scan_1p, tl_nn.hip).  Only where every block of the launch is resident at once on THIS device
+// (scan_1p_applies: tiles <= 15/16 of device_cus); fault: pinned host word the kernel raises if its bounded look-back times out
 size_t scan_1p_ctl_elems(size_t n);
-bool scan_1p_applies(size_t n);
-void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s);
+bool scan_1p_applies(size_t n, int device_cus);
+void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, unsigned* fault,
+                           hipStream_t s);
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
-                                          unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s);
+                                          unsigned long long* ctl, unsigned* fault, const int* cell_of_pt, const int* rank_of_pt, double4* gp,
+                                          hipStream_t s);
 
 struct BuildParams {
   double radius[kKinds];
@@ -323,11 +326,12 @@ struct BuildParams {
 };
 // start-of-frame initialisation, one launch
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
-// scan1p_ctl: control words of the single-pass scan of the query-sort histogram (large frames), or null: the multi-launch scan
+// scan1p_ctl: control words of the single-pass scan of the query-sort histogram (large frames; the caller has checked
+// scan_1p_applies), or null: the multi-launch scan; scan1p_fault: see launch_scan_counts_1p
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr,
-                  unsigned long long* scan1p_ctl = nullptr);
+                  unsigned long long* scan1p_ctl = nullptr, unsigned* scan1p_fault = nullptr);
 int build_tile_count(const GridView grids[kKinds], int n_slots);  // bins of the query counting sort (tiles, or cells of tiles)
 // cap + compaction (after the flag scan)
 // refresh_gate != null: the launch also stands for the refresh alternative (see CompactArgs); tiles > 0: `sv.scan` holds
@@ -375,8 +379,13 @@ struct VoxelWork {           // scratch, sized by the caller (see voxel_table_si
   unsigned long long* host_seg;
   unsigned long long host_seq;
   double* out[2][3];         // (x, y, z) of the down-sampled cloud per segment
+  // k_vox_emit's look-back scan: blocks take their places from blockIdx while the whole grid is resident on this device
+  // (vox_emit_resident_blocks), from a start ticket otherwise; fault: pinned host word raised if the bounded look-back times out
+  int use_ticket;
+  unsigned* fault;
 };
 size_t voxel_table_size(size_t n);
+int vox_emit_resident_blocks(int device_cus);   // blocks of k_vox_emit the device holds at once, with a margin (tl_submap.hip)
 void launch_transform_to_soa(const double* aos, size_t n, const double M[16], double* ox, double* oy, double* oz,
                              hipStream_t s);
 void launch_transform_to_soa2(const double* aos, size_t n, const double M[16], double* ax, double* ay, double* az,
@@ -483,8 +492,8 @@ struct SolveFinish {
   WeightParams wp[kMaxOuterInLaunch];   // per outer iteration
   HostMirror hm[kMaxOuterInLaunch];
 };
-void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s, bool v1 = false);
+void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, int max_sweeps,
+                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s);
 // (gated on st->done: see k_weights)
 void launch_weights(const CorrView& cv, const SlotView& sv, const WeightParams& wp, double* partial /*[blocks*8]*/,
                     int blocks, const GnState* st, hipStream_t s);

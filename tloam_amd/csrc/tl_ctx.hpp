@@ -161,9 +161,10 @@ struct tloam_ctx {
   DBuf<double> fit_x, fit_y, fit_z;  // getFitnessScore scratch
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned long long> scan1p_q;   // control words of the single-pass scan of the query-sort histogram, zero when allocated
+  bool scan1p_q_use = false;           // ... and whether this frame's query sort takes it (outer_reserve: scan_1p_applies on this device)
   bool grids_ahead = false;    // the search grids in `grids` were built over the registered targets at hand-over (tloam_set_target_frame) and are still theirs
   bool no_grid_ahead = false;  // TLOAM_NO_GRID_AHEAD: the grids are always built inside scanMatching (A/B, tests)
-  bool no_scan_1p = false;     // TLOAM_NO_SCAN_1P: the multi-launch scans for the large tables too (A/B, tests)
+  bool no_scan_1p = false;     // set after a single-pass look-back scan timed out (blocks not co-resident): the multi-launch scans from then on
   DBuf<unsigned char> flagb;   // SlotView::flagb
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
   bool fused_large = false;    // TLOAM_FUSED_LARGE: a GN iteration of a large set as ONE launch (k3_sweep_step; sharded + mailbox: sweep, exchange
@@ -194,12 +195,8 @@ struct tloam_ctx {
   bool no_persistent_solve = false;  // TLOAM_NO_PERSISTENT_SOLVE, or set by tloam_scan_match after an in-launch hand-over timed out:
                                      // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
   bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
-  bool solve_v1 = false;           // TLOAM_SOLVE_V1: round 3's one-launch Solve (k_solve_small: ONE consumer wave for the grid) instead of k_solve_all
-  bool stage_memcpy = false;       // TLOAM_STAGE_MEMCPY: staged host clouds go up with hipMemcpyAsync, never with the copy kernel (A/B, tests)
-  bool submap_copy = false;        // TLOAM_SUBMAP_COPY: tloam_submap_update uploads the new scan's clouds with a copy instead of reading the pinned staging in place (A/B, tests)
-  bool sync_set_source = false;    // TLOAM_SYNC_SET_SOURCE: tloam_set_source_frame as four pageable copies + a stream synchronisation (A/B)
   int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
-  int device_cus = 0;              // multiProcessorCount of the device (k_solve_small needs all its blocks resident at once)
+  int device_cus = 0;              // multiProcessorCount of the device (k_solve_all and the single-pass scans need all their blocks resident at once)
   double* h_bbox = nullptr;        // pinned, device-visible: [4][64][6] bounding-box rows
   double* h_bbox_dev = nullptr;
   // bounds of the registered target clouds, taken at hand-over (set_target*: the call synchronises anyway), so that
@@ -207,10 +204,15 @@ struct tloam_ctx {
   double tgt_box[tl::kKinds][6];
   bool tgt_box_valid[tl::kKinds] = {false, false, false, false};
   double wait_us = 0.0;            // time the host spent waiting for the device in the current scan_match
-  bool no_host_mirror = false;     // TLOAM_NO_HOST_MIRROR: read the state back with a copy + stream synchronisation
   tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
   tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;
+  // fault words a kernel raises when a bounded in-launch wait runs out (pinned, device-visible; see check_device_faults):
+  // [0] single-pass look-back scan (tl_nn.hip), [1] k_vox_emit's look-back (tl_submap.hip)
+  unsigned* h_fault = nullptr;
+  unsigned* h_fault_dev = nullptr;
+  bool scan1p_retried = false;     // tloam_scan_match has re-run a frame after a look-back scan timed out (once per context)
+  bool vox_ticket = false;         // set after k_vox_emit's look-back timed out: its blocks take start tickets from then on
   DBuf<double> src_pack;                        // the registered Frame's four source clouds in one piece (tloam_set_source_frame)
   // pinned staging of tloam_set_source_frame: the borrowed host clouds are copied here (two halves, used alternately; an
   // event per half says when the device has read it) and go to HBM with ONE asynchronous copy -- the call returns without
@@ -240,7 +242,6 @@ struct tloam_ctx {
   DBuf<unsigned long long> mbox_ctr;
   DBuf<int> k3_ticket;
   DBuf<unsigned long long> k3_span;    // K3Step::span: streaming span of the one-launch GN iterations (100 MHz ticks, launches)
-  DBuf<unsigned long long> k3_bcast;   // candidate-pose broadcast of the one-launch Solve (k_solve_small)
   // scanMatching host state
   bool active = false;
   bool have_build = false;   // the compact set matches build_x
@@ -274,9 +275,12 @@ struct tloam_ctx {
 // pinned result slots: one per outer iteration of a device-driven frame (slot 0: stepwise API); the last one also
 // carries the sizes of a submap update back (tl_api_submap.hip)
 constexpr int kMirrorSlots = 8;
+constexpr int kFaultWords = 16;
+constexpr int kFaultScan1p = 0, kFaultVoxEmit = 1;   // tloam_ctx::h_fault
 
 namespace tlh {
 // tl_api.hip
+int check_device_faults(tloam_ctx* c);
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
 int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]);
 int stage_and_upload(tloam_ctx* c, const double* const parts[], const size_t counts[], int nparts, double* dev_dst, size_t offs[]);

@@ -234,7 +234,7 @@ __device__ __forceinline__ void fetch_spec(const double* base, int stride, int j
 #undef ld2o
 }
 // cost_out: the lane's two costs, for the wave that keeps its correspondences across Solves and ends the outer iteration
-// itself (k_solve_small); untouched (the caller's zeros) where the lane has no factor.
+// itself (k_solve_all); untouched (the caller's zeros) where the lane has no factor.
 template <int RES, bool NT>
 __device__ __forceinline__ void consume(const Rt& T, const CorrSeg& seg, int j, int n, const ChunkBuf<RES>& b, Acc& a,
                                         double2* cost_out = nullptr) {
@@ -364,9 +364,9 @@ struct SingleWork {
 };
 __device__ __forceinline__ SingleWork single_work_of(const CorrView& cv, int cap0, int gw, int lane) {
   SingleWork wk{-1, 0};
-  // wave 0 of the grid holds no chunk: in the one-launch Solve (k_solve_small) it is the consumer of the rows -- it folds
-  // them and takes the minimiser's step while the others evaluate -- and the one-launch-per-iteration kernels map the same
-  // way so that all of them add the same waves up in the same rows
+  // wave 0 of the grid holds no chunk (in the one-launch Solve the lead's stepper has the state, the set sizes and the
+  // result slots to look after), and the one-launch-per-iteration kernels map the same way so that all of them add the
+  // same waves up in the same rows
   int g = gw - 1;
   if (g < 0) return wk;
   const int n0 = cap0 / kChunk;   // (preloaded: the planar waves need nothing else)
@@ -1086,8 +1086,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
 #endif
 }
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s) {
-  static const bool no_tagged = getenv("TLOAM_NO_TAGGED_ROWS") != nullptr;   // A/B knob: ticket hand-over for every grid size
-  const int tagged = (grid <= kTaggedRows && !no_tagged) ? 1 : 0;
+  const int tagged = grid <= kTaggedRows ? 1 : 0;
   hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
                      cv.seg_n, partials, ticket, cv);
 }
@@ -1328,68 +1327,6 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
   return ok_all;
 }
 
-// ---- small Solves in ONE launch ---------------------------------------------------------------------------------------------
-// A KITTI-size Solve is a chain sweep -> rows -> fold -> 6x6 step -> next pose, one to five times; as one launch per link
-// it pays a launch boundary (~1.5 us of dispatch plus the ramp of a dozen blocks, plus every wave re-reading its chunk) per
-// GN iteration, and the host must guess how many links to enqueue (planned_sweeps_for: learned budgets; a frame that breaks the
-// guess costs a round trip and a second pass over the frame's launch list).  For a grid of <= kTaggedRows blocks -- all
-// resident at once on a 256-CU part -- the chain runs inside one launch instead: every wave keeps its chunk of
-// correspondences in registers; per GN iteration the blocks post their rows (k3_post_row_tagged), wave 0 of block 0 -- which
-// holds no chunk (single_work_of) -- polls and folds them, runs the minimiser step (gn_consume) and publishes the candidate pose:
-// two 64-byte segments (seven words + check word, as the rows) that the other waves poll; a control word says what comes next.
-// Tags carry the launch counter and the hand-over number, so nothing has to be reset between launches.  The same sweep
-// arithmetic per wave, the same fold order, the same step as the one-launch-per-iteration kernels.
-// max_sweeps: evaluations a Solve of this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
-constexpr int kBcastWords = 16;
-// The verdict that ends an outer iteration (3 / 4) follows the "Solve is over" message (2) without anything from the other
-// waves in between -- a wave that is slow to look (the GPU shared with other streams) would find the second message where it
-// expects the first and wait for ever: it has a place of its own.  Every other message is answered by a row of every block
-// before the next one is written.
-#ifndef TLOAM_BCAST_SECOND
-#define TLOAM_BCAST_SECOND 32
-#endif
-constexpr int kBcastSecond = TLOAM_BCAST_SECOND;   // words
-// verdict: 1 go on with this Solve | 2 the Solve is over | 3 next outer iteration in this launch, from this pose | 4 leave |
-// 5 hand-over failed, leave
-__device__ __forceinline__ void solve_publish_pose(unsigned long long* __restrict__ bcast, const GnState* sm /* LDS */, unsigned long long tag,
-                                                   int verdict, int lane) {
-  if (lane < kBcastWords) {
-    const int sgm = lane >> 3, pos = lane & 7, v = sgm * 7 + pos;   // values 0..8: R, 9..11: t, 12: control, 13: spare
-    unsigned long long w = 0ull;
-    if (pos < 7) {
-      if (v < 9) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.r[v]);
-      else if (v < 12) w = (unsigned long long)__double_as_longlong(sm->Rt_eval.t[v - 9]);
-      else if (v == 12) w = (unsigned long long)verdict;
-    }
-    const unsigned long long x = xor8(w);
-    if (pos == 7) w = check_mix(tag) ^ x;
-    __hip_atomic_store(bcast + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// every lane reads all sixteen words (uniform addresses: one transaction per instruction) until both segments check.
-// Returns the control word (see solve_publish_pose), 0: timed out.
-__device__ __forceinline__ int solve_wait_pose(const unsigned long long* __restrict__ bcast, unsigned long long tag, Rt& T) {
-  unsigned long long w[kBcastWords];
-  const unsigned long long mtag = check_mix(tag);
-  const unsigned long long t0 = wall_clock64();
-  for (unsigned spins = 1;; ++spins) {
-#pragma unroll
-    for (int i = 0; i < kBcastWords; ++i) w[i] = __hip_atomic_load(bcast + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long x0 = w[0], x1 = w[8];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) { x0 ^= w[i]; x1 ^= w[8 + i]; }
-    if (x0 == mtag && x1 == mtag) break;
-    if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) return 0;
-    __builtin_amdgcn_s_sleep(1);
-  }
-#pragma unroll
-  for (int v = 0; v < 12; ++v) {
-    const double d = __longlong_as_double((long long)w[(v / 7) * 8 + (v % 7)]);
-    if (v < 9) T.r[v] = d; else T.t[v - 9] = d;
-  }
-  return (int)w[8 + 5];   // value 12 = segment 1, position 5
-}
-
 // ---- the consumer wave's end of an outer iteration (SolveFinish): sums -> state, loop decisions, re-arm, result slot -------
 // fin[0..3]: the kinds' cost sums of the Solve's last evaluation, fin[4]: weights out of range (poll_fold_ext); nseg: the set.
 // Returns 3: the loop goes on with an unchanged pose -- this launch runs the next outer iteration too | 4: leave (the loop
@@ -1433,247 +1370,34 @@ __device__ __forceinline__ int finish_by_consumer(GnState* st, GnState* sm /* LD
   return next;
 }
 
-__global__ __launch_bounds__(256, 1) void k_solve_small(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
-                                                        GnState* __restrict__ st, const int* __restrict__ seg_n,
-                                                        double* __restrict__ partials, int* __restrict__ ticket,
-                                                        unsigned long long* __restrict__ bcast, CorrView cv, SolvePrep prep,
-                                                        int* __restrict__ seg_n_out, SolveFinish F) {
-  __shared__ double red[4][32];
-  __shared__ double s_scr[32];
-  __shared__ double s_rows[kTaggedRows * 28];
-  __shared__ double s_ext[64 * 3];
-  static_assert(kTaggedRows * 4 <= 64, "one lane of the consumer per wave of the grid");
-  __shared__ double s_fin[8];
-  __shared__ double s_sh[16];
-  __shared__ double tot[kReduceBuf];
-  __shared__ GnState s_in;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * 4 + wave;
-  const bool consumer = gw == 0;   // (holds no chunk: single_work_of)
-  // test hook (TLOAM_DEBUG_FAIL_HANDOVER, bit 16 of the argument): the consumer waits for rows that nobody posts, i.e. the
-  // launch behaves as if one of its blocks had never been scheduled -- the bounded wait, OS_COMM_ERROR and the host's
-  // fallback to one launch per GN iteration are exercised by tests/test_gpu_parity.py
-  const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;
-  max_sweeps &= 0xffff;
-  const bool self_prep = prep.sv.flagb != nullptr;
-  unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
-#ifdef TLOAM_STEP_PROFILE
-  // development aid (scripts/solve_profile.py): wall-clock (100 MHz) stamps of the consumer wave and of one producer wave
-  // (block gridDim/2) per GN iteration, in the spare part of the row buffer
-  unsigned long long* const prof = reinterpret_cast<unsigned long long*>(partials) + 1024;
-  const bool prof_p = (int)blockIdx.x == (int)gridDim.x / 2 && wave == 0 && lane == 0;
-#define TL_PROF(cond, slot) if (cond) prof[(slot)] = wall_clock64();
-#else
-#define TL_PROF(cond, slot)
-#endif
-  // Hand-overs of a launch -- rows to the consumer, poses / verdicts from it -- are numbered in the order they happen (both
-  // sides count alike): rows of GN iteration: tag0 | step, the pose that answers them: tag0 | step + 1.
-  if (consumer) {
-    // =================== wave 0 of block 0: folds the rows, takes the minimiser's step, ends the outer iteration ===================
-    FlagBytes fb[kKinds];
-    if (self_prep) {
-#pragma unroll
-      for (int k = 0; k < kKinds; ++k) load_flag_bytes(prep.sv.flagb, k, lane, fb[k]);
-    }
-    {
-      constexpr int kWords = (int)(sizeof(GnState) / 8);
-      for (int w = lane; w < kWords; w += 64)
-        reinterpret_cast<unsigned long long*>(&s_in)[w] = reinterpret_cast<const unsigned long long*>(st)[w];
-    }
-    if (lane < 32) red[0][lane] = 0.0;
-    const unsigned long long tag0 = (*epoch + 1ull) << 8;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    int oi = F.first_iter;
-    // device-driven loop with the finish in the launch: nothing to do once the loop has ended, or when an earlier launch has
-    // run this outer iteration already (every wave of the grid reads the same two words: no block of this launch writes
-    // them before every block has posted a row, i.e. has read them)
-    if (F.enabled && (s_in.stop != 0 || s_in.next_outer != oi)) return;
-    int nseg[kKinds];
-    {
-      const bool build = self_prep && (!prep.run_build || *prep.run_build != 0);
-      if (build) {
-#pragma unroll
-        for (int k = 0; k < kKinds; ++k) nseg[k] = kind_set_of(prep, cv, k, lane, fb[k]).total;
-        if (lane < kKinds) seg_n_out[lane] = lane == 0 ? nseg[0] : (lane == 1 ? nseg[1] : (lane == 2 ? nseg[2] : nseg[3]));
-        if (lane < 6) {   // the set is built at this pose (k_prepare_small's x_build = x)
-          s_in.x_build[lane] = s_in.x[lane];
-          st->x_build[lane] = s_in.x[lane];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < kKinds; ++k) nseg[k] = seg_n[k];
-      }
-    }
-    if (s_in.done) return;            // a Solve that has already ended (uniform over the grid)
-    TL_PROF(lane == 0, 0)
-    unsigned long long step = 0;
-    int oi_now = oi;
-    auto comm_failed = [&](unsigned long long* where, unsigned long long tag) {
-      if (lane == 0) {
-        s_in.done = 1; s_in.comm_error = 1;
-        st->done = 1; st->comm_error = 1;
-        if (F.enabled) {
-          s_in.incomplete = OS_COMM_ERROR;
-          st->incomplete = OS_COMM_ERROR;
-          st->stop = 1; st->run_build = 0; st->run_refresh = 0;
-        }
-        *epoch = tag0 >> 8;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (F.enabled) {
-        mirror_wave(&s_in, F.hm[oi_now], lane, (int)OS_COMM_ERROR);
-        for (int j = oi_now + 1; j < F.n_iter; ++j) mirror_wave(&s_in, F.hm[j], lane, (int)OS_SKIPPED);
-      }
-      solve_publish_pose(where, &s_in, tag, 5, lane);
-    };
-    for (;;) {   // outer iterations run by this launch (exactly one unless F.enabled)
-      int verdict = 2;
-      for (int it = 0;; ++it) {
-        __syncthreads();   // the block's other waves have put their sums into LDS
-        k3_post_row_tagged(partials, red, tag0 | step);
-        TL_PROF(lane == 0, 8 + it * 8 + 0)
-        const bool ok = poll_fold_tagged(partials, (int)gridDim.x, (tag0 | step) ^ sabotage, s_rows, tot, lane);
-        TL_PROF(lane == 0, 8 + it * 8 + 1)
-        if (!ok) {  // a block of the grid never posted: stop the Solve and report OS_COMM_ERROR
-          comm_failed(bcast, tag0 | (step + 1ull));
-          return;
-        }
-        gn_consume(st, tot, lane, &s_in, s_scr);
-        TL_PROF(lane == 0, 8 + it * 8 + 2)
-        verdict = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
-        solve_publish_pose(bcast, &s_in, tag0 | (step + 1ull), verdict, lane);
-        TL_PROF(lane == 0, 8 + it * 8 + 3)
-        step += 2ull;
-        if (verdict != 1) break;
-      }
-      // the finish sums of the Solve's last evaluation (the waves' segments behind the rows of hand-over step - 2), while
-      // the other waves take in the verdict
-      if (F.have_wp && !poll_fold_ext(partials, (int)gridDim.x * 4, tag0 | (step - 2ull), s_ext, s_fin, lane)) {
-        comm_failed(bcast + kBcastSecond, tag0 | step);   // (where the other waves look next, if they look at all)
-        return;
-      }
-      if (!F.enabled) {
-        // the launch ends with the Solve; a finish kernel that follows takes its sums from the state (fin_valid)
-        if (F.have_wp && lane < 5) {
-          const double v = s_fin[lane];
-          if (lane < 4) st->fin_sum[lane] = v; else st->fin_bad = v;
-        }
-        if (lane == 0) { st->fin_valid = F.have_wp ? 1 : 0; *epoch = tag0 >> 8; }   // (plain stores: read by the next launch)
-        return;
-      }
-      const int next = finish_by_consumer(st, &s_in, F, oi, s_fin, nseg, s_sh, lane);
-      solve_publish_pose(bcast + kBcastSecond, &s_in, tag0 | step, next, lane);   // (the pose: exp(x), what the re-armed minimiser starts from)
-      step += 1ull;
-      if (next != 3) {
-        if (lane == 0) *epoch = tag0 >> 8;
-        return;
-      }
-      oi += 1;
-      oi_now = oi;
-    }
-  }
-  // =================== every other wave: one chunk of correspondences, in registers for the whole launch ===================
-  ChunkData pre;
-  const SingleWork wk = single_work_of(cv, cap0, gw, lane);
-  single_fetch(cv, seg0, stride0, wk, pre);   // requested in the wave's first instructions
-  // (with SolvePrep: speculatively -- right if the set is kept or refreshed; a set that is rebuilt is fetched from the slots)
-  FlagBytes fbytes;
-  if (self_prep && wk.kind >= 0) load_flag_bytes(prep.sv.flagb, wk.kind, lane, fbytes);
-  const unsigned long long tag0 = (*epoch + 1ull) << 8;   // (read by every block before it can change: see above)
-  int oi = F.first_iter;
-  if (F.enabled && (st->stop != 0 || st->next_outer != oi)) return;
-  int n_mine = 0;
-  int slot[2] = {0, 0};
-  if (wk.kind >= 0) {
-    const bool build = self_prep && (!prep.run_build || *prep.run_build != 0);
-    if (build) {
-      n_mine = self_compact(prep, cv, wk, lane, fbytes, pre, slot);
-    } else {
-      n_mine = seg_n[wk.kind];
-      if (self_prep) {
-        slots_of_chunk(prep, cv, wk, n_mine, slot);
-        if (prep.run_refresh && *prep.run_refresh != 0) self_refresh(prep, cv, wk, n_mine, slot, pre);
-      }
-    }
-  }
-  if (st->done) return;            // a Solve that has already ended (uniform over the grid)
-  Rt T = st->Rt_eval;
-  unsigned long long step = 0;
-  for (;;) {
-    int verdict;
-    double2 last_cost = double2{0.0, 0.0};
-    for (int it = 0;; ++it) {
-      Acc a;
-      last_cost = double2{0.0, 0.0};
-      sweep_single_n(cv, n_mine, T, wk, pre, a, &last_cost);
-      TL_PROF(prof_p, 64 + it * 8 + 1)
-      const double wtot = wave_reduce_acc(a, lane);
-      if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
-      __syncthreads();
-      k3_post_row_tagged(partials, red, tag0 | step);     // (wave 0 of the block; in block 0 that is the consumer)
-      if (F.have_wp) {   // this chunk's part of the finish sums, behind the row (see post_ext_segment)
-        double cs = last_cost.x + last_cost.y;   // (a lane without a second / any factor holds 0 there)
-        double bad = 0.0;
-        if (wk.kind >= 0) {
-          const bool two = single_chunk_of(wk.kind) == kChunk;
-          if (wk.j < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.x)) bad += 1.0;
-          if (two && wk.j + 1 < n_mine && weight_out_of_range(F.wp[oi], wk.kind, last_cost.y)) bad += 1.0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          cs += __shfl_down(cs, off, 64);
-          bad += __shfl_down(bad, off, 64);
-        }
-        post_ext_segment(partials, gw, cs, bad, wk.kind, tag0 | step, lane);
-      }
-      TL_PROF(prof_p, 64 + it * 8 + 2)
-      verdict = solve_wait_pose(bcast, tag0 | (step + 1ull), T);
-      TL_PROF(prof_p, 64 + (it + 1) * 8 + 0)
-      step += 2ull;
-      if (verdict != 1) break;
-    }
-    if (!F.enabled || verdict != 2) return;
-    // ---- the Solve is over: this chunk's new GNC weights (updateWeight, :858-876) from the costs of its last evaluation,
-    //      while the consumer ends the iteration
-    double2 w_new = pre.w;
-    if (wk.kind >= 0) {
-      const bool two = single_chunk_of(wk.kind) == kChunk;
-      if (wk.j < n_mine) {
-        w_new.x = refreshed_weight(F.wp[oi], wk.kind, last_cost.x, pre.w.x, prep.sv.w_src, slot[0]);
-      }
-      if (two && wk.j + 1 < n_mine) {
-        w_new.y = refreshed_weight(F.wp[oi], wk.kind, last_cost.y, pre.w.y, prep.sv.w_src, slot[1]);
-      }
-    }
-    const int next = solve_wait_pose(bcast + kBcastSecond, tag0 | step, T);
-    step += 1ull;
-    if (next != 3) return;
-    // ---- the next outer iteration on the same correspondences: new captured weights, zeroed side-channel slots (k_refresh)
-    if (wk.kind >= 0) {
-      const CorrSeg& seg = cv.k[wk.kind];
-      const bool two = single_chunk_of(wk.kind) == kChunk;
-      pre.w = w_new;
-      if (wk.j < n_mine) { seg.w[wk.j] = w_new.x; seg.cost[wk.j] = 0.0; }
-      if (two && wk.j + 1 < n_mine) { seg.w[wk.j + 1] = w_new.y; seg.cost[wk.j + 1] = 0.0; }
-    }
-    oi += 1;
-  }
-}
-// ---- the same Solve with EVERY block consuming (round 4) --------------------------------------------------------------------
-// k_solve_small pays two cross-CU hand-overs per GN iteration: rows -> the consumer wave (~1.9 us), candidate pose -> the other
-// waves (~1.1-1.5 us).  Here every block is its own consumer: every block posts its row, wave 0 of EVERY block polls all the
-// rows, folds them in the same order and runs the same step on its own LDS image of the state -- bit-identical in all blocks,
-// the inputs are -- and hands the candidate pose to its block's other waves through LDS and a barrier.  One cross-CU exchange
-// per GN iteration instead of two; the minimiser's step is executed sixteen times side by side, which costs nothing (the
-// other waves of those CUs would be waiting for it anyway).  Block 0 ("lead") alone writes the device state, the compact set's
-// sizes and the result slots.
+// ---- small Solves in ONE launch, every block its own consumer -----------------------------------------------------------------
+// A KITTI-size Solve is a chain sweep -> rows -> fold -> 6x6 step -> next pose, one to five times; as one launch per link
+// it pays a launch boundary (~1.5 us of dispatch plus the ramp of a dozen blocks, plus every wave re-reading its chunk) per
+// GN iteration, and the host must guess how many links to enqueue (planned_sweeps_for: learned budgets; a frame that breaks the
+// guess costs a round trip and a second pass over the frame's launch list).  For a grid of <= kTaggedRows blocks -- all
+// resident at once on a 256-CU part -- the chain runs inside one launch instead: every wave keeps its chunk of
+// correspondences in registers; per GN iteration every block posts its row (k3_post_row_tagged), wave 0 of EVERY block polls
+// all the rows, folds them in the same order and runs the same minimiser step (gn_consume) on its own LDS image of the state
+// -- bit-identical in all blocks, the inputs are -- and hands the candidate pose to its block's other waves through LDS and
+// a barrier.  One cross-CU exchange per GN iteration (round 3's form, one consumer wave for the whole grid publishing the pose
+// to the others, paid two: 8.2-8.5 against 6.8-7.7 us per iteration; removed in round 5); the step is
+// executed sixteen times side by side, which costs nothing (those CUs would be waiting for it anyway).  Block 0 ("lead")
+// alone writes the device state, the compact set's sizes and the result slots.  Tags carry the launch counter and the
+// hand-over number, so nothing has to be reset between launches.  The same sweep arithmetic per wave, the same fold order,
+// the same step as the one-launch-per-iteration kernels.
+// max_sweeps: evaluations a Solve of this launch may run (the stepwise API's budgets and the development knobs keep their meaning).
 // Rows are double-buffered by the parity of the hand-over number h: block A may post row h + 1 while block B is still reading
 // the rows of h; it cannot post h + 2 before B has posted h + 1, which B does only after it has read every row of h.  The waves'
 // finish-sum segments likewise.  Layout of `partials` (64-bit words): rows [2][kTaggedRows][32] at 0, segments [2][64][8] at 1024.
-// Wave 0 of block b >= 1 holds a chunk like the other waves (the chunk -> wave mapping, hence every sum, is k_solve_small's).
+// Wave 0 of block 0 holds no chunk, wave 0 of block b >= 1 holds one like the other waves (single_work_of).
 constexpr int kAllRowsParity = kTaggedRows * kAccStride;   // 512 words
 constexpr int kAllExtBase = 2 * kAllRowsParity;            // 1024
 constexpr int kAllExtParity = 64 * 8;                      // 512 words
+// (the stepper reads its own LDS message back: same wave, stores waited for)
+__device__ __forceinline__ bool next_is_failure(const double* s_msg) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return (int)s_msg[12] == 5;
+}
 __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__ seg0, int stride0, int cap0, int max_sweeps,
                                                       GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                       double* __restrict__ partials, int* __restrict__ ticket, CorrView cv, SolvePrep prep,
@@ -1692,17 +1416,23 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
   const bool stepper = wave == 0;            // the block's consumer: polls the rows, folds them, takes the minimiser's step
   const bool lead = blockIdx.x == 0;         // the block whose image of the state is the one written out
   const bool self_prep = prep.sv.flagb != nullptr;
-  const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;   // test hook, see k_solve_small
+  // test hook (TLOAM_DEBUG_FAIL_HANDOVER, bit 16 of the argument): the steppers wait for rows that nobody posts, i.e. the launch
+  // behaves as if one of its blocks had never been scheduled -- the bounded wait, OS_COMM_ERROR and the host's fallback to one
+  // launch per GN iteration are exercised by tests/test_gpu_parity.py
+  const unsigned long long sabotage = ((max_sweeps >> 16) & 1) ? (1ull << 40) : 0ull;
   max_sweeps &= 0xffff;
   unsigned long long* const epoch = reinterpret_cast<unsigned long long*>(ticket + 2);
 #ifdef TLOAM_STEP_PROFILE
+  // development aid (scripts/solve_profile2.py): wall-clock (100 MHz) stamps of the lead's stepper and of one producer wave
+  // (block gridDim/2) per GN iteration, in the spare part of the row buffer
   unsigned long long* const prof = reinterpret_cast<unsigned long long*>(partials) + 2048;
   const bool prof_c = lead && stepper && lane == 0;
   const bool prof_p = (int)blockIdx.x == (int)gridDim.x / 2 && wave == 1 && lane == 0;
-#undef TL_PROF
 #define TL_PROF(cond, slot) if (cond) prof[(slot)] = wall_clock64();
+#else
+#define TL_PROF(cond, slot)
 #endif
-  // ---- this wave's chunk, requested in its first instructions (speculatively with SolvePrep, see k_solve_small)
+  // ---- this wave's chunk, requested in its first instructions (with SolvePrep: speculatively -- right if the set is kept or refreshed; a set that is rebuilt is fetched from the slots)
   ChunkData pre;
   const SingleWork wk = single_work_of(cv, cap0, gw, lane);
   single_fetch(cv, seg0, stride0, wk, pre);
@@ -1868,7 +1598,17 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
       else if (lane < 12) s_msg[lane] = s_in.Rt_eval.t[lane - 9];
       else if (lane == 12) s_msg[12] = (double)next;
     }
-    if (!F.enabled) return;
+    if (!F.enabled) {
+      // (a Solve outside the device-driven loop, F.have_wp set: if the waves' finish-sum segments never arrived the lead still
+      //  has to say so -- st->fin_valid keeps its old value and the launch counter must advance, or the next launch would take
+      //  this one's stale rows and segments for fresh ones)
+      if (lead && stepper && next_is_failure(s_msg) && lane == 0) {
+        st->done = 1; st->comm_error = 1; s_in.done = 1; s_in.comm_error = 1;
+        st->fin_valid = 0;
+        *epoch = tag0 >> 8;
+      }
+      return;
+    }
     __syncthreads();
     const int next = (int)s_msg[12];
 #pragma unroll
@@ -1904,20 +1644,16 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
     oi += 1;
   }
 }
-void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, unsigned long long* bcast, int grid, int max_sweeps,
-                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s, bool v1) {
+void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, int max_sweeps,
+                        const SolvePrep* prep_or_null, int* seg_n, const SolveFinish* finish_or_null, hipStream_t s) {
   SolvePrep P;
   if (prep_or_null) P = *prep_or_null;
   else memset(&P, 0, sizeof(P));
   SolveFinish F;
   if (finish_or_null) F = *finish_or_null;
   else memset(&F, 0, sizeof(F));
-  if (v1)   // (TLOAM_SOLVE_V1, A/B and tests: one consumer wave for the whole grid -- round 3's k_solve_small)
-    hipLaunchKernelGGL(k_solve_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
-                       cv.seg_n, partials, ticket, bcast, cv, P, seg_n, F);
-  else
-    hipLaunchKernelGGL(k_solve_all, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
-                       cv.seg_n, partials, ticket, cv, P, seg_n, F);
+  hipLaunchKernelGGL(k_solve_all, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, max_sweeps, st,
+                     cv.seg_n, partials, ticket, cv, P, seg_n, F);
 }
 // The launch spin-waits between its blocks, so all of them must be resident at once: one block per CU (the consumer's step
 // wants ~400 registers: one wave per SIMD), i.e. grid <= the device's CU count -- 256 on an MI355X, fewer on a CU-masked or

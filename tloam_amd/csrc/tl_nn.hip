@@ -217,8 +217,11 @@ void launch_exclusive_scan_u64(const unsigned long long* in, unsigned long long*
 // scan + scan of the tile totals + add = three launches and two passes over the array.  Here ONE launch, one pass: a block
 // scans its tile, publishes the tile's total in a status word, looks back over the words of the blocks in front of it (a wave
 // reads 64 of them at a time) until it meets one that already carries its inclusive prefix, publishes its own, and emits its
-// elements with the prefix added.  At most one block per CU (scan_1p_applies), so every block is resident at once and a
-// block only ever waits for blocks that are running.  Status word: [63:62] 0 nothing |
+// elements with the prefix added.  At most one block per CU OF THIS DEVICE (scan_1p_applies looks at the context's CU count: a
+// partitioned or CU-masked part takes the multi-launch scan), so every block is resident at once and a block only ever waits
+// for blocks that are running; the wait is bounded all the same (~1 s of the wall clock, then the block raises Scan1p::fault --
+// a word in pinned host memory -- and goes on with what it has: the host discards the frame's result, switches the context to
+// the multi-launch scans and runs the frame again, tl_api.hip check_device_faults).  Status word: [63:62] 0 nothing |
 // 1 the tile's own total | 2 inclusive prefix, [61:32] the launch's epoch -- a word of an earlier launch reads as "nothing",
 // so the array is never cleared (it is zeroed when it is allocated) --, [31:0] the value: totals below 2^32, i.e. counts.
 // Tiles of 16 Ki elements (64 per thread, in registers): ~200 blocks for 3.2 M entries, all resident at once, so that the
@@ -229,6 +232,7 @@ constexpr int kTile1p = (kScanThreads / 64) * kRows1p * kScanRowElems;       // 
 struct Scan1p {
   unsigned long long* status;   // [tiles]
   unsigned epoch;               // 1 .. 2^30 - 1, different from the previous launch's on the same status array
+  unsigned* fault;              // pinned host word raised when the look-back timed out (null: nobody to tell)
 };
 // returns the block's place (tile index); ex / a as wave_scan_rows leaves them, *base = sum of everything in front of this wave
 __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict__ in, size_t n, const Scan1p& C,
@@ -237,9 +241,9 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
   __shared__ unsigned long long wave_tot[kScanThreads / 64];
   __shared__ unsigned long long s_prefix;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // The block's place is its index: the launcher only uses this kernel when the grid is at most one block per CU
-  // (scan_1p_applies), so every block is resident as soon as the device has room for it and nobody waits for a block that
-  // cannot start.  (Places handed out by an atomic counter -- the usual guard -- cost ~10 us here: ~200 returning atomics on
+  // The block's place is its index: the launcher only uses this kernel when the grid is at most one block per CU of the
+  // device in use (scan_1p_applies), so every block is resident as soon as the device has room for it and nobody waits for a
+  // block that cannot start.  (Places handed out by an atomic counter -- the usual guard -- cost ~10 us here: ~200 returning atomics on
   // one address are served one after the other at the memory side, ~50 ns each.)
   const int bid = (int)blockIdx.x;
   const size_t wbase = (size_t)bid * kTile1p + (size_t)wave * (kRows1p * kScanRowElems);
@@ -259,6 +263,8 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
       if (lane == 0) __hip_atomic_store(&C.status[0], (2ull << 62) | tag | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (lane == 0) __hip_atomic_store(&C.status[bid], (1ull << 62) | tag | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      unsigned spins = 0;
       for (int top = bid - 1;;) {   // lanes look at blocks top, top - 1, ..., top - 63
         const int p = top - lane;
         unsigned long long w = 0ull;
@@ -270,7 +276,14 @@ __device__ __forceinline__ int scan1p_tile(const unsigned long long* __restrict_
         // the nearest block that carries an inclusive prefix, provided every block nearer than it has published its total
         const int first_full = full ? __ffsll((long long)full) - 1 : 64;
         const unsigned long long need = first_full >= 63 ? ~0ull : ((2ull << first_full) - 1ull);
-        if ((have & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }   // somebody in the window is not there yet
+        if ((have & need) != need) {   // somebody in the window is not there yet
+          if ((++spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) {   // ~1 s: a block in front never started
+            if (lane == 0 && C.fault) { __hip_atomic_store(C.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __threadfence_system(); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
         unsigned long long v = (p >= 0 && lane <= first_full) ? (w & 0xffffffffull) : 0ull;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -345,11 +358,15 @@ static unsigned next_scan_epoch() {   // process-wide (contexts on different hos
 }
 size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
 // arrays of more than 1024 small tiles (the 1 M-class frames; smaller ones use the fused / two-launch forms) whose 16 Ki tiles
-// number at most 240 -- one block per CU with room to spare on a 256-CU part: every block resident at once (see scan1p_tile)
-bool scan_1p_applies(size_t n) { return (n + kScanTile - 1) / kScanTile > 1024 && (n + kTile1p - 1) / kTile1p <= 240; }
-void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, hipStream_t s) {
+// number at most 15/16 of the device's CUs -- one block per CU with room to spare (240 on a 256-CU MI355X; a CPX partition or
+// a CU-masked device reports fewer and gets the multi-launch scan): every block resident at once (see scan1p_tile)
+bool scan_1p_applies(size_t n, int device_cus) {
+  return (n + kScanTile - 1) / kScanTile > 1024 && (long long)((n + kTile1p - 1) / kTile1p) <= (long long)device_cus - device_cus / 16;
+}
+void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, unsigned* fault,
+                           hipStream_t s) {
   const size_t tiles = (n + kTile1p - 1) / kTile1p;
-  Scan1p C{ctl, next_scan_epoch()};
+  Scan1p C{ctl, next_scan_epoch(), fault};
   hipLaunchKernelGGL(k_scan_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, out, n, C);
 }
 
@@ -901,9 +918,10 @@ __global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState*
   build_sorted_block<1>(A, st, n_sorted, qrec, (int)blockIdx.x - nfin, lds_rows);
 }
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
-                                          unsigned long long* ctl, const int* cell_of_pt, const int* rank_of_pt, double4* gp, hipStream_t s) {
+                                          unsigned long long* ctl, unsigned* fault, const int* cell_of_pt, const int* rank_of_pt, double4* gp,
+                                          hipStream_t s) {
   const size_t tiles = (ncells_plus_1 + kTile1p - 1) / kTile1p;
-  Scan1p C{ctl, next_scan_epoch()};
+  Scan1p C{ctl, next_scan_epoch(), fault};
   hipLaunchKernelGGL(k_grid_scan_finalize_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, gs, cell_cnt, ncells_plus_1, cell_start, C);
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -912,7 +930,7 @@ void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long*
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate,
-                  unsigned long long* scan1p_ctl) {
+                  unsigned long long* scan1p_ctl, unsigned* scan1p_fault) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -938,7 +956,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     // the pose moves by centimetres.
     // (tile_cnt[0 .. ntiles] was zeroed by k_frame_init -- one launch less at the start of every frame)
     hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
-    if (scan1p_ctl && scan_1p_applies((size_t)ntiles + 1)) launch_scan_counts_1p(tile_cnt, tile_scan, (size_t)ntiles + 1, scan1p_ctl, s);
+    if (scan1p_ctl) launch_scan_counts_1p(tile_cnt, tile_scan, (size_t)ntiles + 1, scan1p_ctl, scan1p_fault, s);   // (the caller has checked scan_1p_applies)
     else launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
     hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
                        tile_fill, qrec);

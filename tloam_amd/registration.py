@@ -140,6 +140,7 @@ def load_library():
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
         "tloam_debug_se3": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
+        "tloam_debug_raise_fault": (C.c_int, [vp, C.c_int]),
         "tloam_submap_default_config": (None, [C.POINTER(SubmapConfig)]),
         "tloam_submap_init": (C.c_int, [vp, C.POINTER(SubmapConfig), dp, sz, dp, sz, dp, sz, dp, sz]),
         "tloam_submap_update": (C.c_int, [vp, dp, dp, sz, dp, sz, dp, sz, dp, sz]),
@@ -173,6 +174,7 @@ EXPORTED_SYMBOLS = (
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
     "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_k3_span", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
+    "tloam_debug_raise_fault",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
     "tloam_comm_mailbox_export", "tloam_comm_init_mailbox",
