@@ -135,6 +135,43 @@ def markdown(js):
     return "\n".join(lines)
 
 
+def relevant_flips(js=None):
+    """the (switch, alternative) pairs whose flip moved a pose by 1e-6 or more in the committed table"""
+    js = js or json.load(open(OUT_DEFAULT))
+    return [(r["switch"], r["alternative"]) for r in js["rows"].values() if r["relevant_to_1e-6_claim"]]
+
+
+def poses_after_each_outer_iteration(unit, assume):
+    """{k: 4x4 pose after k outer iterations} of one run (the GNC schedule of iteration k does not depend on max_iterations:
+    the pose after k iterations is the result of the k-iteration run, which is what oracle/ref_harness/ref_dump.cpp records)"""
+    src, tgt, T_pred, cfg, omega, _ = load_unit(unit)
+    N = onp.NpRegistration(cfg, assume=assume)
+    for k in range(4):
+        N.set_source(k, src[k])
+        N.set_target(k, tgt[k])
+    trace = []
+    N.scan_match(T_pred, omega=omega, trace=trace)
+    return {t["iter"] + 1: onp.se3_exp(t["x"]) for t in trace}
+
+
+def diagnose(ref_poses, unit, flips_to_try=None, tol=1e-6):
+    """Which recalled behaviours are CONSISTENT with result poses of the real reference (tests/golden_ref/case_*.ref.txt "k"
+    lines: {k: 4x4}) on golden case `unit`?  Returns {"default" | "switch=alt": (consistent?, worst dt, worst dR)}.  With the
+    pin in hand this names the recollection to correct: the default must be consistent, every relevant alternative on a case
+    that is sensitive to it must not be."""
+    cands = [("default", None)] + [(f"{n}={a}", {n: a}) for n, a in (flips_to_try or relevant_flips())]
+    out = {}
+    for label, assume in cands:
+        mine = poses_after_each_outer_iteration(unit, assume)
+        wt = wr = 0.0
+        for k, T_ref in ref_poses.items():
+            T = mine.get(k, mine[max(mine)])      # (a run that converged early keeps its last pose)
+            dt, dr = pose_delta(T, np.asarray(T_ref, float))
+            wt, wr = max(wt, dt), max(wr, dr)
+        out[label] = (bool(wt < tol and wr < tol), wt, wr)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=200)

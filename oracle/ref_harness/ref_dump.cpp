@@ -96,6 +96,24 @@ void Solve(const Solver::Options& options, Problem* problem, Solver::Summary* su
     std::fprintf(g_solve_log, "s %d %d initial_cost %.17g final_cost %.17g successful %d unsuccessful %d termination %d\n", g_run,
                  g_call, summary->initial_cost, summary->final_cost, summary->num_successful_steps,
                  summary->num_unsuccessful_steps, static_cast<int>(summary->termination_type));
+    // The quantities that DECIDE the recalled upstream behaviours the pose depends on (oracle/oracle_np.py ASSUMED_UPSTREAM;
+    // tests/golden/assumption_sensitivity.json lists which ones move a pose by more than 1e-6 when flipped), by name -- "q" lines:
+    //   residual_blocks / residuals    dist2_squared: registration.cpp:536 compares distance2[0] with 0.2 -- with squared distances
+    //                                   (the assumption) more sphere blocks survive than with plain distances
+    //   residual_evaluations / jacobian_evaluations   slot_after_solve: one cost sweep more than 1 + candidates means the minimiser
+    //                                   evaluates once more after its loop, i.e. the side-channel slots hold the final state's costs;
+    //                                   evaluate_on_add cannot be seen from inside Solve -- it shows as initial_cost of the NEXT
+    //                                   outer iteration's Solve (the weights follow mu, which follows the slots at :1027-1033)
+    //   iterations / successful / unsuccessful        iteration_count: max_num_iterations = 4 bounds all of them, or the successful ones
+    //   termination / message          tolerance_exits: a Solve that ends by function / parameter tolerance with its last
+    //                                   iteration's step_is_successful = 0 and the state unchanged ("x" lines) tested the
+    //                                   tolerances before the step quality and did not apply the candidate
+    //   (loss_correction shows in the iteration-1 numbers of the "i" lines: step_norm, cost_change, relative_decrease)
+    std::fprintf(g_solve_log, "q %d %d residual_blocks %d residuals %d residual_evaluations %d jacobian_evaluations %d iterations %d "
+                 "successful %d unsuccessful %d termination %d\n", g_run, g_call, problem->NumResidualBlocks(), problem->NumResiduals(),
+                 summary->num_residual_evaluations, summary->num_jacobian_evaluations, static_cast<int>(summary->iterations.size()),
+                 summary->num_successful_steps, summary->num_unsuccessful_steps, static_cast<int>(summary->termination_type));
+    std::fprintf(g_solve_log, "m %d %d %s\n", g_run, g_call, summary->message.c_str());
     for (const IterationSummary& it : summary->iterations)
       std::fprintf(g_solve_log, "i %d %d %d cost %.17g change %.17g step_ok %d radius %.17g step_norm %.17g rel %.17g gmax %.17g valid %d\n",
                    g_run, g_call, it.iteration, it.cost, it.cost_change, it.step_is_successful ? 1 : 0, it.trust_region_radius,
