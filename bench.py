@@ -884,10 +884,10 @@ def cpu_baseline(head, side, args, kitti_seq=None):
     from oracle import binding as ob
     cores = os.cpu_count() or 1
 
-    def port(block, reps, bt, et):
+    def port(block, reps, bt, et, grain=None):
         cfg = block["cfg"]
         oc = ob.make_config(**{f: getattr(cfg, f) for f, _ in cfg._fields_ if f != "reserved0"})
-        O = ob.Oracle(oc, builder_threads=bt, eval_threads=et, fast=True)
+        O = ob.Oracle(oc, builder_threads=bt, eval_threads=et, fast=True, eval_grain=grain)
         O.set_frames(block["scene"].source, block["scene"].target)
         O.scan_match(block["scene"].T_pred)          # warm (thread pool, caches)
         t0 = time.perf_counter()
@@ -905,18 +905,25 @@ def cpu_baseline(head, side, args, kitti_seq=None):
         sweep[et] = {"value": round(v, 3), "ms_per_frame": round(ms, 3)}
     best = max(sweep, key=lambda t: sweep[t]["value"])
     res = {"value": sweep[best]["value"], "unit": "GN iter/s", "cores": best, "host_cores": cores, "kind": "port",
-           "build": "oracle/tloam_oracle.c, gcc -O3 -march=native -fopenmp (the cpu_baseline build; parity uses -ffp-contract=off)",
+           "build": "oracle/tloam_oracle.c, gcc -O3 -march=native -fopenmp -pthread (the cpu_baseline build; parity uses -ffp-contract=off)",
+           "threads": "builders: 4 OpenMP tasks (registration.cpp:976-1020 runs four std::async builders); evaluator: a persistent pool of "
+                      "`cores` threads (Ceres keeps one for the problem's context), static slices, cache-line-padded accumulators; a sweep "
+                      "uses min(cores, blocks / 256) of them (orc_set_eval_grain) -- Ceres has no such bound",
            "ms_per_frame": sweep[best]["ms_per_frame"], "workload": head["workload"],
-           "note": "value = the BEST of the thread sweep (its thread count in `cores`), not the reference's own thread shape -- at "
-                   "hardware_concurrency()/2 evaluator threads (`reference_thread_shape`) the port's OpenMP evaluator is far slower "
-                   "on this frame size; a reported baseline, not a target: the GPU/CPU ratio says nothing about kernel quality",
+           "note": "value = the BEST of the thread sweep (its thread count in `cores`); the reference's own thread shape (4 builder tasks, "
+                   "hardware_concurrency()/2 evaluator threads, registration.cpp:184,:1044) is `reference_thread_shape`, with the port's "
+                   "one-thread-per-256-blocks bound and, under `every_thread_every_sweep`, without it (all 128 threads woken for the 46 "
+                   "blocks each of a KITTI-cap frame: what an unbounded ParallelFor pays); labelled port, NOT Ceres.  A reported "
+                   "baseline, not a target: the GPU/CPU ratio says nothing about kernel quality",
            "single_thread": sweep[1], "thread_sweep": {str(t): sweep[t] for t in sweep},
            "sample": "scan_match of the headline frame pair x10 per thread count (1..32 evaluator threads, min(4, t) builder "
                      "threads) + one 1M frame + the first 8 frames of the KITTI-density sequence"}
     ref_et = max(1, cores // 2)
     if ref_et not in sweep:   # the reference's own shape: 4 builder tasks, Ceres on hardware_concurrency()/2 threads
         v, ms = port(head, 3 if small else 1, 4, ref_et)
-        res["reference_thread_shape"] = {"value": round(v, 3), "ms_per_frame": round(ms, 3), "cores": ref_et}
+        v0, ms0 = port(head, 3 if small else 1, 4, ref_et, grain=0)
+        res["reference_thread_shape"] = {"value": round(v, 3), "ms_per_frame": round(ms, 3), "cores": ref_et,
+                                         "every_thread_every_sweep": {"value": round(v0, 3), "ms_per_frame": round(ms0, 3)}}
     if side is not None and side is not head:
         v1, ms1 = port(side, 1, 4, min(32, max(1, cores // 2)))
         res["m1_frame"] = {"value": round(v1, 3), "ms_per_frame": round(ms1, 2), "cores": min(32, max(1, cores // 2))}

@@ -126,13 +126,17 @@ def _aos(x):
 class Oracle:
     """Same call surface as tloam_amd.HipRegistration, backed by the C restatement."""
 
-    def __init__(self, cfg: TlsConfig | None = None, builder_threads=1, eval_threads=1, fast=False):
+    def __init__(self, cfg: TlsConfig | None = None, builder_threads=1, eval_threads=1, fast=False, eval_grain=None):
         self.L = lib_fast() if fast else lib()   # fast: the cpu_baseline build (never the parity checker)
         self.cfg = cfg or make_config()
         self.h = C.c_void_p()
         rc = self.L.orc_create(C.byref(self.cfg), C.byref(self.h))
         assert rc == 0
         self.L.orc_set_threads(self.h, int(builder_threads), int(eval_threads))
+        if eval_grain is not None:   # residual blocks per evaluator thread at least (library default 256; 0: every thread, every sweep)
+            self.L.orc_set_eval_grain.argtypes = [C.c_void_p, C.c_int]
+            self.L.orc_set_eval_grain.restype = None
+            self.L.orc_set_eval_grain(self.h, int(eval_grain))
         self._n = {}
 
     def __del__(self):

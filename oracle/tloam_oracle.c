@@ -5,6 +5,7 @@
  * Every function cites the reference file:line (relative to /root/reference) it restates.
  * Plain C99 + libm (+ optional OpenMP for the timed CPU baseline).
  */
+#define _POSIX_C_SOURCE 200809L   /* posix_memalign, pthreads (the file is -std=c99) */
 #include "tloam_oracle.h"
 
 #include <float.h>
@@ -14,6 +15,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <pthread.h>
 #endif
 
 #define SOPHUS_EPS 1e-10 /* sophus/common.hpp:93-95 Constants<double>::epsilon() */
@@ -527,6 +529,7 @@ static int kind_res_type(int kind) {
 struct orc_ctx {
   tloam_tls_config cfg;
   int builder_threads, eval_threads;
+  int eval_grain;   /* residual blocks a thread of the evaluator gets at least (0: no lower bound), orc_set_eval_grain */
   double* src[4]; int nsrc[4];
   double* tgt[4]; int ntgt[4];
   double* tree_pts[4]; int tree_n[4]; /* deep copy at SetGeometry (registration.cpp:898-913) */
@@ -550,8 +553,7 @@ struct orc_ctx {
    * + the state after the iteration would show -- held against the REFERENCE's own Solves when tests/golden_ref/ exists */
   double trace[ORC_TRACE_ROWS][ORC_TRACE_COLS];
   int ntrace, nsolve;
-  void* eval_part; /* orc_normal[eval_part_n]: per-thread partial sums of the threaded evaluator */
-  int eval_part_n; /* normal equations at the accepted iterate when the last Solve returned */
+  struct orc_pool* pool; /* the evaluator's persistent worker threads (eval_threads > 1), see eval_pool_* */
 };
 
 static void rset_reserve(orc_rset* s, int cap) {
@@ -570,12 +572,15 @@ static void rset_free(orc_rset* s) {
   memset(s, 0, sizeof(*s));
 }
 
+static void eval_pool_destroy(orc_ctx* c);
+
 int orc_create(const tloam_tls_config* cfg, orc_ctx** out) {
   if (!cfg || !out) return TLOAM_E_INVALID;
   orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
   c->cfg = *cfg;
   c->builder_threads = 1;
   c->eval_threads = 1;
+  c->eval_grain = 256;
   *out = c;
   return TLOAM_OK;
 }
@@ -586,13 +591,20 @@ void orc_destroy(orc_ctx* c) {
     grid_free(&c->grid[k]);
     rset_free(&c->set[k]);
   }
-  free(c->eval_part);
+  eval_pool_destroy(c);
   free(c);
 }
 void orc_set_threads(orc_ctx* c, int builder_threads, int eval_threads) {
   c->builder_threads = builder_threads < 1 ? 1 : builder_threads;
-  c->eval_threads = eval_threads < 1 ? 1 : eval_threads;
+  eval_threads = eval_threads < 1 ? 1 : eval_threads;
+  if (eval_threads != c->eval_threads) eval_pool_destroy(c);   /* (re)created at the next evaluation */
+  c->eval_threads = eval_threads;
 }
+/* The evaluator's team for one sweep = min(eval_threads, blocks / grain), at least 1: Ceres itself has no such bound (every
+ * ParallelFor goes to all num_threads workers), and at the reference's shape -- 128 threads for the 5.9 k blocks of a KITTI-cap
+ * frame, 46 blocks each -- waking and collecting the team costs three times the work (19.5 against 6.2 ms per frame on the
+ * 256-core bench host with all 128 taking part, round 5).  grain = 0 switches the bound off. */
+void orc_set_eval_grain(orc_ctx* c, int blocks_per_thread) { c->eval_grain = blocks_per_thread < 0 ? 0 : blocks_per_thread; }
 static int set_cloud(double** dst, int* n_out, const double* xyz, size_t n) {
   free(*dst);
   *dst = NULL;
@@ -829,48 +841,150 @@ static void eval_block(int res_type, const double q[4], const double t[3], const
   }
 }
 
+/* ---- the evaluator's threads (Ceres: Solver::Options::num_threads, registration.cpp:1044 = hardware_concurrency()/2) ----------
+ * Ceres keeps ONE persistent thread pool for the life of the problem's context and hands every evaluation to it; so does this:
+ * eval_threads - 1 workers created once (orc_set_threads -> first evaluation), the calling thread is worker 0.  An evaluation
+ * publishes a job number; the workers -- spinning for a short while between the evaluations of a Solve, asleep on a condition
+ * variable otherwise -- each take a FIXED contiguous slice of the concatenated block list (static schedule), add into their own
+ * cache-line-padded accumulator, and count themselves out; the caller folds the accumulators in thread order.
+ * (Round 4 used one OpenMP region per evaluation: at the reference's thread shape -- 4 builder tasks, 128 evaluator threads on a
+ * 256-core host -- libgomp tore down and respawned 124 threads every time the team size changed between the two regions, and a
+ * frame took 136-223 ms against 7-8 ms at 4 threads; BENCH_r04.json reference_thread_shape.) */
+typedef struct {
+  orc_normal acc;
+  char pad[64 - sizeof(orc_normal) % 64];
+} orc_part;
+typedef struct orc_pool {
+  int n;                        /* threads incl. the caller */
+  int n_active;                 /* threads that take a slice of the current job (orc_set_eval_grain); the others skip it */
+  pthread_t* th;
+  orc_part* part;               /* [n], 64-byte aligned */
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  unsigned long job;            /* job number, advanced by the caller (atomic) */
+  int pending;                  /* workers still in the current job (atomic) */
+  int sleepers;                 /* workers asleep on cv (under mu) */
+  int stop;
+  /* the job */
+  orc_ctx* c;
+  double q[4], t[3];
+  int want_J;
+  int total;                    /* blocks of the four sets, concatenated */
+} orc_pool;
+typedef struct { orc_pool* P; int tid; } orc_worker_arg;
+
+static void eval_pool_slice(orc_pool* P, int tid) {
+  orc_ctx* c = P->c;
+  orc_normal* acc = &P->part[tid].acc;
+  memset(acc, 0, sizeof(*acc));
+  const long long lo = (long long)P->total * tid / P->n_active, hi = (long long)P->total * (tid + 1) / P->n_active;
+  long long base = 0;
+  for (int kind = 0; kind < 4; ++kind) {
+    orc_rset* s = &c->set[kind];
+    const int rt = kind_res_type(kind);
+    const long long a = lo > base ? lo - base : 0, b = (hi - base < s->n) ? hi - base : s->n;
+    for (long long j = a; j < b; ++j) {
+      double sc;
+      eval_block(rt, P->q, P->t, s->p + 3 * j, s->a + 3 * j, s->b + 3 * j, s->d[j], s->w[j], &sc, P->want_J, acc);
+      s->cost[j] = sc;
+      if (!c->prebuilt) c->resid[kind][s->idx[j]] = sc;
+    }
+    base += s->n;
+  }
+}
+static void* eval_pool_worker(void* argp) {
+  orc_worker_arg* arg = (orc_worker_arg*)argp;
+  orc_pool* P = arg->P;
+  const int tid = arg->tid;
+  free(arg);
+  unsigned long seen = 0;
+  int idle = 0;   /* this thread had no slice in the last job: it does not spin for the next one */
+  for (;;) {
+    /* wait for the next job: spin a little (the evaluations of a Solve follow each other within ~100 us), then sleep */
+    int spins = idle ? 20000 : 0;
+    while (__atomic_load_n(&P->job, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&P->stop, __ATOMIC_ACQUIRE)) {
+      if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+      pthread_mutex_lock(&P->mu);
+      P->sleepers++;
+      while (__atomic_load_n(&P->job, __ATOMIC_ACQUIRE) == seen && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+      P->sleepers--;
+      pthread_mutex_unlock(&P->mu);
+      spins = 0;
+    }
+    if (__atomic_load_n(&P->stop, __ATOMIC_ACQUIRE)) return NULL;
+    seen = __atomic_load_n(&P->job, __ATOMIC_ACQUIRE);
+    idle = tid >= P->n_active;      /* (written before the job number was advanced) */
+    if (idle) continue;
+    eval_pool_slice(P, tid);
+    __atomic_fetch_sub(&P->pending, 1, __ATOMIC_ACQ_REL);
+  }
+}
+static void eval_pool_destroy(orc_ctx* c) {
+  orc_pool* P = c->pool;
+  if (!P) return;
+  pthread_mutex_lock(&P->mu);
+  __atomic_store_n(&P->stop, 1, __ATOMIC_RELEASE);
+  pthread_cond_broadcast(&P->cv);
+  pthread_mutex_unlock(&P->mu);
+  for (int i = 1; i < P->n; ++i) pthread_join(P->th[i], NULL);
+  pthread_mutex_destroy(&P->mu);
+  pthread_cond_destroy(&P->cv);
+  free(P->th);
+  free(P->part);
+  free(P);
+  c->pool = NULL;
+}
+static void eval_pool_run(orc_ctx* c, const double q[4], const double t[3], int want_J, orc_normal* out) {
+  orc_pool* P = c->pool;
+  if (!P) {
+    P = (orc_pool*)calloc(1, sizeof(orc_pool));
+    P->n = c->eval_threads;
+    P->th = (pthread_t*)calloc((size_t)P->n, sizeof(pthread_t));
+    if (posix_memalign((void**)&P->part, 64, sizeof(orc_part) * (size_t)P->n) != 0) abort();
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+    P->c = c;
+    for (int i = 1; i < P->n; ++i) {
+      orc_worker_arg* a = (orc_worker_arg*)malloc(sizeof(orc_worker_arg));
+      a->P = P; a->tid = i;
+      if (pthread_create(&P->th[i], NULL, eval_pool_worker, a) != 0) { free(a); P->n = i; break; }   /* fewer threads: still correct */
+    }
+    c->pool = P;
+  }
+  memcpy(P->q, q, sizeof(P->q));
+  memcpy(P->t, t, sizeof(P->t));
+  P->want_J = want_J;
+  P->total = c->set[0].n + c->set[1].n + c->set[2].n + c->set[3].n;
+  P->n_active = P->n;
+  if (c->eval_grain > 0) {
+    const int by_work = P->total / c->eval_grain;
+    P->n_active = by_work < 1 ? 1 : (by_work < P->n ? by_work : P->n);
+  }
+  __atomic_store_n(&P->pending, P->n_active - 1, __ATOMIC_RELEASE);
+  __atomic_fetch_add(&P->job, 1ul, __ATOMIC_ACQ_REL);
+  pthread_mutex_lock(&P->mu);
+  if (P->sleepers > 0) pthread_cond_broadcast(&P->cv);
+  pthread_mutex_unlock(&P->mu);
+  eval_pool_slice(P, 0);
+  while (__atomic_load_n(&P->pending, __ATOMIC_ACQUIRE) != 0) __builtin_ia32_pause();
+  for (int th = 0; th < P->n_active; ++th) {   /* fold in thread order */
+    const orc_normal* a = &P->part[th].acc;
+    out->cost += a->cost;
+    for (int m = 0; m < 6; ++m) out->g[m] += a->g[m];
+    for (int m = 0; m < 36; ++m) out->H[m] += a->H[m];
+  }
+}
+
 /* One evaluator sweep over all blocks at x.  Side channel: `resid[kind][src]` for built sets
  * (registration.cpp:486 passes &edge_residuals_(i)), set.cost[] for pre-built sets. */
 static void evaluate(orc_ctx* c, const double x[6], int want_J, orc_normal* out) {
   double q[4], t[3];
   orc_se3_exp(x, q, t); /* the reference does this once per block (:22,:58,:98); hoisted */
   memset(out, 0, sizeof(*out));
-#ifdef _OPENMP
   if (c->eval_threads > 1) {
-    /* Ceres' evaluator threads (num_threads, registration.cpp:1044): ONE parallel region per evaluation over all
-     * four kinds, per-thread partial sums kept in the context (no allocation per call), folded in thread order */
-    const int nt = c->eval_threads;
-    if (c->eval_part_n < nt) {
-      free(c->eval_part);
-      c->eval_part = calloc((size_t)nt, sizeof(orc_normal));
-      c->eval_part_n = nt;
-    }
-    orc_normal* part = (orc_normal*)c->eval_part;
-#pragma omp parallel num_threads(nt)
-    {
-      const int tid = omp_get_thread_num();
-      memset(&part[tid], 0, sizeof(orc_normal));
-      for (int kind = 0; kind < 4; ++kind) {
-        orc_rset* s = &c->set[kind];
-        const int rt = kind_res_type(kind);
-        const int n = s->n;
-#pragma omp for schedule(static) nowait
-        for (int j = 0; j < n; ++j) {
-          double sc;
-          eval_block(rt, q, t, s->p + 3 * j, s->a + 3 * j, s->b + 3 * j, s->d[j], s->w[j], &sc, want_J, &part[tid]);
-          s->cost[j] = sc;
-          if (!c->prebuilt) c->resid[kind][s->idx[j]] = sc;
-        }
-      }
-    }
-    for (int th = 0; th < nt; ++th) {
-      out->cost += part[th].cost;
-      for (int m = 0; m < 6; ++m) out->g[m] += part[th].g[m];
-      for (int m = 0; m < 36; ++m) out->H[m] += part[th].H[m];
-    }
+    eval_pool_run(c, q, t, want_J, out);
     return;
   }
-#endif
   for (int kind = 0; kind < 4; ++kind) {
     orc_rset* s = &c->set[kind];
     int rt = kind_res_type(kind);

@@ -54,6 +54,7 @@ int orc_knn_hybrid_brute(const double* tgt_aos, int n, const double q[3], double
 int orc_create(const tloam_tls_config* cfg, orc_ctx** out);
 void orc_destroy(orc_ctx* c);
 void orc_set_threads(orc_ctx* c, int builder_threads, int eval_threads);
+void orc_set_eval_grain(orc_ctx* c, int blocks_per_thread);   /* evaluator team = min(eval_threads, blocks / grain); default 256, 0 = all */
 int orc_set_source(orc_ctx* c, int kind, const double* xyz_aos, size_t n);
 int orc_set_target(orc_ctx* c, int kind, const double* xyz_aos, size_t n);
 int orc_scan_match(orc_ctx* c, const double predict[16], const double* omega3, double result[16],

@@ -632,3 +632,36 @@ def test_hand_over_time_out_falls_back_to_one_launch_per_iteration(hip_module, m
     assert rc == 0 and time.perf_counter() - t < 0.25
     _assert_same_frame(want, _frame_fingerprint(H, T, st))
     H.close()
+
+
+def test_contexts_following_each_other_never_see_each_others_rows(hip_module):
+    """Round 5 regression.  The tagged hand-over rows of the one-launch Solve live in a device buffer; a context created right
+    after another one was destroyed is handed the same memory, still holding the dead context's rows -- with valid check words
+    for ITS launch numbers.  When both counted their launches from zero, a stepper that looked before the fresh row landed
+    folded the dead context's sums (a different scene's), the blocks' images of the minimiser disagreed, and the launch ran into
+    its bounded wait: TLOAM_E_HIP in about one of two such successions.  The launch counter now starts from a per-context base
+    and the row buffer is cleared when allocated.  Twenty successions of contexts solving ALTERNATING scenes through the stepwise
+    API: every one must succeed and reproduce its scene's result bit for bit."""
+    scenes = [synth.make_scene(seed=41), synth.make_scene(seed=33)]
+    want = []
+    for sc in scenes:
+        H = hip_module.HipRegistration()
+        H.set_frames(sc.source, sc.target)
+        rc, T, st = H.scan_match(sc.T_pred)
+        assert rc == 0
+        want.append((T, st["gn_evaluations"], st["n_corr"]))
+        H.close()
+    for i in range(20):
+        sc, (T_want, ev_want, n_want) = scenes[i % 2], want[i % 2]
+        H = hip_module.HipRegistration()
+        H.set_frames(sc.source, sc.target)
+        assert H.sm_begin(sc.T_pred) == 0
+        done = False
+        while not done:
+            rc, done, st = H.sm_outer()
+            assert rc == 0, (i, rc)
+        rc, T, st = H.sm_end()
+        assert rc == 0 and st["gn_evaluations"] == ev_want and st["n_corr"] == n_want, i
+        dt, dr = pose_delta(T, T_want)
+        assert dt < 1e-12 and dr < 1e-12, (i, dt, dr)      # (stepwise: k_prepare_small / separate finish -- same sums, see _assert_same_frame)
+        H.close()

@@ -30,7 +30,10 @@ UNITS = [
     # bit for bit; with `fast` and with `on` the optimiser fused the same source line differently from kernel to kernel):
     # every fused multiply-add in tl_gn.hip / tl_step.hpp is spelled __builtin_fma
     ("tl_gn.hip", ["-ffp-contract=off", *PRELOAD]),
-    ("tl_api.hip", []),
+    ("tl_api.hip", []),          # context lifetime, configuration, sharding rules
+    ("tl_api_frames.hip", []),   # HBM residency: hand-over of the clouds, search grids, staged frames
+    ("tl_api_match.hip", []),    # the scanMatching driver
+    ("tl_api_comm.hip", []),     # multi-GPU exchange (RCCL at run time, callback, mailbox)
     ("tl_api_submap.hip", []),
     ("tl_api_feature.hip", []),
 ]

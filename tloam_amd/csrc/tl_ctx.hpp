@@ -1,5 +1,6 @@
-// tl_ctx.hpp -- host-side context of the C ABI (include/tloam_hip.h), shared by the API translation units
-// (tl_api.hip: registration path, tl_api_submap.hip: device-resident submap, tl_api_feature.hip: PCA features).
+// tl_ctx.hpp -- host-side context of the C ABI (include/tloam_hip.h), shared by the API translation units (tl_api.hip:
+// lifetime, tl_api_frames.hip: HBM residency + search grids, tl_api_match.hip: the scanMatching driver, tl_api_comm.hip: multi-GPU
+// exchange, tl_api_submap.hip: device-resident submap, tl_api_feature.hip: PCA features).
 #pragma once
 
 #include <dlfcn.h>
@@ -279,7 +280,39 @@ constexpr int kFaultWords = 16;
 constexpr int kFaultScan1p = 0, kFaultVoxEmit = 1;   // tloam_ctx::h_fault
 
 namespace tlh {
-// tl_api.hip
+// ---- small helpers shared by the API units
+inline double kind_radius(const tloam_tls_config& c, int k) {
+  switch (k) {
+    case TLOAM_KIND_PLANAR: return c.planar_dist_thres;
+    case TLOAM_KIND_GROUND: return c.ground_dist_thres;
+    case TLOAM_KIND_EDGE: return c.edge_dist_thres;
+    default: return c.sphere_dist_thres;
+  }
+}
+inline int kind_maxnum(const tloam_tls_config& c, int k) {
+  switch (k) {
+    case TLOAM_KIND_PLANAR: return c.planar_maxnum;
+    case TLOAM_KIND_GROUND: return c.ground_maxnum;
+    case TLOAM_KIND_EDGE: return c.edge_maxnum;
+    default: return c.sphere_maxnum;
+  }
+}
+// registration.cpp:979-1016: factor_num 4 -> all four builders, 3 -> planar+ground+edge, 2 -> planar+ground
+inline int kind_active(const tloam_tls_config& c, int k) {
+  if (c.factor_num == 4) return 1;
+  if (c.factor_num == 3) return k != TLOAM_KIND_SPHERE;
+  if (c.factor_num == 2) return k == TLOAM_KIND_PLANAR || k == TLOAM_KIND_GROUND;
+  return 0;
+}
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+// tl_api_comm.hip
+int allreduce(tloam_ctx* c, double* dev, int count);   // sum all-reduce of a small device buffer of doubles across the context's ranks
+void comm_release(tloam_ctx* c);
+// tl_api_match.hip
+int reserve_seg(tloam_ctx* c, int k, size_t n);        // compact correspondence segment of kind k for n factors
+int ensure_common(tloam_ctx* c);                       // the context's small fixed device buffers
+// tl_api_frames.hip
+void exchange_clouds(tloam_ctx* c, FrameClouds& F);    // the registered clouds <-> a FrameClouds (pointers and counts only)
 int check_device_faults(tloam_ctx* c);
 int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq);
 int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long seq, unsigned long long payload[7]);

@@ -16,6 +16,7 @@ no CPU fallback: a missing library or a missing GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -280,6 +281,12 @@ class HipRegistration:
             raise TloamHipError(f"{what}: {STATUS.get(rc, rc)} {msg.decode() if msg else ''}")
 
     # ---- RegistrationInterface ------------------------------------------------------------
+    def _note(self, rc, what):
+        """entry points whose status the caller inspects (they do not raise): a HIP / exchange failure leaves its text on stderr"""
+        if rc in (-4, -5):
+            sys.stderr.write(f"[tloam_amd] {what}: {STATUS.get(rc, rc)}: {self.L.tloam_last_error(self.h).decode(errors='replace')}\n")
+        return rc
+
     def _frame_call(self, fn, name, tag, frame):
         clouds = [_aos(frame.cloud(k)) for k in range(4)]
         ptrs = (C.POINTER(C.c_double) * 4)(*[_dp(a) for a in clouds])
@@ -349,22 +356,23 @@ class HipRegistration:
             assert scan.dtype == np.float64 and scan.flags.c_contiguous
         rc = self.L.tloam_scan_match(self.h, self._pred_buf, _dp(om), self._res_buf, _dp(scan),
                                      0 if scan is None else len(scan), C.byref(st))
+        self._note(rc, "tloam_scan_match")
         return rc, self._res_view.copy(), st.as_dict()
 
     def sm_begin(self, predict, omega=None):
         om = None if omega is None else np.ascontiguousarray(omega, float)
-        return self.L.tloam_sm_begin(self.h, _dp(_colmajor(predict)), _dp(om))
+        return self._note(self.L.tloam_sm_begin(self.h, _dp(_colmajor(predict)), _dp(om)), "tloam_sm_begin")
 
     def sm_outer(self):
         done = C.c_int(0)
         st = Stats()
-        rc = self.L.tloam_sm_outer(self.h, C.byref(done), C.byref(st))
+        rc = self._note(self.L.tloam_sm_outer(self.h, C.byref(done), C.byref(st)), "tloam_sm_outer")
         return rc, bool(done.value), st.as_dict()
 
     def sm_end(self):
         res = np.zeros(16)
         st = Stats()
-        rc = self.L.tloam_sm_end(self.h, _dp(res), C.byref(st))
+        rc = self._note(self.L.tloam_sm_end(self.h, _dp(res), C.byref(st)), "tloam_sm_end")
         return rc, res.reshape(4, 4).T.copy(), st.as_dict()
 
     # ---- device-resident submap (FrontEnd::updateSubmap, front_end.cpp:201-275 / :283-304)
