@@ -75,9 +75,11 @@ def _worker(rank, world, port, q, caps, mode="callback"):
         x, pst = P.solve(x_eval)
         gathered = [None] * world
         dist.all_gather_object(gathered, idx)
+        poses = [None] * world      # every rank's result, bit for bit: the exchange is folded in rank order on every rank
+        dist.all_gather_object(poses, (T.tobytes(), np.asarray(x).tobytes(), [int(st[k]) for k in ("gn_evaluations", "gn_iterations", "accepted_steps")]))
         if rank == 0:
             q.put(dict(T=T, st={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in st.items()},
-                       idx=gathered, H=Hm, g=g, cost=cost, x=x))
+                       idx=gathered, H=Hm, g=g, cost=cost, x=x, all_ranks_identical=all(p == poses[0] for p in poses)))
     finally:
         dist.destroy_process_group()
 
@@ -86,7 +88,21 @@ def _worker(rank, world, port, q, caps, mode="callback"):
 @pytest.mark.parametrize("caps", [{}, dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)],
                          ids=["default_caps", "caps_bind_across_ranks"])
 def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps, mode):
-    world = 2
+    _ranks_on_one_gpu_match_single_rank(hip_module, caps, mode, world=2)
+
+
+@pytest.mark.parametrize("mode", ["callback", "mailbox"])
+def test_eight_ranks_on_one_gpu_match_single_rank(hip_module, mode):
+    """BASELINE.json configs[3] is eight ranks; nothing but this test has ever run more than two real-HIP ranks.  Eight
+    processes on the one device of a test box, the Frame cut by tloam_shard_ranges_frame (a rank holds one or two kinds and builds
+    only those kinds' search grids), caps binding on all four kinds (the cap prefix runs over seven lower ranks), the mailbox's
+    two-parity protocol with seven peers / the caller's all-reduce: pose within 1e-9 of the single-rank solve, counters and the
+    merged index lists identical, and EVERY rank returns the same bits (the 48 doubles are folded in rank order on every rank)."""
+    caps = dict(planar_maxnum=90, ground_maxnum=130, edge_maxnum=70, sphere_maxnum=25)
+    _ranks_on_one_gpu_match_single_rank(hip_module, caps, mode, world=8)
+
+
+def _ranks_on_one_gpu_match_single_rank(hip_module, caps, mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -100,7 +116,10 @@ def test_two_ranks_on_one_gpu_match_single_rank(hip_module, caps, mode):
     rc, T1, st1 = S.scan_match(sc.T_pred)
     dt, dr = pose_delta(res["T"], T1)
     assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    assert res["all_ranks_identical"]
     assert res["st"]["n_corr"] == st1["n_corr"]
+    if caps:
+        assert st1["n_corr"] == [caps["planar_maxnum"], caps["ground_maxnum"], caps["edge_maxnum"], caps["sphere_maxnum"]]   # every cap binds
     for key in ("gn_evaluations", "gn_iterations", "accepted_steps", "outer_iterations"):
         assert res["st"][key] == st1[key], key
     for k in range(4):
@@ -133,8 +152,8 @@ def test_native_rccl_single_rank(hip_module):
 
 
 def _worker_timeout(rank, world, port, q, frames_before_silence=0):
-    """rank 1 sets the mailbox up, solves `frames_before_silence` frames with rank 0 and then never enters the next solve: rank
-    0's exchanges must give up after their bounded wait (the peer's buffer stays mapped: a peer whose process is GONE would take
+    """the last rank sets the mailbox up, solves `frames_before_silence` frames with the others and then never enters the next
+    solve: the other ranks' exchanges must give up after their bounded wait (the peer's buffer stays mapped: a peer whose process is GONE would take
     its memory with it, and a store into it is a GPU page fault -- not something to provoke on a shared box)"""
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -148,34 +167,43 @@ def _worker_timeout(rank, world, port, q, frames_before_silence=0):
         for _ in range(frames_before_silence):
             rc, T, st = H.scan_match(sc.T_pred)
             assert rc == 0
-        if rank == 0:
+        if rank != world - 1:      # the last rank goes silent; every other one must give up by itself
             t0 = time.perf_counter()
             rc, T, st = H.scan_match(sc.T_pred)
             dt = time.perf_counter() - t0
             msg = H.L.tloam_last_error(H.h).decode()
-            q.put(dict(rc=rc, seconds=dt, msg=msg))
-        dist.barrier()      # rank 1 stays alive (its buffer mapped) until rank 0 has given up
+            q.put(dict(rank=rank, rc=rc, seconds=dt, msg=msg))
+        dist.barrier()      # the silent rank stays alive (its buffer mapped) until the others have given up
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("frames_before_silence", [0, 2], ids=["from_the_start", "after_two_frames"])
 def test_mailbox_exchange_times_out_when_a_peer_never_posts(hip_module, frames_before_silence):
+    _mailbox_time_out(frames_before_silence, world=2)
+
+
+def test_mailbox_exchange_times_out_with_seven_live_peers_and_one_silent(hip_module):
+    _mailbox_time_out(frames_before_silence=1, world=8)
+
+
+def _mailbox_time_out(frames_before_silence, world):
     """The bounded wait of the peer mailbox: a rank whose peer never posts -- from the start, or after
     two frames solved together (exchange counters and parities in mid-stream) -- does not hang: every exchange gives up after
-    ~2 s, the Solve is stopped and scan_match returns TLOAM_E_RCCL with a message that says why."""
-    world = 2
+    ~2 s, the Solve is stopped and scan_match returns TLOAM_E_RCCL with a message that says why -- on EVERY live rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker_timeout, args=(r, world, port, q, frames_before_silence)) for r in range(world)]
     for p in procs: p.start()
-    res = q.get(timeout=120)
+    results = [q.get(timeout=180) for _ in range(world - 1)]
     for p in procs:
         p.join(timeout=60); assert p.exitcode == 0
-    assert res["rc"] == -5, res                                  # TLOAM_E_RCCL
-    assert "timed out" in res["msg"] and "peer" in res["msg"], res
-    assert 1.5 < res["seconds"] < 40.0, res                      # bounded: a few exchanges of ~2 s each, not forever
+    assert sorted(r["rank"] for r in results) == list(range(world - 1))
+    for res in results:
+        assert res["rc"] == -5, res                                  # TLOAM_E_RCCL
+        assert "timed out" in res["msg"] and "peer" in res["msg"], res
+        assert 1.5 < res["seconds"] < 60.0, res                      # bounded: a few exchanges of ~2 s each, not forever
 
 
 def _worker_peer_dies(rank, world, port, q, alive, entered):
@@ -251,7 +279,8 @@ def test_callback_exchange_reports_a_peer_that_dies_inside_it(hip_module):
     assert res["rc_after"] == 0, res
 
 
-def test_bench_n_gpus_path_runs_on_one_device(hip_module):
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_n_gpus_path_runs_on_one_device(hip_module, n):
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), with both ranks on
     the one GPU a test box has (TLOAM_BENCH_ONE_DEVICE=1: launcher collectives over gloo): the replica headline aggregates
     over the ranks, and the sharded 1 M frame reports BOTH exchanges -- the mailbox with its figures, RCCL with the reason it
@@ -261,17 +290,17 @@ def test_bench_n_gpus_path_runs_on_one_device(hip_module):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TLOAM_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "3",
            "--m1-steps", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["frames_per_step"] == 2
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_step"] == n
     sh = d["sharded_1m"]
-    assert sh["n_gpus"] == 2 and "mailbox" in sh and "rccl" in sh
+    assert sh["n_gpus"] == n and "mailbox" in sh and "rccl" in sh
     assert sh["mailbox"]["ms_per_frame"] > 0 and sh["mailbox"]["per_sweep_us"]["sweep_plus_exchange"] > 0, sh["mailbox"]
     assert "one device" in sh["rccl"].get("error", ""), sh["rccl"]
     assert sh["fastest_exchange"] == "mailbox" and sh["ms_per_frame"] == sh["mailbox"]["ms_per_frame"]
