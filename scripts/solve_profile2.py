@@ -1,12 +1,11 @@
 """Wall-clock timeline (10 ns units) of the one-launch Solve on a KITTI-cap pre-built set; needs a -DTLOAM_STEP_PROFILE build
 (TLOAM_HIP_LIB=tloam_amd/_variants/lib_stepprof.so).  k_solve_all (default) keeps its stamps at word 2048 of the row buffer,
-k_solve_small (TLOAM_SOLVE_V1=1) at word 1024.  Stamps of the lead block's stepper wave (c) and of one other wave (p)."""
+Stamps of the lead block's stepper wave (c) and of one other wave (p)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tloam_amd import registration as reg, synth
-v1 = os.environ.get("TLOAM_SOLVE_V1") is not None
-base = 1024 if v1 else 2048
+base = 2048
 sets, x_true, x_eval = synth.make_prebuilt(seed=1, n_plane=4500, n_line=1200, n_point=200)
 H = reg.HipRegistration()
 for rt in range(3): H.set_correspondences(rt, *sets[rt])
@@ -16,7 +15,7 @@ for rep in range(4):
     H.L.tloam_debug_partials(H.h, pb.ctypes.data_as(C.POINTER(C.c_double)), 4096)
     u = pb.view(np.uint64)[base:]
     t0 = int(u[0])
-    print("rep", rep, "kernel", "k_solve_small" if v1 else "k_solve_all", "sweeps", st["gn_sweeps"], "evals", st["gn_evaluations"])
+    print("rep", rep, "kernel", "k_solve_all", "sweeps", st["gn_sweeps"], "evals", st["gn_evaluations"])
     prev = None
     for it in range(st["gn_sweeps"]):
         c = [int(v) - t0 for v in u[8 + it * 8: 8 + it * 8 + 4]]

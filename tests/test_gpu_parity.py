@@ -456,25 +456,6 @@ def test_device_driven_loop_equals_host_driven_loop_over_many_frames(hip_module,
     print("census", census)
 
 
-@pytest.mark.parametrize("shape", ["small", "kitti"])
-def test_fused_sweep_step_is_exact(hip_module, monkeypatch, shape):
-    """KITTI-size sets run a GN iteration as ONE launch (the sweep's last block folds the rows and runs the minimiser
-    step); with TLOAM_NO_FUSED_SMALL the sweep and the step are two launches.  Same row fold, same step: same bits."""
-    sc = (synth.make_scene(seed=23, n_src=synth.SMALL_SRC, n_tgt=synth.SMALL_TGT) if shape == "small"
-          else synth.make_scene(seed=24, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT))
-    H1 = hip_module.HipRegistration()
-    H1.set_frames(sc.source, sc.target)
-    monkeypatch.setenv("TLOAM_NO_FUSED_SMALL", "1")      # read once, when the context is created
-    H2 = hip_module.HipRegistration()
-    H2.set_frames(sc.source, sc.target)
-    for frame in range(2):
-        rc1, T1, st1 = H1.scan_match(sc.T_pred)
-        rc2, T2, st2 = H2.scan_match(sc.T_pred)
-        assert rc1 == rc2 == 0
-        _assert_same_frame(_frame_fingerprint(H1, T1, st1), _frame_fingerprint(H2, T2, st2), cost_sum_rtol=1e-13)
-    H1.close(); H2.close()
-
-
 def test_staged_frames_equal_direct_hand_over(hip_module):
     """tloam_frame_stash / tloam_frame_select: frames handed over ahead of their solve and activated later give,
     bit for bit, what handing each frame over right before its solve gives -- in any activation order -- and an unknown
@@ -568,13 +549,12 @@ def test_concurrent_frame_streams_share_the_gpu(hip_module):
     for H in Hs: H.close()
 
 
-@pytest.mark.parametrize("knob", ["TLOAM_NO_SELF_PREPARE=1", "TLOAM_NO_FINISH_IN_SOLVE=1", "TLOAM_ENQUEUE_AHEAD=1",
-                                  "TLOAM_ENQUEUE_AHEAD=4", "TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_NO_GRID_AHEAD=1"])
+@pytest.mark.parametrize("knob", ["TLOAM_NO_PERSISTENT_SOLVE=1", "TLOAM_NO_GRID_AHEAD=1"])
 def test_solve_launch_variants_are_exact(hip_module, monkeypatch, knob):
     """The Solve launch of a KITTI-size frame prepares its own factor set, ends its outer iteration and runs the following ones;
-    the host enqueues launches for two iterations and adds one when the device asks.  Each piece can be switched off --
-    k_prepare_small in front of the Solve, the finish as a kernel of its own, one or all four iterations enqueued ahead, one
-    launch per GN iteration -- and nothing may change: three scenes (one with a large prediction error, whose pose keeps moving
+    the host enqueues launches for two iterations and adds one when the device asks.  The one fallback form -- one launch per GN
+    iteration, k_prepare_small in front, the finish as a kernel of its own: what a context uses after an in-launch hand-over
+    timed out, and what the stepwise API always uses -- must give the same frames: three scenes (one with a large prediction error, whose pose keeps moving
     in later outer iterations: the host-resumed path), two frames each, everything compared bit for bit (with one launch per
     GN iteration the four cost sums are added in the finish kernel's order: last bits, see _assert_same_frame).
     The search grids are built when the targets are handed over (tloam_set_target_frame); TLOAM_NO_GRID_AHEAD builds them inside

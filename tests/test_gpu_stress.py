@@ -39,3 +39,71 @@ def test_randomised_scene(hip_module, seed):
             assert np.array_equal(H.get_correspondences(kind)["idx"], O.get_correspondences(kind)["idx"])
             np.testing.assert_allclose(H.get_weights(kind), O.get_weights(kind), rtol=0, atol=1e-9)
     H.close()
+
+
+def test_soak_three_concurrent_contexts_2000_frames(hip_module):
+    """Standing soak of the lock-free hand-overs (tagged rows between the blocks of a one-launch Solve, pinned result slots to
+    the host; the reference has no sanitizer preset, SURVEY section 5, and neither has this library): three host threads, three
+    contexts on one GPU, 2000 frames each, alternating between two KITTI-size frames staged in HBM (tloam_frame_stash /
+    _select: the registered clouds, the search grids and the learned budgets change under the context every frame) and a
+    context destroyed and re-created every 400 frames (a new context is handed the memory of a dead one).  EVERY result --
+    pose bits and minimiser counters -- is checked against the first pass over the same frame; no call may fail or take
+    anywhere near the one second a timed-out hand-over costs.  Budget: ~20 s."""
+    import threading
+    import time
+    N = 2000
+    scenes = [[synth.make_scene(seed=300 + 10 * i + j, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT,
+                                pred_err=(0.02 * (j + 1), -0.01, 0.005, 0.002, -0.001, 0.003 * (j + 1))) for j in range(2)] for i in range(3)]
+    keys = ("gn_evaluations", "gn_iterations", "accepted_steps", "outer_iterations", "n_corr", "converged_early")
+
+    def new_context(i):
+        H = hip_module.HipRegistration()
+        for j, sc in enumerate(scenes[i]):
+            H.set_frames(sc.source, sc.target)
+            H.frame_stash(j)
+        return H
+
+    def fingerprint(T, st):
+        return (T.tobytes(), tuple(int(x) for k in keys for x in np.atleast_1d(st[k])))
+
+    first = []
+    for i in range(3):     # the first pass: each frame alone on an otherwise idle GPU
+        H = new_context(i)
+        row = []
+        for j, sc in enumerate(scenes[i]):
+            H.frame_select(j)
+            rc, T, st = H.scan_match(sc.T_pred)
+            assert rc == 0
+            row.append(fingerprint(T, st))
+        first.append(row)
+        H.close()
+    problems = [[] for _ in range(3)]
+    worst = [0.0] * 3
+    start = threading.Barrier(3)
+
+    def run(i):
+        H = new_context(i)
+        start.wait()
+        for f in range(N):
+            if f and f % 400 == 0:
+                H.close()
+                H = new_context(i)
+            j = (f + i) & 1
+            H.frame_select(j)
+            t = time.perf_counter()
+            rc, T, st = H.scan_match(scenes[i][j].T_pred)
+            worst[i] = max(worst[i], time.perf_counter() - t)
+            if rc != 0 or fingerprint(T, st) != first[i][j]:
+                problems[i].append((f, j, rc, H.L.tloam_last_error(H.h).decode()))
+                if len(problems[i]) > 5:
+                    break
+        H.close()
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    took = time.perf_counter() - t0
+    assert problems == [[], [], []], problems
+    assert max(worst) < 0.5, worst        # (a timed-out hand-over costs a full second)
+    assert took < 60.0, took

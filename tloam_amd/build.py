@@ -37,7 +37,7 @@ UNITS = [
     ("tl_api_submap.hip", []),
     ("tl_api_feature.hip", []),
 ]
-HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", "tl_walk.hpp", "tl_ctx.hpp", "tl_step.hpp", "tl_finish.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
+HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", "tl_walk.hpp", "tl_ctx.hpp", "tl_step.hpp", "tl_finish.hpp", "tl_prep.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
 
 
 def _hipcc():

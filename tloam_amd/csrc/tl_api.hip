@@ -63,7 +63,6 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->dbg_no_build_reuse = getenv("TLOAM_NO_BUILD_REUSE") != nullptr;
   c->dbg_no_eval_reuse = getenv("TLOAM_NO_EVAL_REUSE") != nullptr;
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
-  c->no_fused_small = getenv("TLOAM_NO_FUSED_SMALL") != nullptr;
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
   c->no_grid_ahead = getenv("TLOAM_NO_GRID_AHEAD") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
@@ -72,11 +71,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) cus = 0;
     c->device_cus = cus;
   }
-  c->no_ride_large = getenv("TLOAM_NO_RIDE_LARGE") != nullptr;
   c->fused_large = getenv("TLOAM_FUSED_LARGE") != nullptr;
-  c->no_self_prepare = getenv("TLOAM_NO_SELF_PREPARE") != nullptr;
-  c->no_finish_in_solve = getenv("TLOAM_NO_FINISH_IN_SOLVE") != nullptr;
-  c->enqueue_ahead = getenv("TLOAM_ENQUEUE_AHEAD") ? std::max(1, atoi(getenv("TLOAM_ENQUEUE_AHEAD"))) : 0;
   if (const char* e = getenv("TLOAM_PLANNED_SWEEPS")) c->dbg_planned_sweeps = atoi(e);
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -191,7 +191,7 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
 bool solve_small_path(const tloam_ctx* c) {
-  return c->nranks == 1 && c->k3_single && !c->no_fused_small && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus);
+  return c->nranks == 1 && c->k3_single && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus);
 }
 // prep: the launch also prepares the factor set (only with solve_small_path and SlotView::flagb, see self_prepare_path)
 // finish: ... and finishes the outer iteration, possibly running the following ones too (SolveFinish; needs prep).
@@ -217,7 +217,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
   // One GN iteration = ONE launch whatever the size of the set (round 4): the streaming sweep's last block folds the rows and
   // advances the minimiser (k3_sweep_step); with a mailbox it also posts, gathers and advances -- sweep + exchange + step.
   // RCCL / callback contexts keep sweep | collective | step: the collective is enqueued by the host between two launches.
-  const bool one_launch = c->fused_large && (c->nranks == 1 ? !(c->k3_single && !c->no_fused_small) : c->comm == COMM_MAILBOX);
+  const bool one_launch = c->fused_large && (c->nranks == 1 ? !c->k3_single : c->comm == COMM_MAILBOX);
   for (int sweep = 0; sweep < sweeps; ++sweep) {
     if (one_launch) {
       const int rc = launch_k3_step_timed(c);
@@ -242,7 +242,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
         if (rc != TLOAM_OK) return rc;
         launch_gn_step(c->state.p, c->red48.p, c->stream);
       }
-    } else if (c->k3_single && !c->no_fused_small) {
+    } else if (c->k3_single) {
       // KITTI-size set: one launch per GN iteration (k_sweep_step_small)
       launch_sweep_step_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, c->stream);
       c->batch_launches++;
@@ -329,7 +329,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   }
   {
     // the one-launch Solve compacts the factor set itself when every kind's flag bytes fit a wave (SlotView::flagb)
-    bool fits = solve_small_path(c) && prepare_small_fits(c->sv) && !c->no_self_prepare;
+    bool fits = solve_small_path(c) && prepare_small_fits(c->sv);
     for (int k = 0; k < kKinds; ++k) fits = fits && c->kd[k].n_src <= (size_t)kFlagbStride;
     c->sv.flagb = nullptr;
     if (fits) {
@@ -430,7 +430,7 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
 // :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
 // caps, the compaction AND the alternative (refresh) are one launch (k_prepare_small) -- `also_refresh` says whether this
 // call stands for both alternatives of a device-gated iteration.
-bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv) && !c->no_fused_small; }
+bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv); }
 // the Solve launch that follows prepares the set itself: no k_prepare_small
 bool self_prepare_path(const tloam_ctx* c) { return c->sv.flagb != nullptr && prepare_small_path(c) && solve_small_path(c); }
 // ride: the finish of the previous outer iteration rides on this search launch (large single-rank sets, device-driven loop:
@@ -450,7 +450,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
     return TLOAM_OK;
   }
-  if (c->nranks == 1 && !c->no_fused_small) {
+  if (c->nranks == 1) {
     // single rank: the tile-local scan only -- the compaction adds the tiles' offsets itself -- and ONE launch for both
     // alternatives of a device-gated iteration (compaction, or the refresh of the unchanged set): two launches less
     const int tiles = scan_tiles_only(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
@@ -673,7 +673,7 @@ struct DeviceLoopPlan {
 // iterations enqueued ahead of the device's verdicts in finish-in-the-Solve mode: iteration 0 almost always moves the pose
 // (so the search and the Solve of iteration 1 will run), the later ones almost never do (they run inside the launch of
 // iteration 1): launches for them would be no-ops that the frame's successor has to queue behind.
-constexpr int kEnqueueAhead = 2;   // (TLOAM_ENQUEUE_AHEAD, read when the context is created: tloam_ctx::enqueue_ahead)
+constexpr int kEnqueueAhead = 2;   // (1 and 4 measured the same within noise and are bit-identical: round 3 / 4 A/Bs)
 // finish-in-the-Solve mode: the launches of iterations [from, to): the search if the pose moved (always in the frame's
 // first), then the Solve + finish -- a launch that returns at once when an earlier one has already run its iteration
 int enqueue_iterations_in_launch_mode(tloam_ctx* c, int from, int to, const BuildParams& bp, const GridView grids[kKinds],
@@ -705,7 +705,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
   const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
   // ... and 1 M-class frames the same way with k_weights + k_outer_finish (k_build_finish_large)
-  const bool ride_large = !ride && c->nranks == 1 && !finish_small_path(c) && build_finish_large_fits(c->sv) && !c->no_ride_large;
+  const bool ride_large = !ride && c->nranks == 1 && !finish_small_path(c) && build_finish_large_fits(c->sv);
   const int wblocks_large = (int)std::min<size_t>(256, std::max<size_t>(64, total_seg_cap(c) / 2048));   // as enqueue_finish
   if (ride_large) HIPC(c, c->fin_rows.reserve((size_t)4 * 256 * 8));
   bool pending = false;   // the finish of the previous iteration has not been enqueued yet (it rides on this search)
@@ -722,7 +722,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   for (int k = 0; k < kKinds; ++k) prep.maxnum[k] = bp.maxnum[k];
   // ... and the finish of an iteration (weights, sums, loop decisions, result slot): a launch of its own / riding on the next
   // search, or the tail of the one-launch Solve, which then goes on with the next iteration itself while the pose stands still
-  const bool fin_in_solve = in_solve && finish_small_path(c) && !c->no_finish_in_solve && M <= kMaxOuterInLaunch;
+  const bool fin_in_solve = in_solve && finish_small_path(c) && M <= kMaxOuterInLaunch;
   P.in_launch_finish = fin_in_solve;
   if (fin_in_solve) {
     SolveFinish& F = P.F;
@@ -742,7 +742,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
     }
     P.prep = prep;
     P.enq_end = first;
-    return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + (c->enqueue_ahead > 0 ? c->enqueue_ahead : kEnqueueAhead)), bp, grids, P);
+    return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + kEnqueueAhead), bp, grids, P);
   }
   for (int iter = first; iter < M; ++iter) {
     if (iter == 0) {
@@ -909,18 +909,10 @@ int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
   return check_device_faults(c);   // (every iteration's result has been waited for: the frame's kernels are done)
 }
 
-// development aid (TLOAM_HOST_PROFILE=1, single frame stream only): where the calling thread's time goes per
-// tloam_scan_match, averaged, printed to stderr every 200 calls
-struct HostProf { double begin_us = 0, enqueue_us = 0, wait_us = 0, tail_us = 0, gap_us = 0; long n = 0; std::chrono::steady_clock::time_point last_ret; bool have_last = false; };
-static HostProf g_hp;
-static const bool g_hp_on = getenv("TLOAM_HOST_PROFILE") != nullptr;
 int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega3, double result[16],
                      double* scan_xyz, size_t n_scan, tloam_stats* stats) {
-  const auto hp_t0 = std::chrono::steady_clock::now();
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
-  const auto hp_t1 = std::chrono::steady_clock::now();
-  const double hp_wait0 = c->wait_us;
   int done = 0;
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
@@ -964,18 +956,6 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     launch_transform_cloud(c->misc.p, n_scan, result, c->stream);
     HIPC(c, hipMemcpyAsync(scan_xyz, c->misc.p, sizeof(double) * 3 * n_scan, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-  }
-  if (g_hp_on) {
-    const auto t2 = std::chrono::steady_clock::now();
-    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    g_hp.begin_us += us(hp_t0, hp_t1);
-    g_hp.wait_us += c->wait_us - hp_wait0;
-    g_hp.enqueue_us += us(hp_t1, t2) - (c->wait_us - hp_wait0);   // enqueue + bookkeeping + end, without the waits
-    if (g_hp.have_last) g_hp.gap_us += us(g_hp.last_ret, hp_t0);
-    g_hp.last_ret = t2; g_hp.have_last = true;
-    if (++g_hp.n % 200 == 0)
-      fprintf(stderr, "[tloam host] per call: sm_begin %.1f us, enqueue + bookkeeping %.1f, waiting %.1f, outside the call %.1f\n",
-              g_hp.begin_us / g_hp.n, g_hp.enqueue_us / g_hp.n, g_hp.wait_us / g_hp.n, g_hp.gap_us / g_hp.n);
   }
   return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;
 }

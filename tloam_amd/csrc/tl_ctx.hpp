@@ -170,7 +170,6 @@ struct tloam_ctx {
   DBuf<double> fin_rows;       // hand-over rows of the finish riding on a thread-per-query search (k_build_finish_large)
   bool fused_large = false;    // TLOAM_FUSED_LARGE: a GN iteration of a large set as ONE launch (k3_sweep_step; sharded + mailbox: sweep, exchange
                                // and step).  Measured slower than sweep + step as two launches: off by default
-  bool no_ride_large = false;  // TLOAM_NO_RIDE_LARGE: k_weights + k_outer_finish as launches of their own (A/B, tests)
   DBuf<int> tile_of_slot, tile_fill;
   DBuf<double4> qrec;  // tile-sorted query records (x, y, z, slot)
   GridBuffers grids;  // the four search grids of the last scanMatching (shared buffers)
@@ -188,10 +187,6 @@ struct tloam_ctx {
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
-  int enqueue_ahead = 0;           // TLOAM_ENQUEUE_AHEAD: outer iterations enqueued ahead of the device's verdicts (0: the default)
-  bool no_finish_in_solve = false; // TLOAM_NO_FINISH_IN_SOLVE: the finish of an outer iteration stays a launch of its own (A/B, tests)
-  bool no_self_prepare = false;    // TLOAM_NO_SELF_PREPARE: k_prepare_small in front of every one-launch Solve (A/B, tests)
-  bool no_fused_small = false;     // TLOAM_NO_FUSED_SMALL: KITTI-size sets keep sweep and step as two launches (A/B, tests)
   bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)
   bool no_persistent_solve = false;  // TLOAM_NO_PERSISTENT_SOLVE, or set by tloam_scan_match after an in-launch hand-over timed out:
                                      // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
