@@ -145,7 +145,13 @@ int tloam_set_target(tloam_ctx* ctx, int kind, const double* xyz_aos, size_t n);
  * grids over the new targets without waiting for it (the next tloam_scan_match / tloam_sm_begin uses them; until then the
  * context's search structures -- what tloam_fitness sees -- remain those of the last scanMatching).  tloam_set_source_frame does not wait for the
  * device at all: it returns when the borrowed buffers have been copied OUT (into pinned staging; one copy is enqueued on the
- * context's stream behind it), so they may be reused at once and the next call on the context is ordered behind the copy. */
+ * context's stream behind it), so they may be reused at once and the next call on the context is ordered behind the copy.
+ * SHARDED contexts: the four source clouds of a frame must reach EVERY rank through the SAME entry point -- all four through
+ * tloam_set_source_frame (the frame is cut as one line, tloam_shard_ranges_frame: a rank holds one or two kinds and builds only
+ * those kinds' search grids) or each through tloam_set_source (every cloud cut by itself, tloam_shard_range) -- never a mix
+ * within a frame, and the same choice on all ranks: the two rules give a rank different index blocks, and a mix leaves source
+ * points unowned or owned twice.  A kind a rank holds no source points of has no search structure on that rank
+ * (tloam_fitness skips it there). */
 int tloam_set_source_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
 int tloam_set_target_frame(tloam_ctx* ctx, const double* const xyz_aos[4], const size_t n[4]);
 /* Frames staged ahead of their solve.  The reference's caller hands a Frame over and solves it at once (front_end.cpp:314,

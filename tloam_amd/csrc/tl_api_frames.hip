@@ -59,7 +59,7 @@ int check_device_faults(tloam_ctx* c) {
   if (__atomic_load_n(&c->h_fault[kFaultScan1p], __ATOMIC_ACQUIRE) != 0u) {
     __atomic_store_n(&c->h_fault[kFaultScan1p], 0u, __ATOMIC_RELEASE);
     c->no_scan_1p = true;
-    c->grids_ahead = false;
+    c->grids_ahead = false; c->tgt_gen++;
     for (int k = 0; k < kKinds; ++k) c->kd[k].grid_valid = false;
     c->have_build = false;
     c->last_error = "a single-pass scan timed out in its look-back (its blocks were not resident together): the context now uses the multi-launch scans";
@@ -68,7 +68,7 @@ int check_device_faults(tloam_ctx* c) {
   if (__atomic_load_n(&c->h_fault[kFaultVoxEmit], __ATOMIC_ACQUIRE) != 0u) {
     __atomic_store_n(&c->h_fault[kFaultVoxEmit], 0u, __ATOMIC_RELEASE);
     c->vox_ticket = true;
-    c->grids_ahead = false;
+    c->grids_ahead = false; c->tgt_gen++;
     c->last_error = "the voxel down-sampling timed out in its look-back (its blocks were not resident together): the context now uses start tickets; "
                     "the submap of this update is undefined -- initialise it again";
     rc = TLOAM_E_HIP;
@@ -320,7 +320,7 @@ void exchange_clouds(tloam_ctx* c, FrameClouds& F) {
     std::swap(c->tgt_box_valid[k], F.tgt_box_valid[k]);
     K.grid_valid = false;   // the search grids belong to the frame they were built over
   }
-  c->grids_ahead = false;
+  c->grids_ahead = false; c->tgt_gen++;
   std::swap(c->src_pack, F.src_pack);
   c->have_build = false;
 }
@@ -381,7 +381,7 @@ int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n, bool c
   KindData& K = c->kd[kind];
   K.n_tgt = n;
   c->tgt_box_valid[kind] = false;
-  c->grids_ahead = false;
+  c->grids_ahead = false; c->tgt_gen++;
   const size_t m = std::max<size_t>(n, 1);
   HIPC(c, K.tgt_aos.reserve(3 * m));
   HIPC(c, K.tx.reserve(m)); HIPC(c, K.ty.reserve(m)); HIPC(c, K.tz.reserve(m));
@@ -453,6 +453,7 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
       if (rc == TLOAM_OK) {
         for (int k = 0; k < kKinds; ++k) c->gv_next[k] = views[k];
         c->grids_ahead = true;
+        c->grids_next_gen = c->tgt_gen;
       }
     }
   }

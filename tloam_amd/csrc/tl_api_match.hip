@@ -359,7 +359,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     if (c->nranks > 1)
       for (int k = 0; k < kKinds; ++k)
         if (c->kd[k].n_src == 0) radius[k] = 0.0;
-    if (c->grids_ahead && c->nranks == 1) {
+    if (c->grids_ahead && c->grids_next_gen == c->tgt_gen && c->nranks == 1) {
       // built when the targets were handed over (tloam_set_target_frame): they become the context's search structures now;
       // the frame's start is a launch of its own, below.  Used once: a second scanMatching over the same targets builds its own
       std::swap(c->grids, c->grids_next);
@@ -368,7 +368,9 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     } else {
       rc = build_grids(c, c->grids, radius, views, &hook);
       if (rc != TLOAM_OK) return rc;
-      for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = true; }
+      // (a kind whose grid was skipped -- radius forced to 0 above: a sharded rank without source points of it -- has an EMPTY
+      //  view: it is not a search structure getFitnessScore or anybody else may use)
+      for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = radius[k] > 0.0; }
     }
   }
   if (!hook.consumed) {  // (no grid launch: cannot happen with >= 10 targets per kind, kept for safety)

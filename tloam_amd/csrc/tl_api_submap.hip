@@ -158,7 +158,7 @@ int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double
   c->kd[TLOAM_KIND_GROUND].n_tgt = ne;  // (single-cloud job: counts[0])
   c->kd[TLOAM_KIND_GROUND].tgt_set = true;
   c->tgt_box_valid[TLOAM_KIND_GROUND] = false;
-  c->grids_ahead = false;
+  c->grids_ahead = false; c->tgt_gen++;
   S.inited = true;
   return TLOAM_OK;
 }
@@ -188,7 +188,7 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
   (void)sphere;
   bool fused_front = false;
   for (int k = 0; k < kKinds; ++k) c->tgt_box_valid[k] = false;  // the targets are about to be rebuilt on the device
-  c->grids_ahead = false;
+  c->grids_ahead = false; c->tgt_gen++;
   // :202-218 push the frame into both buffers, keep the newest *_frame_size
   // The three clouds the device needs (planar, edge, ground) are copied end to end into pinned staging (every cloud on a 16-byte
   // boundary) and the update's front launch reads them THERE, across PCIe, through LDS: the planar cloud is copied to the newest

@@ -309,7 +309,7 @@ void launch_grid_scatter_all(const GridSet& gs, const int* cell_of_pt, const uns
 // large tables (more than 1024 scan tiles: the 1 M-class frames): ONE single-pass launch scans the histogram, writes cell_start
 // and re-zeroes the histogram (no scan array), then the scatter -- count | scan + finalize | scatter.  ctl: scan_1p_ctl_elems(n)
 // words, zero when allocated (k_scan_1p, tl_nn.hip).  Only where every block of the launch is resident at once on THIS device
-// (scan_1p_applies: tiles <= 15/16 of device_cus); fault: pinned host word the kernel raises if its bounded look-back times out
+// (scan_1p_applies: tiles <= device_cus); fault: pinned host word the kernel raises if its bounded look-back times out
 size_t scan_1p_ctl_elems(size_t n);
 bool scan_1p_applies(size_t n, int device_cus);
 void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, unsigned* fault,

@@ -163,7 +163,10 @@ struct tloam_ctx {
   DBuf<unsigned long long> flags, scan, scan_tmp, tile_cnt, tile_scan;
   DBuf<unsigned long long> scan1p_q;   // control words of the single-pass scan of the query-sort histogram, zero when allocated
   bool scan1p_q_use = false;           // ... and whether this frame's query sort takes it (outer_reserve: scan_1p_applies on this device)
-  bool grids_ahead = false;    // the search grids in `grids` were built over the registered targets at hand-over (tloam_set_target_frame) and are still theirs
+  bool grids_ahead = false;    // the search grids in `grids_next` were built over the registered targets at hand-over (tloam_set_target_frame) and are still theirs
+  // ... which is also CHECKED: every path that changes a registered target cloud advances tgt_gen, the grids built ahead remember
+  // the generation they were built over, and tloam_sm_begin swaps them in only if that is still the current one
+  unsigned long long tgt_gen = 0, grids_next_gen = ~0ull;
   bool no_grid_ahead = false;  // TLOAM_NO_GRID_AHEAD: the grids are always built inside scanMatching (A/B, tests)
   bool no_scan_1p = false;     // set after a single-pass look-back scan timed out (blocks not co-resident): the multi-launch scans from then on
   DBuf<unsigned char> flagb;   // SlotView::flagb
