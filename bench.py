@@ -437,12 +437,12 @@ def main():
             if args.workload == "kitti":
                 bb = head["k3"]["back_to_back"]
                 roofline["headline_workload_k3"] = {
-                    "kernel": "k_solve_small (one launch per run of outer iterations: compaction, every GN iteration -- sweep, rows, "
+                    "kernel": "k_solve_all (one launch per run of outer iterations: compaction, every GN iteration -- sweep, rows, "
                               "6x6 step --, weights and loop decisions); the sweep alone = k3_accumulate<true>",
                     "sweep_alone_back_to_back": bb,
                     "note": "KITTI-cap sets (442 KB per sweep) are latency bound, not bandwidth bound: in the frames the sweep runs "
                             "inside the persistent Solve launch with its correspondences held in registers (no K3 launch to time; "
-                            "~8.6 us per GN iteration, profiles/r03_solve_small_timeline.txt); the figure here is the stand-alone "
+                            "6.8-7.7 us per GN iteration, profiles/r04_solve_all_timeline.txt); the figure here is the stand-alone "
                             "sweep kernel on the frame's last correspondence set"}
         out = {
             "metric": "gauss_newton_iters_per_sec", "value": round(head["gn_iters_per_sec"], 2), "unit": "GN iter/s",
@@ -489,7 +489,7 @@ def main():
             out["odometry_loop"] = odometry_loop(args, reg, torch, local_rank)
             out["multi_stream"] = multi_stream(args, reg, synth, local_rank)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(head, side, args, kitti_seq)
+            out["cpu_baseline"] = guarded(lambda: cpu_baseline(head, side, args, kitti_seq), 300.0, "cpu_baseline", out, rank)
         if kitti_seq is not None:   # the honest per-frame cost of the plug-in as wired in INTEGRATION.md section 1
             out["config"]["ms_per_frame_incl_pcie_upload"] = kitti_seq["report"]["ms_per_frame_incl_pcie_upload"]
             for key in ("set_source_ms", "set_target_ms", "scan_match_ms", "set_source_plus_scan_match_ms", "set_target_plus_scan_match_ms",
@@ -506,6 +506,35 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def guarded(fn, seconds, name, out, rank):
+    """The CPU baseline is a reported side figure computed by test infrastructure (the oracle's port on the host's cores): it
+    must never cost the run its line.  `fn` runs on a thread of its own (the port's calls release the GIL); if it has not
+    returned after `seconds` -- round 5 met a hang of the port's thread pool on a 256-core host -- or raises, the JSON line is
+    printed without it, with the reason in its place, and the process ends there."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:   # noqa: BLE001 -- reported, not raised
+            box["error"] = repr(e)
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if "value" in box:
+        return box["value"]
+    if "error" in box:
+        return {"error": box["error"], "kind": "port"}
+    out[name] = {"error": "%s did not finish within %.0f s; every GPU figure of this line was measured before it started" % (name, seconds),
+                 "kind": "port"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os._exit(0)
 
 
 def sharded_frame(args, reg, synth, torch, dist, cfg, n_src, n_tgt, rank, world, local_rank, barrier, cdev="cuda"):

@@ -857,6 +857,9 @@ typedef struct {
 typedef struct orc_pool {
   int n;                        /* threads incl. the caller */
   int n_active;                 /* threads that take a slice of the current job (orc_set_eval_grain); the others skip it */
+  int active_of[8];             /* n_active by job number & 7: a worker that is NOT part of a job may look at it arbitrarily late
+                                 * (nobody waits for it), so it must find the team size that belongs to the job number it read --
+                                 * see eval_pool_worker */
   pthread_t* th;
   orc_part* part;               /* [n], 64-byte aligned */
   pthread_mutex_t mu;
@@ -873,11 +876,11 @@ typedef struct orc_pool {
 } orc_pool;
 typedef struct { orc_pool* P; int tid; } orc_worker_arg;
 
-static void eval_pool_slice(orc_pool* P, int tid) {
+static void eval_pool_slice(orc_pool* P, int tid, int n_active) {
   orc_ctx* c = P->c;
   orc_normal* acc = &P->part[tid].acc;
   memset(acc, 0, sizeof(*acc));
-  const long long lo = (long long)P->total * tid / P->n_active, hi = (long long)P->total * (tid + 1) / P->n_active;
+  const long long lo = (long long)P->total * tid / n_active, hi = (long long)P->total * (tid + 1) / n_active;
   long long base = 0;
   for (int kind = 0; kind < 4; ++kind) {
     orc_rset* s = &c->set[kind];
@@ -912,10 +915,19 @@ static void* eval_pool_worker(void* argp) {
       spins = 0;
     }
     if (__atomic_load_n(&P->stop, __ATOMIC_ACQUIRE)) return NULL;
-    seen = __atomic_load_n(&P->job, __ATOMIC_ACQUIRE);
-    idle = tid >= P->n_active;      /* (written before the job number was advanced) */
+    /* Which job, and am I part of it?  The caller only waits for the threads that ARE part of a job, so a thread that is not may
+     * read the job number just before the caller publishes the next one, and the team size just after: it would then take a
+     * slice of a job it was never counted for and count itself out of the next one twice (the caller's count passes zero
+     * unseen: a hang, met on the 256-core bench host).  So the team size is kept per job number (a ring of eight), and the pair
+     * is only believed if the job number still stands afterwards: a thread that is part of job j finds it standing for as long
+     * as it has not counted itself out; one that is not either sees the pair of j or, having been overtaken, looks again. */
+    const unsigned long j = __atomic_load_n(&P->job, __ATOMIC_ACQUIRE);
+    const int act = __atomic_load_n(&P->active_of[j & 7ul], __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&P->job, __ATOMIC_ACQUIRE) != j) continue;   /* (seen unchanged: the wait loop falls through) */
+    seen = j;
+    idle = tid >= act;
     if (idle) continue;
-    eval_pool_slice(P, tid);
+    eval_pool_slice(P, tid, act);
     __atomic_fetch_sub(&P->pending, 1, __ATOMIC_ACQ_REL);
   }
 }
@@ -960,13 +972,14 @@ static void eval_pool_run(orc_ctx* c, const double q[4], const double t[3], int 
     const int by_work = P->total / c->eval_grain;
     P->n_active = by_work < 1 ? 1 : (by_work < P->n ? by_work : P->n);
   }
+  __atomic_store_n(&P->active_of[(P->job + 1ul) & 7ul], P->n_active, __ATOMIC_RELEASE);
   __atomic_store_n(&P->pending, P->n_active - 1, __ATOMIC_RELEASE);
   __atomic_fetch_add(&P->job, 1ul, __ATOMIC_ACQ_REL);
   pthread_mutex_lock(&P->mu);
   if (P->sleepers > 0) pthread_cond_broadcast(&P->cv);
   pthread_mutex_unlock(&P->mu);
-  eval_pool_slice(P, 0);
-  while (__atomic_load_n(&P->pending, __ATOMIC_ACQUIRE) != 0) __builtin_ia32_pause();
+  eval_pool_slice(P, 0, P->n_active);
+  while (__atomic_load_n(&P->pending, __ATOMIC_ACQUIRE) > 0) __builtin_ia32_pause();
   for (int th = 0; th < P->n_active; ++th) {   /* fold in thread order */
     const orc_normal* a = &P->part[th].acc;
     out->cost += a->cost;

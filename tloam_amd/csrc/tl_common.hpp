@@ -75,7 +75,7 @@ struct SlotView {
   unsigned long long* flags;   // low 32: counted, high 32: valid (then scanned in place -> exclusive prefix)
   unsigned long long* scan;    // exclusive scan of flags
   // the same two bits per slot as ONE BYTE (bit 0 valid, bit 1 counted) at [kind * kFlagbStride + slot-in-kind], or null:
-  // what the one-launch Solve reads when it compacts the factor set itself (k_solve_small, SolvePrep) -- a lane takes in
+  // what the one-launch Solve reads when it compacts the factor set itself (k_solve_all, SolvePrep) -- a lane takes in
   // 64 slots with four 16-byte loads.  Only for frames whose kinds have at most kFlagbStride source points each.
   unsigned char* flagb;
   int slot_off[kKinds + 1];    // concatenated slot ranges per kind
@@ -128,7 +128,7 @@ struct GnState {
   int next_outer;     // device-driven loop: the outer iteration to run next (advanced by every finish).  A one-launch Solve that
                       // also finishes its iteration may run the FOLLOWING ones too (SolveFinish); the launches enqueued for
                       // those find their iteration taken and return
-  int fin_valid;      // fin_sum / fin_bad hold the finish sums of the Solve that has just ended (k_solve_small); consumed by the finish
+  int fin_valid;      // fin_sum / fin_bad hold the finish sums of the Solve that has just ended (k_solve_all); consumed by the finish
   double fin_sum[kKinds], fin_bad;
   double dbg[12];     // LAST: phase time stamps of the step kernel (TLOAM_STEP_PROFILE builds only)
 };

@@ -192,7 +192,7 @@ struct tloam_ctx {
   bool dbg_no_eval_reuse = false;
   bool no_device_loop = false;     // TLOAM_NO_DEVICE_LOOP: tloam_scan_match keeps the host in the outer loop (A/B, tests)
   bool no_persistent_solve = false;  // TLOAM_NO_PERSISTENT_SOLVE, or set by tloam_scan_match after an in-launch hand-over timed out:
-                                     // KITTI-size Solves run one launch per GN iteration instead of k_solve_small
+                                     // KITTI-size Solves run one launch per GN iteration instead of k_solve_all
   bool hand_over_timed_out = false;  // the last TLOAM_E_HIP of the device loop was OS_COMM_ERROR on one rank
   int dbg_fail_handover = 0;       // TLOAM_DEBUG_FAIL_HANDOVER=n: the next n one-launch Solves time out in their first hand-over (test hook)
   int device_cus = 0;              // multiProcessorCount of the device (k_solve_all and the single-pass scans need all their blocks resident at once)

@@ -222,7 +222,7 @@ __device__ __forceinline__ void finish_small_publish(GnState* st, double* __rest
   if (t < 5) {
     double s = 0.0;
     for (int w = 0; w < 16; ++w) s += red[w][t];
-    // a Solve that ran as ONE launch has added the costs of its last evaluation up itself, in ITS order (k_solve_small:
+    // a Solve that ran as ONE launch has added the costs of its last evaluation up itself, in ITS order (k_solve_all:
     // post_ext_row); its finish -- in that launch or here -- publishes those sums, so that the device-driven loop and the
     // stepwise API agree bit for bit
     if (st->fin_valid) s = t < 4 ? st->fin_sum[t] : st->fin_bad;
