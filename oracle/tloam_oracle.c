@@ -863,7 +863,9 @@ typedef struct orc_pool {
   pthread_t* th;
   orc_part* part;               /* [n], 64-byte aligned */
   pthread_mutex_t mu;
-  pthread_cond_t cv;
+  pthread_cond_t cv;            /* threads of the current team that went to sleep between two jobs */
+  pthread_cond_t cv_idle;       /* threads the current team size leaves out: parked until the team grows past them (or stop) */
+  int parked, last_active;      /* (under mu) */
   unsigned long job;            /* job number, advanced by the caller (atomic) */
   int pending;                  /* workers still in the current job (atomic) */
   int sleepers;                 /* workers asleep on cv (under mu) */
@@ -901,10 +903,22 @@ static void* eval_pool_worker(void* argp) {
   const int tid = arg->tid;
   free(arg);
   unsigned long seen = 0;
-  int idle = 0;   /* this thread had no slice in the last job: it does not spin for the next one */
+  int idle = 0;   /* this thread had no slice in the last job it looked at */
   for (;;) {
+    if (idle) {
+      /* not part of the team at its current size: PARKED, on a condition of its own -- woken when the team grows, not by every
+       * job (105 parked threads woken for each of the 19 sweeps of a frame, each taking the mutex twice, held the caller up by
+       * ~1 ms per sweep on the bench host: 29.7 ms per frame at the reference's shape against 5.9 at sixteen threads) */
+      pthread_mutex_lock(&P->mu);
+      P->parked++;
+      while (!P->stop && !(__atomic_load_n(&P->active_of[__atomic_load_n(&P->job, __ATOMIC_ACQUIRE) & 7ul], __ATOMIC_ACQUIRE) > tid))
+        pthread_cond_wait(&P->cv_idle, &P->mu);
+      P->parked--;
+      pthread_mutex_unlock(&P->mu);
+      idle = 0;
+    }
     /* wait for the next job: spin a little (the evaluations of a Solve follow each other within ~100 us), then sleep */
-    int spins = idle ? 20000 : 0;
+    int spins = 0;
     while (__atomic_load_n(&P->job, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&P->stop, __ATOMIC_ACQUIRE)) {
       if (++spins < 20000) { __builtin_ia32_pause(); continue; }
       pthread_mutex_lock(&P->mu);
@@ -937,10 +951,12 @@ static void eval_pool_destroy(orc_ctx* c) {
   pthread_mutex_lock(&P->mu);
   __atomic_store_n(&P->stop, 1, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&P->cv);
+  pthread_cond_broadcast(&P->cv_idle);
   pthread_mutex_unlock(&P->mu);
   for (int i = 1; i < P->n; ++i) pthread_join(P->th[i], NULL);
   pthread_mutex_destroy(&P->mu);
   pthread_cond_destroy(&P->cv);
+  pthread_cond_destroy(&P->cv_idle);
   free(P->th);
   free(P->part);
   free(P);
@@ -955,6 +971,8 @@ static void eval_pool_run(orc_ctx* c, const double q[4], const double t[3], int 
     if (posix_memalign((void**)&P->part, 64, sizeof(orc_part) * (size_t)P->n) != 0) abort();
     pthread_mutex_init(&P->mu, NULL);
     pthread_cond_init(&P->cv, NULL);
+    pthread_cond_init(&P->cv_idle, NULL);
+    P->last_active = P->n;
     P->c = c;
     for (int i = 1; i < P->n; ++i) {
       orc_worker_arg* a = (orc_worker_arg*)malloc(sizeof(orc_worker_arg));
@@ -977,6 +995,8 @@ static void eval_pool_run(orc_ctx* c, const double q[4], const double t[3], int 
   __atomic_fetch_add(&P->job, 1ul, __ATOMIC_ACQ_REL);
   pthread_mutex_lock(&P->mu);
   if (P->sleepers > 0) pthread_cond_broadcast(&P->cv);
+  if (P->parked > 0 && P->n_active > P->last_active) pthread_cond_broadcast(&P->cv_idle);   /* the team grew */
+  P->last_active = P->n_active;
   pthread_mutex_unlock(&P->mu);
   eval_pool_slice(P, 0, P->n_active);
   while (__atomic_load_n(&P->pending, __ATOMIC_ACQUIRE) > 0) __builtin_ia32_pause();
