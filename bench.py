@@ -63,8 +63,8 @@ def _first_existing(*names):
     return next((p for p in paths if os.path.exists(p)), paths[0])
 
 
-PMC_SUMMARY = _first_existing("r04_pmc_k3_prebuilt.json", "r03_pmc_k3_prebuilt.json", "r02_pmc_k3_prebuilt.json")
-PMC_SUMMARY_COLD = _first_existing("r04_pmc_k3_prebuilt_cold.json", "r03_pmc_k3_prebuilt_cold.json")
+PMC_SUMMARY = _first_existing("r05_pmc_k3_prebuilt.json", "r04_pmc_k3_prebuilt.json", "r03_pmc_k3_prebuilt.json", "r02_pmc_k3_prebuilt.json")
+PMC_SUMMARY_COLD = _first_existing("r05_pmc_k3_prebuilt_cold.json", "r04_pmc_k3_prebuilt_cold.json", "r03_pmc_k3_prebuilt_cold.json")
 
 
 def _sha16(path):
