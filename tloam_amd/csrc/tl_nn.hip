@@ -361,8 +361,7 @@ size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
 // number at most the device's CUs: k_scan_1p holds its 64 elements per thread in registers (256 VGPRs + 76 AGPRs: one wave per
 // SIMD, i.e. ONE block per CU), so a grid of up to one block per CU is resident at once on an otherwise idle device -- and on a
 // busy one a block still only waits for blocks of lower index, which the dispatcher started earlier (a CPX partition or a
-// CU-masked device reports fewer CUs and gets the multi-launch scan; round 4 stopped at 240 tiles, which left the 245-tile
-// query-sort histogram of the 1 M frame on the three-launch scan: 39 us against ~20).  The wait is bounded either way.
+// CU-masked device reports fewer CUs and gets the multi-launch scan; round 4 stopped at 240 tiles).  The wait is bounded either way.
 bool scan_1p_applies(size_t n, int device_cus) {
   return (n + kScanTile - 1) / kScanTile > 1024 && (long long)((n + kTile1p - 1) / kTile1p) <= (long long)device_cus;
 }
