@@ -252,7 +252,7 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
   }
   if (cell_total == 0) return TLOAM_OK;
   if (frame) {  // the start of the scan_match rides on the first launch (the query-tile histogram is sized by the grids)
-    const size_t ntiles = (size_t)build_tile_count(out, frame->n_slots);
+    const size_t ntiles = (size_t)build_tile_count(out, frame->fi.slot_off);
     HIPC(c, c->tile_cnt.reserve(ntiles + 1 > c->tile_cnt.cap ? 2 * ntiles + 64 : ntiles + 1));
     frame->fi.tile_cnt = c->tile_cnt.p;
     frame->fi.n_tile_cnt = (int)ntiles + 1;

@@ -376,7 +376,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   if (!hook.consumed) {  // (no grid launch: cannot happen with >= 10 targets per kind, kept for safety)
     GridView gviews[kKinds];
     for (int k = 0; k < kKinds; ++k) gviews[k] = c->kd[k].gv;
-    const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off[kKinds]);
+    const size_t ntiles = (size_t)build_tile_count(gviews, c->sv.slot_off);
     HIPC(c, c->tile_cnt.reserve(ntiles + 1 > c->tile_cnt.cap ? 2 * ntiles + 64 : ntiles + 1));   // (room to spare, as build_grids_over)
     hook.fi.tile_cnt = c->tile_cnt.p;
     hook.fi.n_tile_cnt = (int)ntiles + 1;
@@ -414,7 +414,7 @@ void outer_params(const tloam_ctx* c, BuildParams* bp, GridView grids[kKinds]) {
 }
 int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
-  const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off[kKinds]);
+  const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off);
   // (tile counts follow the bounding boxes like the cell tables: grow with room to spare)
   const size_t nt_res = (ntiles + 1 > c->tile_cnt.cap || ntiles + 1 > c->tile_scan.cap) ? 2 * ntiles + 64 : ntiles;
   HIPC(c, c->tile_cnt.reserve(nt_res + 1)); HIPC(c, c->tile_scan.reserve(nt_res + 1));
@@ -441,7 +441,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
                   const int* refresh_gate = nullptr, bool prepare_in_solve = false, const FinishLargeArgs* ride = nullptr) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
   if (ride && !rebin) {
-    const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off[kKinds]);
+    const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off);
     launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream);
   } else {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,

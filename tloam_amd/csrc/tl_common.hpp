@@ -332,7 +332,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr,
                   unsigned long long* scan1p_ctl = nullptr, unsigned* scan1p_fault = nullptr);
-int build_tile_count(const GridView grids[kKinds], int n_slots);  // bins of the query counting sort (tiles, or cells of tiles)
+int build_tile_count(const GridView grids[kKinds], const int slot_off[kKinds + 1]);  // bins of the query counting sort (per kind: its tiles, or the cells of its tiles)
 // cap + compaction (after the flag scan)
 // refresh_gate != null: the launch also stands for the refresh alternative (see CompactArgs); tiles > 0: `sv.scan` holds
 // tile-local scans and `totals` the tiles' totals (scan_tiles_only)

@@ -739,15 +739,29 @@ constexpr int kWideLimit = TLOAM_K1_WIDE_LIMIT;   // at most this many: sixteen 
 
 struct TileMeta {
   int tdim[kKinds][3];
-  int tile_base[kKinds + 1];  // concatenated tile index space over the 4 kinds
-  int sub;                    // bins per tile: 1 (queries grouped by tile) or 64 (by cell inside the tile, see bin_sub)
+  int bin_base[kKinds + 1];   // concatenated bin index space over the 4 kinds: a kind's tiles x its bins per tile
+  int sub[kKinds];            // bins per tile of the kind: 1 (queries grouped by tile) or 64 (by cell inside the tile, see bin_sub)
 };
 // Thread-per-query frames (> kQuadLimit queries) sort their queries by CELL, tile-major: the 64 lanes of a wave then
 // cover ~25 neighbouring cells instead of 64 scattered ones of a tile, lanes of one cell walk the same nine rows in
 // the same order, and a gather instruction touches 2-3x fewer distinct cache lines -- the walk is bound by the
 // lines the CU's address unit retires, not by bytes.  Smaller frames (several lanes per query) keep the coarse sort:
 // their scan over the bins would cost more than it saves.
-static int bin_sub(int n_slots) { return n_slots > kQuadLimit ? kTile * kTile * kTile : 1; }
+// Per KIND since round 5: a kind with few queries (the 40 k sphere queries of the 1 M frame against 28 k tiles) gains nothing from
+// 64 bins per tile and only lengthens the histogram every frame zeroes, counts into and scans (4.7 M -> 2.9 M bins there).
+static int bin_sub(int n_slots, int n_kind) { return (n_slots > kQuadLimit && n_kind >= 65536) ? kTile * kTile * kTile : 1; }
+// the tile / bin metadata of the sorted query order; returns the number of bins
+static int tile_meta(const GridView grids[kKinds], const int slot_off[kKinds + 1], TileMeta* tm) {
+  int base = 0;
+  for (int k = 0; k < kKinds; ++k) {
+    tm->bin_base[k] = base;
+    for (int a = 0; a < 3; ++a) tm->tdim[k][a] = (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
+    tm->sub[k] = bin_sub(slot_off[kKinds], slot_off[k + 1] - slot_off[k]);
+    base += tm->tdim[k][0] * tm->tdim[k][1] * tm->tdim[k][2] * tm->sub[k];
+  }
+  tm->bin_base[kKinds] = base;
+  return base;
+}
 struct BuildArgs {
   SlotView sv;
   GridView grid[kKinds];
@@ -783,9 +797,9 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   const int cx = clampi(cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]), 0, g.dim[0] - 1);
   const int cy = clampi(cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]), 0, g.dim[1] - 1);
   const int cz = clampi(cell_coord(pw.z, g.org[2], g.inv_cell, g.dim[2]), 0, g.dim[2] - 1);
-  int t = A.tm.tile_base[kind] +
-          ((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile);
-  if (A.tm.sub > 1) t = t * A.tm.sub + ((cz % kTile) * kTile + (cy % kTile)) * kTile + (cx % kTile);
+  const int sub = A.tm.sub[kind];
+  int t = A.tm.bin_base[kind] + (((cz / kTile) * A.tm.tdim[kind][1] + (cy / kTile)) * A.tm.tdim[kind][0] + (cx / kTile)) * sub;
+  if (sub > 1) t += ((cz % kTile) * kTile + (cy % kTile)) * kTile + (cx % kTile);
   tile_of_slot[slot] = t;
   rank_in_tile[slot] = (int)atomicAdd(&tile_cnt[t], 1ull);  // the one atomic of the sort: count AND rank
 }
@@ -938,16 +952,8 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   BuildArgs A;
   A.sv = sv;
   A.bp = bp;
-  int base = 0;
-  for (int k = 0; k < kKinds; ++k) {
-    A.grid[k] = grids[k];
-    A.tm.tile_base[k] = base;
-    for (int a = 0; a < 3; ++a) A.tm.tdim[k][a] = (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
-    base += A.tm.tdim[k][0] * A.tm.tdim[k][1] * A.tm.tdim[k][2];
-  }
-  A.tm.tile_base[kKinds] = base;
-  A.tm.sub = bin_sub(n);
-  const int ntiles = base * A.tm.sub;   // bins of the counting sort
+  for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
+  const int ntiles = tile_meta(grids, sv.slot_off, &A.tm);   // bins of the counting sort
   // KITTI-size frames (sixteen lanes per query) are searched in SLOT order, unsorted: their target records (2-3 MB)
   // stay L2-resident whatever the order, and the sort's three launches (bin, scan, scatter: 13 us of a 270 us frame)
   // cost more than its locality saves -- measured with randomly ordered source clouds, the worst case: 0.273 -> 0.261 ms.
@@ -1033,7 +1039,6 @@ void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds],
   A.bp = bp;
   for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
   memset(&A.tm, 0, sizeof(A.tm));   // slot order: no tiles
-  A.tm.sub = 1;
   A.identity_n = n;
   WeightArgs W;
   W.cv = *fin.cv;
@@ -1051,15 +1056,8 @@ void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds],
   BuildArgs A;
   A.sv = sv;
   A.bp = bp;
-  int base = 0;
-  for (int k = 0; k < kKinds; ++k) {   // (as launch_build: the tile metadata of the sorted query order)
-    A.grid[k] = grids[k];
-    A.tm.tile_base[k] = base;
-    for (int a = 0; a < 3; ++a) A.tm.tdim[k][a] = (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
-    base += A.tm.tdim[k][0] * A.tm.tdim[k][1] * A.tm.tdim[k][2];
-  }
-  A.tm.tile_base[kKinds] = base;
-  A.tm.sub = bin_sub(n);
+  for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
+  (void)tile_meta(grids, sv.slot_off, &A.tm);   // (as launch_build: the tile metadata of the sorted query order)
   A.identity_n = 0;
   WeightArgs W;
   W.cv = *fin.cv;
@@ -1070,14 +1068,9 @@ void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds],
                      fin.sums16, fin.hm, fin.ctl, W, FinishRideLarge{fin.rows, fin.ticket, fin.wblocks});
 }
 
-int build_tile_count(const GridView grids[kKinds], int n_slots) {
-  int base = 0;
-  for (int k = 0; k < kKinds; ++k) {
-    int t = 1;
-    for (int a = 0; a < 3; ++a) t *= (std::max(grids[k].dim[a], 1) + kTile - 1) / kTile;
-    base += t;
-  }
-  return base * bin_sub(n_slots);
+int build_tile_count(const GridView grids[kKinds], const int slot_off[kKinds + 1]) {
+  TileMeta tm;
+  return tile_meta(grids, slot_off, &tm);
 }
 
 // ================================================================================================
