@@ -4,11 +4,14 @@ Tolerances: bit-exact for index work (k-NN indices, correspondence index lists, 
 |dt| < 1e-6 m and |dR| < 1e-6 rad for poses (BASELINE.json north_star); 1e-9 relative for the
 fp64 normal equations (different summation order / FMA contraction only).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 from conftest import pose_delta
 from oracle import binding as ob
+from oracle import oracle_np as onp
 from tloam_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -70,11 +73,19 @@ def test_scan_match_stepwise_parity(hip_module, seed):
     nb2 = cfg.noise_bound * cfg.noise_bound
     mu = 1e-10                                             # registration.cpp:1027-1033 with every residual slot still 0
     w_prev = [np.ones(len(sc.source.cloud(k))) for k in range(4)]   # :931-949
+    gn_iterations_before = 0
     for it in range(4):
         rc_h, done_h, st_h = H.sm_outer()
         rc_o, done_o, st_o = O.sm_outer()
         assert rc_h == 0 and rc_o == 0
         assert st_h["n_corr"] == st_o["n_corr"], (it, st_h["n_corr"], st_o["n_corr"])
+        # the point the last sweep of this Solve evaluated: the last candidate (GnState::x_cand survives the re-arming; accepted
+        # or not, the sweep that evaluated it is the last one), or the start point if the Solve never took a step
+        raw = np.zeros(64)
+        assert H.L.tloam_debug_state(H.h, raw.ctypes.data_as(C.POINTER(C.c_double)), 64) > 0
+        took_a_step = st_h["gn_iterations"] > gn_iterations_before
+        T_last = onp.se3_exp(raw[17:23] if took_a_step else np.asarray(st_h["se3"]))
+        gn_iterations_before = st_h["gn_iterations"]
         for kind in range(4):
             ch, co = H.get_correspondences(kind), O.get_correspondences(kind)
             # updateWeight (registration.cpp:858-876) EXACTLY, on the HIP path's OWN side-channel costs: the cross-check against
@@ -92,6 +103,19 @@ def test_scan_match_stepwise_parity(hip_module, seed):
             assert np.all(np.abs(got - want) <= 2 * np.spacing(np.maximum(np.abs(want), mu))), (it, kind, np.abs(got - want).max())
             assert np.array_equal(got[want == 0.0], want[want == 0.0]) and np.array_equal(got[want == 1.0], want[want == 1.0])
             w_prev[kind] = got
+            # R1-R3 + the side-channel semantics (registration.cpp:19-117) at the pose the LAST sweep of this Solve
+            # evaluated -- the HIP path's OWN candidate, read back from the device state -- with the HIP path's own factors,
+            # through the independent numpy restatement: tight in EVERY iteration.  (The comparison with the oracle's costs below
+            # is loose from iteration 1 on, because the two sides' rejected candidates differ by the conditioning of the step; a
+            # 1e-7 relative error in the residual code that only showed at such far-away poses would hide there -- round-4 review.)
+            if len(ch["idx"]):
+                cs = onp.CorrSet(kind, ch["idx"].astype(np.int64), sc.source.cloud(kind)[ch["idx"]], ch["a"], ch["b"], ch["d"], ch["w"])
+                _, _, side = onp.residual_blocks(cs, T_last)
+                # cost = r^2 with r a difference of coordinates of ~50 m: r carries ~1e-14 m of rounding whatever the operation
+                # order, the cost 2 |r| times that; beyond it only 1e-12 relative
+                tol = 4e-14 * np.sqrt(np.abs(side)) + 1e-12 * np.abs(side) + 1e-28
+                bad = np.abs(ch["cost"] - side) > tol
+                assert not bad.any(), (it, kind, int(bad.sum()), float(np.abs(ch["cost"] - side)[bad].max()))
             assert np.array_equal(ch["idx"], co["idx"]), (it, kind)
             np.testing.assert_allclose(ch["a"], co["a"], rtol=0, atol=1e-9)
             if kind == 2:   # the edge line's second endpoint (registration.cpp:484)
