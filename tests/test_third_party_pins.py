@@ -15,6 +15,7 @@ against that library, through the C ABI:
 hypothesis draws the clouds (uniform, clustered, jittered lattice, float32-rounded like the ROS wire), so the cases are not
 the ones the oracle's author thought of."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -132,7 +133,8 @@ def knn_ctx(hip_module):
 
 
 @pytest.mark.gpu
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("HYPOTHESIS_MAX_EXAMPLES", "40")), deadline=None,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(seed=st.integers(0, 2 ** 31 - 1), n_t=st.integers(10, 20000), n_q=st.integers(1, 3000),
        shape=st.sampled_from(["uniform", "clustered", "planes", "lattice"]),
        rk=st.sampled_from([(0.5, 5), (1.0, 5), (0.5, 1), (0.02, 1), (0.2, 8), (2.5, 8)]), kind=st.integers(0, 3))
