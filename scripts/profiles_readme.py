@@ -14,6 +14,9 @@ WHAT = {
     "m1_frame_timeline.txt": "the same for the 1 M frame (`bench.py --workload m1`)",
     "solve_all_timeline.txt": "`scripts/solve_profile2.py` on a `-DTLOAM_STEP_PROFILE` build: wall-clock stamps (10 ns) inside the one-launch Solve `k_solve_all` per GN iteration -- lead block's stepper wave and one other wave",
     "kitti_sequence_4540.json": "`python bench.py --kitti-frames 4540 --no-m1 --no-cpu-baseline` (`scripts/gpu_seq4540.sh`): the KITTI-density sequence over the WHOLE published KITTI-00 trajectory of the reference (SURVEY 8(d) config 2); numbers below",
+    "bench_gpus2_one_device.json": "`scripts/gpu_one_device_ranks.sh`: `bench.py --gpus 2` launched as the driver launches it (`torch.distributed.run`, one rank per process) with `TLOAM_BENCH_ONE_DEVICE=1` -- every rank on the ONE GPU of the box, launcher collectives over gloo.  NOT a scaling measurement (the ranks share the GPU): it shows the replica headline aggregating over the ranks and the sharded 1 M frame (BASELINE.json configs[3]) running end to end over the mailbox; RCCL refuses two ranks on one device and is reported as such",
+    "bench_gpus4_one_device.json": "the same with 4 ranks",
+    "bench_gpus8_one_device.json": "the same with 8 ranks",
     "solve_small_timeline.txt": "the same with `TLOAM_SOLVE_V1=1` (round 3's `k_solve_small`: one consumer wave for the whole grid)",
 }
 print("## Round %s\n" % tag[1:].lstrip("0"))
