@@ -305,3 +305,25 @@ def test_bench_n_gpus_path_runs_on_one_device(hip_module, n):
     assert "one device" in sh["rccl"].get("error", ""), sh["rccl"]
     assert sh["fastest_exchange"] == "mailbox" and sh["ms_per_frame"] == sh["mailbox"]["ms_per_frame"]
     assert sh["pose_err_vs_truth_m"] < 1e-2
+
+
+def test_bench_sharded_deadline_prints_the_line(hip_module):
+    """The sharded 1 M frame is on a deadline (`--sharded-timeout`): with one that cannot be met, `bench.py --gpus 2` still prints
+    its line -- the replica headline, and sharded_1m saying what was cut off -- and every rank leaves with exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TLOAM_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--m1-steps", "2", "--sharded-timeout", "0.05"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    sh = d["sharded_1m"]
+    assert "cut off" in sh["note"] and "ms_per_frame" not in sh
+    assert "did not finish" in sh["mailbox"]["error"] and "did not finish" in sh["rccl"]["error"]
