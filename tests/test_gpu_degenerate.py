@@ -1,0 +1,141 @@
+"""-m gpu: degenerate geometry through the C ABI -- the inputs a uniform search grid, a plane fit and a 3x3 eigen solve like
+least: coincident points, exactly coplanar / collinear neighbourhoods, clouds with fewer points than a neighbourhood needs,
+coordinates of a UTM-sized frame, two clusters kilometres apart in one cloud.  Every case is held against the C restatement of
+the reference (same gates, registration.cpp:445 / :589 / :605-613 / :481) and, for the search, against brute force: nothing may
+crash, hang, or differ."""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+from oracle import binding as ob
+from tloam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(hip_module, source, target, cfg=None):
+    H = hip_module.HipRegistration(cfg) if cfg else hip_module.HipRegistration()
+    O = ob.Oracle(cfg) if cfg else ob.Oracle()
+    for R in (H, O):
+        R.set_frames(source, target)
+    return H, O
+
+
+def _same_solve(H, O, T_pred, what):
+    rc, T, st = H.scan_match(T_pred)
+    rco, To, sto = O.scan_match(T_pred)
+    assert rc == rco, (what, rc, rco)
+    if rc != 0:
+        return
+    assert st["n_corr"] == sto["n_corr"], (what, st["n_corr"], sto["n_corr"])
+    assert st["outer_iterations"] == sto["outer_iterations"] and st["gn_evaluations"] == sto["gn_evaluations"], what
+    dt, dr = pose_delta(T, To)
+    assert dt < 1e-6 and dr < 1e-6, (what, dt, dr)
+
+
+def _knn_equals_brute_force(H, kind, tgt, q, radius, k):
+    hi, hd, hc = H.knn(kind, q, radius, k)
+    for j in range(len(q)):
+        bi, bd = ob.knn_brute(tgt, q[j], radius, k)
+        assert hc[j] == len(bi), (j, hc[j], len(bi))
+        # coincident targets tie exactly: the reference's order among equal distances is the kd-tree's, unspecified; the
+        # distances must agree bit for bit and the index sets wherever the distances are distinct
+        assert np.array_equal(hd[j, :hc[j]], bd), j
+        if len(np.unique(bd)) == len(bd):
+            assert np.array_equal(hi[j, :hc[j]], bi), j
+        else:
+            assert set(hi[j, :hc[j]]) <= set(np.flatnonzero(np.isin(((tgt - q[j]) ** 2).sum(1), bd))), j
+
+
+def test_coincident_target_points(hip_module):
+    """2000 copies of ONE target point among ordinary ones: a single grid cell holds them all (the walk is long, not wrong);
+    every neighbourhood that reaches the pile is five identical points -- a zero covariance for the edge builder (no direction:
+    rejected at :481), a rank-deficient plane fit for the others."""
+    sc = synth.make_scene(seed=51)
+    rng = np.random.default_rng(1)
+    tgt = [sc.target.cloud(k).copy() for k in range(4)]
+    for k in range(4):
+        pile = tgt[k][rng.integers(0, len(tgt[k]))]
+        tgt[k] = np.concatenate([tgt[k], np.repeat(pile[None], 2000, 0)])
+    target = synth.Frame(*tgt)
+    H, O = _pair(hip_module, sc.source, target)
+    for k in (0, 2, 3):
+        q = np.concatenate([tgt[k][-1:] + 0.01, tgt[k][-1:], sc.source.cloud(k)[:40]])
+        _knn_equals_brute_force(H, k, tgt[k], q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
+    _same_solve(H, O, sc.T_pred, "coincident")
+
+
+def test_exactly_coplanar_and_collinear_targets(hip_module):
+    """Targets on an exact lattice of the plane z = 0 (planar / ground kinds: the fit's residuals are exact zeros, equal
+    distances everywhere) and on the exact line y = z = 0 (edge kind: two zero eigenvalues)."""
+    g = np.arange(-10, 10.01, 0.25)
+    X, Y = np.meshgrid(g, g)
+    plane = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], 1)
+    line = np.stack([np.arange(-20, 20, 0.1), np.zeros(400), np.zeros(400)], 1)
+    rng = np.random.default_rng(2)
+    src_plane = np.stack([rng.uniform(-8, 8, 300), rng.uniform(-8, 8, 300), rng.normal(0, 0.02, 300)], 1)
+    src_line = np.stack([rng.uniform(-15, 15, 100), rng.normal(0, 0.02, 100), rng.normal(0, 0.02, 100)], 1)
+    sc = synth.make_scene(seed=52)
+    Fr = type(sc.source)
+    # Frame(planar, ground, edge, sphere) in the binding's kind order
+    source = Fr(src_plane, src_plane[::2] + 0.001, src_line, src_plane[:50])
+    target = Fr(plane, plane + np.array([0.125, 0.125, 0.0]), line, plane[::7])
+    H, O = _pair(hip_module, source, target)
+    for k, tg in ((0, plane), (2, line)):
+        q = (src_plane if k == 0 else src_line)[:60]
+        hi, hd, hc = H.knn(k, q, 1.0, 5)
+        oi, od, oc = O.knn(k, q, 1.0, 5)
+        assert np.array_equal(hc, oc) and np.array_equal(hd, od)
+    T_pred = np.eye(4)
+    T_pred[:3, 3] = (0.03, -0.02, 0.05)
+    _same_solve(H, O, T_pred, "coplanar / collinear")
+
+
+@pytest.mark.parametrize("n_tgt", [1, 3, 4, 5])
+def test_fewer_targets_than_a_neighbourhood(hip_module, n_tgt):
+    """Target clouds of 1 / 3 / 4 / 5 points: below `cnt > 3` (:445) / `cnt > 4` (:589) nothing is built; with exactly five the
+    planar builders just qualify.  The grid degenerates to a handful of cells."""
+    sc = synth.make_scene(seed=53)
+    Fr = type(sc.source)
+    tgt = [sc.target.cloud(k)[:n_tgt].copy() for k in range(4)]
+    near = [np.repeat(tgt[k].mean(0)[None], 30, 0) + np.random.default_rng(3 + k).normal(0, 0.05, (30, 3)) for k in range(4)]
+    H, O = _pair(hip_module, Fr(*near), Fr(*tgt))
+    for k in range(4):
+        _knn_equals_brute_force(H, k, tgt[k], near[k][:10], 0.5, 1 if k == 3 else 5)
+    _same_solve(H, O, np.eye(4), f"{n_tgt} targets")
+
+
+def test_utm_sized_coordinates(hip_module):
+    """The whole scene shifted by (4.5e5, 5.4e6, 300) m: cell indices, the packed keys of the top-k lists (low mantissa bits
+    replaced by the candidate's position) and the un-fused squared distances at coordinates where one ulp is 1e-9 m."""
+    sc = synth.make_scene(seed=54)
+    off = np.array([4.5e5, 5.4e6, 300.0])
+    Fr = type(sc.source)
+    source = Fr(*[sc.source.cloud(k) + off for k in range(4)])
+    target = Fr(*[sc.target.cloud(k) + off for k in range(4)])
+    T_pred = sc.T_pred.copy()
+    T_pred[:3, 3] += off - T_pred[:3, :3] @ off      # the same prediction, about the shifted origin
+    H, O = _pair(hip_module, source, target)
+    for k in range(4):
+        q = (T_pred[:3, :3] @ source.cloud(k)[:80].T).T + T_pred[:3, 3]
+        hi, hd, hc = H.knn(k, q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
+        oi, od, oc = O.knn(k, q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
+        assert np.array_equal(hc, oc) and np.array_equal(hi, oi) and np.array_equal(hd, od), k
+    _same_solve(H, O, T_pred, "UTM offset")
+
+
+def test_two_clusters_kilometres_apart(hip_module):
+    """One target cloud = the scene + a copy of it 7 km away: the bounding box is ~10^4 x its cell size per axis, the dense cell
+    table cannot hold cells of one search radius (<= 4 M cells), so the cells grow and every cell holds hundreds of points --
+    the search must still return the exact neighbours."""
+    sc = synth.make_scene(seed=55)
+    far = np.array([7000.0, -3000.0, 40.0])
+    Fr = type(sc.source)
+    tgt = [np.concatenate([sc.target.cloud(k), sc.target.cloud(k)[::3] + far]) for k in range(4)]
+    H, O = _pair(hip_module, sc.source, Fr(*tgt))
+    for k in range(4):
+        q = np.concatenate([sc.source.cloud(k)[:40], sc.source.cloud(k)[:10] + far])
+        hi, hd, hc = H.knn(k, q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
+        oi, od, oc = O.knn(k, q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
+        assert np.array_equal(hc, oc) and np.array_equal(hi, oi) and np.array_equal(hd, od), k
+    _same_solve(H, O, sc.T_pred, "two clusters")
