@@ -62,7 +62,8 @@ typedef enum tloam_status {
   TLOAM_OK = 0,
   TLOAM_E_INVALID = -1,        /* null pointer / bad enum / bad size                        */
   TLOAM_E_TOO_FEW_POINTS = -2, /* < 10 points in one of the 8 clouds (registration.cpp:928) */
-  TLOAM_E_BAD_POSE = -3,       /* predict pose is not a rigid transform (sophus se3.hpp:497) */
+  TLOAM_E_BAD_POSE = -3,       /* predict pose is not a rigid transform (sophus se3.hpp:497), or its translation is
+                                  not finite (the reference goes on and returns a NaN pose)                  */
   TLOAM_E_HIP = -4,            /* HIP runtime error / no device                             */
   TLOAM_E_RCCL = -5,           /* RCCL error / librccl not loadable                         */
   TLOAM_E_NOT_READY = -6,      /* call sequence violated (e.g. outer step before begin)     */

@@ -99,6 +99,10 @@ def test_host_se3_helpers_match_the_oracle():
     bad = reg.se3_exp(x); bad[:3, :3] *= 1.01
     with pytest.raises(reg.TloamHipError, match="BAD_POSE"):
         reg.se3_log(bad)
+    for v in (np.nan, np.inf, -np.inf):   # a non-finite translation passes Sophus' checks; here it is a bad pose too
+        bad = reg.se3_exp(x); bad[1, 3] = v
+        with pytest.raises(reg.TloamHipError, match="BAD_POSE"):
+            reg.se3_log(bad)
 
 
 @pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 1_000_003])

@@ -93,8 +93,9 @@ def test_exactly_coplanar_and_collinear_targets(hip_module):
 
 @pytest.mark.parametrize("n_tgt", [1, 3, 4, 5])
 def test_fewer_targets_than_a_neighbourhood(hip_module, n_tgt):
-    """Target clouds of 1 / 3 / 4 / 5 points: below `cnt > 3` (:445) / `cnt > 4` (:589) nothing is built; with exactly five the
-    planar builders just qualify.  The grid degenerates to a handful of cells."""
+    """Target clouds of 1 / 3 / 4 / 5 points: the search over a grid that has degenerated to a handful of cells returns the
+    exact neighbours (fewer than k of them), and scanMatching refuses the frame with the status that stands for the reference's
+    assert on clouds of fewer than ten points (registration.cpp:928-929), as the restatement does."""
     sc = synth.make_scene(seed=53)
     Fr = type(sc.source)
     tgt = [sc.target.cloud(k)[:n_tgt].copy() for k in range(4)]
@@ -139,3 +140,51 @@ def test_two_clusters_kilometres_apart(hip_module):
         oi, od, oc = O.knn(k, q, 1.0 if k == 2 else 0.5, 1 if k == 3 else 5)
         assert np.array_equal(hc, oc) and np.array_equal(hi, oi) and np.array_equal(hd, od), k
     _same_solve(H, O, sc.T_pred, "two clusters")
+
+
+def test_no_correspondence_at_all(hip_module):
+    """Every source point 2 km from every target: four empty residual sets, `ceres::Solve` on an empty problem in every outer
+    iteration, the plateau break of :1108 on 0 - inf ... the restatement and the device agree on whatever that gives."""
+    sc = synth.make_scene(seed=56)
+    Fr = type(sc.source)
+    source = Fr(*[sc.source.cloud(k) + np.array([2000.0, 0.0, 0.0]) for k in range(4)])
+    H, O = _pair(hip_module, source, sc.target)
+    rc, T, st = H.scan_match(sc.T_pred)
+    rco, To, sto = O.scan_match(sc.T_pred)
+    assert rc == rco and st["n_corr"] == sto["n_corr"] == [0, 0, 0, 0]
+    assert st["outer_iterations"] == sto["outer_iterations"]
+    dt, dr = pose_delta(T, To)
+    assert dt < 1e-9 and dr < 1e-9
+    dt, dr = pose_delta(T, sc.T_pred)
+    assert dt < 1e-9 and dr < 1e-9          # nothing to minimise: the prediction comes back
+
+
+def test_all_clouds_empty_and_non_finite_prediction(hip_module):
+    """No point in any of the eight clouds; then a prediction holding a NaN / an Inf: a status code, never a hang or a crash
+    (the reference would run into SOPHUS_ENSURE, se3.hpp:497-504)."""
+    sc = synth.make_scene(seed=57)
+    Fr = type(sc.source)
+    empty = Fr(*[np.zeros((0, 3)) for _ in range(4)])
+    H, O = _pair(hip_module, empty, empty)
+    rc, T, st = H.scan_match(np.eye(4))
+    rco, To, sto = O.scan_match(np.eye(4))
+    assert rc == rco and st["n_corr"] == sto["n_corr"] == [0, 0, 0, 0]
+    if rc == 0:
+        assert np.array_equal(T, np.eye(4))
+    H2 = hip_module.HipRegistration()
+    H2.set_frames(sc.source, sc.target)
+    for bad in (np.nan, np.inf):
+        P = sc.T_pred.copy()
+        P[0, 3] = bad
+        rc, T, st = H2.scan_match(P)
+        assert rc != 0, bad
+        P = sc.T_pred.copy()
+        P[1, 1] = bad
+        rc, T, st = H2.scan_match(P)
+        assert rc != 0, bad
+    rc, T, st = H2.scan_match(sc.T_pred)       # the context is still good
+    O2 = ob.Oracle()
+    O2.set_frames(sc.source, sc.target)
+    rco, To, sto = O2.scan_match(sc.T_pred)
+    dt, dr = pose_delta(T, To)
+    assert rc == 0 and dt < 1e-6 and dr < 1e-6

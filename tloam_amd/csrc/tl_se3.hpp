@@ -168,6 +168,10 @@ TL_HD void se3_plus(const double x[6], const double delta[6], double out[6]) {
 // M is column-major 4x4 (Eigen::Isometry3d::matrix()).
 inline bool pose_from_matrix(const double M[16], Pose* out) {
   auto m = [&](int r, int c) { return M[c * 4 + r]; };
+  // (a non-finite translation passes Sophus' checks -- they look at the rotation and the last row -- and the reference then
+  //  computes on NaNs; here it is a bad pose like the others: a status code instead of a NaN result)
+  auto finite = [](double v) { return v - v == 0.0; };   // false for NaN and +-Inf
+  if (!(finite(m(0, 3)) && finite(m(1, 3)) && finite(m(2, 3)))) return false;
   const double last = m(3, 0) * m(3, 0) + m(3, 1) * m(3, 1) + m(3, 2) * m(3, 2) +
                       (m(3, 3) - 1.0) * (m(3, 3) - 1.0);
   if (!(last < kSophusEps)) return false;
