@@ -156,3 +156,48 @@ def test_look_back_time_out_switches_to_start_tickets(hip_module):
         A.update(T, *cl); B.update(T, *cl)
         for k in range(4):
             assert np.array_equal(A.get(k), B.get(k)), (f, k)
+
+
+def test_non_finite_points_in_the_scans(hip_module):
+    """NaN and +-Inf coordinates in the edge / ground scans.  Behind the crop box (`updateSubmap`, front_end.cpp:246-262) they
+    disappear: the box's comparisons are false for a NaN, an infinity is outside every box.  Where a cloud is voxel-sampled
+    WITHOUT a crop (the first-frame branch, :283-304) an infinite extent is Open3D's "voxel_size is too small" error: a status
+    code here, in the restatement and on the device alike, and the submap can be initialised again afterwards."""
+    cfg = dict(edge_crop_box_length=25.0, ground_crop_box_length=20.0, planar_frame_size=3)
+    A = _HipSubmap(hip_module, cfg)
+    B = ob.OracleSubmap(ob.make_submap_config(**cfg))
+    rng = np.random.default_rng(11)
+
+    def spoil(clouds):
+        out = [c.copy() for c in clouds]
+        for k in (2, 3):                       # edge, ground (the planar / sphere selections feed a kd-tree build: kept finite)
+            c = out[k]
+            j = rng.choice(len(c), 6, replace=False)
+            c[j[0], 0] = np.nan; c[j[1], 2] = np.nan; c[j[2]] = np.nan
+            c[j[3], 1] = np.inf; c[j[4], 0] = -np.inf; c[j[5]] = (np.inf, -np.inf, np.nan)
+        return out
+
+    def status(fn, *args):
+        try:
+            rc = fn(*args)
+            return 0 if rc is None else int(rc)
+        except hip_module.TloamHipError as e:
+            assert "TLOAM_E_INVALID" in str(e), e
+            return -1
+
+    first = ss.frame_clouds(4, 0)
+    ra, rb = status(A.init, *spoil(first)), status(B.init, *spoil(first))
+    assert (ra != 0) == (rb != 0), (ra, rb)
+    if ra != 0:                                  # refused alike: start over with a finite first frame
+        assert status(A.init, *first) == 0 and status(B.init, *first) == 0
+    for f in range(1, 6):
+        cl = spoil(ss.frame_clouds(4, f))
+        T = ss.frame_pose(f, step=2.0, yaw_rate=0.03)
+        ra, rb = status(A.update, T, *cl), status(B.update, T, *cl)
+        assert (ra != 0) == (rb != 0), (f, ra, rb)
+        assert ra == 0, f                        # behind the crop box the non-finite points are simply gone
+        for k in range(4):
+            a, b = A.get(k), B.get(k)
+            assert a.shape == b.shape, (f, k, a.shape, b.shape)
+            assert np.array_equal(a, b, equal_nan=True), (f, k)
+            assert np.isfinite(a).all(), (f, k)
