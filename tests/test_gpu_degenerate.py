@@ -188,3 +188,32 @@ def test_all_clouds_empty_and_non_finite_prediction(hip_module):
     rco, To, sto = O2.scan_match(sc.T_pred)
     dt, dr = pose_delta(T, To)
     assert rc == 0 and dt < 1e-6 and dr < 1e-6
+
+
+def test_refused_frame_leaves_the_registered_one_alone(hip_module):
+    """`tloam_set_source_frame` / `tloam_set_target_frame` with a NULL cloud of non-zero size are refused AS A WHOLE: the frame
+    registered before stays registered -- its sizes, its pointers -- so the fitness score and the next solve are those of the
+    frame before (until round 5 the kinds in front of the offending one had already taken the new sizes, and getFitnessScore
+    then read past the old clouds: a GPU memory fault found by tests/tools/fuzz_call_order.py)."""
+    import ctypes as C
+    sc = synth.make_scene(seed=58)
+    H = hip_module.HipRegistration()
+    O = ob.Oracle()
+    for R in (H, O):
+        R.set_frames(sc.source, sc.target)
+    rc, T0, st0 = H.scan_match(sc.T_pred)
+    assert rc == 0
+    f0 = H.get_fitness_score()
+    big = [np.ascontiguousarray(np.random.default_rng(k).normal(0, 20, (50_000, 3))) for k in range(4)]
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    for fn in (H.L.tloam_set_source_frame, H.L.tloam_set_target_frame):
+        for bad in range(4):
+            ptrs = (C.POINTER(C.c_double) * 4)(*[dp(b) for b in big])
+            ptrs[bad] = C.POINTER(C.c_double)()
+            assert fn(H.h, ptrs, (C.c_size_t * 4)(*[len(b) for b in big])) == -1      # TLOAM_E_INVALID
+            assert H.get_fitness_score() == f0
+    rc, T1, st1 = H.scan_match(sc.T_pred)
+    assert rc == 0 and T1.tobytes() == T0.tobytes() and st1["n_corr"] == st0["n_corr"]
+    rco, To, sto = O.scan_match(sc.T_pred)
+    dt, dr = pose_delta(T1, To)
+    assert dt < 1e-6 and dr < 1e-6

@@ -201,3 +201,59 @@ def test_non_finite_points_in_the_scans(hip_module):
             assert a.shape == b.shape, (f, k, a.shape, b.shape)
             assert np.array_equal(a, b, equal_nan=True), (f, k)
             assert np.isfinite(a).all(), (f, k)
+
+
+def test_non_finite_pose_is_a_status_code(hip_module):
+    """`tloam_submap_update` with a NaN / an infinity anywhere in the pose: TLOAM_E_BAD_POSE, the submap untouched and usable
+    (until round 5 the NaN crop box ended in a GPU memory fault -- found by tests/tools/fuzz_call_order.py).  Any FINITE 4x4 is
+    taken as Open3D's Transform takes it, scaled rotation and projective last row included."""
+    cfg = dict(edge_crop_box_length=40.0, ground_crop_box_length=30.0, planar_frame_size=2)
+    A = _HipSubmap(hip_module, cfg)
+    B = ob.OracleSubmap(ob.make_submap_config(**cfg))
+    cl = ss.frame_clouds(6, 0)
+    A.init(*cl); B.init(*cl)
+    before = [A.get(k) for k in range(4)]
+    for r, c_, v in ((0, 3, np.nan), (1, 3, np.inf), (2, 3, -np.inf), (1, 1, np.nan), (3, 3, np.inf), (3, 0, np.nan)):
+        T = ss.frame_pose(1, step=2.0, yaw_rate=0.03).copy()
+        T[r, c_] = v
+        with pytest.raises(hip_module.TloamHipError, match="BAD_POSE"):
+            A.update(T, *ss.frame_clouds(6, 1))
+    for k in range(4):
+        assert np.array_equal(A.get(k), before[k]), k
+    T = ss.frame_pose(1, step=2.0, yaw_rate=0.03).copy()
+    T[:3, :3] *= 1.2
+    T[3, :] = (0.001, -0.002, 0.0005, 1.1)
+    cl = ss.frame_clouds(6, 1)
+    A.update(T, *cl); B.update(T, *cl)
+    for k in range(4):
+        a, b = A.get(k), B.get(k)
+        assert a.shape == b.shape and np.array_equal(a, b), k
+
+
+def test_submaps_that_outgrow_their_arrays(hip_module):
+    """A submap initialised from a handful of points and then fed scans a hundred times that size: the edge / ground arrays
+    are input (the old submap) and output of every update and have to grow while keeping their points (round 5: the one-launch
+    front used to read the old points from a block that had just been freed).  Other contexts allocate and free blocks of the
+    same sizes in between, so a freed block does not stay intact by luck."""
+    cfg = dict(edge_crop_box_length=200.0, ground_crop_box_length=200.0, planar_frame_size=2, edge_down_sample_submap=0.05,
+               ground_down_sample_submap=0.05, ground_down_sample=0.05)
+    A = _HipSubmap(hip_module, cfg)
+    B = ob.OracleSubmap(ob.make_submap_config(**cfg))
+    rng = np.random.default_rng(21)
+    sizes = [12, 40, 700, 9000, 300, 30000, 50]
+    for f, n in enumerate(sizes):
+        cl = [np.ascontiguousarray(rng.uniform(-60, 60, (n + 3 * k, 3)).astype(np.float32).astype(np.float64)) for k in range(4)]
+        if f == 0:
+            A.init(*cl); B.init(*cl)
+        else:
+            T = ss.frame_pose(f, step=1.0, yaw_rate=0.02)
+            A.update(T, *cl); B.update(T, *cl)
+        # stir the allocator: a context that takes and returns blocks of this frame's sizes
+        X = hip_module.HipRegistration()
+        for k in range(4):
+            X.set_target(k, cl[k]); X.set_source(k, cl[k])
+        X.close()
+        for k in range(4):
+            a, b = A.get(k), B.get(k)
+            assert a.shape == b.shape, (f, k, a.shape, b.shape)
+            assert np.array_equal(a, b), (f, k)

@@ -350,9 +350,10 @@ int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
 int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
   size_t off[kKinds] = {0, 0, 0, 0};
   size_t lo4[kKinds], hi4[kKinds], cnt4[kKinds];
+  for (int k = 0; k < kKinds; ++k)   // (refused as a whole, before anything of the registered frame has been touched)
+    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
   tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
   for (int k = 0; k < kKinds; ++k) {
-    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
     KindData& K = c->kd[k];
     K.n_src_full = n[k];
     K.src_lo = lo4[k];
@@ -422,6 +423,8 @@ int tloam_set_source_frame(tloam_ctx* c, const double* const xyz[4], const size_
 
 int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
+  for (int k = 0; k < kKinds; ++k)   // (refused as a whole, before any of the registered targets has been replaced)
+    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   int rc = TLOAM_OK;
   // four copies, then ONE launch that converts all four clouds and takes their bounds (rows into pinned memory)

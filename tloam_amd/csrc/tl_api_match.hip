@@ -978,7 +978,7 @@ int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
     const int k = order[o];
     KindData& K = c->kd[k];
     // the kd-trees are the ones built by the last scanMatching (:889-915); none yet -> no hits
-    if (!K.grid_valid || K.n_src == 0) continue;
+    if (!K.grid_valid || K.n_src == 0 || !K.src_set || !K.src_ptr) continue;   // (a hand-over that failed registered nothing)
     // raw scan-frame source points (:271): this kind's AoS block as SoA, in scratch of its own (the slot arrays
     // sx/sy/sz belong to scan_match: SlotView holds their addresses)
     HIPC(c, c->fit_x.reserve(K.n_src)); HIPC(c, c->fit_y.reserve(K.n_src)); HIPC(c, c->fit_z.reserve(K.n_src));

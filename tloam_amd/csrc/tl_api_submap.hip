@@ -173,6 +173,11 @@ int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* plana
   if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
     return TLOAM_E_INVALID;
   if (!c->submap.inited) return TLOAM_E_NOT_READY;
+  // Open3D's Transform takes any 4x4 (front_end.cpp:246-247 hands it an Isometry3d's matrix: no orthogonality test anywhere on
+  // this path), but a non-finite entry makes the crop box of :250-262 and every transformed point non-finite: a bad pose here
+  // (the reference would go on with NaN clouds)
+  for (int i = 0; i < 16; ++i)
+    if (!(pose[i] - pose[i] == 0.0)) return TLOAM_E_BAD_POSE;
   HIPC(c, hipSetDevice(c->device));
   const int rc = submap_update_body(c, pose, planar, n_planar, sphere, n_sphere, edge, n_edge, ground, n_ground);
   // The host clouds are borrowed for the call only and are copied asynchronously; the success path ends in the one
@@ -277,6 +282,26 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     for (int s = 0; s < 2; ++s) grow = grow || c->kd[accs[s].kind].tx.cap < std::max<size_t>(n_in[s], 1);
     if (grow) HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, S.wx.reserve(m)); HIPC(c, S.wy.reserve(m)); HIPC(c, S.wz.reserve(m));
+    // The edge / ground submaps are INPUT (the old points, read by the assembly) and OUTPUT (the crop + voxel job writes the
+    // new submap into the same arrays, sized for all n_in points): an array that has to grow keeps its old points.  (DBuf::reserve
+    // does not; until round 5 the one-launch front read the old points through the pointer of a block that the job's
+    // reserve had just freed -- right only as long as nobody else was handed that block in between.)
+    for (int s = 0; s < 2; ++s) {
+      KindData& K = c->kd[accs[s].kind];
+      const size_t need = std::max<size_t>(n_in[s], 1);
+      DBuf<double>* arr[3] = {&K.tx, &K.ty, &K.tz};
+      for (DBuf<double>* b : arr) {
+        if (need <= b->cap) continue;
+        DBuf<double> nb;
+        HIPC(c, nb.reserve(std::max(need, b->cap + b->cap / 2)));
+        if (n_old[s] > 0 && b->p) {
+          const hipError_t e = hipMemcpy(nb.p, b->p, sizeof(double) * n_old[s], hipMemcpyDeviceToDevice);
+          if (e != hipSuccess) { nb.release(); c->last_error = hipGetErrorString(e); return TLOAM_E_HIP; }
+        }
+        b->release();
+        *b = nb;
+      }
+    }
   }
   double lo[2][3], hi[2][3];
   {
