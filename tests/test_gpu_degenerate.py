@@ -217,3 +217,32 @@ def test_refused_frame_leaves_the_registered_one_alone(hip_module):
     rco, To, sto = O.scan_match(sc.T_pred)
     dt, dr = pose_delta(T1, To)
     assert dt < 1e-6 and dr < 1e-6
+
+
+def test_large_frame_after_prebuilt_sets_on_a_used_context(hip_module):
+    """The call sequence tests/tools/fuzz_call_order.py shrank a GPU memory fault to: a small frame, a pre-built correspondence
+    set (its buffers fill and free blocks of device memory), then the context's FIRST frame large enough for the sorted query
+    order.  The query-tile histogram was re-allocated after the frame's start had zeroed it; on a block that was not fresh the
+    counting sort scattered the queries by garbage.  The solve must equal the restatement's -- and a second context that does
+    the same with its allocations in another order."""
+    small = synth.make_scene(seed=60)
+    big = synth.make_scene(seed=80, n_src=(6000, 8000, 5000, 1000), n_tgt=(8000, 9000, 6000, 1500))
+    O = ob.Oracle()
+    O.set_frames(big.source, big.target)
+    rco, To, sto = O.scan_match(big.T_pred)
+    assert rco == 0
+    rng = np.random.default_rng(5)
+    for order in range(3):
+        H = hip_module.HipRegistration()
+        H.set_frames(small.source, small.target)
+        if order != 1:
+            assert H.scan_match(small.T_pred)[0] == 0
+        for rt, m in ((0, 3000), (1, 700), (2, 300))[: 1 + order]:
+            p = rng.normal(0, 10, (m, 3)); a = rng.normal(0, 1, (m, 3)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+            H.set_correspondences(rt, p, a, rng.normal(0, 10, (m, 3)), rng.normal(0, 1, m), rng.uniform(0.1, 1, m) * 1e300)
+        H.set_frames(big.source, big.target)
+        rc, T, st = H.scan_match(big.T_pred)
+        assert rc == 0 and st["n_corr"] == sto["n_corr"], (order, st["n_corr"], sto["n_corr"])
+        dt, dr = pose_delta(T, To)
+        assert dt < 1e-6 and dr < 1e-6, (order, dt, dr)
+        H.close()

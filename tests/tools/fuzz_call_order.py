@@ -38,12 +38,16 @@ def main():
     rng = np.random.default_rng(seed)
     scenes = [synth.make_scene(seed=70 + i) for i in range(3)]
     want = []
-    for sc in scenes:
+    for sc in (scenes if not os.environ.get("FUZZ_ONLY") else []):   # (a reducer trial makes no clean-frame check)
         O = ob.Oracle()
         O.set_frames(sc.source, sc.target)
         rc, T, st = O.scan_match(sc.T_pred)
         assert rc == 0
         want.append((T, st["n_corr"]))
+    # two larger frames for the hand-over ops only (four-lane and thread-per-query search, the large-set sweep and finish kernels,
+    # the query sort): what is checked on them is "a status code and the context stays good", not the pose
+    big = [synth.make_scene(seed=80, n_src=(6000, 8000, 5000, 1000), n_tgt=(8000, 9000, 6000, 1500)),
+           synth.make_scene(seed=81, n_src=(40_000, 50_000, 35_000, 8_000), n_tgt=(30_000, 30_000, 20_000, 5_000))]
     H = reg.HipRegistration()
     L, h = H.L, H.h
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))          # noqa: E731
@@ -108,7 +112,8 @@ def main():
         elif op == 2:
             note("set_source(null)", L.tloam_set_source(h, kind, null_d, n))
         elif op == 3:
-            sc = scenes[rng.integers(0, 3)]
+            j = int(rng.integers(0, 16))
+            sc = big[j - 14] if j >= 14 else scenes[j % 3]
             H.set_frames(sc.source, sc.target)
         elif op == 4:
             note("sm_begin", L.tloam_sm_begin(h, dp(some_pose()), null_d))
@@ -243,7 +248,8 @@ def main():
             L.tloam_sm_end(h, dp(res), C.byref(stats))
             clean_check(i // 250)
     L.tloam_sm_end(h, dp(res), C.byref(stats))
-    clean_check(0)
+    if only is None:
+        clean_check(0)
     H.close()
     print("fuzz ok: %d calls in %.1f s; statuses seen per entry point:" % (steps, time.time() - t0))
     for k in sorted(seen):

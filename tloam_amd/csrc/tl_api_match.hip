@@ -417,7 +417,19 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off);
   // (tile counts follow the bounding boxes like the cell tables: grow with room to spare)
   const size_t nt_res = (ntiles + 1 > c->tile_cnt.cap || ntiles + 1 > c->tile_scan.cap) ? 2 * ntiles + 64 : ntiles;
-  HIPC(c, c->tile_cnt.reserve(nt_res + 1)); HIPC(c, c->tile_scan.reserve(nt_res + 1));
+  {
+    // The query-tile histogram is zeroed by the frame's start (k_frame_init / the extra blocks of the grid build's first launch),
+    // which has been enqueued by now: a histogram that has to be re-allocated HERE -- the scan's table was shorter than the
+    // histogram's, or the sizes asked for at the two places differ by the one element that crosses an allocation step -- is
+    // zeroed again.  (Until round 5 it was not: the counting sort then ranked the queries on what the new block happened to
+    // hold and scattered them out of bounds -- a GPU memory fault or a silently wrong query order on the first large frame of a
+    // context, whenever the block was not fresh; found by tests/tools/fuzz_call_order.py.)
+    const size_t before = c->tile_cnt.cap;
+    HIPC(c, c->tile_cnt.reserve(nt_res + 1));
+    if (c->tile_cnt.cap != before)
+      HIPC(c, hipMemsetAsync(c->tile_cnt.p, 0, c->tile_cnt.cap * sizeof(unsigned long long), c->stream));
+  }
+  HIPC(c, c->tile_scan.reserve(nt_res + 1));
   HIPC(c, c->tile_fill.reserve(std::max<size_t>((size_t)nt_res, (size_t)n_slots + 1))  /* rank of every slot inside its tile */); HIPC(c, c->tile_of_slot.reserve(n_slots + 1));
   HIPC(c, c->qrec.reserve(n_slots + 1));
   HIPC(c, c->scan_tmp.reserve(scan_tmp_elems(std::max(nt_res + 1, n_slots + 1))));
