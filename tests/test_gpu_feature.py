@@ -141,3 +141,44 @@ def test_near_ties_take_the_exact_path(hip_module):
         for k in ("flatness", "cvr", "sphericity", "normal"):
             assert _same(g[k], o[k]), k
     H.close()
+
+
+@pytest.mark.parametrize("radius", [0.0, 1e-9, 50.0, 1e6, float("inf")])
+def test_search_radius_at_the_ends_of_its_range(hip_module, radius):
+    """`assert(r_ >= 0.0 ...)` (feature_extract.cpp:55) admits a radius of ZERO -- SearchHybrid then finds nobody, every point comes
+    out with no neighbour -- and an infinite one (plain k-NN).  Until round 5 a zero radius left the search grid empty and the
+    walk faulted on it (tests/tools/fuzz_call_order.py); NaN and negative radii are TLOAM_E_INVALID."""
+    p = ss.feature_cloud(3, n=2500)
+    H = hip_module.HipRegistration()
+    g = H.pca_info(p, hip_module.default_feature_config(radius=radius))
+    o = ob.pca_info(p, ob.make_feature_config(radius=radius))
+    for k in ("num_sum", "neigh", "flatness", "cvr", "sphericity", "normal"):
+        assert _same(g[k], o[k]), k
+    assert (g["num_sum"].max() == 0) == (radius < 1e-6)
+    lists_g = H.extract_planar_sphere(p, hip_module.default_feature_config(radius=radius))
+    lists_o = ob.extract_planar_sphere(p, ob.make_feature_config(radius=radius))
+    for a, b in zip(lists_g, lists_o):
+        assert np.array_equal(a, b)
+    for bad in (-1.0, float("nan")):
+        with pytest.raises(hip_module.TloamHipError, match="INVALID"):
+            H.pca_info(p, hip_module.default_feature_config(radius=bad))
+    H.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 3000])
+@pytest.mark.parametrize("val", [np.nan, np.inf])
+def test_cloud_without_a_finite_point(hip_module, n, val):
+    """Every coordinate NaN / infinite: there are no bounds to size a search grid from (a GPU memory fault until round 5:
+    tests/tools/fuzz_call_order.py, a one-point cloud whose point is NaN) and nobody has a neighbour.  Run AFTER an ordinary
+    cloud on the same context, so that whatever is not written would show the previous call's values."""
+    H = hip_module.HipRegistration()
+    H.pca_info(ss.feature_cloud(5, n=4000))
+    a = np.full((n, 3), val)
+    g = H.pca_info(a)
+    o = ob.pca_info(a)
+    for k in ("num_sum", "neigh", "flatness", "cvr", "sphericity", "normal"):
+        assert _same(g[k], o[k]), k
+    assert g["num_sum"].max() == 0 and (g["neigh"] == -1).all()
+    for x, y in zip(H.extract_planar_sphere(a), ob.extract_planar_sphere(a)):
+        assert np.array_equal(x, y)
+    H.close()

@@ -98,7 +98,8 @@ def main():
         rng = np.random.default_rng([seed, i])
         if only is not None and i not in only:
             continue
-        op = int(rng.integers(0, 27))
+        h = H.h
+        op = int(rng.integers(0, 29))
         kind = int(rng.choice([-1, 0, 1, 2, 3, 4, 7]))
         n = int(rng.choice([0, 1, 9, 10, 11, 200, 3000]))
         if os.environ.get("FUZZ_LOG"):     # (a fault of the GPU ends the process: the last lines say which call it was)
@@ -218,6 +219,8 @@ def main():
                 fc.radius = float(rng.choice([-1.0, 0.0, 0.3, 5.0, 1e6, np.nan]))
             fl = np.zeros(max(m, 1)); cv = np.zeros(max(m, 1)); sp = np.zeros(max(m, 1)); nm = np.zeros((max(m, 1), 3))
             ns_ = np.zeros(max(m, 1), np.int32); ng = np.zeros((max(m, 1), max(int(fc.K), 1)), np.int32)
+            if os.environ.get("FUZZ_LOG"):
+                print("   pca_info m %d radius %r K %d nan-point %s" % (m, fc.radius, fc.K, bool(np.isnan(a).any())), file=sys.stderr, flush=True)
             note("pca_info", L.tloam_pca_info(h, C.byref(fc), dp(a), m, dp(fl), dp(cv), dp(sp), dp(nm), ip(ns_), ip(ng)))
         elif op == 24:
             m = int(rng.choice([0, 1, 19, 20, 21, 500, 5000]))
@@ -241,6 +244,25 @@ def main():
         elif op == 26:
             # sharding set-up with arguments that cannot be right, then the context must still solve alone
             note("comm_init_mailbox(bad)", L.tloam_comm_init_mailbox(h, int(rng.choice([-1, 0, 3, 99])), int(rng.choice([-2, 0, 1, 17, 64])), None))
+        elif op == 27:
+            # the context destroyed in whatever state it is in (a stepwise frame open, clouds staged, a submap) and a new one in its
+            # place: it is handed the dead one's device memory
+            if rng.integers(0, 4) == 0:
+                H.close()
+                H.__init__()
+                h = H.h
+                note("destroy + create", 0)
+        elif op == 28:
+            # a second context working beside this one for a moment (allocations interleave; its blocks come back to the pool)
+            sc = scenes[int(rng.integers(0, 3))]
+            X = reg.HipRegistration()
+            X.set_frames(sc.source, sc.target)
+            rc2, T2, st2 = X.scan_match(sc.T_pred)
+            note("second context", rc2)
+            if rng.integers(0, 2):
+                m = int(rng.choice([100, 5000, 60000]))
+                X.set_correspondences(0, cloud(m), cloud(m), None, rng.normal(0, 1, m), None)
+            X.close()
         if os.environ.get("FUZZ_SYNC"):   # a blocking copy after every call: a GPU fault is then reported in the call that caused it
             L.tloam_debug_state(h, dp(sync_buf), 8)
         if i % 250 == 249 and only is None:

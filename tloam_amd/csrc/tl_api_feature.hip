@@ -29,7 +29,10 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
     HIPC(c, hipMemcpyAsync(F.aos.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
   }
   GridView views[kKinds];
-  double radii[kKinds] = {cfg.radius, 0, 0, 0};
+  // (the reference's assert admits r_ == 0: SearchHybrid then finds nobody -- not even the point itself, its squared distance 0
+  //  is not below 0 -- and every point comes out with zero neighbours.  The grid still needs cells of SOME size: the walk's own
+  //  radius test does the rest)
+  double radii[kKinds] = {cfg.radius > 0.0 ? cfg.radius : 1.0, 0, 0, 0};
   CloudRef clouds[kKinds] = {{F.x.p, F.y.p, F.z.p, n}, {nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0},
                              {nullptr, nullptr, nullptr, 0}};
   double boxes[kKinds][6];
@@ -54,7 +57,17 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
   A.radius = cfg.radius; A.K = cfg.K; A.min_neigh = cfg.min_neigh;
   A.flatness = F.flatness.p; A.cvr = F.cvr.p; A.sphericity = F.sphericity.p; A.normal = F.normal.p;
   A.num_sum = F.num_sum.p; A.neigh = F.neigh.p;
-  launch_pca_info(A, c->stream);
+  if (n > 0 && A.g.n <= 0) {
+    // no search structure: the cloud holds no finite point (build_grids_over).  Every point then has no neighbour -- nanoflann's
+    // result set never admits a NaN / infinite distance -- and keeps what calculatePCAInfo initialises: zeros, indices -1.
+    // (The PCA pass takes its points in the GRID's order: without a grid it would write nothing at all.)
+    HIPC(c, hipMemsetAsync(F.flatness.p, 0, sizeof(double) * n, c->stream)); HIPC(c, hipMemsetAsync(F.cvr.p, 0, sizeof(double) * n, c->stream));
+    HIPC(c, hipMemsetAsync(F.sphericity.p, 0, sizeof(double) * n, c->stream)); HIPC(c, hipMemsetAsync(F.normal.p, 0, sizeof(double) * 3 * n, c->stream));
+    HIPC(c, hipMemsetAsync(F.num_sum.p, 0, sizeof(int) * n, c->stream));
+    HIPC(c, hipMemsetAsync(F.neigh.p, 0xff, sizeof(int) * n * (size_t)cfg.K, c->stream));
+  } else {
+    launch_pca_info(A, c->stream);
+  }
   *out = A;
   return TLOAM_OK;
 }

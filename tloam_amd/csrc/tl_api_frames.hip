@@ -202,6 +202,10 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     GridView& g = out[k];
     memset(&g, 0, sizeof(g));
     gs.cell_base[k] = cell_total;
+    // (a cloud without a single finite point has no bounds -- the rows come back as they were initialised, lo > hi -- and
+    //  nothing to search: no grid, like an empty cloud.  Sizing a cell table from such a box was a GPU memory fault until
+    //  round 5: tests/tools/fuzz_call_order.py, a one-point cloud whose point is NaN)
+    if (gs.n[k] > 0 && !(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) gs.n[k] = 0;
     if (gs.n[k] == 0) { gs.ncell[k] = 0; gs.dim[k][0] = gs.dim[k][1] = gs.dim[k][2] = 1; gs.inv_cell[k] = 1.0; continue; }
     double cell = radius[k] * (1.0 + 1e-6);  // every target within `radius` of a query lies in its 27 cells
     double dims[3];
