@@ -1,0 +1,23 @@
+"""-m gpu: the C ABI under random call orders and bad arguments (tests/tools/fuzz_call_order.py), a short standing run: a status
+code for every call, never a crash (the tool runs in a process of its own: the failures it hunts end the process), a hang or a
+context that no longer solves a clean frame like the CPU restatement does.  Round 5 found five defects this way (tests/tools/README.md)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_random_call_orders_end_in_status_codes(hip_module, seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_call_order.py"), "2000", str(seed)],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, FUZZ_SYNC="1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "fuzz ok: 2000 calls" in r.stdout
+    # every entry point the tool drives answered at least once with something other than OK, and scan_match also with OK
+    lines = {l.split()[0]: l for l in r.stdout.splitlines() if l.startswith("  ")}
+    assert "TLOAM_E_BAD_POSE" in lines["scan_match"] and "'OK'" in lines["scan_match"]
+    assert "TLOAM_E_BAD_POSE" in lines["submap_update"]
