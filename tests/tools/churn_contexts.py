@@ -51,7 +51,18 @@ def main():
     keeper.set_frames(scenes[2].source, scenes[2].target)
     worst = 0.0
     t_start = time.time()
+
+    def footprint():
+        """(free device memory, resident host memory of this process) in MB"""
+        import resource
+        import torch
+        free, _ = torch.cuda.mem_get_info(0)
+        return free / 2**20, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+    base = None
     for i in range(n):
+        if i == min(200, n // 4):     # (allocator pools, the HIP runtime's own caches and the largest scene have been seen by now)
+            base = footprint()
         k = (i * 7 + i // 5) % len(scenes)
         sc, (T_want, c_want) = scenes[k], want[k]
         H = reg.HipRegistration()
@@ -79,6 +90,11 @@ def main():
             assert rc == 0 and T.tobytes() == want[2][0].tobytes() and counters(st) == want[2][1], ("keeper", i)
         H.close()
     keeper.close()
+    if base is not None:
+        end = footprint()
+        print("footprint after %d successions: device free %.0f -> %.0f MB, host peak RSS %.0f -> %.0f MB" % (n, base[0], end[0], base[1], end[1]))
+        assert base[0] - end[0] < 256.0, "device memory is leaking: %.0f MB in %d successions" % (base[0] - end[0], n - min(200, n // 4))
+        assert end[1] - base[1] < 256.0, "host memory is leaking: %.0f MB" % (end[1] - base[1])
     print("churn ok: %d successions over %d scenes in %.1f s, slowest call %.1f ms" % (n, len(scenes), time.time() - t_start, worst * 1e3))
     assert worst < 0.5, worst
 
