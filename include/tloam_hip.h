@@ -295,7 +295,10 @@ int tloam_submap_init(tloam_ctx* ctx, const tloam_submap_config* cfg, const doub
                       const double* sphere_submap_xyz, size_t n_sphere, const double* edge_xyz, size_t n_edge,
                       const double* ground_xyz, size_t n_ground);
 /* every later frame (front_end.cpp:201-275) with lidar_odom_pose = pose_colmajor: planar/sphere frame
- * buffers, edge/ground accumulate -> crop around the pose's translation -> voxel grid; setInputTarget. */
+ * buffers, edge/ground accumulate -> crop around the pose's translation -> voxel grid; setInputTarget.
+ * The pose is taken as Open3D's Transform takes a 4x4 (no orthogonality test on this path: a scaled rotation or a projective
+ * last row is applied as it stands); a NaN or an infinity anywhere in it is TLOAM_E_BAD_POSE and leaves the submap as it was
+ * (the reference would go on with NaN clouds).  TLOAM_E_NOT_READY before tloam_submap_init. */
 int tloam_submap_update(tloam_ctx* ctx, const double pose_colmajor[16], const double* planar_submap_xyz,
                         size_t n_planar, const double* sphere_submap_xyz, size_t n_sphere,
                         const double* edge_scan_xyz, size_t n_edge, const double* ground_scan_xyz, size_t n_ground);
@@ -326,7 +329,9 @@ typedef struct tloam_feature_config {
 void tloam_feature_default_config(tloam_feature_config* cfg);
 /* per-point PCAInfo (feature_extract.hpp:33-39); any output pointer may be NULL.  Points that are skipped
  * (no more than min_neigh neighbours) keep the value-initialised zeros of the reference; neigh_index is
- * n x K, padded with -1. */
+ * n x K, padded with -1.  radius >= 0 and 3 <= K <= 20, else TLOAM_E_INVALID (assert(r_ >= 0.0 && K_ >= 3),
+ * feature_extract.cpp:55): a radius of exactly 0 finds nobody, an infinite one is plain k-NN; a cloud without a single finite
+ * point has no search structure and every point keeps the zeros. */
 int tloam_pca_info(tloam_ctx* ctx, const tloam_feature_config* cfg, const double* xyz_aos, size_t n,
                    double* flatness, double* cvr, double* sphericity, double* normal_aos, int32_t* num_sum,
                    int32_t* neigh_index);
