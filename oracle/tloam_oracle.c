@@ -383,6 +383,10 @@ static inline double dist2(const double* a, const double* b) {
   return r;
 }
 static inline void topk_insert(int k, int* cnt, int* idx, double* d2, int i, double d) {
+  /* nanoflann only offers its result set a candidate whose distance is below the set's worst, which starts at the largest
+   * double (KNNResultSet::worstDist): a NaN or infinite distance is never admitted -- also not while the set is still filling
+   * (round 5: it used to be appended then, and the finite candidates that came after it stayed behind it) */
+  if (!(d < DBL_MAX)) return;
   int n = *cnt;
   if (n == k && !(d < d2[n - 1] || (d == d2[n - 1] && i < idx[n - 1]))) return;
   int pos = (n < k) ? n : k - 1;

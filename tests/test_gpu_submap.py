@@ -257,3 +257,57 @@ def test_submaps_that_outgrow_their_arrays(hip_module):
             a, b = A.get(k), B.get(k)
             assert a.shape == b.shape, (f, k, a.shape, b.shape)
             assert np.array_equal(a, b), (f, k)
+
+
+@pytest.mark.parametrize("seed,trial", [(2, 21), (1, 358)])
+def test_sizes_of_consecutive_updates_that_xor_alike(hip_module, seed, trial):
+    """The two sizes of an update come back through a pinned result segment whose check word used to be the sequence number XOR
+    the payload words: when the check word had arrived and the payload had not, the segment still checked if the old and the new
+    payload XORed alike -- (58, 58) after (0, 0); (459, 16) after (458, 17) -- and the update's clouds were cut to the sizes of
+    the update before (2-4 % of fresh contexts; found by tests/tools/stress_rows.py, whose two failing sequences these are).
+    Every payload word now enters the check through a position-dependent mix (tl_common.hpp seg_word).  300 fresh contexts each."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("stress_rows", os.path.join(os.path.dirname(__file__), "tools", "stress_rows.py"))
+    sr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sr)
+    rng = np.random.default_rng([seed, trial, 1])
+    extent = float(rng.choice([5.0, 20.0, 60.0]))
+    vox = float(rng.choice([0.02, 0.1, 0.3, 0.45, 1.0, 5.0]))
+    cfg = dict(edge_crop_box_length=float(rng.choice([extent * 0.3, extent, extent * 3])),
+               ground_crop_box_length=float(rng.choice([extent * 0.3, extent, extent * 3])),
+               planar_frame_size=int(rng.integers(1, 6)), sphere_frame_size=int(rng.integers(1, 6)),
+               edge_down_sample_submap=vox, ground_down_sample_submap=float(rng.choice([vox, vox * 1.5])), ground_down_sample=vox)
+    frames, poses, T = [], [], np.eye(4)
+    for f in range(int(rng.integers(3, 9))):
+        cl = []
+        for k in range(4):
+            c = sr.rand_cloud(rng, int(rng.choice([0, 1, 2, 7, 60, 700, 6000])), extent, vox)
+            if k < 2 or f == 0:
+                c = c[np.isfinite(c).all(1)]
+            cl.append(np.ascontiguousarray(c))
+        if f > 0:
+            T = T @ ss._se3_exp((rng.uniform(0, 2), rng.normal(0, 0.2), rng.normal(0, 0.05), rng.normal(0, 0.02), rng.normal(0, 0.02),
+                                 rng.normal(0, 0.3)))
+        frames.append(cl)
+        poses.append(T.copy())
+    B = ob.OracleSubmap(ob.make_submap_config(**cfg))
+    want = []
+    for f, cl in enumerate(frames):
+        assert (B.init(*cl) if f == 0 else B.update(poses[f], *cl)) == 0
+        want.append([B.get(k) for k in range(4)])
+    # the payload of every call's result segment: (edge, ground) sizes of an update; the first frame's job is the ground cloud alone
+    sizes = [(len(want[0][1]), 0)] + [(len(w[2]), len(w[1])) for w in want[1:]]
+    assert any(a != b and (a[0] ^ a[1]) == (b[0] ^ b[1]) for a, b in zip(sizes, sizes[1:])), sizes   # the case this test is about
+    hcfg = hip_module.default_submap_config(**cfg)
+    for rep in range(300):
+        H = hip_module.HipRegistration()
+        for f, cl in enumerate(frames):
+            if f == 0:
+                H.submap_init(*cl, cfg=hcfg)
+            else:
+                H.submap_update(poses[f], *cl)
+            for k in range(4):
+                a = H.get_target(k)
+                assert a.shape == want[f][k].shape and np.array_equal(a, want[f][k], equal_nan=True), (rep, f, k, a.shape, want[f][k].shape)
+        H.close()

@@ -20,14 +20,14 @@ int wait_word(tloam_ctx* c, const unsigned long long* p, unsigned long long seq)
     __builtin_ia32_pause();
   }
 }
-// One 64-byte segment of a result slot (MirrorSlot: seven payload words, then the sequence number XORed with them): wait
-// until the XOR of the eight words equals `seq` -- a segment that has only partly arrived does not check -- and copy the
-// payload out.  Same return convention as wait_word.
+// One 64-byte segment of a result slot (MirrorSlot: seven payload words, then check_mix(sequence number) XOR seg_word of every
+// payload word): wait until the check word agrees with the payload read -- a segment that has only partly arrived does not
+// check, whichever part it is -- and copy the payload out.  Same return convention as wait_word.
 int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long number, unsigned long long payload[7]) {
   const unsigned long long seq = check_mix(number);   // (what the check word carries, tl_common.hpp)
   for (unsigned spins = 1;; ++spins) {
     unsigned long long w[8], x = 0ull;
-    for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= w[i]; }
+    for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= i < 7 ? tl::seg_word(w[i], i) : w[i]; }
     if (x == seq) {
       for (int i = 0; i < 7; ++i) payload[i] = w[i];
       return TLOAM_OK;
@@ -36,7 +36,7 @@ int wait_segment(tloam_ctx* c, const unsigned long long* seg, unsigned long long
       const hipError_t e = hipStreamQuery(c->stream);
       if (e == hipSuccess) {
         x = 0ull;
-        for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= w[i]; }
+        for (int i = 0; i < 8; ++i) { w[i] = __atomic_load_n(seg + i, __ATOMIC_ACQUIRE); x ^= i < 7 ? tl::seg_word(w[i], i) : w[i]; }
         if (x != seq) return 1;
         for (int i = 0; i < 7; ++i) payload[i] = w[i];
         return TLOAM_OK;

@@ -139,9 +139,9 @@ static_assert(offsetof(GnState, host_seq) == kMirrorWords * 8, "host-visible pre
 // copy kernel plus a stream synchronisation per outer iteration (registration.cpp:1108 is a host decision).
 // out == nullptr: off.
 // The slot is written WITHOUT any fence: it is three 64-byte segments, each carrying seven words of the prefix and,
-// last, the sequence number XORed with those seven words; one wave stores all 24 words with one instruction.  In
+// last, check_mix(sequence number) XOR seg_word of each of those seven words; one wave stores all 24 words with one instruction.  In
 // practice every segment leaves the GPU as one aligned 64-byte write (a full cache line for the host); the host does
-// not rely on that: it accepts a segment only when the XOR of its eight words equals the number it waits for
+// not rely on that: it accepts a segment only when the check word agrees with the payload it reads
 // (tlh::wait_segment), so a torn segment reads as "not there yet".  (A system-scope release would first write back
 // every dirty L2 line of the kernel, ~2 us; writing the number behind the words with only a wave-level wait is NOT
 // safe: the two cache lines travel through different L2 channels.)
@@ -154,6 +154,14 @@ struct MirrorSlot {
 // word has arrived can only pass if that word changed by exactly that 64-bit pattern -- not by a counter step or a
 // last-mantissa-bit change.  Zeroed memory checks for number 0 only; numbers start at 1.
 __host__ __device__ inline unsigned long long check_mix(unsigned long long number) { return number * 0x9E3779B97F4A7C15ull; }
+// The segments the HOST reads (result slots, submap sizes) enter their check word through seg_word: position-dependent and
+// non-linear in the word.  With a plain XOR of the payload a segment whose check word had arrived and whose payload had not
+// passed whenever the old and the new payload XORed alike -- (58, 58) after (0, 0), (459, 16) after (458, 17): the sizes of a
+// submap update read back as those of the update before in 2-4 % of contexts (round 5, tests/tools/stress_rows.py).
+__host__ __device__ inline unsigned long long seg_word(unsigned long long w, int pos) {
+  unsigned long long v = (w + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1)) * 0xBF58476D1CE4E5B9ull;
+  return v ^ (v >> 29);
+}
 struct HostMirror {
   MirrorSlot* out;
   unsigned long long seq;

@@ -43,9 +43,9 @@ __device__ __forceinline__ void mirror_wave(const GnState* st, const HostMirror&
     static_assert(offsetof(GnState, incomplete) % 8 == 4, "incomplete is the high half of its word");
     if (status >= 0 && word == kStatusWord) w = (w & 0xffffffffull) | ((unsigned long long)(unsigned)status << 32);
   }
-  // last word of the segment = sequence number XOR the segment's seven payload words: the host accepts a segment only
-  // when the XOR of its eight words equals the number it waits for, so a torn segment reads as "not there yet"
-  unsigned long long x = w;
+  // last word of the segment = check_mix(sequence number) XOR seg_word of the segment's seven payload words: the host accepts a
+  // segment only when its check word agrees with the payload it reads, so a torn segment reads as "not there yet"
+  unsigned long long x = pos < 7 ? seg_word(w, pos) : 0ull;
   x ^= __shfl_xor(x, 1, 64);
   x ^= __shfl_xor(x, 2, 64);
   x ^= __shfl_xor(x, 4, 64);

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxelJob J, VoxelWork W, int n
     if (W.host_seg) {  // ... and straight to the host: every leader's stores precede this block's in no particular order, so the
                        // host reads the clouds only through the stream (it waits for this word, then enqueues behind the launch)
       unsigned long long w = tid == 0 ? n0_out : tid == 1 ? n1_out : tid == 2 ? (unsigned long long)W.overflow[0] : 0ull;
-      // word 7 = check_mix(sequence number) XOR the payload words (tlh::wait_segment: a torn segment reads as "not there yet")
-      unsigned long long x = w;
+      // word 7 = check_mix(sequence number) XOR seg_word of the payload words (tlh::wait_segment: a torn segment reads as "not there yet")
+      unsigned long long x = tid < 7 ? seg_word(w, tid) : 0ull;
       x ^= __shfl_xor(x, 1, 64);
       x ^= __shfl_xor(x, 2, 64);
       x ^= __shfl_xor(x, 4, 64);
