@@ -88,6 +88,14 @@ def trial(rng, t):
         for kind in range(4):
             ih, io = H.get_correspondences(kind)["idx"], O.get_correspondences(kind)["idx"]
             assert np.array_equal(ih, io), ("lists", t, kind, len(ih), len(io), over)
+        # getFitnessScore (:257-296) on the frame's own dirty clouds, with the search structures the solve left behind
+        if t % 5 != 0:          # (the restatement's fitness walk is the slow part of a trial: every fifth one)
+            H.close()
+            return rh
+        (rcf, f, r), (rco, fo, ro_) = H.fitness(), O.fitness()
+        assert rcf == rco and (np.isnan(f) == np.isnan(fo)) and (np.isnan(r) == np.isnan(ro_)), ("fitness status", t, rcf, rco, f, fo, r, ro_)
+        if not np.isnan(fo):
+            assert abs(f - fo) <= 1e-12 * max(1.0, abs(fo)) and (np.isnan(ro_) or abs(r - ro_) <= 1e-10 * max(1.0, abs(ro_))), ("fitness", t, f, fo, r, ro_)
     H.close()
     return rh
 
