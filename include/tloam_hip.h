@@ -130,6 +130,8 @@ const char* tloam_status_string(int status);
 /* text of the last HIP/RCCL error seen by this context ("" if none) */
 const char* tloam_last_error(const tloam_ctx* ctx);
 
+/* Sizes: a cloud, a correspondence set or a query batch holds at most 2^29 points (slots, cells and ranks are 32-bit integers on
+ * the device, and the four kinds of a frame share one slot space); more is TLOAM_E_INVALID at the entry point. */
 /* ---- inputs: RegistrationInterface::setInputSource / setInputTarget -------------------
  * (registration.cpp:232-248).  The reference keeps shared_ptrs; here the cloud is copied
  * to HBM (AoS -> SoA on device).  In a sharded context (tloam_comm_*) every rank passes

@@ -246,3 +246,36 @@ def test_large_frame_after_prebuilt_sets_on_a_used_context(hip_module):
         dt, dr = pose_delta(T, To)
         assert dt < 1e-6 and dr < 1e-6, (order, dt, dr)
         H.close()
+
+
+def test_sizes_beyond_the_slot_space_are_refused(hip_module):
+    """A count of more than 2^29 points (slots, cells and ranks are 32-bit integers on the device) is TLOAM_E_INVALID at every entry
+    point that takes one -- before the buffer it claims to describe is touched -- and the context goes on working."""
+    import ctypes as C
+    sc = synth.make_scene(seed=59)
+    H = hip_module.HipRegistration()
+    H.set_frames(sc.source, sc.target)
+    L, h = H.L, H.h
+    a = np.zeros((16, 3))
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))    # noqa: E731
+    huge = (1 << 29) + 1
+    assert L.tloam_set_source(h, 0, dp(a), huge) == -1
+    assert L.tloam_set_target(h, 1, dp(a), huge) == -1
+    ptrs = (C.POINTER(C.c_double) * 4)(*[dp(a)] * 4)
+    assert L.tloam_set_source_frame(h, ptrs, (C.c_size_t * 4)(16, 16, huge, 16)) == -1
+    assert L.tloam_set_target_frame(h, ptrs, (C.c_size_t * 4)(huge, 16, 16, 16)) == -1
+    idx = np.zeros(64, np.int32); d2 = np.zeros(64); cnt = np.zeros(16, np.int32)
+    assert L.tloam_knn(h, 0, dp(a), huge, 1.0, 5, ip(idx), dp(d2), ip(cnt)) == -1
+    w = np.ones(16)
+    assert L.tloam_set_correspondences(h, 0, huge, dp(a), dp(a), dp(a), dp(w), dp(w)) == -1
+    st = hip_module.Stats(); res = np.zeros(16)
+    assert L.tloam_scan_match(h, dp(np.ascontiguousarray(sc.T_pred.T.ravel())), None, dp(res), dp(a), huge, C.byref(st)) == -1
+    fc = hip_module.default_feature_config()
+    assert L.tloam_pca_info(h, C.byref(fc), dp(a), huge, None, None, None, None, None, None) == -1
+    assert L.tloam_submap_init(h, None, dp(a), 16, dp(a), 16, dp(a), huge, dp(a), 16) == -1
+    rc, T, s2 = H.scan_match(sc.T_pred)
+    O = ob.Oracle(); O.set_frames(sc.source, sc.target)
+    rco, To, so = O.scan_match(sc.T_pred)
+    dt, dr = pose_delta(T, To)
+    assert rc == 0 and dt < 1e-6 and dr < 1e-6

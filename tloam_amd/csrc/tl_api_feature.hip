@@ -75,7 +75,7 @@ int feature_pca(tloam_ctx* c, const tloam_feature_config& cfg, const double* xyz
 
 int tloam_pca_info(tloam_ctx* c, const tloam_feature_config* cfg, const double* xyz, size_t n, double* flatness,
                    double* cvr, double* sphericity, double* normal, int32_t* num_sum, int32_t* neigh) {
-  if (!c || !cfg || (n > 0 && !xyz) || n > (size_t)INT32_MAX) return TLOAM_E_INVALID;
+  if (!c || !cfg || (n > 0 && !xyz) || n > kMaxPoints) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   FeatBuffers& F = c->feat;
   FeatArgs A;
@@ -99,7 +99,7 @@ int tloam_pca_info(tloam_ctx* c, const tloam_feature_config* cfg, const double* 
 int tloam_extract_planar_sphere(tloam_ctx* c, const tloam_feature_config* cfg, const double* xyz, size_t n,
                                 int32_t* planar_scan, size_t* n_ps, int32_t* planar_submap, size_t* n_pm,
                                 int32_t* sphere_scan, size_t* n_ss, int32_t* sphere_submap, size_t* n_sm) {
-  if (!c || !cfg || (n > 0 && !xyz) || n > (size_t)INT32_MAX || !n_ps || !n_pm || !n_ss || !n_sm) return TLOAM_E_INVALID;
+  if (!c || !cfg || (n > 0 && !xyz) || n > kMaxPoints || !n_ps || !n_pm || !n_ss || !n_sm) return TLOAM_E_INVALID;
   *n_ps = *n_pm = *n_ss = *n_sm = 0;
   if (n == 0) return TLOAM_OK;  // "cloud_in_ does not contain points" (:50-53): the lists stay empty
   if (!planar_scan || !planar_submap || !sphere_scan || !sphere_submap) return TLOAM_E_INVALID;

@@ -335,7 +335,7 @@ extern "C" {
 // ---- setInputSource / setInputTarget (registration.cpp:232-248) --------------------------------
 namespace {
 int set_source_async(tloam_ctx* c, int kind, const double* xyz, size_t n) {
-  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
+  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz) || n > kMaxPoints) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   size_t lo = 0, hi = n;
   tloam_shard_range(n, c->rank, c->nranks, &lo, &hi);
@@ -355,7 +355,7 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
   size_t off[kKinds] = {0, 0, 0, 0};
   size_t lo4[kKinds], hi4[kKinds], cnt4[kKinds];
   for (int k = 0; k < kKinds; ++k)   // (refused as a whole, before anything of the registered frame has been touched)
-    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
+    if ((n[k] > 0 && !xyz[k]) || n[k] > kMaxPoints) return TLOAM_E_INVALID;
   tloam_shard_ranges_frame(n, c->rank, c->nranks, lo4, hi4);
   for (int k = 0; k < kKinds; ++k) {
     KindData& K = c->kd[k];
@@ -382,7 +382,7 @@ int set_source_frame_packed(tloam_ctx* c, const double* const xyz[4], const size
   return rc;
 }
 int set_target_async(tloam_ctx* c, int kind, const double* xyz, size_t n, bool convert = true) {
-  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz)) return TLOAM_E_INVALID;
+  if (kind < 0 || kind >= kKinds || (n > 0 && !xyz) || n > kMaxPoints) return TLOAM_E_INVALID;
   KindData& K = c->kd[kind];
   K.n_tgt = n;
   c->tgt_box_valid[kind] = false;
@@ -428,7 +428,7 @@ int tloam_set_source_frame(tloam_ctx* c, const double* const xyz[4], const size_
 int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_t n[4]) {
   if (!c || !xyz || !n) return TLOAM_E_INVALID;
   for (int k = 0; k < kKinds; ++k)   // (refused as a whole, before any of the registered targets has been replaced)
-    if (n[k] > 0 && !xyz[k]) return TLOAM_E_INVALID;
+    if ((n[k] > 0 && !xyz[k]) || n[k] > kMaxPoints) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   int rc = TLOAM_OK;
   // four copies, then ONE launch that converts all four clouds and takes their bounds (rows into pinned memory)

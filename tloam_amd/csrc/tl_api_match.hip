@@ -925,6 +925,7 @@ int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
 
 int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega3, double result[16],
                      double* scan_xyz, size_t n_scan, tloam_stats* stats) {
+  if (n_scan > kMaxPoints) return TLOAM_E_INVALID;
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
   int done = 0;
@@ -979,7 +980,7 @@ int tloam_fitness(tloam_ctx* c, double* fitness, double* rmse) {
   if (!c || !fitness || !rmse) return TLOAM_E_INVALID;
   *fitness = 0.0;
   *rmse = 0.0;
-  if (c->cfg.fitness_thres <= 0.0) return TLOAM_OK;  // :258-261
+  if (!(c->cfg.fitness_thres > 0.0)) return TLOAM_OK;  // :258-261 (a NaN threshold finds nobody either)
   if (c->active) return TLOAM_E_NOT_READY;  // between sm_begin and sm_end the context belongs to the solve
   HIPC(c, hipSetDevice(c->device));
   const int blocks = 64;
@@ -1065,7 +1066,8 @@ int tloam_get_weights(tloam_ctx* c, int kind, size_t capacity, size_t* n, double
 
 int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius, int k, int32_t* out_idx,
               double* out_d2, int32_t* out_cnt) {
-  if (!c || kind < 0 || kind >= kKinds || !q || k < 1 || k > kMaxK || !(radius > 0.0) || !out_idx || !out_d2 || !out_cnt)
+  if (!c || kind < 0 || kind >= kKinds || !q || k < 1 || k > kMaxK || !(radius > 0.0) || !out_idx || !out_d2 || !out_cnt ||
+      nq > kMaxPoints / (size_t)k)
     return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   KindData& K = c->kd[kind];
@@ -1112,7 +1114,7 @@ int tloam_knn(tloam_ctx* c, int kind, const double* q, size_t nq, double radius,
 // ---- pre-built correspondence sets ------------------------------------------------------------------
 int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double* p, const double* a, const double* b,
                               const double* d, const double* w) {
-  if (!c || res_type < 0 || res_type >= TLOAM_NUM_RES) return TLOAM_E_INVALID;
+  if (!c || res_type < 0 || res_type >= TLOAM_NUM_RES || n > kMaxPoints) return TLOAM_E_INVALID;
   if (n > 0 && (!p || !a || !w || (res_type == TLOAM_RES_LINE && !b) || (res_type == TLOAM_RES_PLANE && !d)))
     return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));

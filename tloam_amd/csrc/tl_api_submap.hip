@@ -122,16 +122,19 @@ const double kNoLo[3] = {-INFINITY, -INFINITY, -INFINITY}, kNoHi[3] = {INFINITY,
 int tloam_submap_init(tloam_ctx* c, const tloam_submap_config* cfg, const double* planar, size_t n_planar,
                       const double* sphere, size_t n_sphere, const double* edge, size_t n_edge, const double* ground,
                       size_t n_ground) {
-  if (!c || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
+  if (!c || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground) ||
+      n_planar > kMaxPoints || n_sphere > kMaxPoints || n_edge > kMaxPoints || n_ground > kMaxPoints)
     return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   SubmapState& S = c->submap;
+  tloam_submap_config want;
+  if (cfg) want = *cfg;
+  else tloam_submap_default_config(&want);
+  if (want.planar_frame_size < 1 || want.sphere_frame_size < 1 || !(want.edge_down_sample_submap > 0.0) ||
+      !(want.ground_down_sample_submap > 0.0) || !(want.ground_down_sample > 0.0))
+    return TLOAM_E_INVALID;  // "[VoxelDownSample] voxel_size <= 0." (PointCloud2.cpp:361-363); the submap in place stays
   S.release();
-  if (cfg) S.cfg = *cfg;
-  else tloam_submap_default_config(&S.cfg);
-  if (S.cfg.planar_frame_size < 1 || S.cfg.sphere_frame_size < 1 || !(S.cfg.edge_down_sample_submap > 0.0) ||
-      !(S.cfg.ground_down_sample_submap > 0.0) || !(S.cfg.ground_down_sample > 0.0))
-    return TLOAM_E_INVALID;  // "[VoxelDownSample] voxel_size <= 0." (PointCloud2.cpp:361-363)
+  S.cfg = want;
   // :286 / :290-291 submap += cloud on empty submaps: the clouds as given
   int rc = tloam_set_target(c, TLOAM_KIND_EDGE, edge, n_edge);
   if (rc == TLOAM_OK) rc = tloam_set_target(c, TLOAM_KIND_PLANAR, planar, n_planar);
@@ -170,7 +173,8 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
 int tloam_submap_update(tloam_ctx* c, const double pose[16], const double* planar, size_t n_planar,
                         const double* sphere, size_t n_sphere, const double* edge, size_t n_edge,
                         const double* ground, size_t n_ground) {
-  if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground))
+  if (!c || !pose || (n_planar && !planar) || (n_sphere && !sphere) || (n_edge && !edge) || (n_ground && !ground) ||
+      n_planar > kMaxPoints || n_sphere > kMaxPoints || n_edge > kMaxPoints || n_ground > kMaxPoints)
     return TLOAM_E_INVALID;
   if (!c->submap.inited) return TLOAM_E_NOT_READY;
   // Open3D's Transform takes any 4x4 (front_end.cpp:246-247 hands it an Isometry3d's matrix: no orthogonality test anywhere on

@@ -276,6 +276,10 @@ struct tloam_ctx {
 constexpr int kMirrorSlots = 8;
 constexpr int kFaultWords = 16;
 constexpr int kFaultScan1p = 0, kFaultVoxEmit = 1;   // tloam_ctx::h_fault
+// Points a single cloud / correspondence set / query batch may hold: slots, cells and ranks are 32-bit integers throughout, and the
+// four kinds of a frame share one slot space -- 2^29 points (12.9 GB as doubles) per cloud keeps every sum and every 3 n inside it.
+// More is TLOAM_E_INVALID at the entry point, not an overflow behind it.
+constexpr size_t kMaxPoints = (size_t)1 << 29;
 
 namespace tlh {
 // ---- small helpers shared by the API units
