@@ -106,6 +106,7 @@ int tloam_comm_init_rccl(tloam_ctx* c, int rank, int nranks, const void* unique_
     c->last_error = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
     return TLOAM_E_RCCL;
   }
+  if (c->nccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl_comm);   // (a second set-up on the same context)
   c->nccl_comm = comm;
   c->rank = rank;
   c->nranks = nranks;
@@ -153,6 +154,8 @@ int tloam_comm_init_mailbox(tloam_ctx* c, int rank, int nranks, const void* hand
   if (!c || !handles64 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
   if (!c->mbox_local) return TLOAM_E_NOT_READY;  // export first
   HIPC(c, hipSetDevice(c->device));
+  for (int r = 0; r < kMaxRanks; ++r)   // (a second set-up on the same context: the first one's mappings go)
+    if (c->mbox_opened[r]) { (void)hipIpcCloseMemHandle(c->mbox_opened[r]); c->mbox_opened[r] = nullptr; }
   memset(&c->mbox, 0, sizeof(c->mbox));
   for (int r = 0; r < nranks; ++r) {
     if (r == rank) { c->mbox.peer[r] = c->mbox_local; continue; }
