@@ -56,7 +56,7 @@ struct PointsAccessor {
 template <class FrameT, class PoseT>
 class HipRegistrationCore {
  public:
-  explicit HipRegistrationCore(const tloam_tls_config& cfg, int device_id = 0) {
+  explicit HipRegistrationCore(const tloam_tls_config& cfg, int device_id = 0) : cfg_(cfg) {
     status_ = tloam_create(&cfg, device_id, &ctx_);
     ok(status_, "tloam_create", nullptr);
   }
@@ -75,6 +75,12 @@ class HipRegistrationCore {
     have_omega_ = unit3_or_null != nullptr;
     if (have_omega_) for (int i = 0; i < 3; ++i) omega_[i] = unit3_or_null[i];
   }
+
+  // The reference's builders end with a diagnostic when they added few factors (registration.cpp:500-502 edge, :554-556 sphere,
+  // :630-632 planar, :773-775 ground; ROS_WARN, the planar one std::cout).  The adapter repeats them after scanMatching from what
+  // the solve reports -- same thresholds, same texts, on stderr (no ROS in this header) -- for the LAST outer iteration's factor
+  // set (the reference prints them in every outer iteration: up to four times per frame).  On by default, like the reference.
+  void setFewFactorWarnings(bool on) { warn_few_ = on; }
 
   bool setInputSource(FrameT& f) { return upload(f, /*source=*/true); }
   bool setInputTarget(FrameT& f) { return upload(f, /*source=*/false); }
@@ -95,7 +101,19 @@ class HipRegistrationCore {
       return false;
     }
     for (int i = 0; i < 16; ++i) result_pose.matrix().data()[i] = result[i];  // registration.cpp:1124
+    if (warn_few_) warnFewFactors();
     return true;
+  }
+
+  // registration.cpp:500-502, :554-556, :630-632, :773-775 -- the builders' own thresholds and texts.  The sphere builder tests
+  // `sphere_sum`, which counts the SOURCE POINTS it looked at, not the factors it added (:551), and returns past the
+  // warning once the cap is reached (:538): it warns exactly when the sphere cloud has <= 10 points.  The edge builder runs for
+  // factor_num >= 3, the sphere builder for factor_num == 4 (:979-1016).
+  void warnFewFactors() const {
+    if (stats_.n_corr[TLOAM_KIND_EDGE] <= 20 && cfg_.factor_num >= 3) std::fprintf(stderr, "[ WARN] not enough edge points !!!\n");
+    if (n_src_[TLOAM_KIND_SPHERE] <= 10 && cfg_.factor_num >= 4) std::fprintf(stderr, "[ WARN] not enough sphere point..\n");
+    if (stats_.n_corr[TLOAM_KIND_PLANAR] < 20 && cfg_.factor_num >= 2) std::fprintf(stdout, "not enough ground points\n");   // (sic, :631: std::cout)
+    if (stats_.n_corr[TLOAM_KIND_GROUND] <= 20 && cfg_.factor_num >= 2) std::fprintf(stderr, "[ WARN] not enough ground point..\n");
   }
 
   // ---- device-resident submap (optional; replaces the body of FrontEnd::updateSubmap, front_end.cpp:201-275,
@@ -165,14 +183,18 @@ class HipRegistrationCore {
     put(TLOAM_KIND_GROUND, f.ground_feature);
     put(TLOAM_KIND_EDGE, f.edge_feature);
     put(TLOAM_KIND_SPHERE, f.sphere_feature);
+    if (source) for (int k = 0; k < 4; ++k) n_src_[k] = cnt[k];
     // the four clouds of the Frame in one call: one host synchronisation per frame
     return source ? ok(tloam_set_source_frame(ctx_, ptr, cnt), "tloam_set_source_frame", ctx_)
                   : ok(tloam_set_target_frame(ctx_, ptr, cnt), "tloam_set_target_frame", ctx_);
   }
 
   tloam_ctx* ctx_ = nullptr;
+  tloam_tls_config cfg_;
   int status_ = TLOAM_OK;
   tloam_stats stats_{};
+  std::size_t n_src_[4] = {0, 0, 0, 0};
+  bool warn_few_ = true;
   bool have_omega_ = false;
   double omega_[3] = {0.0, 0.0, 1.0};
 };
@@ -186,11 +208,26 @@ namespace tloam {
 class HipRegistration : public RegistrationInterface {
  public:
   // same constructor argument as LocalRegistration (registration.cpp:182-206, initConfig :212-230)
-  explicit HipRegistration(const YAML::Node& node, int device_id = 0) : core_(fromYaml(node), device_id) {}
+  // (reference_random_omega: see setReferenceRandomOmega)
+  explicit HipRegistration(const YAML::Node& node, int device_id = 0, bool reference_random_omega = false)
+      : core_(fromYaml(node), device_id), reference_random_omega_(reference_random_omega) {}
   bool setInputSource(Frame& f) override { return core_.setInputSource(f); }
   bool setInputTarget(Frame& f) override { return core_.setInputTarget(f); }
   bool scanMatching(Frame& out, Eigen::Isometry3d& predict, Eigen::Isometry3d& result) override {
+    if (reference_random_omega_) {
+      // registration.cpp:884-886: when the predicted rotation is below 1e-2 rad the reference replaces it by
+      // Eigen::Vector3d::Random().normalized() * 1e-4 -- a fresh draw per call, from Eigen's (std::rand) generator.  The library
+      // uses the direction only when that branch is taken.
+      const Eigen::Vector3d u = Eigen::Vector3d::Random().normalized();
+      core_.setOmegaPerturbation(u.data());
+    }
     return core_.scanMatching(out, predict, result);
+  }
+  // opt-in: draw the omega perturbation as the reference does (non-deterministic, like the reference).  Off: the library's
+  // fixed (0, 0, 1) -- or whatever core().setOmegaPerturbation was given -- and two runs over the same input agree bit for bit.
+  void setReferenceRandomOmega(bool on) {
+    reference_random_omega_ = on;
+    if (!on) core_.setOmegaPerturbation(nullptr);
   }
   std::pair<double, double> getFitnessScore() override { return core_.getFitnessScore(); }
   // beyond the interface: the device-resident submap entry points
@@ -221,6 +258,7 @@ class HipRegistration : public RegistrationInterface {
 
  private:
   tloam_hip::HipRegistrationCore<Frame, Eigen::Isometry3d> core_;
+  bool reference_random_omega_ = false;
 };
 }  // namespace tloam
 #endif

@@ -37,13 +37,14 @@
 extern "C" {
 #endif
 
-#define TLOAM_ABI_VERSION 7  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
+#define TLOAM_ABI_VERSION 8  /* 2: tloam_stats gained gn_sweeps; submap + feature entry points
                                * 3: tloam_set_source_frame / tloam_set_target_frame; tloam_stats.host_wait_us
                                * 4: tloam_get_normal_equations; tloam_comm_mailbox_*; tloam_stats.reserved0 ->
                                *    weight_range_violations (same slot), TLOAM_E_WEIGHT_RANGE is returned
                                * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve)
                                * 6: tloam_k3_span, tloam_shard_ranges_frame
-                               * 7: tloam_debug_raise_fault */
+                               * 7: tloam_debug_raise_fault
+                               * 8: tloam_get_info, tloam_gn_iter_timer, tloam_time_read_stream */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
@@ -132,6 +133,31 @@ const char* tloam_last_error(const tloam_ctx* ctx);
 
 /* Sizes: a cloud, a correspondence set or a query batch holds at most 2^29 points (slots, cells and ranks are 32-bit integers on
  * the device, and the four kinds of a frame share one slot space); more is TLOAM_E_INVALID at the entry point. */
+/* What a context is and what has happened to it -- read by the bench (so that a multi-GPU line says what it ran on), by the
+ * co-residency test and by anybody who wants to know whether a context has left its fast forms. */
+#define TLOAM_FALLBACK_SCAN 1   /* a single-pass look-back scan timed out: multi-launch scans from then on            */
+#define TLOAM_FALLBACK_VOXEL 2  /* the voxel down-sampling's look-back timed out: start tickets from then on          */
+#define TLOAM_FALLBACK_SOLVE 4  /* the one-launch Solve's in-launch hand-over timed out: one launch per GN iteration  */
+typedef struct tloam_ctx_info {
+  int32_t abi_version;
+  int32_t device;
+  int32_t device_cus;       /* hipDeviceAttributeMultiprocessorCount: what the forms that need all their blocks resident are sized by */
+  int32_t comm_mode;        /* 0 one rank, 1 caller's all-reduce, 2 RCCL, 3 peer mailbox                               */
+  int32_t rank, nranks;
+  int32_t rccl_comm_count;  /* ncclCommCount of the context's communicator; -1: no RCCL communicator                    */
+  int32_t rccl_comm_rank;   /* ncclCommUserRank; -1 likewise                                                            */
+  int32_t fallbacks_taken;  /* TLOAM_FALLBACK_* bits: bounded in-launch waits that ran out and moved the context to a form
+                             * that waits for nothing (knobs of the environment are not reported here)                  */
+  int32_t fallback_events;  /* how many times that happened (each one cost a ~1-2 s wait and a re-run)                   */
+  int32_t k3_grid;          /* blocks of the residual/Jacobian sweep over the current correspondence set               */
+  int32_t k3_single;        /* 1: one wave per chunk (KITTI-size sets), 0: the streaming form                           */
+  int32_t one_launch_solve; /* 1: a ceres::Solve on the current set runs as ONE launch (k_solve_all)                    */
+  int32_t loopback;         /* 1: a mailbox / RCCL set-up with nranks == 1 -- the sharded launch forms run, the exchange is
+                             * a loop-back                                                                               */
+  int32_t reserved[2];
+} tloam_ctx_info;
+int tloam_get_info(tloam_ctx* ctx, tloam_ctx_info* out);
+
 /* ---- inputs: RegistrationInterface::setInputSource / setInputTarget -------------------
  * (registration.cpp:232-248).  The reference keeps shared_ptrs; here the cloud is copied
  * to HBM (AoS -> SoA on device).  In a sharded context (tloam_comm_*) every rank passes
@@ -256,6 +282,15 @@ int tloam_k3_timer_all(tloam_ctx* ctx, double* total_us, int64_t* launches);
  * tail -- accumulated on the device since the last reset; synchronises the stream.  launches counts working sweeps only
  * (a launch that finds the Solve finished returns before the span is taken). */
 int tloam_k3_span(tloam_ctx* ctx, int reset, double* total_us, int64_t* launches);
+/* The period of a GN iteration (sweep + reduction + exchange + 6x6 step + pose update) as the DEVICE clocks it:
+ * every kernel that ends an iteration stamps the 100 MHz wall clock when its step is done, and the time between two consecutive
+ * stamps of ONE Solve is added up -- launch boundaries, fold, exchange and step included; a Solve's first iteration has no stamp
+ * to start from and is not counted.  The first call arms the counter (until then the kernels skip it); synchronises the stream. */
+int tloam_gn_iter_timer(tloam_ctx* ctx, int reset, double* total_us, int64_t* iterations);
+/* On-box bandwidth of a READ stream with the sweep's access pattern (eight fp64 streams, 16-byte loads, persistent waves, two
+ * blocks per CU): `launches` passes over ~`bytes`, one HIP event pair; *gbps = bytes read / s / 1e9.  bytes >> 256 MiB: from HBM;
+ * bytes = a sweep's 75 MB: from the Infinity Cache, as the sweeps of a Solve.  Allocates and frees its own buffer. */
+int tloam_time_read_stream(tloam_ctx* ctx, size_t bytes, int launches, double* gbps);
 /* Test aid: the DEVICE SE(3) arithmetic the minimiser step uses (vendored-Sophus restatements sophus/so3.hpp:583-619,
  * se3.hpp:761-785 exp; so3.hpp:247-290, se3.hpp:223-256 log; registration.cpp:162-173 Plus), n items.  out26 per item:
  * [0..6] exp(delta) as (qw qx qy qz tx ty tz), [7..12] log(exp(x)), [13..18] Plus(x, delta), [19..25] exp(x) (shared form). */
@@ -349,6 +384,10 @@ int tloam_extract_planar_sphere(tloam_ctx* ctx, const tloam_feature_config* cfg,
  *     by tloam_rccl_unique_id and broadcast by the launcher. */
 int tloam_rccl_unique_id(void* out128);
 int tloam_comm_init_rccl(tloam_ctx* ctx, int rank, int nranks, const void* unique_id128);
+/* nranks == 1 in (a) and (c): the context exchanges with itself -- every launch of the sharded forms runs (fused sweep + post,
+ * gather + step, the side exchanges of the caps and the cost sums), the all-reduce / the mailbox is a loop-back, and the results
+ * are those of the single-rank forms bit for bit.  It is how the sharded forms are timed at shard size on ONE GPU and how a
+ * one-rank RCCL communicator gets to carry the all-reduce. */
 /* (b) caller-provided sum all-reduce on a DEVICE buffer of `count` doubles, enqueued on (or
  *     synchronised with) `hip_stream`; returns 0 on success.  Used by the gloo-backed tests
  *     and by hosts that already own a communicator. */

@@ -72,6 +72,7 @@ import pytest        # noqa: E402
 SRC_GPU = r'''
 #include <array>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 #include "adapters/hip_registration.hpp"
@@ -103,6 +104,7 @@ int main(int argc, char** argv) {
   if (std::fread(pred.mat.m, 8, 16, f) != 16) return 3;
   std::fclose(f);
   tloam_tls_config cfg; tloam_default_config(&cfg);
+  if (argc > 2) cfg.edge_maxnum = std::atoi(argv[2]);
   tloam_hip::HipRegistrationCore<Frame, Pose> reg(cfg, 0);
   if (!reg.valid()) return 4;
   if (!reg.setInputSource(src) || !reg.setInputTarget(tgt)) return 5;
@@ -141,7 +143,12 @@ def test_adapter_success_path_on_the_gpu(hip_module):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", ROOT, src, "-o", exe, "-L", lib_dir,
                                "-l:libtloam_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
         out = subprocess.run([exe, dat], capture_output=True, text=True)
+        few = subprocess.run([exe, dat, "7"], capture_output=True, text=True)     # edge_maxnum = 7: the edge builder adds <= 20 factors
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    # the builders' few-factor diagnostics (registration.cpp:500-502 ...): silent on a healthy frame, the reference's text otherwise
+    assert "not enough" not in out.stderr and "not enough" not in out.stdout, (out.stdout, out.stderr)
+    assert few.returncode == 0 and "[ WARN] not enough edge points !!!" in few.stderr and "sphere" not in few.stderr, few.stderr
+    assert int(few.stdout.strip().splitlines()[1].split()[2]) == 7
     lines = out.stdout.strip().splitlines()
     T_cpp = np.array(lines[0].split(), float).reshape(4, 4).T
     H = hip_module.HipRegistration(); H.set_frames(sc.source, sc.target)

@@ -87,6 +87,16 @@ int main() {
   const std::pair<double, double> fit = local_registration_ptr_->getFitnessScore();
   auto* hip = dynamic_cast<HipRegistration*>(local_registration_ptr_.get());
   const bool have_gpu = hip && hip->core().valid();
+  // the reference's default behaviour at registration.cpp:884-886, opt-in: a fresh Eigen::Vector3d::Random() per call (the
+  // identity prediction above takes that branch); and the builders' few-factor diagnostics (:500-502, :554-556, :630-632,
+  // :773-775), which the 32-point clouds of this frame trigger
+  hip->setReferenceRandomOmega(true);
+  const bool m2 = local_registration_ptr_->scanMatching(result_frame, predict_pose, result_pose);
+  hip->setReferenceRandomOmega(false);
+  hip->core().setFewFactorWarnings(false);
+  const bool m3 = local_registration_ptr_->scanMatching(result_frame, predict_pose, result_pose);
+  if (have_gpu && !(m2 && m3)) return 4;
+  HipRegistration drawn(static_cast<const YAML::Node&>(config_node)["TLS"], 0, /*reference_random_omega=*/true);
   std::printf("gpu=%d target=%d source=%d match=%d fitness=%g,%g\n", (int)have_gpu, (int)t, (int)s, (int)m, fit.first, fit.second);
   local_registration_ptr_.reset();                                   // virtual destructor through the base
   // no device: every call reports failure (there is no CPU fallback); with one they all succeed

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert set(reg.EXPORTED_SYMBOLS) == set(names)
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tloam_hip.h")).read()
-    assert L.tloam_abi_version() == int(re.search(r"#define\s+TLOAM_ABI_VERSION\s+(\d+)", hdr).group(1)) == 7
+    assert L.tloam_abi_version() == int(re.search(r"#define\s+TLOAM_ABI_VERSION\s+(\d+)", hdr).group(1)) == 8
 
 
 def test_struct_layout_matches_the_c_header():
@@ -42,9 +42,9 @@ def test_struct_layout_matches_the_c_header():
 #include <stddef.h>
 #include "tloam_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(tloam_tls_config), offsetof(tloam_tls_config, sphere_dist_thres),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tloam_tls_config), offsetof(tloam_tls_config, sphere_dist_thres),
          offsetof(tloam_tls_config, cost_threshold), sizeof(tloam_stats), offsetof(tloam_stats, kind_cost),
-         offsetof(tloam_stats, se3));
+         offsetof(tloam_stats, se3), sizeof(tloam_ctx_info), offsetof(tloam_ctx_info, one_launch_solve));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -56,6 +56,7 @@ int main(void) {
         assert vals[0] == C.sizeof(S) and vals[1] == S.sphere_dist_thres.offset and vals[2] == S.cost_threshold.offset
     for S in (reg.Stats, ob.Stats):
         assert vals[3] == C.sizeof(S) and vals[4] == S.kind_cost.offset and vals[5] == S.se3.offset
+    assert vals[6] == C.sizeof(reg.CtxInfo) and vals[7] == reg.CtxInfo.one_launch_solve.offset
 
 
 def test_default_config_is_the_shipped_yaml():

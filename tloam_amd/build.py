@@ -36,6 +36,7 @@ UNITS = [
     ("tl_api_comm.hip", []),     # multi-GPU exchange (RCCL at run time, callback, mailbox)
     ("tl_api_submap.hip", []),
     ("tl_api_feature.hip", []),
+    ("tl_probe.hip", []),        # read-stream bandwidth probe (the on-box ceiling of the bench's roofline block)
 ]
 HEADERS = ["tl_common.hpp", "tl_se3.hpp", "tl_knn.hpp", "tl_walk.hpp", "tl_ctx.hpp", "tl_step.hpp", "tl_finish.hpp", "tl_prep.hpp", os.path.join("..", "..", "include", "tloam_hip.h")]
 

@@ -113,7 +113,7 @@ void tloam_destroy(tloam_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   tlh::comm_release(c);
-  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->fin_rows.release(); c->flagb.release();
+  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->iter_span.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)
@@ -180,6 +180,26 @@ void tloam_shard_ranges_frame(const size_t n[4], int rank, int nranks, size_t lo
     hi[k] = h - base;
     base += n[k];
   }
+}
+
+int tloam_get_info(tloam_ctx* c, tloam_ctx_info* out) {
+  if (!c || !out) return TLOAM_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->abi_version = TLOAM_ABI_VERSION;
+  out->device = c->device;
+  out->device_cus = c->device_cus;
+  out->comm_mode = (int32_t)c->comm;
+  out->rank = c->rank;
+  out->nranks = c->nranks;
+  out->loopback = c->loopback ? 1 : 0;
+  tlh::comm_rccl_info(c, &out->rccl_comm_count, &out->rccl_comm_rank);
+  out->fallbacks_taken = (c->no_scan_1p ? TLOAM_FALLBACK_SCAN : 0) | (c->vox_ticket ? TLOAM_FALLBACK_VOXEL : 0) |
+                         (c->persistent_solve_timed_out ? TLOAM_FALLBACK_SOLVE : 0);
+  out->fallback_events = c->fallback_events;
+  out->k3_grid = c->k3_grid;
+  out->k3_single = c->k3_single ? 1 : 0;
+  out->one_launch_solve = (one_rank(c) && c->k3_single && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus)) ? 1 : 0;
+  return TLOAM_OK;
 }
 
 int tloam_debug_raise_fault(tloam_ctx* c, int which) {

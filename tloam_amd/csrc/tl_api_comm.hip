@@ -15,6 +15,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, Uid128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;       // (optional: what the communicator itself says its size / this rank is)
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -37,6 +39,8 @@ bool load_rccl(std::string* err) {
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+  g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     if (err) *err = "librccl: missing symbols";
     return false;
@@ -51,7 +55,7 @@ constexpr int kNcclSum = 0;      // ncclRedOp_t ncclSum
 namespace tlh {
 // sum all-reduce of a small device buffer of doubles across the ranks of this context
 int allreduce(tloam_ctx* c, double* dev, int count) {
-  if (c->nranks <= 1 || c->comm == COMM_NONE) return TLOAM_OK;
+  if (!exchanging(c) || c->comm == COMM_NONE) return TLOAM_OK;
   if (c->comm == COMM_MAILBOX) {
     if (count > 64) { c->last_error = "mailbox exchange: more than 64 values"; return TLOAM_E_INVALID; }
     launch_mbox_allreduce(dev, count, c->mbox, c->stream);
@@ -68,6 +72,26 @@ int allreduce(tloam_ctx* c, double* dev, int count) {
     return TLOAM_E_RCCL;
   }
   return TLOAM_OK;
+}
+
+void comm_rccl_info(const tloam_ctx* c, int32_t* count, int32_t* user_rank) {
+  int n = -1, r = -1;
+  if (c->nccl_comm && g_rccl.CommCount && g_rccl.CommCount(c->nccl_comm, &n) != 0) n = -1;
+  if (c->nccl_comm && g_rccl.CommUserRank && g_rccl.CommUserRank(c->nccl_comm, &r) != 0) r = -1;
+  if (count) *count = n;
+  if (user_rank) *user_rank = r;
+}
+
+// a sharded set-up that failed half way, or is being replaced: the context is a single rank again (a later sharded call must not
+// launch exchange kernels over peers that are not mapped)
+static void comm_reset(tloam_ctx* c) {
+  for (int r = 0; r < kMaxRanks; ++r)
+    if (c->mbox_opened[r]) { (void)hipIpcCloseMemHandle(c->mbox_opened[r]); c->mbox_opened[r] = nullptr; }
+  memset(&c->mbox, 0, sizeof(c->mbox));
+  c->comm = COMM_NONE;
+  c->rank = 0;
+  c->nranks = 1;
+  c->loopback = false;
 }
 
 // what tloam_destroy releases of the exchange
@@ -111,6 +135,7 @@ int tloam_comm_init_rccl(tloam_ctx* c, int rank, int nranks, const void* unique_
   c->rank = rank;
   c->nranks = nranks;
   c->comm = COMM_RCCL;
+  c->loopback = nranks == 1;   // a one-rank communicator still carries the all-reduce (tl_ctx.hpp)
   return TLOAM_OK;
 }
 
@@ -121,6 +146,7 @@ int tloam_comm_init_callback(tloam_ctx* c, int rank, int nranks, tloam_allreduce
   c->cb = fn;
   c->cb_user = user;
   c->comm = COMM_CALLBACK;
+  c->loopback = false;
   return TLOAM_OK;
 }
 
@@ -143,6 +169,15 @@ int tloam_comm_mailbox_export(tloam_ctx* c, void* handle64) {
     HIPC(c, e);
     HIPC(c, hipMemset(p, 0, bytes));
     c->mbox_local = (double*)p;
+  } else {
+    // A second set-up on this context.  The export is the first step of a set-up and every rank takes it before
+    // any rank can finish tloam_comm_init_mailbox (the launcher all-gathers the handles in between), so no exchange of the NEW
+    // session can have been posted here yet; the exchanges of the OLD one are over on every rank once its last sharded call has
+    // returned everywhere, which a caller that sets up again has seen.  What is in the buffer now are the old session's rows with
+    // their exchange ids -- and the new session counts its ids from 1 again: left in place, new exchange 1 or 2 would find a
+    // matching id and add stale rows without waiting.  So: drain this context's own work, then clear the buffer.
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemset(c->mbox_local, 0, sizeof(double) * kMboxDoubles));
   }
   hipIpcMemHandle_t h;
   HIPC(c, hipIpcGetMemHandle(&h, c->mbox_local));
@@ -154,9 +189,7 @@ int tloam_comm_init_mailbox(tloam_ctx* c, int rank, int nranks, const void* hand
   if (!c || !handles64 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return TLOAM_E_INVALID;
   if (!c->mbox_local) return TLOAM_E_NOT_READY;  // export first
   HIPC(c, hipSetDevice(c->device));
-  for (int r = 0; r < kMaxRanks; ++r)   // (a second set-up on the same context: the first one's mappings go)
-    if (c->mbox_opened[r]) { (void)hipIpcCloseMemHandle(c->mbox_opened[r]); c->mbox_opened[r] = nullptr; }
-  memset(&c->mbox, 0, sizeof(c->mbox));
+  comm_reset(c);   // (a second set-up on the same context: the first one's mappings go; until this one is complete the context is one rank)
   for (int r = 0; r < nranks; ++r) {
     if (r == rank) { c->mbox.peer[r] = c->mbox_local; continue; }
     hipIpcMemHandle_t h;
@@ -166,19 +199,28 @@ int tloam_comm_init_mailbox(tloam_ctx* c, int rank, int nranks, const void* hand
     if (e != hipSuccess) {
       c->last_error = std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e);
       (void)hipGetLastError();
+      comm_reset(c);   // the handles opened so far are closed, the context stays a single rank
       return TLOAM_E_RCCL;
     }
     c->mbox_opened[r] = p;
     c->mbox.peer[r] = (double*)p;
   }
-  HIPC(c, c->mbox_ctr.reserve(4));
-  HIPC(c, hipMemset(c->mbox_ctr.p, 0, 4 * sizeof(unsigned long long)));
+  {
+    hipError_t e = c->mbox_ctr.reserve(4);
+    if (e == hipSuccess) e = hipMemset(c->mbox_ctr.p, 0, 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+      c->last_error = std::string("mailbox exchange counter: ") + hipGetErrorString(e);
+      comm_reset(c);
+      return TLOAM_E_HIP;
+    }
+  }
   c->mbox.ctr = c->mbox_ctr.p;
   c->mbox.rank = rank;
   c->mbox.nranks = nranks;
   c->rank = rank;
   c->nranks = nranks;
   c->comm = COMM_MAILBOX;
+  c->loopback = nranks == 1;   // the rank posts to, and gathers from, its own buffer (tl_ctx.hpp)
   return TLOAM_OK;
 }
 

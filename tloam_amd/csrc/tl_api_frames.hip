@@ -59,6 +59,7 @@ int check_device_faults(tloam_ctx* c) {
   if (__atomic_load_n(&c->h_fault[kFaultScan1p], __ATOMIC_ACQUIRE) != 0u) {
     __atomic_store_n(&c->h_fault[kFaultScan1p], 0u, __ATOMIC_RELEASE);
     c->no_scan_1p = true;
+    c->fallback_events++;
     c->grids_ahead = false; c->tgt_gen++;
     for (int k = 0; k < kKinds; ++k) c->kd[k].grid_valid = false;
     c->have_build = false;
@@ -68,6 +69,7 @@ int check_device_faults(tloam_ctx* c) {
   if (__atomic_load_n(&c->h_fault[kFaultVoxEmit], __ATOMIC_ACQUIRE) != 0u) {
     __atomic_store_n(&c->h_fault[kFaultVoxEmit], 0u, __ATOMIC_RELEASE);
     c->vox_ticket = true;
+    c->fallback_events++;
     c->grids_ahead = false; c->tgt_gen++;
     c->last_error = "the voxel down-sampling timed out in its look-back (its blocks were not resident together): the context now uses start tickets; "
                     "the submap of this update is undefined -- initialise it again";
@@ -448,7 +450,7 @@ int tloam_set_target_frame(tloam_ctx* c, const double* const xyz[4], const size_
   // hand-over's own synchronisation and not waited for: the targets are final once setInputTarget returns, the next scan is a
   // sensor period away, and the ~24 us of launches leave the bracket around scanMatching (front_end.cpp:320-322).  The grids
   // stay valid until a target changes; a frame brought in by tloam_frame_select is built over inside scanMatching as before.
-  if (rc == TLOAM_OK && c->nranks == 1 && !c->no_grid_ahead) {
+  if (rc == TLOAM_OK && one_rank(c) && !c->no_grid_ahead) {
     double radius[kKinds];
     GridView views[kKinds];
     bool all = true;

@@ -70,6 +70,8 @@ int ensure_common(tloam_ctx* c) {
     }
     HIPC(c, c->k3_span.reserve(4));     // K3Step::span
     HIPC(c, hipMemsetAsync(c->k3_span.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPC(c, c->iter_span.reserve(4));   // iter_span_note
+    HIPC(c, hipMemsetAsync(c->iter_span.p, 0, 4 * sizeof(unsigned long long), c->stream));
   }
   c->cv.seg_n = c->seg_n.p;
   return TLOAM_OK;
@@ -83,6 +85,8 @@ namespace {
 // a frame, so over a few frames every position is sampled equally): timing EVERY launch through
 // hipExtLaunchKernelGGL cost ~8 % of the 1 M frame.
 constexpr int kK3SampleStride = 3;
+// the device-side period counter of the GN iterations, once tloam_gn_iter_timer has armed it (null otherwise: the kernels skip it)
+unsigned long long* iter_span_of(const tloam_ctx* c) { return c->iter_timing ? c->iter_span.p : nullptr; }
 int launch_k3_timed(tloam_ctx* c, bool force) {
   const bool sample = c->k3_timing && (c->k3_seq++ % kK3SampleStride) == 0;
   const int idx = c->batch_launches++;
@@ -106,7 +110,7 @@ int launch_k3_timed(tloam_ctx* c, bool force) {
 int launch_k3_step_timed(tloam_ctx* c) {
   const bool sample = c->k3_timing && (c->k3_seq++ % kK3SampleStride) == 0;
   const int idx = c->batch_launches++;
-  const MboxView* mb = (c->nranks > 1 && c->comm == COMM_MAILBOX) ? &c->mbox : nullptr;
+  const MboxView* mb = (exchanging(c) && c->comm == COMM_MAILBOX) ? &c->mbox : nullptr;
   if (sample) {
     if (c->ev_used + 2 > c->ev_pool.size()) {
       const size_t old = c->ev_pool.size();
@@ -114,11 +118,12 @@ int launch_k3_step_timed(tloam_ctx* c) {
       for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
     }
     launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream,
-                   c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1]);
+                   c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], iter_span_of(c));
     c->ev_used += 2;
     c->ev_batch_idx.push_back(idx);
   } else {
-    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream);
+    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream, nullptr,
+                   nullptr, iter_span_of(c));
   }
   return TLOAM_OK;
 }
@@ -191,7 +196,7 @@ int wait_state(tloam_ctx* c, const HostMirror& hm, int slot = 0) {
 // sweeps after a tolerance exit are no-op launches (GnState.done).
 constexpr int kSolveSweeps = 5;  // max_num_iterations 4 -> at most 1 + 4 evaluations per Solve
 bool solve_small_path(const tloam_ctx* c) {
-  return c->nranks == 1 && c->k3_single && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus);
+  return one_rank(c) && c->k3_single && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus);
 }
 // prep: the launch also prepares the factor set (only with solve_small_path and SlotView::flagb, see self_prepare_path)
 // finish: ... and finishes the outer iteration, possibly running the following ones too (SolveFinish; needs prep).
@@ -209,6 +214,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       memset(&F, 0, sizeof(F));
       if (wp) { F.have_wp = 1; F.wp[0] = *wp; }
     }
+    F.iter_span = iter_span_of(c);
     const int sabotage = c->dbg_fail_handover > 0 ? (c->dbg_fail_handover--, 1 << 16) : 0;   // test hook, see k_solve_all
     launch_solve_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, sweeps | sabotage, prep, c->seg_n.p, &F, c->stream);
     c->batch_launches++;
@@ -217,14 +223,14 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
   // One GN iteration = ONE launch whatever the size of the set (round 4): the streaming sweep's last block folds the rows and
   // advances the minimiser (k3_sweep_step); with a mailbox it also posts, gathers and advances -- sweep + exchange + step.
   // RCCL / callback contexts keep sweep | collective | step: the collective is enqueued by the host between two launches.
-  const bool one_launch = c->fused_large && (c->nranks == 1 ? !c->k3_single : c->comm == COMM_MAILBOX);
+  const bool one_launch = c->fused_large && (one_rank(c) ? !c->k3_single : c->comm == COMM_MAILBOX);
   for (int sweep = 0; sweep < sweeps; ++sweep) {
     if (one_launch) {
       const int rc = launch_k3_step_timed(c);
       if (rc != TLOAM_OK) return rc;
       continue;
     }
-    if (c->nranks > 1) {
+    if (exchanging(c)) {
       // sharded GN iteration = 2 launches (+ the collective): the sweep, whose last block folds the rows into the
       // 48-double buffer (the 42 normal-equation scalars + cost) and -- with the mailbox -- stores it straight into
       // every rank's buffer over xGMI; then the step, which (mailbox) adds the ranks' rows in rank order itself
@@ -236,20 +242,20 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, false, fuse, c->stream);
       c->batch_launches++;
       if (c->comm == COMM_MAILBOX) {
-        launch_gn_step_mbox(c->state.p, c->mbox, c->stream);
+        launch_gn_step_mbox(c->state.p, c->mbox, c->stream, iter_span_of(c));
       } else {
         const int rc = allreduce(c, c->red48.p, kReduceBuf);
         if (rc != TLOAM_OK) return rc;
-        launch_gn_step(c->state.p, c->red48.p, c->stream);
+        launch_gn_step(c->state.p, c->red48.p, c->stream, iter_span_of(c));
       }
     } else if (c->k3_single) {
       // KITTI-size set: one launch per GN iteration (k_sweep_step_small)
-      launch_sweep_step_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, c->stream);
+      launch_sweep_step_small(c->cv, c->state.p, c->partials.p, c->k3_ticket.p, c->k3_grid, c->stream, iter_span_of(c));
       c->batch_launches++;
     } else {
       const int rc = launch_k3_timed(c, false);
       if (rc != TLOAM_OK) return rc;
-      launch_reduce_and_step(c->partials.p, c->k3_grid, c->state.p, c->stream);
+      launch_reduce_and_step(c->partials.p, c->k3_grid, c->state.p, c->stream, iter_span_of(c));
     }
   }
   return TLOAM_OK;
@@ -324,7 +330,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   {
     int caps[kKinds];
     for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
-    k3_plan(caps, &c->k3_grid, &c->k3_single);
+    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single);
     (void)total_cap;
   }
   {
@@ -359,7 +365,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     if (c->nranks > 1)
       for (int k = 0; k < kKinds; ++k)
         if (c->kd[k].n_src == 0) radius[k] = 0.0;
-    if (c->grids_ahead && c->grids_next_gen == c->tgt_gen && c->nranks == 1) {
+    if (c->grids_ahead && c->grids_next_gen == c->tgt_gen && one_rank(c)) {
       // built when the targets were handed over (tloam_set_target_frame): they become the context's search structures now;
       // the frame's start is a launch of its own, below.  Used once: a second scanMatching over the same targets builds its own
       std::swap(c->grids, c->grids_next);
@@ -444,7 +450,7 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
 // :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
 // caps, the compaction AND the alternative (refresh) are one launch (k_prepare_small) -- `also_refresh` says whether this
 // call stands for both alternatives of a device-gated iteration.
-bool prepare_small_path(const tloam_ctx* c) { return c->nranks == 1 && prepare_small_fits(c->sv); }
+bool prepare_small_path(const tloam_ctx* c) { return one_rank(c) && prepare_small_fits(c->sv); }
 // the Solve launch that follows prepares the set itself: no k_prepare_small
 bool self_prepare_path(const tloam_ctx* c) { return c->sv.flagb != nullptr && prepare_small_path(c) && solve_small_path(c); }
 // ride: the finish of the previous outer iteration rides on this search launch (large single-rank sets, device-driven loop:
@@ -464,7 +470,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
     return TLOAM_OK;
   }
-  if (c->nranks == 1) {
+  if (one_rank(c)) {
     // single rank: the tile-local scan only -- the compaction adds the tiles' offsets itself -- and ONE launch for both
     // alternatives of a device-gated iteration (compaction, or the refresh of the unchanged set): two launches less
     const int tiles = scan_tiles_only(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
@@ -475,7 +481,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
   }
   launch_exclusive_scan_u64(c->flags.p, c->scan.p, n_slots + 1, c->scan_tmp.p, c->stream, gate);
   const double* rank_counts = nullptr;
-  if (c->nranks > 1) {
+  if (exchanging(c)) {
     launch_rank_counts(c->sv, c->rank_counts.p, c->rank, c->nranks, c->stream);
     const int rc = allreduce(c, c->rank_counts.p, c->nranks * kKinds);
     if (rc != TLOAM_OK) return rc;
@@ -483,7 +489,7 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
   }
   // seg_n: every kind with slots and a positive cap is rewritten by the compaction, the others keep the 0 of
   // k_frame_init; only a sharded rank can find its cap already filled by the lower ranks and write nothing
-  if (c->nranks > 1) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
+  if (exchanging(c)) HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
   launch_compact(c->sv, c->cv, bp, c->seg_n.p, rank_counts, c->rank, c->nranks, c->state.p, c->stream, gate);
   if (refresh_gate) launch_refresh(c->sv, c->cv, c->stream, refresh_gate);
   return TLOAM_OK;
@@ -514,7 +520,7 @@ size_t total_seg_cap(const tloam_ctx* c) {
   return cap;
 }
 // one 1024-thread block does weights + sums + publish in a single launch
-bool finish_small_path(const tloam_ctx* c) { return c->nranks == 1 && total_seg_cap(c) <= 16384; }
+bool finish_small_path(const tloam_ctx* c) { return one_rank(c) && total_seg_cap(c) <= 16384; }
 int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl) {
   // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
   const size_t cap = total_seg_cap(c);
@@ -524,7 +530,7 @@ int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, c
     return TLOAM_OK;
   }
   launch_weights(c->cv, c->sv, wp, c->wpart.p, wblocks, c->state.p, c->stream);
-  if (c->nranks > 1) {
+  if (exchanging(c)) {
     launch_outer_finish(c->wpart.p, wblocks, c->seg_n.p, nullptr, c->state.p, c->sums16.p, hm, ctl, c->stream);
     const int rc = allreduce(c, c->sums16.p, 16);
     if (rc != TLOAM_OK) return rc;
@@ -639,9 +645,9 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
     if (rc != TLOAM_OK) return rc;
     if (!c->h_state->incomplete) break;
     if (c->h_state->incomplete == OS_COMM_ERROR) {
-      c->last_error = c->nranks > 1 ? "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)"
+      c->last_error = exchanging(c) ? "mailbox exchange timed out: a peer rank did not post (dead process or diverged call sequence)"
                                     : "in-launch hand-over of the fused GN iteration timed out (a block of the grid never posted its row)";
-      return c->nranks > 1 ? TLOAM_E_RCCL : TLOAM_E_HIP;
+      return exchanging(c) ? TLOAM_E_RCCL : TLOAM_E_HIP;
     }
     if (attempt > 0 || planned >= kSolveSweeps) {
       c->last_error = "the minimiser did not terminate within its evaluation budget";
@@ -719,7 +725,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
   // search of iteration k (k_build_finish_small: they are independent of each other); the last one stands alone
   const bool ride = prepare_small_path(c) && finish_small_path(c) && build_finish_small_fits(c->sv);
   // ... and 1 M-class frames the same way with k_weights + k_outer_finish (k_build_finish_large)
-  const bool ride_large = !ride && c->nranks == 1 && !finish_small_path(c) && build_finish_large_fits(c->sv);
+  const bool ride_large = !ride && one_rank(c) && !finish_small_path(c) && build_finish_large_fits(c->sv);
   const int wblocks_large = (int)std::min<size_t>(256, std::max<size_t>(64, total_seg_cap(c) / 2048));   // as enqueue_finish
   if (ride_large) HIPC(c, c->fin_rows.reserve((size_t)4 * 256 * 8));
   bool pending = false;   // the finish of the previous iteration has not been enqueued yet (it rides on this search)
@@ -746,6 +752,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
     F.n_iter = M;
     F.cost_threshold = c->cfg.cost_threshold;
     F.sums16 = c->sums16.p;
+    F.iter_span = iter_span_of(c);
     double m = mu;
     for (int iter = first; iter < M; ++iter) {
       P.mus[iter] = m;
@@ -932,7 +939,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
   // iterations fit the result slots, no development knob that needs the host between iterations
-  if (c->nranks == 1 && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
+  if (one_rank(c) && c->cfg.max_iterations >= 1 && c->cfg.max_iterations <= kMaxOuterFast &&
       !c->dbg_no_build_reuse && !c->no_device_loop) {
     const bool persistent = solve_small_path(c);
     rc = scan_match_device_loop(c, &weight_violation);
@@ -941,6 +948,8 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
       // fewer usable CUs than the attribute says): the waits inside the launch are bounded, the frame is intact in HBM --
       // solve it again with one launch per GN iteration, and keep this context on that path.
       c->no_persistent_solve = true;
+      c->persistent_solve_timed_out = true;
+      c->fallback_events++;
       c->hand_over_timed_out = false;
       (void)hipStreamSynchronize(c->stream);
       c->active = false;
@@ -1175,7 +1184,7 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
   {
     int caps[kKinds];
     for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
-    k3_plan(caps, &c->k3_grid, &c->k3_single);
+    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single);
     (void)total_cap;
   }
   return reserve_partials(c);
@@ -1300,7 +1309,7 @@ int tloam_time_sharded_sweep(tloam_ctx* c, const double se3[6], int launches, in
   memset(&fuse, 0, sizeof(fuse));
   fuse.ticket = c->k3_ticket.p;
   fuse.out48 = c->red48.p;
-  const bool mbox = with_exchange && c->comm == COMM_MAILBOX && c->nranks > 1;
+  const bool mbox = with_exchange && c->comm == COMM_MAILBOX && exchanging(c);
   if (mbox) fuse.mb = c->mbox;
   hipEvent_t e0, e1;
   HIPC(c, hipEventCreate(&e0));
@@ -1403,6 +1412,23 @@ int tloam_k3_timer_all(tloam_ctx* c, double* total_us, int64_t* launches) {
   if (!c) return TLOAM_E_INVALID;
   if (total_us) *total_us = c->k3_all_us;
   if (launches) *launches = c->k3_all_launches;
+  return TLOAM_OK;
+}
+
+// The period of a GN iteration as the DEVICE clocks it (iter_span_note, tl_gn.hip): between the ends of two consecutive
+// minimiser steps of one Solve -- sweep, launch boundaries, fold, exchange, step.  The first call arms it.
+int tloam_gn_iter_timer(tloam_ctx* c, int reset, double* total_us, int64_t* iterations) {
+  if (!c) return TLOAM_E_INVALID;
+  HIPC(c, hipSetDevice(c->device));
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (c->iter_span.p) {
+    HIPC(c, hipMemcpyAsync(h, c->iter_span.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (reset) HIPC(c, hipMemsetAsync(c->iter_span.p, 0, sizeof(h), c->stream));
+  }
+  if (total_us) *total_us = (double)h[1] * 0.01;   // 100 MHz wall clock
+  if (iterations) *iterations = (int64_t)h[2];
+  c->iter_timing = true;
   return TLOAM_OK;
 }
 

@@ -443,8 +443,8 @@ void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long lo
                         double* out, hipStream_t s);
 
 // K3 and the minimiser
-int k3_grid_for(int total_cap);
-void k3_plan(const int cap[kKinds], int* grid, bool* single);  // one wave per chunk (small sets) vs the streaming variant
+int k3_grid_for(int total_cap, int device_cus);
+void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single);  // one wave per chunk (small sets) vs the streaming variant
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // sharded contexts: the sweep whose LAST block (ticket counter) also folds the block rows into out48 and, with a
@@ -458,18 +458,21 @@ void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid
                      const K3Fuse& fuse, hipStream_t s);
 // one GN iteration in ONE launch, whatever the size of the set: the sweep whose last block folds the rows and advances the
 // minimiser (mailbox contexts: posts, gathers and advances) -- k3_sweep_step, tl_gn.hip.  span: see K3Step (may be null)
+// iter_span (every launcher of a kernel that ends a GN iteration): the device-side period counter of tloam_gn_iter_timer, or null
 void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
-                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s);   // gather (rank order) + consume
+                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                    unsigned long long* iter_span = nullptr);
+void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s, unsigned long long* iter_span = nullptr);   // gather (rank order) + consume
 void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream_t s);  // buf <- sum over ranks
 void launch_mbox_gather_only(double* out48, const MboxView& mb, hipStream_t s);
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
 void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);
-void launch_gn_step(GnState* st, const double* in48, hipStream_t s);  // consume a reduced sweep
-void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s);
+void launch_gn_step(GnState* st, const double* in48, hipStream_t s, unsigned long long* iter_span = nullptr);  // consume a reduced sweep
+void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s, unsigned long long* iter_span = nullptr);
 // small sets on one rank: sweep + step in ONE launch (ticket: zero between launches)
-void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s);
+void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s,
+                             unsigned long long* iter_span = nullptr);
 // sets whose sweep is a grid of a dozen blocks: a whole ceres::Solve (up to max_sweeps evaluations) in ONE launch
 bool solve_small_fits(int grid, int device_cus);
 // The factor set of an outer iteration prepared by the Solve launch itself (no k_prepare_small launch in front of it):
@@ -497,6 +500,7 @@ struct SolveFinish {
   int first_iter, n_iter;    // outer iteration this launch was enqueued for; max_iterations
   double cost_threshold;     // registration.cpp:1108
   double* sums16;
+  unsigned long long* iter_span;   // the lead's stepper notes the period of its GN iterations here (tloam_gn_iter_timer), or null
   WeightParams wp[kMaxOuterInLaunch];   // per outer iteration
   HostMirror hm[kMaxOuterInLaunch];
 };

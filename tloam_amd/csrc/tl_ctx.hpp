@@ -230,6 +230,11 @@ struct tloam_ctx {
   // comm
   int rank = 0, nranks = 1;
   CommMode comm = COMM_NONE;
+  // A mailbox or RCCL set-up with nranks == 1: the context exchanges with ITSELF -- every launch of the sharded forms runs (fused
+  // sweep + post, gather + step, the side exchanges), the exchange is a loop-back, the results are those of the single-rank forms
+  // bit for bit (one row folded onto +0.0).  What times the sharded forms at shard size on ONE GPU (bench: shard_size_iterations)
+  // and makes a one-rank RCCL communicator actually carry the all-reduce (tests/test_gpu_multirank.py)
+  bool loopback = false;
   tloam_allreduce_fn cb = nullptr;
   void* cb_user = nullptr;
   void* nccl_comm = nullptr;
@@ -241,6 +246,12 @@ struct tloam_ctx {
   DBuf<unsigned long long> mbox_ctr;
   DBuf<int> k3_ticket;
   DBuf<unsigned long long> k3_span;    // K3Step::span: streaming span of the one-launch GN iterations (100 MHz ticks, launches)
+  DBuf<unsigned long long> iter_span;  // iter_span_note (tl_gn.hip): [0] last stamp, [1] ticks, [2] periods; handed to the kernels once
+  bool iter_timing = false;            // tloam_gn_iter_timer has armed it
+  // bounded in-launch waits that ran out on this context (look-back scan, voxel look-back, one-launch Solve hand-over): every
+  // one moved the context to a form that waits for nothing -- tloam_get_info reports which, and how often
+  int fallback_events = 0;
+  bool persistent_solve_timed_out = false;   // no_persistent_solve was set by a time-out, not by TLOAM_NO_PERSISTENT_SOLVE
   // scanMatching host state
   bool active = false;
   bool have_build = false;   // the compact set matches build_x
@@ -307,9 +318,12 @@ inline int kind_active(const tloam_tls_config& c, int k) {
   return 0;
 }
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+inline bool one_rank(const tloam_ctx* c) { return c->nranks == 1 && !c->loopback; }    // the single-rank launch forms apply
+inline bool exchanging(const tloam_ctx* c) { return c->nranks > 1 || c->loopback; }    // the sharded launch forms run
 // tl_api_comm.hip
 int allreduce(tloam_ctx* c, double* dev, int count);   // sum all-reduce of a small device buffer of doubles across the context's ranks
 void comm_release(tloam_ctx* c);
+void comm_rccl_info(const tloam_ctx* c, int32_t* count, int32_t* user_rank);   // ncclCommCount / ncclCommUserRank of the context's communicator, -1 without one
 // tl_api_match.hip
 int reserve_seg(tloam_ctx* c, int k, size_t n);        // compact correspondence segment of kind k for n factors
 int ensure_common(tloam_ctx* c);                       // the context's small fixed device buffers

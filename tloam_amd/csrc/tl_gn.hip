@@ -692,17 +692,20 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
 }
 
 
-int k3_grid_for(int total_cap) {
+// blocks of the streaming sweep the device holds at once: two per CU.  The CU count is the context's (tloam_ctx::device_cus,
+// hipDeviceAttributeMultiprocessorCount); a device that reports none is taken for the full part
+static int k3_resident_blocks(int device_cus) { return (device_cus > 0 ? device_cus : 256) * 2; }
+int k3_grid_for(int total_cap, int device_cus) {
   if (const char* e = getenv("TLOAM_K3_BLOCKS")) {  // tuning aid
     const int b = atoi(e);
     if (b > 0) return b;
   }
-  // one wave per 128-correspondence chunk up to a full-chip resident grid (256 CUs x 2 blocks)
+  // one wave per 128-correspondence chunk up to a full-chip resident grid (the device's CUs x 2 blocks: 512 on an MI355X)
   int waves = (total_cap + kChunk - 1) / kChunk;
   int blocks = (waves + 3) / 4;
   if (blocks < 1) blocks = 1;
 
-  const int resident = 256 * 2;  // two blocks of 4 waves per CU (2 waves per SIMD): more resident waves only lengthen the dispatch ramp
+  const int resident = k3_resident_blocks(device_cus);  // two blocks of 4 waves per CU (2 waves per SIMD): more resident waves only lengthen the dispatch ramp
   if (blocks > resident) {
     // balance: every wave gets the same number of chunks
     const int per_wave = (waves + resident * 4 - 1) / (resident * 4);
@@ -713,19 +716,19 @@ int k3_grid_for(int total_cap) {
 }
 // The sweep of a set with segment capacities cap[k] (multiples of kChunk): one wave per chunk (sweep_single: chunks of
 // single_chunk_of(kind) correspondences) while that fits the resident chip, the streaming variant otherwise.
-void k3_plan(const int cap[kKinds], int* grid, bool* single) {
+void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single) {
   long long waves = 0, total = 0;
   for (int k = 0; k < kKinds; ++k) {
     waves += (cap[k] + single_chunk_of(k) - 1) / single_chunk_of(k);
     total += cap[k];
   }
   waves += 1;   // wave 0 of the grid holds no chunk (single_work_of)
-  if (waves <= 256 * 2 * 4 && !getenv("TLOAM_K3_BLOCKS")) {
+  if (waves <= (long long)k3_resident_blocks(device_cus) * 4 && !getenv("TLOAM_K3_BLOCKS")) {
     *single = true;
     *grid = (int)((waves + 3) / 4) < 1 ? 1 : (int)((waves + 3) / 4);
     return;
   }
-  *grid = k3_grid_for((int)total);
+  *grid = k3_grid_for((int)total, device_cus);
   *single = ((total + kChunk - 1) / kChunk <= (long long)*grid * 4) && TLOAM_SMALL_LINE_CHUNK == kChunk;
 }
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
@@ -770,6 +773,19 @@ void launch_reduce(const double* partials, int grid, GnState* st, double* out48,
 #include "tl_step.hpp"   // K5: the minimiser step (gn_consume)
 namespace tl {
 
+// ---- the period of a GN iteration, measured on the device (bench aid: tloam_gn_iter_timer; span may be null) ---------------
+// a GN iteration = one sweep + reduction (+ exchange) + 6x6 step + pose update.  Every kernel that ends one -- the
+// step kernels of the launch-per-iteration forms, the lead's stepper inside the one-launch Solve -- stamps the device's 100 MHz
+// wall clock when its step is done: span[0] = that stamp, span[1] += stamp - span[0] for every iteration that FOLLOWS another one
+// of the same Solve (the first has no stamp to start from: the kernel in front of it is a search or a compaction), span[2] += 1.
+// The period therefore holds everything between two poses: sweep, launch boundaries, fold, exchange, step.  One thread.
+__device__ __forceinline__ void iter_span_note(unsigned long long* span, bool first_of_solve) {
+  if (!span) return;
+  const unsigned long long now = wall_clock64();
+  if (!first_of_solve) { span[1] += now - span[0]; span[2] += 1ull; }
+  span[0] = now;
+}
+
 __global__ void k_solve_init(GnState* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->T_cur = se3_exp(st->x);
@@ -806,7 +822,7 @@ __device__ __forceinline__ void load_state_lds(const GnState* st, GnState* sm, i
   for (int i = lane; i < kWords; i += 64)
     reinterpret_cast<unsigned long long*>(sm)[i] = reinterpret_cast<const unsigned long long*>(st)[i];
 }
-__global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __restrict__ in48) {
+__global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __restrict__ in48, unsigned long long* iter_span) {
   __shared__ double tot[kReduceBuf];
   __shared__ double scr[32];
   __shared__ GnState s_in;
@@ -814,14 +830,16 @@ __global__ __launch_bounds__(64) void k_gn_step(GnState* st, const double* __res
   load_state_lds(st, &s_in, threadIdx.x);
   __syncthreads();
   if (s_in.done) return;
+  const bool first = s_in.phase == PH_ITER0;
   gn_consume(st, tot, threadIdx.x, &s_in, scr);
+  if (threadIdx.x == 0) iter_span_note(iter_span, first);
 }
-void launch_gn_step(GnState* st, const double* in48, hipStream_t s) {
-  hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48);
+void launch_gn_step(GnState* st, const double* in48, hipStream_t s, unsigned long long* iter_span) {
+  hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, s, st, in48, iter_span);
 }
 // mailbox contexts: wait for every rank's totals of this sweep (posted by the last block of its K3), add them in
 // rank order and advance the minimiser -- identically on every rank
-__global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
+__global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb, unsigned long long* iter_span) {
   __shared__ double tot[kMboxSlot];
   __shared__ double scr[32];
   __shared__ GnState s_in;
@@ -839,10 +857,12 @@ __global__ __launch_bounds__(64) void k_gn_step_mbox(GnState* st, MboxView mb) {
     if (threadIdx.x == 0) { st->done = 1; st->comm_error = 1; }
     return;
   }
+  const bool first = s_in.phase == PH_ITER0;
   gn_consume(st, tot, threadIdx.x, &s_in, scr);
+  if (threadIdx.x == 0) iter_span_note(iter_span, first);
 }
-void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s) {
-  hipLaunchKernelGGL(k_gn_step_mbox, dim3(1), dim3(64), 0, s, st, mb);
+void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s, unsigned long long* iter_span) {
+  hipLaunchKernelGGL(k_gn_step_mbox, dim3(1), dim3(64), 0, s, st, mb, iter_span);
 }
 // timing aid (tloam_time_sharded_sweep): the gather half of the step without the minimiser
 __global__ __launch_bounds__(64) void k_mbox_gather_only(double* out48, MboxView mb) {
@@ -880,7 +900,7 @@ void launch_mbox_allreduce(double* buf, int count, const MboxView& mb, hipStream
 
 // single-GPU fast path: reduce the block rows and advance the minimiser in ONE launch
 __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* __restrict__ partials, int rows,
-                                                                 GnState* __restrict__ st) {
+                                                                 GnState* __restrict__ st, unsigned long long* iter_span) {
   __shared__ double lds[8 * 33];
   __shared__ double tot[kReduceBuf];
   __shared__ GnState s_in;
@@ -898,7 +918,9 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
   }
   fold_rows<false>(partials, rows, lds, tot);  // (its barriers also publish s_in)
   if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
+  const bool first = s_in.phase == PH_ITER0;
   if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, lds /* free again: the fold is over */);
+  if (threadIdx.x == 0) iter_span_note(iter_span, first);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
@@ -922,6 +944,7 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
 struct K3Step {
   int* ticket;                 // zero between launches
   unsigned long long* span;    // [4] or null
+  unsigned long long* iter_span;   // iter_span_note, or null
   MboxView mb;                 // mb.nranks == 0: one rank
 };
 template <bool SINGLE>
@@ -986,15 +1009,18 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
       return;
     }
   }
+  const bool first = s_in.phase == PH_ITER0;
   gn_consume(st, tot, (int)threadIdx.x, &s_in, s_grp /* free again: the fold is over */);
+  if (threadIdx.x == 0) iter_span_note(fs.iter_span, first);
 }
 void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
-                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                    const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned long long* iter_span) {
   auto kern = single ? k3_sweep_step<true> : k3_sweep_step<false>;
   K3Step fs;
   memset(&fs, 0, sizeof(fs));
   fs.ticket = ticket;
   fs.span = span;
+  fs.iter_span = iter_span;
   if (mb_or_null) fs.mb = *mb_or_null;
   if (ev_start && ev_stop) {
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
@@ -1015,7 +1041,7 @@ void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid,
 __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __restrict__ seg0, int stride0, int cap0, int tagged,
                                                              GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                              double* __restrict__ partials, int* __restrict__ ticket,
-                                                             CorrView cv) {
+                                                             CorrView cv, unsigned long long* iter_span) {
   __shared__ double red[4][32];
   __shared__ double s_grp[8 * 33];
   __shared__ double s_rows[kTaggedRows * 28];
@@ -1080,15 +1106,18 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
     fold_rows<true>(partials, (int)gridDim.x, s_grp, tot);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
   }
+  const bool first = s_in.phase == PH_ITER0;
   if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, s_grp /* free again: the fold is over */);
+  if (threadIdx.x == 0) iter_span_note(iter_span, first);
 #ifdef TLOAM_STEP_PROFILE
   if (threadIdx.x == 0) st->dbg[6] = (double)__builtin_readcyclecounter();
 #endif
 }
-void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s) {
+void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s,
+                             unsigned long long* iter_span) {
   const int tagged = grid <= kTaggedRows ? 1 : 0;
   hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
-                     cv.seg_n, partials, ticket, cv);
+                     cv.seg_n, partials, ticket, cv, iter_span);
 }
 #include "tl_prep.hpp"   // SolvePrep: the Solve's own caps / compaction / refresh (kind_set_of, self_compact, self_refresh)
 
@@ -1370,6 +1399,7 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
         if (ok) {
           gn_consume(st, tot, lane, &s_in, s_scr, /*WRITE_GLOBAL=*/false);
           vd = (s_in.done == 0 && it + 1 < max_sweeps) ? 1 : 2;
+          if (lead && lane == 0) iter_span_note(F.iter_span, it == 0);
         }
         TL_PROF(prof_c, 8 + it * 8 + 2)
         if (lane < 9) s_msg[lane] = s_in.Rt_eval.r[lane];
@@ -1501,8 +1531,8 @@ void launch_solve_small(const CorrView& cv, GnState* st, double* partials, int* 
 // wants ~400 registers: one wave per SIMD), i.e. grid <= the device's CU count -- 256 on an MI355X, fewer on a CU-masked or
 // partitioned device (then the one-launch-per-iteration kernels run instead).
 bool solve_small_fits(int grid, int device_cus) { return grid <= kTaggedRows && grid <= device_cus; }
-void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st);
+void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s, unsigned long long* iter_span) {
+  hipLaunchKernelGGL(k_reduce_and_step, dim3(1), dim3(kRedThreads), 0, s, partials, grid, st, iter_span);
 }
 
 // ---- test aid: the DEVICE SE(3) arithmetic of the minimiser step, exposed one operation at a time --------------------

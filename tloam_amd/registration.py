@@ -62,6 +62,14 @@ class TlsConfig(C.Structure):
     ]
 
 
+class CtxInfo(C.Structure):
+    """tloam_ctx_info."""
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("device_cus", C.c_int32), ("comm_mode", C.c_int32),
+                ("rank", C.c_int32), ("nranks", C.c_int32), ("rccl_comm_count", C.c_int32), ("rccl_comm_rank", C.c_int32),
+                ("fallbacks_taken", C.c_int32), ("fallback_events", C.c_int32), ("k3_grid", C.c_int32), ("k3_single", C.c_int32),
+                ("one_launch_solve", C.c_int32), ("loopback", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
 class Stats(C.Structure):
     """tloam_stats."""
     _fields_ = [
@@ -138,6 +146,9 @@ def load_library():
         "tloam_k3_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64), dp]),
         "tloam_k3_timer_all": (C.c_int, [vp, dp, C.POINTER(C.c_int64)]),
         "tloam_k3_span": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64)]),
+        "tloam_gn_iter_timer": (C.c_int, [vp, C.c_int, dp, C.POINTER(C.c_int64)]),
+        "tloam_time_read_stream": (C.c_int, [vp, sz, C.c_int, dp]),
+        "tloam_get_info": (C.c_int, [vp, C.POINTER(CtxInfo)]),
         "tloam_debug_state": (C.c_int, [vp, dp, C.c_int]),
         "tloam_debug_se3": (C.c_int, [vp, C.c_int, dp, dp, dp]),
         "tloam_debug_partials": (C.c_int, [vp, dp, C.c_int]),
@@ -174,7 +185,7 @@ EXPORTED_SYMBOLS = (
     "tloam_sm_outer", "tloam_sm_end", "tloam_fitness", "tloam_get_correspondences", "tloam_get_weights",
     "tloam_knn", "tloam_set_correspondences", "tloam_accumulate", "tloam_get_costs", "tloam_get_normal_equations",
     "tloam_solve",
-    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_k3_span", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
+    "tloam_time_accumulate", "tloam_time_sharded_sweep", "tloam_time_build", "tloam_k3_timer", "tloam_k3_timer_all", "tloam_k3_span", "tloam_gn_iter_timer", "tloam_time_read_stream", "tloam_get_info", "tloam_debug_state", "tloam_debug_partials", "tloam_debug_se3",
     "tloam_debug_raise_fault",
     "tloam_submap_default_config", "tloam_submap_init", "tloam_submap_update", "tloam_get_target",
     "tloam_feature_default_config", "tloam_pca_info", "tloam_extract_planar_sphere", "tloam_rccl_unique_id", "tloam_comm_init_rccl",
@@ -534,6 +545,24 @@ class HipRegistration:
         us = C.c_double(0); n = C.c_int64(0)
         self._check(self.L.tloam_k3_span(self.h, int(bool(reset)), C.byref(us), C.byref(n)), "tloam_k3_span")
         return us.value, n.value
+
+    def gn_iter_timer(self, reset=False):
+        """(total us, periods) of the GN iterations as the device clocks them (tloam_gn_iter_timer); the first call arms it."""
+        us = C.c_double(0); n = C.c_int64(0)
+        self._check(self.L.tloam_gn_iter_timer(self.h, int(bool(reset)), C.byref(us), C.byref(n)), "tloam_gn_iter_timer")
+        return us.value, n.value
+
+    def time_read_stream(self, nbytes, launches=20):
+        """GB/s of a read stream with the sweep's access pattern over ~nbytes (tloam_time_read_stream)."""
+        g = C.c_double(0)
+        self._check(self.L.tloam_time_read_stream(self.h, int(nbytes), int(launches), C.byref(g)), "tloam_time_read_stream")
+        return g.value
+
+    def info(self):
+        """tloam_get_info as a dict."""
+        ci = CtxInfo()
+        self._check(self.L.tloam_get_info(self.h, C.byref(ci)), "tloam_get_info")
+        return {f: getattr(ci, f) for f, _ in CtxInfo._fields_ if f != "reserved"}
 
     # ---- multi-GPU ---------------------------------------------------------------------------
     def comm_init_rccl(self, rank, nranks, unique_id: bytes):
