@@ -25,7 +25,9 @@ def test_within_reports_a_call_that_does_not_return():
 def test_sharded_summary_reports_what_had_finished():
     import bench
     mailbox = {"exchange": "mailbox", "frames": 4, "ms_per_frame": 0.9, "gn_iters_per_sec": 1.0, "gn_iters_per_frame": 14.0,
-               "n_corr": [1, 2, 3, 4], "pose_err_vs_truth_m": 1e-4, "per_sweep_us": {"sweep_alone": 3.0}}
+               "n_corr": [1, 2, 3, 4], "pose_err_vs_truth_m": 1e-4, "per_sweep_us": {"sweep_alone": 3.0, "exchange_adds": 2.5},
+               "verified": True, "pose_delta_vs_one_rank": {"dt_m": 1e-15, "dR_rad": 2e-16}, "ranks_bit_identical": True,
+               "counters_equal_one_rank": True, "gn_iteration_us": 9.5}
     # the deadline passed while the second exchange was running
     cut = bench.sharded_summary({"workload": "w", "n_gpus": 8, "modes": ["mailbox", "rccl"], "mailbox": mailbox}, False, 300.0)
     assert cut["fastest_exchange"] == "mailbox" and cut["ms_per_frame"] == 0.9
@@ -33,11 +35,27 @@ def test_sharded_summary_reports_what_had_finished():
     # ... before anything had finished
     none = bench.sharded_summary({}, False, 300.0)
     assert "ms_per_frame" not in none and "mailbox: did not finish" in none["error"] and "rccl: did not finish" in none["error"]
+    flat = bench.sharded_flat(none, 8)
+    assert flat["sharded_1m_verified"] is False and flat["sharded_1m_ms_per_frame"] is None and flat["sharded_1m_predicted_speedup"] == 3.05
     # both ran: the faster one on top, nothing else added
     both = bench.sharded_summary({"modes": ["mailbox", "rccl"], "mailbox": mailbox, "rccl": dict(mailbox, exchange="rccl", ms_per_frame=1.2)},
                                  True, 300.0)
     assert both["fastest_exchange"] == "mailbox" and "note" not in both and "error" not in both
     json.dumps(both)
+    # a form that FAILED its self-check (pose delta against the one-rank solve, ranks not bit-identical ...) never becomes the
+    # figure of the line, however fast it was
+    wrong = dict(mailbox, ms_per_frame=0.1, verified=False, error="verification failed: pose delta 3.0e-04 m")
+    mixed = bench.sharded_summary({"modes": ["mailbox", "rccl"], "mailbox": wrong, "rccl": dict(mailbox, exchange="rccl", ms_per_frame=1.2,
+                                                                                              rccl_comm_count=8)}, True, 300.0)
+    assert mixed["fastest_exchange"] == "rccl" and mixed["ms_per_frame"] == 1.2
+    mixed["speedup_vs_one_gpu_frame"] = 1.1
+    flat = bench.sharded_flat(mixed, 8)
+    assert flat["sharded_1m_ms_per_frame"] == 1.2 and flat["sharded_1m_speedup"] == 1.1 and flat["rccl_nranks"] == 8
+    assert flat["sharded_1m_verified"] is True and flat["sharded_1m_pose_delta"] == 1e-15 and flat["sharded_1m_exchange_adds_us"] == 2.5
+    assert flat["sharded_1m_mailbox_verified"] is False and flat["sharded_1m_rccl_ms_per_frame"] == 1.2
+    assert all(not isinstance(v, (dict, list)) for v in flat.values())      # scalars only: what the driver's parser keeps
+    none_ok = bench.sharded_summary({"modes": ["mailbox"], "mailbox": wrong}, True, 300.0)
+    assert "ms_per_frame" not in none_ok and "verification failed" in none_ok["error"]
 
 
 def test_guarded_side_figure_prints_the_line_and_leaves():
