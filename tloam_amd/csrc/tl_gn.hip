@@ -509,15 +509,25 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
   double v[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) v[u] = 0.0;
-  for (int b0 = grp; b0 < rows; b0 += kU * 8) {
-    double x[kU];
+  // FOUR passes of sixteen loads requested before the first is added (a full-chip grid of 512 rows is four passes: four dependent
+  // trips to memory became one -- round 6: the 1 M GN iteration 21.8 -> 21.5 us, three interleaved pairs on one box); the additions
+  // keep the order of the one-pass-at-a-time form, so the sums keep their bits
+  constexpr int kP = 4;
+  for (int b00 = grp; b00 < rows; b00 += kP * kU * 8) {
+    double x[kP][kU];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const double* p = partials + (size_t)min(b0 + u * 8, rows - 1) * kAccStride + comp;
-      x[u] = AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    for (int q = 0; q < kP; ++q)
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const double* p = partials + (size_t)min(b00 + (q * kU + u) * 8, rows - 1) * kAccStride + comp;
+        x[q][u] = AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+      }
+#pragma unroll
+    for (int q = 0; q < kP; ++q) {
+      if (b00 + q * kU * 8 >= rows) break;   // (a pass the one-pass form would not have run: nothing is added, not even zeros)
+#pragma unroll
+      for (int u = 0; u < kU; ++u) v[u] += (b00 + (q * kU + u) * 8 < rows) ? x[q][u] : 0.0;
     }
-#pragma unroll
-    for (int u = 0; u < kU; ++u) v[u] += (b0 + u * 8 < rows) ? x[u] : 0.0;
   }
 #pragma unroll
   for (int w = kU / 2; w >= 1; w >>= 1)
@@ -1407,9 +1417,10 @@ __global__ __launch_bounds__(256, 1) void k_solve_all(const double* __restrict__
         else if (lane == 12) s_msg[12] = (double)vd;
       }
       __syncthreads();
-      // (the lead's image of the state goes out to the device state now, beside the other waves' evaluation)
-      if (lead && stepper && (int)s_msg[12] != 5) gn_write_back(st, &s_in, lane);
       verdict = (int)s_msg[12];
+      // (the lead's image of the state goes out to the device state now, beside the other waves' evaluation.  Holding it back until
+      //  the lead's next row is out -- round 6 -- changed nothing: 5.42 against 5.42 us per GN iteration)
+      if (lead && stepper && verdict != 5) gn_write_back(st, &s_in, lane);
 #pragma unroll
       for (int v = 0; v < 9; ++v) T.r[v] = s_msg[v];
 #pragma unroll
