@@ -154,7 +154,10 @@ typedef struct tloam_ctx_info {
   int32_t one_launch_solve; /* 1: a ceres::Solve on the current set runs as ONE launch (k_solve_all)                    */
   int32_t loopback;         /* 1: a mailbox / RCCL set-up with nranks == 1 -- the sharded launch forms run, the exchange is
                              * a loop-back                                                                               */
-  int32_t reserved[2];
+  int32_t direct_set;       /* 1: the frame in progress / the last one keeps its factors as a DIRECT set (large frames whose caps
+                             * cannot bind: rows in the search's own order, no compaction -- DESIGN.md section 4)              */
+  int32_t set_stale;        /* 1: ... and its rows will be rebuilt before a getter reads them (the loop ended beside a search
+                             * that had already run)                                                                          */
 } tloam_ctx_info;
 int tloam_get_info(tloam_ctx* ctx, tloam_ctx_info* out);
 

@@ -247,3 +247,112 @@ def test_single_pass_scans_and_their_time_out_fallback_are_exact(hip_module):
     a, b = H1.knn(0, q, 0.5, 5), H2.knn(0, q, 0.5, 5)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     H1.close(); H2.close()
+
+
+# ---- the DIRECT factor set of large frames (tloam_amd/csrc/tl_common.hpp DirectSet) ------------------------------------------
+def _direct_fingerprint(H, sc):
+    out = {}
+    for k in range(4):
+        c = H.get_correspondences(k, capacity=len(sc.source.cloud(k)))
+        out[k] = {f: np.asarray(c[f]).copy() for f in ("idx", "a", "b", "d", "w", "cost") if f in c and c[f] is not None}
+        out[k]["weights"] = H.get_weights(k).copy()
+    return out
+
+
+def test_direct_set_against_compact_set_and_stepwise_api(hip_module, monkeypatch):
+    """Frames searched one thread per query whose caps cannot bind keep their factors as a DIRECT set: the search writes every
+    factor into the row of its query (tile-sorted order, fixed for the frame), queries without a factor leave holes that add exact
+    zeros, the Solve reads one of two weight streams and the finish writes the other -- no flag scan, no compaction.  Held here
+    against (i) the COMPACT set of the same frames (TLOAM_NO_DIRECT_SET): the same factors -- every index list, every captured
+    weight and GNC weight, every counter --, the same geometry, and a pose within 1e-12 (the sums run in another order: the last
+    bits differ); (ii) the stepwise API (TLOAM_NO_DEVICE_LOOP: the finish as a launch of its own instead of riding on the next
+    search): bit for bit; (iii) the oracle: index lists and pose.  Three frames, so that the learned sweep budgets are in play."""
+    n_src, n_tgt = (70_000, 40_000, 30_000, 6_000), (80_000, 50_000, 40_000, 8_000)
+    sc = synth.make_scene(seed=5, n_src=n_src, n_tgt=n_tgt, density=40.0)
+    over = dict(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+    Hd = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.setenv("TLOAM_NO_DEVICE_LOOP", "1")
+    Hs = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.delenv("TLOAM_NO_DEVICE_LOOP")
+    monkeypatch.setenv("TLOAM_NO_DIRECT_SET", "1")
+    Hc = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.delenv("TLOAM_NO_DIRECT_SET")
+    for H in (Hd, Hs, Hc):
+        H.set_frames(sc.source, sc.target)
+    for frame in range(3):
+        rd, Td, sd = Hd.scan_match(sc.T_pred)
+        rs, Ts, ss = Hs.scan_match(sc.T_pred)
+        rcc, Tc, scs = Hc.scan_match(sc.T_pred)
+        assert rd == rs == rcc == 0
+        assert Hd.info()["direct_set"] == 1 and Hs.info()["direct_set"] == 1 and Hc.info()["direct_set"] == 0
+        fd, fs, fc = _direct_fingerprint(Hd, sc), _direct_fingerprint(Hs, sc), _direct_fingerprint(Hc, sc)
+        # (ii) device-driven loop == stepwise API, bit for bit
+        assert np.array_equal(Td, Ts)
+        for key in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "outer_iterations", "kind_cost", "se3", "converged_early"):
+            assert np.array_equal(np.asarray(sd[key]), np.asarray(ss[key])), key
+        for k in range(4):
+            for f in fd[k]:
+                assert np.array_equal(fd[k][f], fs[k][f], equal_nan=True), (k, f)
+        # (i) direct == compact: the same factors, the same geometry, the pose to the last bits' rounding
+        dt, dr = pose_delta(Td, Tc)
+        assert dt < 1e-12 and dr < 1e-12, (dt, dr)
+        for key in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "outer_iterations", "converged_early"):
+            assert np.array_equal(np.asarray(sd[key]), np.asarray(scs[key])), key
+        np.testing.assert_allclose(sd["kind_cost"], scs["kind_cost"], rtol=1e-9)
+        for k in range(4):
+            assert np.array_equal(fd[k]["idx"], fc[k]["idx"]), k
+            assert len(fd[k]["idx"]) == sd["n_corr"][k] > 0
+            for f in ("a", "b", "d"):
+                if f in fd[k] and fd[k][f] is not None and len(np.atleast_1d(fd[k][f])):
+                    np.testing.assert_allclose(fd[k][f], fc[k][f], rtol=0, atol=1e-9, err_msg=f"{k} {f}")
+            np.testing.assert_allclose(fd[k]["w"], fc[k]["w"], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(fd[k]["weights"], fc[k]["weights"], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(fd[k]["cost"], fc[k]["cost"], rtol=1e-6, atol=1e-18)
+    # (iii) the oracle
+    O = ob.Oracle(ob.make_config(**over), builder_threads=4, eval_threads=16)
+    O.set_frames(sc.source, sc.target)
+    ro, To, so = O.scan_match(sc.T_pred)
+    assert ro == 0 and sd["n_corr"] == so["n_corr"]
+    for k in range(4):
+        assert np.array_equal(fd[k]["idx"], O.get_correspondences(k, capacity=len(sc.source.cloud(k)))["idx"])
+    dt, dr = pose_delta(Td, To)
+    assert dt < 1e-9 and dr < 1e-9
+    for H in (Hd, Hs, Hc):
+        H.close()
+
+
+def test_direct_set_is_rebuilt_when_the_loop_ends_beside_a_search_that_had_run(hip_module, monkeypatch):
+    """The device-driven loop runs the search of outer iteration k in the launch that finishes iteration k - 1, on the Solve's
+    own verdict ("ended at another pose than the set was built at").  If that finish then ends the loop (the plateau test of
+    registration.cpp:1108) the search has written the rows of a set that will never be solved: the result slot says so
+    (OS_SET_STALE) and the getters rebuild the rows at the pose of the SOLVED set before they read them.  Forced here: a large
+    prediction error (the first Solve runs out of its four iterations still moving), a noise bound that keeps every weight at 1
+    (the second Solve moves on), a plateau threshold that ends the loop right after it.  The compact path of the same frame
+    (which never had the problem: a discarded search only leaves raw records behind) is the reference."""
+    n_src, n_tgt = (70_000, 40_000, 30_000, 6_000), (80_000, 50_000, 40_000, 8_000)
+    pred_err = tuple(12.0 * np.array((0.012, -0.008, 0.004, 0.0015, -0.001, 0.002)))
+    sc = synth.make_scene(seed=6, n_src=n_src, n_tgt=n_tgt, density=40.0, pred_err=pred_err)
+    over = dict(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG, noise_bound=1.0e4, cost_threshold=1.0e15)
+    Hd = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.setenv("TLOAM_NO_DIRECT_SET", "1")
+    Hc = hip_module.HipRegistration(hip_module.default_config(**over))
+    monkeypatch.delenv("TLOAM_NO_DIRECT_SET")
+    for H in (Hd, Hc):
+        H.set_frames(sc.source, sc.target)
+    rd, Td, sd = Hd.scan_match(sc.T_pred)
+    rcc, Tc, scs = Hc.scan_match(sc.T_pred)
+    assert rd == rcc == 0 and sd["converged_early"] == 1 and sd["outer_iterations"] == 2 == scs["outer_iterations"]
+    info = Hd.info()
+    assert info["direct_set"] == 1 and info["set_stale"] == 1, (info, sd)      # the case the test is about did happen
+    fd = _direct_fingerprint(Hd, sc)
+    assert Hd.info()["set_stale"] == 0                                          # ... and the getters have dealt with it
+    fc = _direct_fingerprint(Hc, sc)
+    dt, dr = pose_delta(Td, Tc)
+    assert dt < 1e-12 and dr < 1e-12
+    for k in range(4):
+        assert np.array_equal(fd[k]["idx"], fc[k]["idx"]), k
+        for f in ("a", "b", "d"):
+            if f in fd[k] and fd[k][f] is not None and len(np.atleast_1d(fd[k][f])):
+                np.testing.assert_allclose(fd[k][f], fc[k][f], rtol=0, atol=1e-9, err_msg=f"{k} {f}")
+        np.testing.assert_allclose(fd[k]["cost"], fc[k]["cost"], rtol=1e-6, atol=1e-18)
+    Hd.close(); Hc.close()

@@ -65,6 +65,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_device_loop = getenv("TLOAM_NO_DEVICE_LOOP") != nullptr;
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
   c->no_grid_ahead = getenv("TLOAM_NO_GRID_AHEAD") != nullptr;
+  c->no_direct_set = getenv("TLOAM_NO_DIRECT_SET") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;
@@ -113,7 +114,7 @@ void tloam_destroy(tloam_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   tlh::comm_release(c);
-  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->iter_span.release(); c->fin_rows.release(); c->flagb.release();
+  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->iter_span.release(); c->state_scratch.release(); c->blk_cnt.release(); c->row_of_pos.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)
@@ -192,6 +193,8 @@ int tloam_get_info(tloam_ctx* c, tloam_ctx_info* out) {
   out->rank = c->rank;
   out->nranks = c->nranks;
   out->loopback = c->loopback ? 1 : 0;
+  out->direct_set = (c->direct && !c->prebuilt) ? 1 : 0;
+  out->set_stale = c->set_stale ? 1 : 0;
   tlh::comm_rccl_info(c, &out->rccl_comm_count, &out->rccl_comm_rank);
   out->fallbacks_taken = (c->no_scan_1p ? TLOAM_FALLBACK_SCAN : 0) | (c->vox_ticket ? TLOAM_FALLBACK_VOXEL : 0) |
                          (c->persistent_solve_timed_out ? TLOAM_FALLBACK_SOLVE : 0);

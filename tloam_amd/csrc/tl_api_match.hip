@@ -80,6 +80,43 @@ int ensure_common(tloam_ctx* c) {
 
 namespace {
 
+// ---- the direct factor set (tl_common.hpp DirectSet) ------------------------------------------------------------------------
+// Which frames take it: one rank, searched one thread per query, all four builders running, and no cap that could bind -- a
+// kind's cap >= its source points ("first N valid in index order", registration.cpp:448 / :538 / :592 / :735, then selects
+// everything valid, whatever the order).  Everything else compacts.
+bool direct_applies(const tloam_ctx* c, size_t n_slots) {
+  if (c->no_direct_set || !one_rank(c) || c->cfg.factor_num != 4 || !direct_set_size((int)std::min<size_t>(n_slots, (size_t)INT32_MAX))) return false;
+  for (int k = 0; k < kKinds; ++k)
+    if ((long long)c->kd[k].n_src > (long long)kind_maxnum(c->cfg, k) || c->kd[k].n_tgt == 0) return false;
+  return true;
+}
+double* direct_w_stream(const tloam_ctx* c, int k, int parity) {
+  return c->kd[k].c_buf.p + (size_t)(parity ? SS_W2 : SS_W) * c->kd[k].c_stride;
+}
+// the Solve of outer iteration `iter` reads weight stream iter & 1 (c->cv), its finish writes the other one
+void direct_set_parity(tloam_ctx* c, int iter) {
+  for (int k = 0; k < kKinds; ++k) c->cv.k[k].w = direct_w_stream(c, k, iter & 1);
+}
+// rows of the hand-over buffer of the finish, compact (riding) or direct
+constexpr size_t kFinRowsDoubles = (size_t)4 * 256 * 16;
+int direct_wblocks(const tloam_ctx* c) {
+  size_t cap = 0;
+  for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
+  return (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));   // as enqueue_finish: a fixed function of the capacity
+}
+int* direct_blk_cnt(const tloam_ctx* c, int iter) { return c->blk_cnt.p + (size_t)(iter & 1) * c->blk_cnt_n * kKinds; }
+// built: 1 the set of outer iteration `iter` was built in it, 0 it is the previous one, -1 the device knows (GnState::run_build)
+FinishLargeArgs direct_finish_args(tloam_ctx* c, const CorrView* cv_iter, const WeightParams* wp, const HostMirror& hm, OuterCtl ctl,
+                                   int iter, int riding, int built) {
+  ctl.direct = riding ? 2 : 1;
+  FinishLargeArgs fin{cv_iter, wp, c->seg_n.p, c->sums16.p, hm, ctl, c->fin_rows.p, c->k3_ticket.p + 1, direct_wblocks(c), {}, nullptr, 0, 0};
+  for (int k = 0; k < kKinds; ++k) fin.w_next[k] = direct_w_stream(c, k, (iter + 1) & 1);
+  fin.blk_cnt = direct_blk_cnt(c, iter);
+  fin.nblk = (int)c->blk_cnt_n;
+  fin.built = built;
+  return fin;
+}
+
 // K3 launch; when the bench armed the timer, with a HIP event pair bound to the dispatch itself
 // Every kK3SampleStride-th launch carries the pair (stride 3 is coprime to the 5 sweeps of a Solve and the 20 of
 // a frame, so over a few frames every position is sampled equally): timing EVERY launch through
@@ -318,7 +355,16 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   c->sv.sx = c->sx.p; c->sv.sy = c->sy.p; c->sv.sz = c->sz.p; c->sv.w_src = c->w_src.p;
   c->sv.raw = c->raw.p;
   c->sv.flags = c->flags.p; c->sv.scan = c->scan.p;
-  // ---- compact segments: at most min(n_src, maxnum) factors per kind
+  c->direct = direct_applies(c, off);
+  c->set_stale = false;
+  c->w_parity = 0;
+  if (c->direct) {
+    HIPC(c, c->fin_rows.reserve(kFinRowsDoubles));
+    c->blk_cnt_n = (off + 63) / 64;   // one-wave blocks of the thread-per-query search (logical: the sorted queries, 64 each)
+    HIPC(c, c->blk_cnt.reserve(2 * c->blk_cnt_n * kKinds + 8));
+    HIPC(c, c->row_of_pos.reserve(off + 64));
+  }
+  // ---- compact segments: at most min(n_src, maxnum) factors per kind (a direct set: one row per source point, which is the same)
   size_t total_cap = 0;
   for (int k = 0; k < kKinds; ++k) {
     const size_t cap = std::min<size_t>(c->kd[k].n_src, (size_t)std::max(kind_maxnum(c->cfg, k), 0));
@@ -354,6 +400,8 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   hook.fi.slot_off[kKinds] = c->sv.slot_off[kKinds];
   for (int i = 0; i < 6; ++i) hook.fi.x[i] = x[i];
   hook.fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
+  hook.fi.direct = c->direct ? 1 : 0;
+  if (c->direct) direct_set_parity(c, 0);
   hook.b = FrameInitBufs{c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p};
   hook.n_slots = c->sv.slot_off[kKinds];
   // ---- :889-915 four search structures over the submap clouds: one launch per build phase for all kinds
@@ -387,6 +435,16 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     hook.fi.tile_cnt = c->tile_cnt.p;
     hook.fi.n_tile_cnt = (int)ntiles + 1;
     launch_frame_init(hook.fi, hook.b, c->stream);
+  }
+  if (c->direct) {
+    // a kind whose target cloud has no finite point has no search grid: its queries are not in the sorted order, and the rows of a
+    // direct set ARE that order -- such a frame compacts (the frame's start, already enqueued, has set seg_n to the row counts)
+    bool all = true;
+    for (int k = 0; k < kKinds; ++k) all = all && c->kd[k].gv.n > 0;
+    if (!all) {
+      c->direct = false;
+      HIPC(c, hipMemsetAsync(c->seg_n.p, 0, kKinds * sizeof(int), c->stream));
+    }
   }
   c->wait_us = 0.0;
   c->mu = 1.0;  // :961
@@ -456,15 +514,20 @@ bool self_prepare_path(const tloam_ctx* c) { return c->sv.flagb != nullptr && pr
 // ride: the finish of the previous outer iteration rides on this search launch (large single-rank sets, device-driven loop:
 // k_build_finish_large; the search then runs on GnState::spec_build instead of `gate`)
 int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKinds], bool rebin, const int* gate,
-                  const int* refresh_gate = nullptr, bool prepare_in_solve = false, const FinishLargeArgs* ride = nullptr) {
+                  const int* refresh_gate = nullptr, bool prepare_in_solve = false, const FinishLargeArgs* ride = nullptr, int iter = 0) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
+  // direct set: the search writes the rows itself -- no flag scan, no compaction, no refresh (the Solve reads the live weight stream)
+  const DirectSet ds{c->direct ? 1 : 0, rebin ? 1 : 0, (ride && !rebin) ? 0 : 1, c->direct ? direct_blk_cnt(c, iter) : nullptr,
+                     c->tile_of_slot.p, c->tile_scan.p, c->direct ? c->row_of_pos.p : nullptr};
   if (ride && !rebin) {
     const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off);
-    launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream);
+    launch_build_finish_large(c->sv, grids, bp, c->state.p, c->tile_scan.p + ntiles, c->qrec.p, *ride, c->stream, c->direct ? &ds : nullptr);
   } else {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
-                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->scan1p_q_use ? c->scan1p_q.p : nullptr, c->h_fault_dev + kFaultScan1p);
+                 c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->scan1p_q_use ? c->scan1p_q.p : nullptr, c->h_fault_dev + kFaultScan1p,
+                 c->direct ? &c->cv : nullptr, c->direct ? &ds : nullptr);
   }
+  if (c->direct) return TLOAM_OK;
   if (prepare_in_solve) return TLOAM_OK;
   if (prepare_small_path(c)) {
     launch_prepare_small(c->sv, c->cv, bp, c->seg_n.p, c->state.p, gate, refresh_gate, c->stream);
@@ -521,7 +584,12 @@ size_t total_seg_cap(const tloam_ctx* c) {
 }
 // one 1024-thread block does weights + sums + publish in a single launch
 bool finish_small_path(const tloam_ctx* c) { return one_rank(c) && total_seg_cap(c) <= 16384; }
-int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl) {
+int enqueue_finish(tloam_ctx* c, const WeightParams& wp, const HostMirror& hm, const OuterCtl& ctl, int iter = 0, int built = 1) {
+  if (c->direct) {   // (c->cv carries the weight stream of outer iteration `iter`: direct_set_parity)
+    const FinishLargeArgs fin = direct_finish_args(c, &c->cv, &wp, hm, ctl, iter, /*riding=*/0, built);
+    launch_finish_direct(fin, c->state.p, c->stream);
+    return TLOAM_OK;
+  }
   // fixed function of the capacity (so the summation tree, hence the bits, do not depend on timing)
   const size_t cap = total_seg_cap(c);
   const int wblocks = (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
@@ -617,12 +685,13 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   // captured weights and the zeroed side-channel slots of the compact set have to be refreshed.
   const bool same_pose = iter > 0 && c->have_build && memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) == 0 &&
                          !c->dbg_no_build_reuse;
+  if (c->direct) direct_set_parity(c, iter);
   if (!same_pose) {
-    rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, nullptr);
+    rc = enqueue_build(c, bp, grids, /*rebin=*/iter == 0, nullptr, nullptr, false, nullptr, iter);
     if (rc != TLOAM_OK) return rc;
     memcpy(c->build_x, c->stats.se3, sizeof(c->build_x));
     c->have_build = true;
-  } else {
+  } else if (!c->direct) {
     launch_refresh(c->sv, c->cv, c->stream);
   }
   if (iter == 0) c->mu = initial_mu(c);
@@ -639,7 +708,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   const int sweeps_before = c->stats.gn_sweeps;
   for (int attempt = 0;; ++attempt) {
     const HostMirror hm = next_mirror(c);
-    rc = enqueue_finish(c, wp, hm, host_decides);
+    rc = enqueue_finish(c, wp, hm, host_decides, iter, same_pose ? 0 : 1);
     if (rc != TLOAM_OK) return rc;
     rc = wait_state(c, hm);
     if (rc != TLOAM_OK) return rc;
@@ -661,6 +730,7 @@ int tloam_sm_outer(tloam_ctx* c, int* done, tloam_stats* stats) {
   if (rc != TLOAM_OK) return rc;
   bool weight_violation = false;
   const bool fin = account_outer(c, iter, S, mu, sweeps_before, &weight_violation);
+  if (c->direct) c->w_parity = (iter + 1) & 1;   // (c->cv stays on the stream this Solve captured)
   if (done) *done = fin ? 1 : 0;
   if (stats) *stats = c->stats;
   return weight_violation ? TLOAM_E_WEIGHT_RANGE : TLOAM_OK;  // the iteration is complete either way (:871)
@@ -766,6 +836,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
     return enqueue_iterations_in_launch_mode(c, first, std::min(M, first + kEnqueueAhead), bp, grids, P);
   }
   for (int iter = first; iter < M; ++iter) {
+    if (c->direct) direct_set_parity(c, iter);   // what this iteration's Solve (and its finish) read; the search does not care
     if (iter == 0) {
       rc = enqueue_build(c, bp, grids, /*rebin=*/true, nullptr, nullptr, in_solve);
       prep.run_build = nullptr;
@@ -778,14 +849,19 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
       prep.run_refresh = run_refresh;
       pending = false;
     } else if (pending_large) {
-      const FinishLargeArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, P.hms[iter - 1], ctl_prev, c->fin_rows.p, c->k3_ticket.p + 1,
-                                wblocks_large};
-      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve, &fin);
+      FinishLargeArgs fin{&c->cv, &wp_prev, c->seg_n.p, c->sums16.p, P.hms[iter - 1], ctl_prev, c->fin_rows.p, c->k3_ticket.p + 1,
+                          wblocks_large, {}};
+      CorrView cv_prev = c->cv;
+      if (c->direct) {   // the finish of iteration iter - 1 reads ITS weight stream and writes this iteration's
+        for (int k = 0; k < kKinds; ++k) cv_prev.k[k].w = direct_w_stream(c, k, (iter - 1) & 1);
+        fin = direct_finish_args(c, &cv_prev, &wp_prev, P.hms[iter - 1], ctl_prev, iter - 1, /*riding=*/1, iter - 1 == 0 ? 1 : -1);
+      }
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve, &fin, iter);
       prep.run_build = run_build;
       prep.run_refresh = run_refresh;
       pending_large = false;
     } else {
-      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve);   // both alternatives, device-gated
+      rc = enqueue_build(c, bp, grids, /*rebin=*/false, run_build, run_refresh, in_solve, nullptr, iter);   // both alternatives, device-gated
       prep.run_build = run_build;
       prep.run_refresh = run_refresh;
     }
@@ -807,7 +883,7 @@ int enqueue_outer_iterations(tloam_ctx* c, int first, double mu, const BuildPara
       ctl_prev = ctl;
       pending_large = true;
     } else {
-      rc = enqueue_finish(c, weight_params(c, mu, bp), P.hms[iter], ctl);
+      rc = enqueue_finish(c, weight_params(c, mu, bp), P.hms[iter], ctl, iter, iter == 0 ? 1 : -1);
       if (rc != TLOAM_OK) return rc;
     }
     mu = mu * exp((double)(iter + 1) * c->cfg.gnc_factor);  // :1089
@@ -842,7 +918,8 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
     }
     GnState* Sm = &c->h_state[iter];
     const bool needs_host = (Sm->incomplete & OS_NEEDS_HOST) != 0;
-    Sm->incomplete &= ~(int)OS_NEEDS_HOST;
+    if (Sm->incomplete & OS_SET_STALE) c->set_stale = true;   // (direct set: the loop ended beside a search that had already run)
+    Sm->incomplete &= ~(int)(OS_NEEDS_HOST | OS_SET_STALE);
     const GnState* S = Sm;
     if (S->host_seq != P.hms[iter].seq) {
       c->last_error = "device-driven loop: the result slot of an outer iteration was not written";
@@ -868,10 +945,14 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
       P.solve_start[iter] = c->batch_launches;
       P.planned[iter] = kSolveSweeps;
       const WeightParams wp_top = weight_params(c, P.mus[iter], bp);
+      if (c->direct) direct_set_parity(c, iter);
       rc = enqueue_solve(c, /*armed=*/true, kSolveSweeps, &wp_top);
       if (rc != TLOAM_OK) return rc;
       P.hms[iter] = next_mirror(c, iter);
-      rc = enqueue_finish(c, wp_top, P.hms[iter], OuterCtl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0});
+      // (the finish that found the Solve unfinished has cleared the device's gates: whether this iteration built its set is the
+      //  host's to say -- the pose the previous iteration ended at against the pose of the last build, as the bookkeeping below)
+      const int built_top = (iter == 0 || memcmp(c->build_x, c->stats.se3, sizeof(c->build_x)) != 0) ? 1 : 0;
+      rc = enqueue_finish(c, wp_top, P.hms[iter], OuterCtl{c->cfg.cost_threshold, 1, iter == M - 1 ? 1 : 0}, iter, built_top);
       if (rc != TLOAM_OK) return rc;
       if (iter + 1 < M) {
         rc = enqueue_outer_iterations(c, iter + 1, P.mus[iter] * exp((double)(iter + 1) * c->cfg.gnc_factor), bp, grids, P);
@@ -917,6 +998,11 @@ int scan_match_device_loop(tloam_ctx* c, bool* weight_violation) {
   }
   rc = harvest_k3_events_multi(c, M, P.solve_start, P.used);
   if (rc != TLOAM_OK) return rc;
+  if (c->direct) {   // what the getters and the timing helpers see: the weights the LAST Solve captured; the current ones: the other stream
+    const int K = std::max(c->stats.outer_iterations, 1);
+    direct_set_parity(c, K - 1);
+    c->w_parity = K & 1;
+  }
   return 0;
 }
 }  // namespace
@@ -1040,11 +1126,61 @@ static int download_soa3(tloam_ctx* c, const double* x, const double* y, const d
   return TLOAM_OK;
 }
 
+// ---- a direct set through the getters: rebuilt first if it is stale, then filtered (idx >= 0) and put into source-index order ----
+static int regen_direct_set(tloam_ctx* c) {
+  // the rows hold the geometry of a search that ran on the last Solve's own verdict before the loop ended (OS_SET_STALE): search
+  // again at the pose the SOLVED set was built at (x_build) -- same queries, same order, same arithmetic: the same rows
+  BuildParams bp;
+  GridView grids[kKinds];
+  outer_params(c, &bp, grids);
+  HIPC(c, c->state_scratch.reserve(1));
+  HIPC(c, hipMemcpyAsync(c->state_scratch.p, c->state.p, sizeof(GnState), hipMemcpyDeviceToDevice, c->stream));
+  launch_pose_from_x_build(c->state_scratch.p, c->stream);
+  const DirectSet ds{1, 0, 0, nullptr, c->tile_of_slot.p, c->tile_scan.p, c->row_of_pos.p};
+  launch_build(c->sv, grids, bp, c->state_scratch.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p, c->qrec.p,
+               c->scan_tmp.p, /*rebin=*/false, c->stream, nullptr, nullptr, nullptr, &c->cv, &ds);
+  HIPC(c, hipStreamSynchronize(c->stream));
+  c->set_stale = false;
+  return TLOAM_OK;
+}
+static int get_correspondences_direct(tloam_ctx* c, int kind, size_t capacity, size_t* n, int32_t* src_index, double* a, double* b,
+                                      double* d, double* w, double* cost) {
+  if (c->set_stale) { const int rc = regen_direct_set(c); if (rc != TLOAM_OK) return rc; }
+  const size_t rows = c->kd[kind].n_src;
+  const CorrSeg& s = c->cv.k[kind];
+  std::vector<int> idx(rows);
+  if (rows > 0) HIPC(c, hipMemcpy(idx.data(), s.idx, sizeof(int) * rows, hipMemcpyDeviceToHost));
+  std::vector<std::pair<int, size_t>> order;   // (source index, row) of the factors
+  order.reserve(rows);
+  for (size_t r = 0; r < rows; ++r)
+    if (idx[r] >= 0) order.emplace_back(idx[r], r);
+  std::sort(order.begin(), order.end());
+  const size_t m = order.size();
+  *n = m;
+  if (m > capacity) return TLOAM_E_INVALID;
+  if (m == 0) return TLOAM_OK;
+  std::vector<double> tmp(rows);
+  auto stream = [&](const double* dev, double* out, size_t stride_out, size_t off) -> int {
+    HIPC(c, hipMemcpy(tmp.data(), dev, sizeof(double) * rows, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; ++i) out[i * stride_out + off] = tmp[order[i].second];
+    return TLOAM_OK;
+  };
+  int rc = TLOAM_OK;
+  if (src_index) for (size_t i = 0; i < m; ++i) src_index[i] = order[i].first;
+  if (a && ((rc = stream(s.ax, a, 3, 0)) || (rc = stream(s.ay, a, 3, 1)) || (rc = stream(s.az, a, 3, 2)))) return rc;
+  if (b && kind == TLOAM_KIND_EDGE && ((rc = stream(s.bx, b, 3, 0)) || (rc = stream(s.by, b, 3, 1)) || (rc = stream(s.bz, b, 3, 2)))) return rc;
+  if (d && kind <= TLOAM_KIND_GROUND && (rc = stream(s.d, d, 1, 0))) return rc;
+  if (w && (rc = stream(s.w, w, 1, 0))) return rc;
+  if (cost && (rc = stream(s.cost, cost, 1, 0))) return rc;
+  return TLOAM_OK;
+}
+
 int tloam_get_correspondences(tloam_ctx* c, int kind, size_t capacity, size_t* n, int32_t* src_index, double* a,
                               double* b, double* d, double* w, double* cost) {
   if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
   HIPC(c, hipStreamSynchronize(c->stream));
+  if (c->direct && !c->prebuilt) return get_correspondences_direct(c, kind, capacity, n, src_index, a, b, d, w, cost);
   int segn[kKinds];
   HIPC(c, hipMemcpy(segn, c->seg_n.p, sizeof(segn), hipMemcpyDeviceToHost));
   const size_t m = (size_t)segn[kind];
@@ -1069,6 +1205,18 @@ int tloam_get_weights(tloam_ctx* c, int kind, size_t capacity, size_t* n, double
   *n = m;
   if (m > capacity || !c->w_src.p) return TLOAM_E_INVALID;
   HIPC(c, hipStreamSynchronize(c->stream));
+  if (c->direct && !c->prebuilt) {   // the current GNC weights live in the rows' weight stream `w_parity`: back to source-index order
+    if (w && m > 0 && !c->have_build) {   // (no search has run in this frame yet: registration.cpp:931-949, every weight is 1)
+      for (size_t i = 0; i < m; ++i) w[i] = 1.0;
+    } else if (w && m > 0) {
+      std::vector<int> idx(m);
+      std::vector<double> wr(m);
+      HIPC(c, hipMemcpy(idx.data(), c->cv.k[kind].idx, sizeof(int) * m, hipMemcpyDeviceToHost));
+      HIPC(c, hipMemcpy(wr.data(), direct_w_stream(c, kind, c->w_parity), sizeof(double) * m, hipMemcpyDeviceToHost));
+      for (size_t r = 0; r < m; ++r) w[(size_t)(idx[r] >= 0 ? idx[r] : ~idx[r]) - c->kd[kind].src_lo] = wr[r];
+    }
+    return TLOAM_OK;
+  }
   if (w && m > 0) HIPC(c, hipMemcpy(w, c->w_src.p + c->sv.slot_off[kind], sizeof(double) * m, hipMemcpyDeviceToHost));
   return TLOAM_OK;
 }
@@ -1131,6 +1279,7 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
   if (rc != TLOAM_OK) return rc;
   const int kind = res_type == TLOAM_RES_PLANE ? TLOAM_KIND_PLANAR : (res_type == TLOAM_RES_LINE ? TLOAM_KIND_EDGE : TLOAM_KIND_SPHERE);
   if (!c->prebuilt) {
+    c->direct = false;   // a pre-built set is compact
     HIPC(c, hipMemsetAsync(c->seg_n.p, 0, 8 * sizeof(int), c->stream));
     for (int k = 0; k < kKinds; ++k) {
       rc = reserve_seg(c, k, 1);

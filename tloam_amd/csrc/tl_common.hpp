@@ -46,7 +46,8 @@ struct GridView {
 
 // ---- compact correspondence set: one SoA segment per kind ------------------------------------
 // stream order inside a kind's buffer (stream s starts at base + s * stride doubles)
-enum SegStream : int { SS_PX = 0, SS_PY, SS_PZ, SS_AX, SS_AY, SS_AZ, SS_W, SS_D, SS_BX, SS_BY, SS_BZ, SS_COST, kSegStreams };
+enum SegStream : int { SS_PX = 0, SS_PY, SS_PZ, SS_AX, SS_AY, SS_AZ, SS_W, SS_D, SS_BX, SS_BY, SS_BZ, SS_COST, SS_W2, kSegStreams };
+// (SS_W2: the second weight stream of a DIRECT set -- see DirectSet below; unused by compact sets)
 struct CorrSeg {
   int* idx;                 // global source index of each correspondence
   double *px, *py, *pz;     // source point (sensor frame)
@@ -62,6 +63,45 @@ struct CorrView {
   CorrSeg k[kKinds];
   const int* seg_n;         // DEVICE: number of valid entries per kind [4]
 };
+
+// ---- the DIRECT factor set of large frames (round 6) ------------------------------------------------------------------------
+// Frames searched one thread per query (> 131072 source points), on one rank, with every kind active and caps that cannot bind
+// (a kind's cap >= its source points: the 1 M-class frames) do not compact at all.  The search processes its queries in the
+// TILE-SORTED order of the frame's query sort; ROW r of kind k's segment IS the query at sorted position slot_off[k] + r, for the
+// whole frame, and the search writes the factor's geometry straight into that row (coalesced: consecutive lanes are consecutive
+// rows).  A query without a factor leaves a HOLE: a row that adds exact zeros to every sum and whose side-channel cost is exactly
+// 0 -- plane n = 0, d = 0 (r = 0, J = 0 whatever the weight); line a = b = 0 (the sweep takes 1 / |a - b| as 0); point q.x = NaN
+// (the sweep takes weight and q.x as 0) -- so the sweep and the weight update run over the rows as they are, ~10 % of them holes.
+//   p, idx     written by the frame's first search (the rows never move); idx[r] = the source index, ~index (negative) on a hole:
+//              what the finish counts the factors by and the getters filter on
+//   a, b, d    written by every search
+//   w          TWO streams: the Solve of outer iteration k reads stream k & 1 -- the weights "captured by value at construction"
+//              (registration.hpp:51,76,96) --, its finish writes every row of stream (k + 1) & 1 (updateWeight, registration.cpp:
+//              858-876; a row it leaves alone is copied).  No capture pass, no per-slot weight array
+//   cost       written by every sweep (every row: a hole's is 0), read by the finish
+// What is gone: the flag scan, the compaction (~45 us per outer iteration of the 1 M frame) and the raw records.  What it costs:
+// the holes in the sweep (+10 % rows).  The sums run over the rows in tile order instead of index order: same factors, another
+// rounding of the last bits (the parity bar on the pose is 1e-9).  Frames whose caps CAN bind, sharded frames and everything
+// smaller keep the compact set: "first N valid in index order" (registration.cpp:448, :538, :592, :735) needs the index order.
+struct DirectSet {
+  int on;          // 0: raw records + flags (compacted afterwards)
+  int first;       // the frame's first search: also writes p, idx, and weight stream 0 = 1 (registration.cpp:931-949)
+  int set_x_build; // the launch records the pose the set is built at (GnState::x_build); 0 when a finish in the SAME launch does
+  // factors per kind found by every one-wave block of THIS search, [blocks][4]: what n_corr is added up from -- by the finish of
+  // the outer iteration the set is solved in, not from the rows (the NEXT search may be rewriting them beside that finish).
+  // Two buffers, by the parity of the outer iteration the search belongs to.
+  int* blk_cnt;
+  // The ROW of a sorted position.  The frame's query sort places the queries of one bin (a cell, or a tile) in the ARRIVAL order of
+  // an atomic: two runs over the same frame permute them, and a factor set whose rows followed the sorted positions would add its
+  // sums up in another order every time (same factors, other last bits).  The rows therefore take the bins' queries in SLOT order:
+  // the frame's first search works out, per query, how many queries of its bin have a lower slot (bins hold one or two queries on
+  // average; beyond kDirectBinMax the arrival order stands) and keeps the row of every sorted position for the later searches.
+  // Run to run the same rows, the same sums, the same bits -- as with a compact set.
+  const int* tile_of_slot;
+  const unsigned long long* tile_scan;
+  int* row_of_pos;
+};
+constexpr int kDirectBinMax = 1024;
 
 // ---- per-source-slot arrays of one scan_match (concatenated over kinds) ----------------------
 constexpr int kFlagbStride = 4096;   // 64 lanes x 64 slots
@@ -170,12 +210,16 @@ struct HostMirror {
 // OS_NEEDS_HOST (a flag on top of the status, result slot only): the launch that finished this iteration inside the Solve
 // has ended because the pose moved -- the loop goes on with a correspondence search, which the host enqueues unless it
 // already has
-enum OuterStatus : int { OS_OK = 0, OS_INCOMPLETE = 1, OS_COMM_ERROR = 3, OS_PLATEAU = 4, OS_SKIPPED = 8, OS_NEEDS_HOST = 16 };
+// OS_SET_STALE (a flag like OS_NEEDS_HOST, direct sets only): the loop ended in the launch whose search had already run on the
+// Solve's own verdict -- the rows hold the geometry of a set that was never solved; the host rebuilds them before anybody reads
+enum OuterStatus : int { OS_OK = 0, OS_INCOMPLETE = 1, OS_COMM_ERROR = 3, OS_PLATEAU = 4, OS_SKIPPED = 8, OS_NEEDS_HOST = 16, OS_SET_STALE = 32 };
 // device-driven loop control handed to the finish kernels (fast == 0: the host decides, as in the stepwise API)
 struct OuterCtl {
   double cost_threshold;  // registration.cpp:1108
   int fast;               // 1: evaluate the plateau test / pose comparison on the device and set the gates
   int last;               // this is outer iteration max_iterations - 1
+  int direct;             // direct set: a finish that sends the loop into a rebuild records the pose of that build (x_build) itself
+                          // -- the search that does the rebuild runs beside it in the same launch -- and flags a stale set
 };
 
 // ---- one-shot peer exchange of a sharded context ("mailbox") -------------
@@ -228,6 +272,7 @@ struct IngestArgs {   // k_ingest_targets: the four target clouds as uploaded (A
 void launch_ingest_targets(const IngestArgs& A, double* bbox_rows /*[kind][64][6]*/, hipStream_t s);
 struct FrameInit {
   const double* src_aos[kKinds];
+  int direct;         // direct set: seg_n[k] = the kind's rows (= its source points) for the whole frame instead of 0
   int slot_off[kKinds + 1];
   double x[6];
   int no_eval_reuse;  // development knob, copied into the state
@@ -283,7 +328,8 @@ __device__ __forceinline__ void frame_init_body(const FrameInit& fi, const Frame
   if (block == 0) {
     constexpr int kWords = (int)(sizeof(GnState) / sizeof(double));
     for (int i = threadIdx.x; i < kWords; i += 256) reinterpret_cast<double*>(b.st)[i] = 0.0;
-    if (threadIdx.x < 8) b.seg_n[threadIdx.x] = 0;
+    if (threadIdx.x < 8)
+      b.seg_n[threadIdx.x] = (fi.direct && threadIdx.x < kKinds) ? fi.slot_off[threadIdx.x + 1] - fi.slot_off[threadIdx.x] : 0;
     if (threadIdx.x == 0) b.flags[n] = 0ull;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -336,10 +382,13 @@ struct BuildParams {
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 // scan1p_ctl: control words of the single-pass scan of the query-sort histogram (large frames; the caller has checked
 // scan_1p_applies), or null: the multi-launch scan; scan1p_fault: see launch_scan_counts_1p
-void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
+// direct_cv != null: the search writes the DIRECT set (DirectSet) -- st is then written (x_build) where ds.set_x_build says so
+void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr,
-                  unsigned long long* scan1p_ctl = nullptr, unsigned* scan1p_fault = nullptr);
+                  unsigned long long* scan1p_ctl = nullptr, unsigned* scan1p_fault = nullptr, const CorrView* direct_cv = nullptr,
+                  const DirectSet* ds = nullptr);
+bool direct_set_size(int n_slots);   // frames the thread-per-query search takes (the size class of the direct set)
 int build_tile_count(const GridView grids[kKinds], const int slot_off[kKinds + 1]);  // bins of the query counting sort (per kind: its tiles, or the cells of its tiles)
 // cap + compaction (after the flag scan)
 // refresh_gate != null: the launch also stands for the refresh alternative (see CompactArgs); tiles > 0: `sv.scan` holds
@@ -468,6 +517,7 @@ void launch_mbox_gather_only(double* out48, const MboxView& mb, hipStream_t s);
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s);
 void launch_solve_init(GnState* st, hipStream_t s);                   // begin one ceres::Solve at st->x
 void launch_set_eval(GnState* st, const double* se3_dev, hipStream_t s);
+void launch_pose_from_x_build(GnState* st, hipStream_t s);   // st->T_cur = exp(st->x_build)
 void launch_gn_step(GnState* st, const double* in48, hipStream_t s, unsigned long long* iter_span = nullptr);  // consume a reduced sweep
 void launch_reduce_and_step(const double* partials, int grid, GnState* st, hipStream_t s, unsigned long long* iter_span = nullptr);
 // small sets on one rank: sweep + step in ONE launch (ticket: zero between launches)
@@ -542,10 +592,20 @@ struct FinishLargeArgs {
   double* rows;
   int* ticket;
   int wblocks;
+  // direct set: the weight stream the finish WRITES (every row), per kind; cv->k[].w is the one it reads.  null: compact set
+  double* w_next[kKinds];
+  // ... and where n_corr comes from: the per-block counts of the search that built the set solved in this iteration (blk_cnt,
+  // nblk blocks) if built != 0 -- built < 0: GnState::run_build says whether it was (device-driven loop) --, else unchanged
+  const int* blk_cnt;
+  int nblk, built;
 };
+// the finish of a direct set as a launch of its own (stepwise API, the frame's last outer iteration, a topped-up Solve): the same
+// one-wave blocks as the riding form, bit for bit
+void launch_finish_direct(const FinishLargeArgs& fin, GnState* st, hipStream_t s);
 bool build_finish_large_fits(const SlotView& sv);
 void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
-                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s);
+                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s,
+                               const DirectSet* ds = nullptr);
 void launch_weights_finish_small(const CorrView& cv, const SlotView& sv, const WeightParams& wp, const int* seg_n,
                                  double* sums16, GnState* st, HostMirror hm, OuterCtl ctl, hipStream_t s);
 void launch_transform_cloud(double* aos, size_t n, const double M[16], hipStream_t s);

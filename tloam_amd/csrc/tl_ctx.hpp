@@ -252,6 +252,16 @@ struct tloam_ctx {
   // one moved the context to a form that waits for nothing -- tloam_get_info reports which, and how often
   int fallback_events = 0;
   bool persistent_solve_timed_out = false;   // no_persistent_solve was set by a time-out, not by TLOAM_NO_PERSISTENT_SOLVE
+  // the DIRECT factor set of large frames (tl_common.hpp DirectSet): chosen per frame by tloam_sm_begin
+  bool no_direct_set = false;  // TLOAM_NO_DIRECT_SET: large frames compact as the others do (A/B, tests)
+  bool direct = false;         // this frame's set is direct: rows = tile-sorted queries, holes, two weight streams
+  bool set_stale = false;      // ... and its rows hold the geometry of a search whose set was never solved (OS_SET_STALE): rebuilt at
+                               // x_build before a getter reads them
+  int w_parity = 0;            // weight stream the CURRENT GNC weights are in (the captured ones of the last Solve: the other)
+  DBuf<GnState> state_scratch; // a copy of the state with T_cur = exp(x_build), for that rebuild
+  DBuf<int> row_of_pos;        // DirectSet::row_of_pos: the row of every sorted query position
+  DBuf<int> blk_cnt;           // DirectSet::blk_cnt: [2 parities][search blocks][4]
+  size_t blk_cnt_n = 0;        // search blocks of this frame
   // scanMatching host state
   bool active = false;
   bool have_build = false;   // the compact set matches build_x

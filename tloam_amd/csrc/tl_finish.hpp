@@ -85,9 +85,16 @@ __device__ __forceinline__ void publish_and_rearm(const double* sums16, GnState*
           for (int i = 0; i < 6; ++i) moved = moved || (st->x[i] != st->x_build[i]);
           st->run_build = moved ? 1 : 0;
           st->run_refresh = moved ? 0 : 1;
+          if (ctl.direct && moved) {   // the rebuild runs beside this finish (same launch) or behind it: it is built at this pose
+#pragma unroll
+            for (int i = 0; i < 6; ++i) st->x_build[i] = st->x[i];
+          }
           arm_solver(*st);
         }
       }
+      // direct set, the loop has just ended in a launch whose search ran on the Solve's own verdict (spec_build): the rows hold
+      // the geometry of a set that will never be solved -- the host rebuilds them at x_build before anybody reads them
+      if (ctl.direct == 2 && st->stop == 1 && st->spec_build) st->incomplete |= (int)OS_SET_STALE;
     }
     if (st->comm_error) {   // an in-launch hand-over timed out (tagged rows of the fused GN iteration / a mailbox exchange)
       st->incomplete = OS_COMM_ERROR;
@@ -392,6 +399,127 @@ __device__ __forceinline__ void weights_finish_large_ride(GnState* st, const int
     sh[8] = t5[4];
   }
   if (lane >= 4 && lane < 8) sh[lane] = (double)seg_n[lane - 4];
+  __syncthreads();
+  if (lane < 16) sums16[lane] = sh[lane];
+  publish_and_rearm(sh, st, lane, ctl);
+  mirror_to_host(st, hm, lane, 64);
+}
+
+
+// ---- the finish of a DIRECT set (tl_common.hpp DirectSet): nblocks one-wave blocks, riding on the search of the next iteration
+//      (k_build_finish_large) or as a launch of their own (k_finish_direct) -- the same function, bit for bit -----------------------
+// Per row: the side-channel cost into its kind's sum, idx >= 0 counted (the factors: holes carry ~index), updateWeight
+// (registration.cpp:858-876) from the cost and the weight the Solve read, written to the OTHER weight stream -- every row, a row the
+// reference leaves alone copied.  Hand-over as the riding finish of the compact sets: a row of sums per block with device-scope
+// stores, a ticket, the last block adds the rows in a fixed order and publishes.
+constexpr int kDirRow = 16;   // [0..3] cost sums, [4] weights out of [0, 1], [8..11] factors per kind
+struct FinishDirect {
+  double* rows;               // [nblocks][kDirRow]
+  int* ticket;                // zero between launches
+  int nblocks;
+  double* w_next[kKinds];     // the weight stream this finish writes (cv.k[].w is the one the Solve read)
+  const int* blk_cnt;         // [nblk][4] factors per search block of the set this iteration solved (DirectSet::blk_cnt)
+  int nblk;
+  int built;                  // 1: this iteration built its set | 0: it solved the previous one | < 0: GnState::run_build tells
+};
+__device__ __forceinline__ void finish_direct_block(GnState* st, const int* __restrict__ seg_n, double* __restrict__ sums16,
+                                                    const HostMirror& hm, const OuterCtl& ctl, const WeightArgs& A,
+                                                    const FinishDirect& R, int b) {
+  __shared__ double sh[16];
+  __shared__ int s_last;
+  const int lane = threadIdx.x;
+  const int stop0 = ctl.fast ? st->stop : 0, done0 = st->done;   // every block reads the flags before the last one may change them
+  const int built0 = R.built < 0 ? st->run_build : R.built;      // (likewise: as the finish of the iteration before left it)
+  int ncorr0 = 0;
+  if (lane < kKinds) ncorr0 = st->n_corr[lane];
+  const int g = stop0 ? 1 : (!done0 ? 2 : 0);
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (g == 0) {
+    const int tid = b * 64 + lane, stride = R.nblocks * 64;
+    if (built0) {   // the factors of the set this iteration built: the search's per-block counts, added up (integers: any order)
+      for (int j = tid; j < R.nblk; j += stride) {
+        const int4 c4 = *reinterpret_cast<const int4*>(R.blk_cnt + (size_t)j * kKinds);
+        v[5] += (double)c4.x; v[6] += (double)c4.y; v[7] += (double)c4.z; v[8] += (double)c4.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kKinds; ++k) {
+      const int n = seg_n[k];
+      const CorrSeg& seg = A.cv.k[k];
+      const double* __restrict__ cost = seg.cost;
+      const double* __restrict__ w_cur = seg.w;
+      double* __restrict__ w_out = R.w_next[k];
+      constexpr int kU = 4;
+      for (int i0 = tid; i0 < n; i0 += kU * stride) {
+        double cu[kU], wu[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int i = i0 + u * stride;
+          cu[u] = (i < n) ? cost[i] : 0.0;
+          wu[u] = (i < n) ? w_cur[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int i = i0 + u * stride;
+          if (i >= n) break;
+          const double c = cu[u];
+          v[k] += c;
+          double w = wu[u];
+          if (A.wp.active[k] && c != 0) {                // :862
+            if (c >= A.wp.th1) w = 0.0;                  // :865
+            else if (c <= A.wp.th2) w = 1.0;             // :867
+            else {
+              w = sqrt(A.wp.noise_bound_sq * A.wp.mu * (A.wp.mu + 1) / c) - A.wp.mu;  // :870
+              if (!(w >= 0.0 && w <= 1.0)) v[4] += 1.0;  // the reference asserts here (:871)
+            }
+          }
+          w_out[i] = w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) __hip_atomic_store(R.rows + (size_t)b * kDirRow + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) __hip_atomic_store(R.rows + (size_t)b * kDirRow + 8 + i, v[5 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (row acknowledged, flags read -- see weights_finish_small_ride)
+  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == R.nblocks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  if (lane == 0) __hip_atomic_store(R.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (g != 0) {
+    finish_gate_writes(st, ctl, g, lane);
+    mirror_to_host(st, hm, lane, 64, g == 1 ? (int)OS_SKIPPED : -1);
+    return;
+  }
+  double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int rb = lane; rb < R.nblocks; rb += 64) {   // lane t: rows t, t + 64, ... in order; then one shuffle tree
+    const double* r = R.rows + (size_t)rb * kDirRow;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) t9[c] += __hip_atomic_load(r + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t9[5 + c] += __hip_atomic_load(r + 8 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t9[c] += __shfl_down(t9[c], off, 64);
+  if (lane < 16) sh[lane] = 0.0;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sh[c] = t9[c];   // kind_cost
+    sh[8] = t9[4];
+  }
+  // n_corr: the counts of the set's own search if this iteration built it, what the state holds otherwise (as doubles: exact)
+  const double nc_built = __shfl(t9[5], 0, 64), nc1 = __shfl(t9[6], 0, 64), nc2 = __shfl(t9[7], 0, 64), nc3 = __shfl(t9[8], 0, 64);
+  if (lane < kKinds) sh[4 + lane] = built0 ? (lane == 0 ? nc_built : (lane == 1 ? nc1 : (lane == 2 ? nc2 : nc3))) : (double)ncorr0;
   __syncthreads();
   if (lane < 16) sums16[lane] = sh[lane];
   publish_and_rearm(sh, st, lane, ctl);

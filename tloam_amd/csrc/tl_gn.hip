@@ -107,7 +107,10 @@ __device__ __forceinline__ double eval_line(const Rt& T, Vec3 p, Vec3 la, Vec3 l
   const Vec3 pw = act_rt(T, p);
   const Vec3 nu = fcross(pw - la, pw - lb);  // :62
   const Vec3 e = lb - la;                    // :80  (|la - lb| = |e|, :63)
-  const double k = w * fast_rsqrt(fdot(e, e));
+  // (a HOLE of a direct set -- tl_common.hpp DirectSet -- is a = b = 0: 1 / |e| taken as 0 makes the row add exact zeros and its
+  //  side-channel cost exactly 0; a real line has |e| = 0.2, :483-484, and takes the same value as ever)
+  const double e2 = fdot(e, e);
+  const double k = e2 > 0.0 ? w * fast_rsqrt(e2) : 0.0;
   const double r0 = nu.x * k, r1 = nu.y * k, r2 = nu.z * k;    // :65-67  nu / |de| * w
   const double rs = (r0 + r1) + r2;
   // J = hat(e) [I w, -hat(pw) w] / |de|  :77-83 ; hat(a) hat(b) = b a^T - (a.b) I  =>
@@ -125,8 +128,12 @@ __device__ __forceinline__ double eval_line(const Rt& T, Vec3 p, Vec3 la, Vec3 l
 }
 
 // PointToPointErr::Evaluate (registration.cpp:19-47)
-__device__ __forceinline__ double eval_point(const Rt& T, Vec3 p, Vec3 q, double w, Acc& a) {
+__device__ __forceinline__ double eval_point(const Rt& T, Vec3 p, Vec3 q, double w_in, Acc& a) {
   const Vec3 pw = act_rt(T, p);
+  // (a HOLE of a direct set is q = (NaN, 0, 0): weight and q.x taken as 0 -- exact zeros, side-channel cost exactly 0)
+  const bool hole = q.x != q.x;
+  const double w = hole ? 0.0 : w_in;
+  q.x = hole ? 0.0 : q.x;
   const double r0 = (q.x - pw.x) * w, r1 = (q.y - pw.y) * w, r2 = (q.z - pw.z) * w;  // :26-30
   const double rs = (r0 + r1) + r2;
   const double wx = pw.x * w, wy = pw.y * w, wz = pw.z * w;
@@ -222,14 +229,16 @@ __device__ __forceinline__ void fetch(const CorrSeg& seg, int j, ChunkBuf<RES>& 
 #undef ld2o
 }
 // the planar segment's chunk straight from (base, stride): the kernel's first arguments, preloaded into SGPRs
+// w2: the weights come from the segment's SECOND weight stream (a direct set's odd outer iterations, tl_common.hpp DirectSet) --
+// known to the launcher, handed over in a preloaded argument like the base itself
 template <bool NT>
-__device__ __forceinline__ void fetch_spec(const double* base, int stride, int j, ChunkBuf<TLOAM_RES_PLANE>& b) {
+__device__ __forceinline__ void fetch_spec(const double* base, int stride, int j, ChunkBuf<TLOAM_RES_PLANE>& b, bool w2 = false) {
 #define ld2o ld2o_t<NT>
   const unsigned o = (unsigned)j * 8u;
   const size_t st = (size_t)stride;
   b.px = ld2o(base + SS_PX * st, o); b.py = ld2o(base + SS_PY * st, o); b.pz = ld2o(base + SS_PZ * st, o);
   b.ax = ld2o(base + SS_AX * st, o); b.ay = ld2o(base + SS_AY * st, o); b.az = ld2o(base + SS_AZ * st, o);
-  b.w = ld2o(base + SS_W * st, o);
+  b.w = ld2o(base + (w2 ? SS_W2 : SS_W) * st, o);
   b.d = ld2o(base + SS_D * st, o);
 #undef ld2o
 }
@@ -382,8 +391,8 @@ __device__ __forceinline__ SingleWork single_work_of(const CorrView& cv, int cap
   return wk;
 }
 __device__ __forceinline__ void single_fetch(const CorrView& cv, const double* __restrict__ seg0, int stride0, const SingleWork& wk,
-                                             ChunkData& b) {
-  if (wk.kind == TLOAM_KIND_PLANAR) fetch_spec<false>(seg0, stride0, wk.j, b);
+                                             ChunkData& b, bool w2 = false) {
+  if (wk.kind == TLOAM_KIND_PLANAR) fetch_spec<false>(seg0, stride0, wk.j, b, w2);
   else if (wk.kind == TLOAM_KIND_GROUND) fetch<TLOAM_RES_PLANE, false>(cv.k[TLOAM_KIND_GROUND], wk.j, b);
   else if (wk.kind == TLOAM_KIND_EDGE) {
     if (single_chunk_of(TLOAM_KIND_EDGE) == kChunk) fetch<TLOAM_RES_LINE, false>(cv.k[TLOAM_KIND_EDGE], wk.j, b);
@@ -502,7 +511,7 @@ __device__ __forceinline__ bool k3_take_ticket(double* __restrict__ partials, co
 // sixteen independent loads in flight per thread (a 489-row fold is four rounds), one tree -- the SAME tree whether the
 // rows are folded by the last block of the sweep (AGENT: device-scope loads, the rows come from other XCDs), by the
 // separate reduce kernel or by the step kernel, so the paths agree bit for bit.
-template <bool AGENT>
+template <bool AGENT, int kP = 1>
 __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, int rows, double* s_grp /*[8*33]*/, double* s_tot) {
   const int comp = threadIdx.x & 31, grp = threadIdx.x >> 5;
   constexpr int kU = 16;
@@ -512,7 +521,8 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
   // FOUR passes of sixteen loads requested before the first is added (a full-chip grid of 512 rows is four passes: four dependent
   // trips to memory became one -- round 6: the 1 M GN iteration 21.8 -> 21.5 us, three interleaved pairs on one box); the additions
   // keep the order of the one-pass-at-a-time form, so the sums keep their bits
-  constexpr int kP = 4;
+  // (kP = 4 where the kernel has the registers -- the step kernels, one wave per SIMD; the sweeps that fold in their last block run
+  //  at 128 registers per wave and keep one pass in flight: 64 more doubles there are scratch)
   for (int b00 = grp; b00 < rows; b00 += kP * kU * 8) {
     double x[kP][kU];
 #pragma unroll
@@ -664,11 +674,13 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   ChunkData pre;
   SingleWork wk{-1, 0};
   const bool spec = !SINGLE && (TLOAM_K3_PLANE_DEPTH <= 2) && (gw + 1) * kChunk <= cap0;
+  const bool w2 = (force & 2) != 0;   // (bit 1 of the flag word: the planar weights are in the second stream)
+  force &= 1;
   if (SINGLE) {
     wk = single_work_of(cv, cap0, gw, lane);
-    single_fetch(cv, seg0, stride0, wk, pre);
+    single_fetch(cv, seg0, stride0, wk, pre, w2);
   } else if (spec) {
-    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
+    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre, w2);
   }
   if (!force && st->done) return;  // after a tolerance exit the remaining launches are no-ops
   const Rt T = st->Rt_eval;        // exp(point), hoisted out of the per-block Evaluate (:22,:58,:98)
@@ -741,6 +753,11 @@ void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single) {
   *grid = k3_grid_for((int)total, device_cus);
   *single = ((total + kChunk - 1) / kChunk <= (long long)*grid * 4) && TLOAM_SMALL_LINE_CHUNK == kChunk;
 }
+// bit 1 of the sweep kernels' flag word: the planar segment's weight pointer is the segment's SECOND weight stream (the planar
+// streams are addressed from the preloaded (base, stride), not through the view -- see fetch_spec)
+static int w2_flag(const CorrView& cv) {
+  return (cv.k[0].w != nullptr && cv.k[0].w == cv.k[0].px + (size_t)(SS_W2 - SS_PX) * (size_t)cv.k[0].stride) ? 2 : 0;
+}
 void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop) {
   auto kern = single ? k3_accumulate<true, false> : k3_accumulate<false, false>;
@@ -750,16 +767,16 @@ void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool
     // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
     // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
-                          cv.k[0].cap, force ? 1 : 0, st, cv.seg_n, partials, cv, none);
+                          cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st, cv.seg_n, partials, cv, none);
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, force ? 1 : 0, st,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
                        cv.seg_n, partials, cv, none);
   }
 }
 void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
                      const K3Fuse& fuse, hipStream_t s) {
   auto kern = single ? k3_accumulate<true, true> : k3_accumulate<false, true>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, force ? 1 : 0, st,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
                      cv.seg_n, partials, cv, fuse);
 }
 
@@ -772,7 +789,7 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce(const double* __restrict
   __shared__ double lds[8 * 33];
   __shared__ double tot[kReduceBuf];
   (void)st;
-  fold_rows<false>(partials, rows, lds, tot);
+  fold_rows<false, 4>(partials, rows, lds, tot);
   if (threadIdx.x < kReduceBuf) out48[threadIdx.x] = (threadIdx.x < kAccN) ? tot[threadIdx.x] : 0.0;
 }
 void launch_reduce(const double* partials, int grid, GnState* st, double* out48, hipStream_t s) {
@@ -814,6 +831,13 @@ void launch_frame_init(const FrameInit& fi, const FrameInitBufs& b, hipStream_t 
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
   hipLaunchKernelGGL(k_frame_init, dim3(blocks), dim3(256), 0, s, fi, b);
 }
+
+// a copy of the state whose builder pose is that of the set's last build: the rebuild of a stale direct set (tloam_ctx::set_stale)
+__global__ void k_pose_from_x_build(GnState* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->T_cur = se3_exp(st->x_build);
+}
+void launch_pose_from_x_build(GnState* st, hipStream_t s) { hipLaunchKernelGGL(k_pose_from_x_build, dim3(1), dim3(64), 0, s, st); }
 
 __global__ void k_set_eval(GnState* st, const double* se3) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -926,7 +950,7 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
     const unsigned long long w = threadIdx.x < kWords ? reinterpret_cast<const unsigned long long*>(st)[threadIdx.x] : 0ull;
     if (threadIdx.x < kWords) reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = w;
   }
-  fold_rows<false>(partials, rows, lds, tot);  // (its barriers also publish s_in)
+  fold_rows<false, 4>(partials, rows, lds, tot);  // (its barriers also publish s_in)
   if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
   const bool first = s_in.phase == PH_ITER0;
   if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, lds /* free again: the fold is over */);
@@ -965,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
   __shared__ double s_grp[8 * 33];
   __shared__ double tot[kMboxSlot];
   __shared__ GnState s_in;
-  (void)unused;
+  const bool w2 = (unused & 2) != 0;   // (as k3_accumulate's flag word)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * 4 + wave;
   ChunkData pre;
@@ -973,9 +997,9 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
   const bool spec = !SINGLE && (gw + 1) * kChunk <= cap0;
   if (SINGLE) {
     wk = single_work_of(cv, cap0, gw, lane);
-    single_fetch(cv, seg0, stride0, wk, pre);
+    single_fetch(cv, seg0, stride0, wk, pre, w2);
   } else if (spec) {
-    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre);
+    fetch_spec<TLOAM_K3_NT>(seg0, stride0, gw * kChunk + lane * 2, pre, w2);
   }
   if (fs.span && blockIdx.x == 0 && threadIdx.x == 0)   // (device-scope: read by the last block, on another XCD)
     __hip_atomic_store(fs.span, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1034,9 +1058,9 @@ void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid,
   if (mb_or_null) fs.mb = *mb_or_null;
   if (ev_start && ev_stop) {
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
-                          cv.k[0].cap, 0, st, cv.seg_n, partials, cv, fs);
+                          cv.k[0].cap, w2_flag(cv), st, cv.seg_n, partials, cv, fs);
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, 0, st, cv.seg_n,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, w2_flag(cv), st, cv.seg_n,
                        partials, cv, fs);
   }
 }
@@ -1064,7 +1088,9 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
 #endif
   ChunkData pre;
   const SingleWork wk = single_work_of(cv, cap0, gw, lane);
-  single_fetch(cv, seg0, stride0, wk, pre);
+  const bool w2 = (tagged & 2) != 0;   // (as k3_accumulate's flag word)
+  tagged &= 1;
+  single_fetch(cv, seg0, stride0, wk, pre, w2);
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
     static_assert(kWords <= 256, "one word per thread");
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep_step_small(const double* __res
 void launch_sweep_step_small(const CorrView& cv, GnState* st, double* partials, int* ticket, int grid, hipStream_t s,
                              unsigned long long* iter_span) {
   const int tagged = grid <= kTaggedRows ? 1 : 0;
-  hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged, st,
+  hipLaunchKernelGGL(k_sweep_step_small, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, tagged | w2_flag(cv), st,
                      cv.seg_n, partials, ticket, cv, iter_span);
 }
 #include "tl_prep.hpp"   // SolvePrep: the Solve's own caps / compaction / refresh (kind_set_of, self_compact, self_refresh)

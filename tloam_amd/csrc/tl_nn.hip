@@ -768,13 +768,40 @@ struct BuildArgs {
   BuildParams bp;
   TileMeta tm;
   int identity_n;   // > 0: no query sort -- query i is source slot i, identity_n of them
+  DirectSet ds;     // ds.on: the search writes the factor set itself, row = sorted position (tl_common.hpp DirectSet) ...
+  CorrView cv;      // ... into these segments
 };
+bool direct_set_size(int n_slots) { return n_slots > kQuadLimit; }
 
 __device__ __forceinline__ int slot_kind(const SlotView& sv, int slot) {
   int kind = 0;
 #pragma unroll
   for (int k = 1; k < kKinds; ++k) kind += (slot >= sv.slot_off[k]) ? 1 : 0;
   return kind;
+}
+// The factor of the query at sorted position `pos` straight into its ROW of the direct set (tl_common.hpp DirectSet); q = the
+// query record (source point in the sensor frame, slot).  Consecutive lanes are consecutive rows: every stream is written coalesced.
+__device__ __forceinline__ void store_direct(const BuildArgs& A, int kind, int pos, const double4& q, int slot, const RawRec& r) {
+  // (every one-wave block of the search also leaves its factor counts per kind: build_sorted_block)
+  const CorrSeg& seg = A.cv.k[kind];
+  const int row = pos - A.sv.slot_off[kind];
+  if (row < 0 || row >= seg.cap) return;   // (cannot happen while every kind is searched -- the host checks -- but never out of bounds)
+  const bool valid = (r.flag >> 32) != 0ull;
+  const int id = slot - A.sv.slot_off[kind] + A.sv.src_lo[kind];
+  seg.idx[row] = valid ? id : ~id;
+  if (A.ds.first) {
+    seg.px[row] = q.x; seg.py[row] = q.y; seg.pz[row] = q.z;
+    seg.w[row] = 1.0;   // registration.cpp:931-949: every weight starts at 1 (weight stream 0: what the first Solve reads)
+  }
+  if (kind == TLOAM_KIND_SPHERE) {
+    seg.ax[row] = valid ? r.a[0] : __builtin_nan("");
+    seg.ay[row] = valid ? r.a[1] : 0.0;
+    seg.az[row] = valid ? r.a[2] : 0.0;
+  } else {
+    seg.ax[row] = valid ? r.a[0] : 0.0; seg.ay[row] = valid ? r.a[1] : 0.0; seg.az[row] = valid ? r.a[2] : 0.0;
+    if (kind == TLOAM_KIND_EDGE) { seg.bx[row] = valid ? r.b[0] : 0.0; seg.by[row] = valid ? r.b[1] : 0.0; seg.bz[row] = valid ? r.b[2] : 0.0; }
+    else seg.d[row] = valid ? r.d : 0.0;
+  }
 }
 
 // pass 1: tile of every source slot under the current pose; histogram of queries per tile
@@ -839,12 +866,12 @@ __device__ __forceinline__ int k1_prof_which() {   // four sampled one-wave work
 namespace tl {
 
 template <int LPQ>
-__device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Pose& T, const double4& q, int slot,
-                                          int sub, int2* __restrict__ lds_rows) {
+__device__ __forceinline__ bool query_one(const BuildArgs& A, int kind, const Pose& T, const double4& q, int slot,
+                                          int sub, int2* __restrict__ lds_rows, int pos = 0) {
   const GridView& g = A.grid[kind];
   if (!A.bp.active[kind] || g.n <= 0) {   // (never reached in sorted order: k_query_bin leaves these slots out, same flags)
     if (sub == 0) store_flag(A.sv, slot, (A.bp.active[kind] && kind == TLOAM_KIND_SPHERE) ? 1ull : 0ull);
-    return;
+    return false;
   }
   TL_K1_STAMP(0)
   const Vec3 pw = act(T, Vec3{q.x, q.y, q.z});
@@ -867,8 +894,12 @@ __device__ __forceinline__ void query_one(const BuildArgs& A, int kind, const Po
 #endif
   }
   TL_K1_STAMP(6)
-  if (sub == 0) store_raw(A.sv, slot, rec);
+  if (sub == 0) {
+    if (LPQ == 1 && A.ds.on) store_direct(A, kind, pos, q, slot, rec);
+    else store_raw(A.sv, slot, rec);
+  }
   TL_K1_STAMP(7)
+  return (rec.flag >> 32) != 0ull;
 }
 
 // pass 3: the queries in TILE-SORTED order: the lanes of a wave query the same few cells, so the packed
@@ -904,17 +935,45 @@ __device__ __forceinline__ void build_sorted_block(const BuildArgs& A, const GnS
   const int qi = live ? i : ns - 1;
   const double4 q = A.identity_n ? double4{A.sv.sx[qi], A.sv.sy[qi], A.sv.sz[qi], __longlong_as_double((long long)qi)} : qrec[qi];
   const int slot = (int)__double_as_longlong(q.w);
-  query_one<LPQ>(A, slot_kind(A.sv, slot), st->T_cur, q, slot, live ? sub : 1, lds_rows);
+  const int kind = slot_kind(A.sv, slot);
+  int row_pos = qi;
+  if (LPQ == 1 && A.ds.on && A.ds.row_of_pos) {   // the row of this sorted position: its bin's queries in slot order (DirectSet)
+    if (A.ds.first) {
+      if (live) {
+        const int t = A.ds.tile_of_slot[slot];
+        const unsigned long long s0 = A.ds.tile_scan[t], e0 = A.ds.tile_scan[t + 1];
+        if (e0 - s0 > 1ull && e0 - s0 <= (unsigned long long)kDirectBinMax) {
+          int rank = 0;
+          for (unsigned long long j = s0; j < e0; ++j) rank += ((int)__double_as_longlong(qrec[j].w) < slot) ? 1 : 0;
+          row_pos = (int)s0 + rank;
+        }
+        A.ds.row_of_pos[qi] = row_pos;
+      }
+    } else {
+      row_pos = A.ds.row_of_pos[qi];
+    }
+  }
+  const bool valid = query_one<LPQ>(A, kind, st->T_cur, q, slot, live ? sub : 1, lds_rows, row_pos);
+  if (LPQ == 1 && A.ds.on && A.ds.blk_cnt) {   // this block's factors per kind (a wave can straddle a kind boundary), by LOGICAL block
+    const bool f = live && valid;
+#pragma unroll
+    for (int k = 0; k < kKinds; ++k) {
+      const int cnt = __popcll(__ballot(f && kind == k));
+      if (threadIdx.x == 0) A.ds.blk_cnt[(size_t)lb * kKinds + k] = cnt;
+    }
+  }
 }
 template <int LPQ>
 __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState* __restrict__ st,
                                                      const unsigned long long* __restrict__ n_sorted,
-                                                     const double4* __restrict__ qrec, const int* __restrict__ gate) {
+                                                     const double4* __restrict__ qrec, const int* __restrict__ gate, GnState* st_w) {
   if (gate && *gate == 0) return;  // device-driven outer loop: the pose did not move, the set is only refreshed
 #ifdef TLOAM_K1_PROF
   if (LPQ == 16 && threadIdx.x == 0 && blockIdx.x == 0) g_k1_prof[15] = wall_clock64();   // (about when the launch starts)
 #endif
   __shared__ int2 lds_rows[LPQ == 1 ? 9 * 64 : 1];
+  // a direct set is built at the pose this search runs at (what the compaction records for a compact set)
+  if (LPQ == 1 && A.ds.on && A.ds.set_x_build && blockIdx.x == 0 && threadIdx.x < 6) st_w->x_build[threadIdx.x] = st->x[threadIdx.x];
   build_sorted_block<LPQ>(A, st, n_sorted, qrec, (int)blockIdx.x, lds_rows);
 }
 // ---- large sets, device-driven loop: the finish of outer iteration k-1 (k_weights + k_outer_finish as one-wave blocks,
@@ -923,15 +982,29 @@ __global__ __launch_bounds__(64) void k_build_sorted(BuildArgs A, const GnState*
 __global__ __launch_bounds__(64) void k_build_finish_large(BuildArgs A, GnState* st, const unsigned long long* __restrict__ n_sorted,
                                                            const double4* __restrict__ qrec, const int* __restrict__ seg_n,
                                                            double* __restrict__ sums16, HostMirror hm, OuterCtl ctl, WeightArgs W,
-                                                           FinishRideLarge R) {
+                                                           FinishRideLarge R, FinishDirect D) {
   const int nfin = 4 * R.wblocks;
   if ((int)blockIdx.x < nfin) {
-    weights_finish_large_ride(st, seg_n, sums16, hm, ctl, W, R, (int)blockIdx.x);
+    if (A.ds.on) finish_direct_block(st, seg_n, sums16, hm, ctl, W, D, (int)blockIdx.x);
+    else weights_finish_large_ride(st, seg_n, sums16, hm, ctl, W, R, (int)blockIdx.x);
     return;
   }
   if (st->spec_build == 0 || __hip_atomic_load(&st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   __shared__ int2 lds_rows[9 * 64];
   build_sorted_block<1>(A, st, n_sorted, qrec, (int)blockIdx.x - nfin, lds_rows);
+}
+// the finish of a direct set as a launch of its own
+__global__ __launch_bounds__(64) void k_finish_direct(GnState* st, const int* __restrict__ seg_n, double* __restrict__ sums16, HostMirror hm,
+                                                      OuterCtl ctl, WeightArgs W, FinishDirect D) {
+  finish_direct_block(st, seg_n, sums16, hm, ctl, W, D, (int)blockIdx.x);
+}
+void launch_finish_direct(const FinishLargeArgs& fin, GnState* st, hipStream_t s) {
+  WeightArgs W;
+  memset(&W, 0, sizeof(W));
+  W.cv = *fin.cv;
+  W.wp = *fin.wp;
+  FinishDirect D{fin.rows, fin.ticket, 4 * fin.wblocks, {fin.w_next[0], fin.w_next[1], fin.w_next[2], fin.w_next[3]}, fin.blk_cnt, fin.nblk, fin.built};
+  hipLaunchKernelGGL(k_finish_direct, dim3(4 * fin.wblocks), dim3(64), 0, s, st, fin.seg_n, fin.sums16, fin.hm, fin.ctl, W, D);
 }
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
                                           unsigned long long* ctl, unsigned* fault, const int* cell_of_pt, const int* rank_of_pt, double4* gp,
@@ -943,15 +1016,18 @@ void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long*
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_grid_scatter_start_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_start, rank_of_pt, gp);
 }
-void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, const GnState* st,
+void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate,
-                  unsigned long long* scan1p_ctl, unsigned* scan1p_fault) {
+                  unsigned long long* scan1p_ctl, unsigned* scan1p_fault, const CorrView* direct_cv, const DirectSet* ds) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
   A.sv = sv;
   A.bp = bp;
+  memset(&A.ds, 0, sizeof(A.ds));
+  memset(&A.cv, 0, sizeof(A.cv));
+  if (direct_cv && ds && direct_set_size(n)) { A.ds = *ds; A.cv = *direct_cv; }
   for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
   const int ntiles = tile_meta(grids, sv.slot_off, &A.tm);   // bins of the counting sort
   // KITTI-size frames (sixteen lanes per query) are searched in SLOT order, unsorted: their target records (2-3 MB)
@@ -975,11 +1051,11 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
   // lanes per query: the smaller the frame, the more the build is a latency chain per query and the more lanes
   // pay (KITTI-size 9.4 k queries: 0.371-0.378 ms per frame with 4, 0.36 with 8, 0.348-0.36 with 16)
   if (n <= kWideLimit)
-    hipLaunchKernelGGL(k_build_sorted<16>, dim3(grid8(16LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
+    hipLaunchKernelGGL(k_build_sorted<16>, dim3(grid8(16LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate, st);
   else if (n <= kQuadLimit)
-    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
+    hipLaunchKernelGGL(k_build_sorted<4>, dim3(grid8(4LL * n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate, st);
   else
-    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate);
+    hipLaunchKernelGGL(k_build_sorted<1>, dim3(grid8(n)), dim3(64), 0, s, A, st, tile_scan + ntiles, qrec, gate, st);
 }
 // ---- the small-set finish (tl_finish.hpp), stand-alone -----------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_weights_finish_small(GnState* st, const int* __restrict__ seg_n,
@@ -1039,6 +1115,8 @@ void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds],
   A.bp = bp;
   for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
   memset(&A.tm, 0, sizeof(A.tm));   // slot order: no tiles
+  memset(&A.ds, 0, sizeof(A.ds));
+  memset(&A.cv, 0, sizeof(A.cv));
   A.identity_n = n;
   WeightArgs W;
   W.cv = *fin.cv;
@@ -1051,7 +1129,8 @@ void launch_build_finish_small(const SlotView& sv, const GridView grids[kKinds],
 
 bool build_finish_large_fits(const SlotView& sv) { return sv.slot_off[kKinds] > kQuadLimit; }
 void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
-                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s) {
+                               const unsigned long long* n_sorted, const double4* qrec, const FinishLargeArgs& fin, hipStream_t s,
+                               const DirectSet* ds) {
   const int n = sv.slot_off[kKinds];
   BuildArgs A;
   A.sv = sv;
@@ -1059,13 +1138,17 @@ void launch_build_finish_large(const SlotView& sv, const GridView grids[kKinds],
   for (int k = 0; k < kKinds; ++k) A.grid[k] = grids[k];
   (void)tile_meta(grids, sv.slot_off, &A.tm);   // (as launch_build: the tile metadata of the sorted query order)
   A.identity_n = 0;
+  memset(&A.ds, 0, sizeof(A.ds));
+  memset(&A.cv, 0, sizeof(A.cv));
+  if (ds) { A.ds = *ds; A.cv = *fin.cv; }
+  const FinishDirect D{fin.rows, fin.ticket, 4 * fin.wblocks, {fin.w_next[0], fin.w_next[1], fin.w_next[2], fin.w_next[3]}, fin.blk_cnt, fin.nblk, fin.built};
   WeightArgs W;
   W.cv = *fin.cv;
   W.sv = sv;
   W.wp = *fin.wp;
   const unsigned build_blocks = (unsigned)((((long long)n + 63) / 64 + 127) / 128 * 128);   // 8 XCDs x kXcdChunk, as launch_build
   hipLaunchKernelGGL(k_build_finish_large, dim3(4 * fin.wblocks + build_blocks), dim3(64), 0, s, A, st, n_sorted, qrec, fin.seg_n,
-                     fin.sums16, fin.hm, fin.ctl, W, FinishRideLarge{fin.rows, fin.ticket, fin.wblocks});
+                     fin.sums16, fin.hm, fin.ctl, W, FinishRideLarge{fin.rows, fin.ticket, fin.wblocks}, D);
 }
 
 int build_tile_count(const GridView grids[kKinds], const int slot_off[kKinds + 1]) {
