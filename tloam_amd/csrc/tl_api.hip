@@ -114,7 +114,7 @@ void tloam_destroy(tloam_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   tlh::comm_release(c);
-  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->iter_span.release(); c->state_scratch.release(); c->blk_cnt.release(); c->row_of_pos.release(); c->fin_rows.release(); c->flagb.release();
+  c->scan1p_q.release(); c->k3_ticket.release(); c->k3_span.release(); c->iter_span.release(); c->state_scratch.release(); c->blk_cnt.release(); c->row_of_pos.release(); c->fin_tickets.release(); c->fin_rows.release(); c->flagb.release();
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   // (a slot still selected: its clouds are in kd[], the context's own in the slot -- put them back first, so that every
   //  buffer is released exactly once below)

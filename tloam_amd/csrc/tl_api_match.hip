@@ -98,18 +98,21 @@ void direct_set_parity(tloam_ctx* c, int iter) {
   for (int k = 0; k < kKinds; ++k) c->cv.k[k].w = direct_w_stream(c, k, iter & 1);
 }
 // rows of the hand-over buffer of the finish, compact (riding) or direct
-constexpr size_t kFinRowsDoubles = (size_t)4 * 256 * 16;
+constexpr size_t kFinRowsDoubles = (size_t)(4 * 256 + 64) * 16;   // the blocks' rows + the rows of their groups of 64
+// (a quarter of the) one-wave blocks of a direct finish: a fixed function of the capacity, so that the riding form and the launch of
+// its own cut the rows alike.  (Twice as many blocks on ONE ticket measured 52 instead of 31 us for the frame's last finish: the
+// arrivals on the ticket are what it waits for -- hence the two-level hand-over of finish_direct_block.)
 int direct_wblocks(const tloam_ctx* c) {
   size_t cap = 0;
   for (int k = 0; k < kKinds; ++k) cap += c->kd[k].c_cap;
-  return (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));   // as enqueue_finish: a fixed function of the capacity
+  return (int)std::min<size_t>(256, std::max<size_t>(64, cap / 2048));
 }
 int* direct_blk_cnt(const tloam_ctx* c, int iter) { return c->blk_cnt.p + (size_t)(iter & 1) * c->blk_cnt_n * kKinds; }
 // built: 1 the set of outer iteration `iter` was built in it, 0 it is the previous one, -1 the device knows (GnState::run_build)
 FinishLargeArgs direct_finish_args(tloam_ctx* c, const CorrView* cv_iter, const WeightParams* wp, const HostMirror& hm, OuterCtl ctl,
                                    int iter, int riding, int built) {
   ctl.direct = riding ? 2 : 1;
-  FinishLargeArgs fin{cv_iter, wp, c->seg_n.p, c->sums16.p, hm, ctl, c->fin_rows.p, c->k3_ticket.p + 1, direct_wblocks(c), {}, nullptr, 0, 0};
+  FinishLargeArgs fin{cv_iter, wp, c->seg_n.p, c->sums16.p, hm, ctl, c->fin_rows.p, c->fin_tickets.p, direct_wblocks(c), {}, nullptr, 0, 0};
   for (int k = 0; k < kKinds; ++k) fin.w_next[k] = direct_w_stream(c, k, (iter + 1) & 1);
   fin.blk_cnt = direct_blk_cnt(c, iter);
   fin.nblk = (int)c->blk_cnt_n;
@@ -363,6 +366,10 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     c->blk_cnt_n = (off + 63) / 64;   // one-wave blocks of the thread-per-query search (logical: the sorted queries, 64 each)
     HIPC(c, c->blk_cnt.reserve(2 * c->blk_cnt_n * kKinds + 8));
     HIPC(c, c->row_of_pos.reserve(off + 64));
+    if (!c->fin_tickets.p) {
+      HIPC(c, c->fin_tickets.reserve(128));
+      HIPC(c, hipMemsetAsync(c->fin_tickets.p, 0, c->fin_tickets.cap * sizeof(int), c->stream));
+    }
   }
   // ---- compact segments: at most min(n_src, maxnum) factors per kind (a direct set: one row per source point, which is the same)
   size_t total_cap = 0;

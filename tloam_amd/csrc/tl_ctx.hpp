@@ -260,6 +260,7 @@ struct tloam_ctx {
   int w_parity = 0;            // weight stream the CURRENT GNC weights are in (the captured ones of the last Solve: the other)
   DBuf<GnState> state_scratch; // a copy of the state with T_cur = exp(x_build), for that rebuild
   DBuf<int> row_of_pos;        // DirectSet::row_of_pos: the row of every sorted query position
+  DBuf<int> fin_tickets;       // FinishDirect::ticket: the top ticket + one per group of 64 finish blocks (zero between launches)
   DBuf<int> blk_cnt;           // DirectSet::blk_cnt: [2 parities][search blocks][4]
   size_t blk_cnt_n = 0;        // search blocks of this frame
   // scanMatching host state

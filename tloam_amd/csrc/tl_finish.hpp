@@ -414,8 +414,8 @@ __device__ __forceinline__ void weights_finish_large_ride(GnState* st, const int
 // stores, a ticket, the last block adds the rows in a fixed order and publishes.
 constexpr int kDirRow = 16;   // [0..3] cost sums, [4] weights out of [0, 1], [8..11] factors per kind
 struct FinishDirect {
-  double* rows;               // [nblocks][kDirRow]
-  int* ticket;                // zero between launches
+  double* rows;               // [nblocks][kDirRow], then [groups of 64 blocks][kDirRow]
+  int* ticket;                // [1 + groups]: the top ticket, then one per group; zero between launches
   int nblocks;
   double* w_next[kKinds];     // the weight stream this finish writes (cv.k[].w is the one the Solve read)
   const int* blk_cnt;         // [nblk][4] factors per search block of the set this iteration solved (DirectSet::blk_cnt)
@@ -449,7 +449,7 @@ __device__ __forceinline__ void finish_direct_block(GnState* st, const int* __re
       const double* __restrict__ cost = seg.cost;
       const double* __restrict__ w_cur = seg.w;
       double* __restrict__ w_out = R.w_next[k];
-      constexpr int kU = 4;
+      constexpr int kU = 4;   // (eight at a time measured the same: 26.9 against 26.6 us for the launch of its own, 1 M rows)
       for (int i0 = tid; i0 < n; i0 += kU * stride) {
         double cu[kU], wu[kU];
 #pragma unroll
@@ -488,19 +488,52 @@ __device__ __forceinline__ void finish_direct_block(GnState* st, const int* __re
       for (int i = 0; i < 4; ++i) __hip_atomic_store(R.rows + (size_t)b * kDirRow + 8 + i, v[5 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  // ---- hand-over in TWO levels: a thousand arrivals on ONE counter are a thousand serialised atomics (~12 ns each: 13 us of the
+  //      31 us this finish took as a launch of its own with one ticket) -- groups of 64 blocks take a ticket of their own, the
+  //      last block of a group adds the group's rows (one per lane, one shuffle tree), stores a group row and takes the top
+  //      ticket; the last group adds the group rows the same way.  Fixed orders throughout.
+  const int group = b >> 6, ngroups = (R.nblocks + 63) >> 6, gsize = min(64, R.nblocks - (group << 6));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (row acknowledged, flags read -- see weights_finish_small_ride)
-  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == R.nblocks - 1) ? 1 : 0;
+  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket + 1 + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  if (lane == 0) __hip_atomic_store(R.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  if (lane == 0) __hip_atomic_store(R.ticket + 1 + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double* const grows = R.rows + (size_t)R.nblocks * kDirRow;   // [ngroups][kDirRow] behind the blocks' rows
+  if (g == 0) {
+    if (lane < gsize) {
+      const double* r = R.rows + (size_t)((group << 6) + lane) * kDirRow;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) t9[c] = __hip_atomic_load(r + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t9[5 + c] = __hip_atomic_load(r + 8 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t9[c] += __shfl_down(t9[c], off, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) __hip_atomic_store(grows + (size_t)group * kDirRow + c, t9[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) __hip_atomic_store(grows + (size_t)group * kDirRow + 8 + c, t9[5 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (lane == 0) s_last = (__hip_atomic_fetch_add(R.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  if (lane == 0) __hip_atomic_store(R.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (g != 0) {
     finish_gate_writes(st, ctl, g, lane);
     mirror_to_host(st, hm, lane, 64, g == 1 ? (int)OS_SKIPPED : -1);
     return;
   }
-  double t9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int rb = lane; rb < R.nblocks; rb += 64) {   // lane t: rows t, t + 64, ... in order; then one shuffle tree
-    const double* r = R.rows + (size_t)rb * kDirRow;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) t9[c] = 0.0;
+  for (int rb = lane; rb < ngroups; rb += 64) {   // (at most 64 groups: one per lane)
+    const double* r = grows + (size_t)rb * kDirRow;
 #pragma unroll
     for (int c = 0; c < 5; ++c) t9[c] += __hip_atomic_load(r + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
