@@ -66,6 +66,7 @@ int tloam_create(const tloam_tls_config* cfg, int device_id, tloam_ctx** out) {
   c->no_persistent_solve = getenv("TLOAM_NO_PERSISTENT_SOLVE") != nullptr;
   c->no_grid_ahead = getenv("TLOAM_NO_GRID_AHEAD") != nullptr;
   c->no_direct_set = getenv("TLOAM_NO_DIRECT_SET") != nullptr;
+  c->no_qbin_ride = getenv("TLOAM_NO_QBIN_RIDE") != nullptr;
   if (const char* e = getenv("TLOAM_DEBUG_FAIL_HANDOVER")) c->dbg_fail_handover = atoi(e);
   {
     int cus = 0;

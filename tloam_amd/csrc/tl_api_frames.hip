@@ -271,8 +271,20 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     const size_t before = G.scan1p.cap;
     HIPC(c, G.scan1p.reserve(scan_1p_ctl_elems(nc_res + 1)));
     if (G.scan1p.cap != before) HIPC(c, hipMemsetAsync(G.scan1p.p, 0, G.scan1p.cap * sizeof(unsigned long long), c->stream));
+    const QueryBinRide* qbin = nullptr;
+    if (frame && frame->qbin) {
+      // the query sort's buffers, sized exactly as the sort itself will ask for them (nothing may be re-allocated in between)
+      const int rc = reserve_query_sort(c, out);
+      if (rc != TLOAM_OK) return rc;
+      frame->qbin->tile_of_slot = c->tile_of_slot.p;
+      frame->qbin->rank_in_tile = c->tile_fill.p;
+      frame->qbin->tile_cnt = c->tile_cnt.p;
+      // (the frame's start, riding on the first launch above, zeroes the histogram it was handed: the same array only if the
+      //  reservation just made did not move it)
+      if (frame->fi.tile_cnt == c->tile_cnt.p) { qbin = frame->qbin; frame->qbin_done = true; }
+    }
     launch_grid_scan_finalize_scatter_1p(gs, G.cell_cnt.p, nc + 1, G.cell_start.p, G.scan1p.p, c->h_fault_dev + kFaultScan1p, G.cell_of_pt.p,
-                                         G.rank_of_pt.p, G.gp.p, c->stream);
+                                         G.rank_of_pt.p, G.gp.p, c->stream, qbin, out);
     return TLOAM_OK;
   }
   const int tiles = scan_tiles_only(G.cell_cnt.p, G.cell_scan.p, nc + 1, G.scan_tmp.p, c->stream);

@@ -409,6 +409,21 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   hook.fi.no_eval_reuse = c->dbg_no_eval_reuse ? 1 : 0;
   hook.fi.direct = c->direct ? 1 : 0;
   if (c->direct) direct_set_parity(c, 0);
+  // 1 M-class single-rank frames: the first pass of the query sort rides on the last launch of the grid build (QueryBinRide)
+  QueryBinRide qbin;
+  memset(&qbin, 0, sizeof(qbin));
+  c->qbin_rode = false;
+  if (one_rank(c) && !c->no_qbin_ride && direct_set_size((int)std::min<size_t>(off, (size_t)INT32_MAX))) {
+    qbin.sv = c->sv;
+    for (int k = 0; k < kKinds; ++k) {
+      qbin.bp.radius[k] = kind_radius(c->cfg, k);
+      qbin.bp.maxnum[k] = kind_maxnum(c->cfg, k);
+      qbin.bp.active[k] = kind_active(c->cfg, k);
+    }
+    qbin.bp.edge_dir_thres = c->cfg.edge_dir_thres;
+    qbin.st = c->state.p;
+    hook.qbin = &qbin;
+  }
   hook.b = FrameInitBufs{c->sx.p, c->sy.p, c->sz.p, c->w_src.p, c->flags.p, c->state.p, c->seg_n.p};
   hook.n_slots = c->sv.slot_off[kKinds];
   // ---- :889-915 four search structures over the submap clouds: one launch per build phase for all kinds
@@ -429,6 +444,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
     } else {
       rc = build_grids(c, c->grids, radius, views, &hook);
       if (rc != TLOAM_OK) return rc;
+      c->qbin_rode = hook.qbin_done;
       // (a kind whose grid was skipped -- radius forced to 0 above: a sharded rank without source points of it -- has an EMPTY
       //  view: it is not a search structure getFitnessScore or anybody else may use)
       for (int k = 0; k < kKinds; ++k) { c->kd[k].gv = views[k]; c->kd[k].grid_valid = radius[k] > 0.0; }
@@ -483,7 +499,13 @@ void outer_params(const tloam_ctx* c, BuildParams* bp, GridView grids[kKinds]) {
   }
   bp->edge_dir_thres = c->cfg.edge_dir_thres;
 }
-int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
+int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) { return tlh::reserve_query_sort(c, grids); }
+}  // namespace
+extern "C++" {
+namespace tlh {
+// (also called from the grid build when the sort's first pass rides on it: the SAME sizes, so that nothing is re-allocated -- and
+//  lost -- between that pass and the rest of the sort)
+int reserve_query_sort(tloam_ctx* c, const GridView grids[kKinds]) {
   const size_t n_slots = (size_t)c->sv.slot_off[kKinds];
   const size_t ntiles = (size_t)build_tile_count(grids, c->sv.slot_off);
   // (tile counts follow the bounding boxes like the cell tables: grow with room to spare)
@@ -512,6 +534,9 @@ int outer_reserve(tloam_ctx* c, const GridView grids[kKinds]) {
   }
   return TLOAM_OK;
 }
+}  // namespace tlh
+}  // extern "C++"
+namespace {
 // :976-1020 the four builders (K1 + K2), the flag scan, the index-order caps.  Small single-rank frames: the scan, the
 // caps, the compaction AND the alternative (refresh) are one launch (k_prepare_small) -- `also_refresh` says whether this
 // call stands for both alternatives of a device-gated iteration.
@@ -532,7 +557,8 @@ int enqueue_build(tloam_ctx* c, const BuildParams& bp, const GridView grids[kKin
   } else {
     launch_build(c->sv, grids, bp, c->state.p, c->tile_of_slot.p, c->tile_cnt.p, c->tile_scan.p, c->tile_fill.p,
                  c->qrec.p, c->scan_tmp.p, rebin, c->stream, gate, c->scan1p_q_use ? c->scan1p_q.p : nullptr, c->h_fault_dev + kFaultScan1p,
-                 c->direct ? &c->cv : nullptr, c->direct ? &ds : nullptr);
+                 c->direct ? &c->cv : nullptr, c->direct ? &ds : nullptr, rebin && c->qbin_rode);
+    if (rebin) c->qbin_rode = false;   // (consumed: a second sort of this frame -- a re-run -- bins for itself)
   }
   if (c->direct) return TLOAM_OK;
   if (prepare_in_solve) return TLOAM_OK;

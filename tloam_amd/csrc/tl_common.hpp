@@ -287,11 +287,31 @@ struct FrameInitBufs {
 };
 // start of a scan_match folded into the first launch of the grid build (k_grid_count_all): `on` = 0 leaves the launch
 // as it was; `consumed` tells the caller whether a launch carried it (no targets at all = no grid launch)
+struct BuildParams {
+  double radius[kKinds];
+  int maxnum[kKinds];
+  int active[kKinds];
+  double edge_dir_thres;
+};
+// The first pass of the frame's query sort (k_query_bin: the bin of every source point under the predicted pose, one returning
+// atomic each) needs the grids' DIMENSIONS, not the grids: on the 1 M-class frames it rides on the last launch of the grid build
+// (the scatter of the targets into their cells -- writes against atomics) as one more row of blocks instead of following it.
+struct QueryBinRide {
+  SlotView sv;
+  BuildParams bp;
+  const GnState* st;
+  int* tile_of_slot;
+  int* rank_in_tile;
+  unsigned long long* tile_cnt;
+};
 struct FrameInitHook {
   FrameInit fi;
   FrameInitBufs b;
   int n_slots;
   bool consumed;
+  // in: non-null = the caller wants the query binning to ride (it has filled sv / bp / st); out: qbin_done
+  QueryBinRide* qbin;
+  bool qbin_done;
 };
 #if defined(__HIPCC__)
 // start-of-Solve values of the minimiser (Ceres defaults: initial_trust_region_radius 1e4, min_mu 1e-8);
@@ -370,14 +390,8 @@ void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out
                            hipStream_t s);
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
                                           unsigned long long* ctl, unsigned* fault, const int* cell_of_pt, const int* rank_of_pt, double4* gp,
-                                          hipStream_t s);
+                                          hipStream_t s, const QueryBinRide* qbin = nullptr, const GridView* views = nullptr);
 
-struct BuildParams {
-  double radius[kKinds];
-  int maxnum[kKinds];
-  int active[kKinds];
-  double edge_dir_thres;
-};
 // start-of-frame initialisation, one launch
 // K1+K2: per source slot kNN + fit + gates -> raw records + flags
 // scan1p_ctl: control words of the single-pass scan of the query-sort histogram (large frames; the caller has checked
@@ -387,7 +401,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate = nullptr,
                   unsigned long long* scan1p_ctl = nullptr, unsigned* scan1p_fault = nullptr, const CorrView* direct_cv = nullptr,
-                  const DirectSet* ds = nullptr);
+                  const DirectSet* ds = nullptr, bool binned = false);   // binned: the sort's first pass rode on the grid build
 bool direct_set_size(int n_slots);   // frames the thread-per-query search takes (the size class of the direct set)
 int build_tile_count(const GridView grids[kKinds], const int slot_off[kKinds + 1]);  // bins of the query counting sort (per kind: its tiles, or the cells of its tiles)
 // cap + compaction (after the flag scan)

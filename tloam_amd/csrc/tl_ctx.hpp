@@ -253,6 +253,8 @@ struct tloam_ctx {
   int fallback_events = 0;
   bool persistent_solve_timed_out = false;   // no_persistent_solve was set by a time-out, not by TLOAM_NO_PERSISTENT_SOLVE
   // the DIRECT factor set of large frames (tl_common.hpp DirectSet): chosen per frame by tloam_sm_begin
+  bool no_qbin_ride = false;   // TLOAM_NO_QBIN_RIDE: the query sort's first pass as a launch of its own (A/B)
+  bool qbin_rode = false;      // this frame's query binning rode on the grid build (launch_build skips its own)
   bool no_direct_set = false;  // TLOAM_NO_DIRECT_SET: large frames compact as the others do (A/B, tests)
   bool direct = false;         // this frame's set is direct: rows = tile-sorted queries, holes, two weight streams
   bool set_stale = false;      // ... and its rows hold the geometry of a search whose set was never solved (OS_SET_STALE): rebuilt at
@@ -338,6 +340,7 @@ void comm_rccl_info(const tloam_ctx* c, int32_t* count, int32_t* user_rank);   /
 // tl_api_match.hip
 int reserve_seg(tloam_ctx* c, int k, size_t n);        // compact correspondence segment of kind k for n factors
 int ensure_common(tloam_ctx* c);                       // the context's small fixed device buffers
+int reserve_query_sort(tloam_ctx* c, const tl::GridView grids[tl::kKinds]);   // the buffers of the frame's query sort, sized by the grids
 // tl_api_frames.hip
 void exchange_clouds(tloam_ctx* c, FrameClouds& F);    // the registered clouds <-> a FrameClouds (pointers and counts only)
 int check_device_faults(tloam_ctx* c);

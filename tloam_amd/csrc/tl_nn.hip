@@ -805,10 +805,8 @@ __device__ __forceinline__ void store_direct(const BuildArgs& A, int kind, int p
 }
 
 // pass 1: tile of every source slot under the current pose; histogram of queries per tile
-__global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* __restrict__ st,
-                                                   int* __restrict__ tile_of_slot, int* __restrict__ rank_in_tile,
-                                                   unsigned long long* __restrict__ tile_cnt) {
-  const int slot = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void query_bin_slot(const BuildArgs& A, const GnState* __restrict__ st, int* __restrict__ tile_of_slot,
+                                               int* __restrict__ rank_in_tile, unsigned long long* __restrict__ tile_cnt, int slot) {
   if (slot >= A.sv.slot_off[kKinds]) return;
   const int kind = slot_kind(A.sv, slot);
   const GridView& g = A.grid[kind];
@@ -829,6 +827,36 @@ __global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* _
   if (sub > 1) t += ((cz % kTile) * kTile + (cy % kTile)) * kTile + (cx % kTile);
   tile_of_slot[slot] = t;
   rank_in_tile[slot] = (int)atomicAdd(&tile_cnt[t], 1ull);  // the one atomic of the sort: count AND rank
+}
+__global__ __launch_bounds__(256) void k_query_bin(BuildArgs A, const GnState* __restrict__ st,
+                                                   int* __restrict__ tile_of_slot, int* __restrict__ rank_in_tile,
+                                                   unsigned long long* __restrict__ tile_cnt) {
+  query_bin_slot(A, st, tile_of_slot, rank_in_tile, tile_cnt, blockIdx.x * 256 + threadIdx.x);
+}
+// the scatter of the one-pass grid build (k_grid_scatter_start_all) with the query binning riding on it: rows blockIdx.y >= kKinds
+// of the launch are k_query_bin's blocks
+__global__ __launch_bounds__(256) void k_grid_scatter_qbin(GridSet gs, const int* __restrict__ cell_of_pt, const int* __restrict__ cell_start,
+                                                           const int* __restrict__ rank_of_pt, double4* __restrict__ gp, BuildArgs A,
+                                                           const GnState* __restrict__ st, int* __restrict__ tile_of_slot,
+                                                           int* __restrict__ rank_in_tile, unsigned long long* __restrict__ tile_cnt, int rows) {
+  // ONE row of blocks, the roles interleaved (block L: role L % roles, place L / roles): dispatched in index order, scatter and
+  // binning blocks then run side by side from the first to the last -- as whole rows (binning behind the scatter) the launch
+  // took 78 us, the two kernels apart 37 + 51
+  const int roles = kKinds + rows, role = (int)blockIdx.x % roles, bx = (int)blockIdx.x / roles, gx = (int)gridDim.x / roles;
+  if (role >= kKinds) {
+    const int n = A.sv.slot_off[kKinds];
+    const int rider = (role - kKinds) * gx + bx, nriders = gx * rows;
+    for (int slot = rider * 256 + (int)threadIdx.x; slot < n; slot += nriders * 256) query_bin_slot(A, st, tile_of_slot, rank_in_tile, tile_cnt, slot);
+    return;
+  }
+  const int k = role;
+  const int n = gs.n[k];
+  const long long base = gs.cell_base[k] + k;
+  for (int i = bx * (int)blockDim.x + (int)threadIdx.x; i < n; i += gx * (int)blockDim.x) {
+    const int c = cell_of_pt[gs.tgt_off[k] + i];
+    const int pos = cell_start[base + c] + rank_of_pt[gs.tgt_off[k] + i];
+    gp[gs.tgt_off[k] + pos] = double4{gs.tx[k][i], gs.ty[k][i], gs.tz[k][i], __longlong_as_double((long long)i)};
+  }
 }
 // pass 2: slots grouped by tile (order inside a tile is irrelevant: every result goes to its own slot)
 // The sorted entry is a 32-byte record (x, y, z, slot): K1 then reads its queries coalesced instead of
@@ -1008,18 +1036,31 @@ void launch_finish_direct(const FinishLargeArgs& fin, GnState* st, hipStream_t s
 }
 void launch_grid_scan_finalize_scatter_1p(const GridSet& gs, unsigned long long* cell_cnt, size_t ncells_plus_1, int* cell_start,
                                           unsigned long long* ctl, unsigned* fault, const int* cell_of_pt, const int* rank_of_pt, double4* gp,
-                                          hipStream_t s) {
+                                          hipStream_t s, const QueryBinRide* qbin, const GridView* views) {
   const size_t tiles = (ncells_plus_1 + kTile1p - 1) / kTile1p;
   Scan1p C{ctl, next_scan_epoch(), fault};
   hipLaunchKernelGGL(k_grid_scan_finalize_1p, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, gs, cell_cnt, ncells_plus_1, cell_start, C);
   int blocks = (max_n(gs) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (qbin && views) {   // the query sort's first pass as extra rows of this launch (QueryBinRide)
+    BuildArgs A;
+    memset(&A, 0, sizeof(A));
+    A.sv = qbin->sv;
+    A.bp = qbin->bp;
+    for (int k = 0; k < kKinds; ++k) A.grid[k] = views[k];
+    (void)tile_meta(views, qbin->sv.slot_off, &A.tm);
+    const int n = qbin->sv.slot_off[kKinds];
+    const int rows = std::max(1, std::min(4, ((n + 255) / 256 + blocks - 1) / blocks));
+    hipLaunchKernelGGL(k_grid_scatter_qbin, dim3(blocks * (kKinds + rows)), dim3(256), 0, s, gs, cell_of_pt, cell_start, rank_of_pt, gp, A, qbin->st,
+                       qbin->tile_of_slot, qbin->rank_in_tile, qbin->tile_cnt, rows);
+    return;
+  }
   hipLaunchKernelGGL(k_grid_scatter_start_all, dim3(blocks, kKinds), dim3(256), 0, s, gs, cell_of_pt, cell_start, rank_of_pt, gp);
 }
 void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildParams& bp, GnState* st,
                   int* tile_of_slot, unsigned long long* tile_cnt, unsigned long long* tile_scan, int* tile_fill,
                   double4* qrec, unsigned long long* scan_tmp, bool rebin, hipStream_t s, const int* gate,
-                  unsigned long long* scan1p_ctl, unsigned* scan1p_fault, const CorrView* direct_cv, const DirectSet* ds) {
+                  unsigned long long* scan1p_ctl, unsigned* scan1p_fault, const CorrView* direct_cv, const DirectSet* ds, bool binned) {
   const int n = sv.slot_off[kKinds];
   if (n <= 0) return;
   BuildArgs A;
@@ -1039,7 +1080,7 @@ void launch_build(const SlotView& sv, const GridView grids[kKinds], const BuildP
     // so the tile sort is done once per frame (first outer iteration, predicted pose) and reused while
     // the pose moves by centimetres.
     // (tile_cnt[0 .. ntiles] was zeroed by k_frame_init -- one launch less at the start of every frame)
-    hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
+    if (!binned) hipLaunchKernelGGL(k_query_bin, dim3((n + 255) / 256), dim3(256), 0, s, A, st, tile_of_slot, tile_fill, tile_cnt);
     if (scan1p_ctl) launch_scan_counts_1p(tile_cnt, tile_scan, (size_t)ntiles + 1, scan1p_ctl, scan1p_fault, s);   // (the caller has checked scan_1p_applies)
     else launch_exclusive_scan_u64(tile_cnt, tile_scan, (size_t)ntiles + 1, scan_tmp, s);
     hipLaunchKernelGGL(k_query_scatter, dim3((n + 255) / 256), dim3(256), 0, s, sv, tile_of_slot, tile_scan,
