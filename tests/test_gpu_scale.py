@@ -356,3 +356,78 @@ def test_direct_set_is_rebuilt_when_the_loop_ends_beside_a_search_that_had_run(h
                 np.testing.assert_allclose(fd[k][f], fc[k][f], rtol=0, atol=1e-9, err_msg=f"{k} {f}")
         np.testing.assert_allclose(fd[k]["cost"], fc[k]["cost"], rtol=1e-6, atol=1e-18)
     Hd.close(); Hc.close()
+
+
+def test_one_context_through_direct_compact_small_and_prebuilt_frames(hip_module):
+    """State must not leak between the forms a context's frames take.  ONE context is walked through: a large frame with lifted
+    caps (direct set) | a KITTI-size frame (one-launch Solve) | the large frame with the reference's caps (compact: they bind) |
+    a LARGER lifted frame (direct, buffers grow, other row counts) | a pre-built set (compact by definition) | the first frame
+    again -- and after every step a FRESH context solves the same input: pose, counters, index lists, captured weights, GNC
+    weights and side-channel costs must agree bit for bit (weight-stream parity, stale-set flag, the sort's riding first pass,
+    the planar weight-stream bit of the sweep's flag word are all per frame)."""
+    big = dict(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+    A = synth.make_scene(seed=21, n_src=(70_000, 40_000, 30_000, 6_000), n_tgt=(80_000, 50_000, 40_000, 8_000), density=40.0)
+    B = synth.make_scene(seed=22, n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT)
+    C_ = synth.make_scene(seed=23, n_src=(90_000, 50_000, 40_000, 9_000), n_tgt=(90_000, 60_000, 50_000, 9_000), density=40.0)
+    sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=30_001, n_line=7_777, n_point=1_300)
+    steps = [("direct", A, big, 1), ("small", B, {}, 0), ("caps", A, {}, 0), ("direct_larger", C_, big, 1), ("prebuilt", None, None, 0), ("direct_again", A, big, 1)]
+    ctx = {}   # one long-lived context per configuration (the caps are part of a context): each sees every frame of ITS configuration in turn
+
+    def fingerprint(H, sc, T, st):
+        out = [T.tobytes(), tuple(st[k] if not hasattr(st[k], "tolist") else tuple(np.asarray(st[k]).tolist())
+                                  for k in ("n_corr", "gn_evaluations", "gn_sweeps", "gn_iterations", "accepted_steps", "outer_iterations", "converged_early"))]
+        for k in range(4):
+            c = H.get_correspondences(k, capacity=len(sc.source.cloud(k)))
+            out += [c["idx"].tobytes(), c["w"].tobytes(), c["cost"].tobytes(), H.get_weights(k).tobytes()]
+        return out
+
+    # the long-lived contexts: `big` and default caps; every step runs on the one its caps ask for, so each of the two is taken
+    # through direct -> (prebuilt) -> direct and small -> caps respectively, interleaved with the other's frames on the same GPU
+    for name, sc, over, direct in steps:
+        if name == "prebuilt":
+            for key in list(ctx):
+                H = ctx[key]
+                for rt in range(3):
+                    H.set_correspondences(rt, *sets[rt])
+                x, ps = H.solve(x_eval)
+                F = hip_module.HipRegistration()
+                for rt in range(3):
+                    F.set_correspondences(rt, *sets[rt])
+                xf, pf = F.solve(x_eval)
+                assert np.array_equal(x, xf) and ps["gn_evaluations"] == pf["gn_evaluations"], name
+                assert H.info()["direct_set"] == 0
+                F.close()
+            continue
+        key = tuple(sorted(over.items()))
+        if key not in ctx:
+            ctx[key] = hip_module.HipRegistration(hip_module.default_config(**over))
+        H = ctx[key]
+        H.set_frames(sc.source, sc.target)
+        rc, T, st = H.scan_match(sc.T_pred)
+        assert rc == 0 and H.info()["direct_set"] == direct, (name, H.info())
+        F = hip_module.HipRegistration(hip_module.default_config(**over))
+        F.set_frames(sc.source, sc.target)
+        rcf, Tf, stf = F.scan_match(sc.T_pred)
+        assert rcf == 0
+        for i, (a, b) in enumerate(zip(fingerprint(H, sc, T, st), fingerprint(F, sc, Tf, stf))):
+            assert a == b, (name, i)
+        # ... and the same frame a second time on the long-lived context (learned sweep budgets, grids built ahead or not)
+        rc2, T2, st2 = H.scan_match(sc.T_pred)
+        assert rc2 == 0 and T2.tobytes() == T.tobytes(), name
+        F.close()
+    # the SAME context across the cap change: a context cannot change its caps, so the direct <-> compact switch on one context is
+    # driven by the frame's SIZE instead -- a frame below the thread-per-query limit compacts, the large one is direct again
+    H = ctx[tuple(sorted(big.items()))]
+    mid = synth.make_scene(seed=24, n_src=(14_000, 10_000, 9_000, 3_000), n_tgt=(40_000, 30_000, 25_000, 5_000), density=25.0)
+    for sc, direct in ((mid, 0), (A, 1), (mid, 0)):
+        H.set_frames(sc.source, sc.target)
+        rc, T, st = H.scan_match(sc.T_pred)
+        F = hip_module.HipRegistration(hip_module.default_config(**big))
+        F.set_frames(sc.source, sc.target)
+        rcf, Tf, stf = F.scan_match(sc.T_pred)
+        assert rc == rcf == 0 and H.info()["direct_set"] == direct
+        for i, (a, b) in enumerate(zip(fingerprint(H, sc, T, st), fingerprint(F, sc, Tf, stf))):
+            assert a == b, ("size switch", direct, i)
+        F.close()
+    for H in ctx.values():
+        H.close()
