@@ -63,8 +63,8 @@ def _first_existing(*names):
     return next((p for p in paths if os.path.exists(p)), paths[0])
 
 
-PMC_SUMMARY = _first_existing("r05_pmc_k3_prebuilt.json", "r04_pmc_k3_prebuilt.json", "r03_pmc_k3_prebuilt.json", "r02_pmc_k3_prebuilt.json")
-PMC_SUMMARY_COLD = _first_existing("r05_pmc_k3_prebuilt_cold.json", "r04_pmc_k3_prebuilt_cold.json", "r03_pmc_k3_prebuilt_cold.json")
+PMC_SUMMARY = _first_existing("r06_pmc_k3_prebuilt.json", "r05_pmc_k3_prebuilt.json", "r04_pmc_k3_prebuilt.json")
+PMC_SUMMARY_COLD = _first_existing("r06_pmc_k3_prebuilt_cold.json", "r05_pmc_k3_prebuilt_cold.json", "r04_pmc_k3_prebuilt_cold.json")
 
 
 def _sha16(path):
@@ -470,7 +470,7 @@ def main():
                     "sweep_alone_back_to_back": bb,
                     "note": "KITTI-cap sets (442 KB per sweep) are latency bound, not bandwidth bound: in the frames the sweep runs "
                             "inside the persistent Solve launch with its correspondences held in registers (no K3 launch to time; "
-                            "6.8-7.7 us per GN iteration, profiles/r04_solve_all_timeline.txt); the figure here is the stand-alone "
+                            "5.3-5.5 us per GN iteration by the device clock, gn_iteration_us; profiles/r06_solve_all_timeline.txt); the figure here is the stand-alone "
                             "sweep kernel on the frame's last correspondence set"}
         out = {
             "metric": "gauss_newton_iters_per_sec", "value": round(head["gn_iters_per_sec"], 2), "unit": "GN iter/s",
