@@ -149,7 +149,7 @@ typedef struct tloam_ctx_info {
   int32_t fallbacks_taken;  /* TLOAM_FALLBACK_* bits: bounded in-launch waits that ran out and moved the context to a form
                              * that waits for nothing (knobs of the environment are not reported here)                  */
   int32_t fallback_events;  /* how many times that happened (each one cost a ~1-2 s wait and a re-run)                   */
-  int32_t k3_grid;          /* blocks of the residual/Jacobian sweep over the current correspondence set               */
+  int32_t k3_grid;          /* blocks of the residual/Jacobian sweep over the current correspondence set (= rows it leaves) */
   int32_t k3_single;        /* 1: one wave per chunk (KITTI-size sets), 0: the streaming form                           */
   int32_t one_launch_solve; /* 1: a ceres::Solve on the current set runs as ONE launch (k_solve_all)                    */
   int32_t loopback;         /* 1: a mailbox / RCCL set-up with nranks == 1 -- the sharded launch forms run, the exchange is
@@ -158,6 +158,8 @@ typedef struct tloam_ctx_info {
                              * cannot bind: rows in the search's own order, no compaction -- DESIGN.md section 4)              */
   int32_t set_stale;        /* 1: ... and its rows will be rebuilt before a getter reads them (the loop ended beside a search
                              * that had already run)                                                                          */
+  int32_t k3_wide;          /* 1: the streaming sweep goes out as blocks of EIGHT waves, one per CU (full-chip grids: half the rows
+                             * for the block that folds them), 0: four waves                                                   */
 } tloam_ctx_info;
 int tloam_get_info(tloam_ctx* ctx, tloam_ctx_info* out);
 

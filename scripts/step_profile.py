@@ -23,5 +23,6 @@ for (a, b, c) in [(4500, 1200, 200), (760000, 200000, 40000)]:
         dbg = buf[n - 12:n]
         d = np.diff(dbg[:7])
         print(a + b + c, "sweeps", ms, "cycles: entry->consume %d  decide+take %d  dogleg %d  step+mcc %d  plus %d  writeback %d  total %d" %
-              (d[0], d[1], d[2], d[3], d[4], d[5], dbg[6] - dbg[0]), flush=True)
+              (d[0], d[1], d[2], d[3], d[4], d[5], dbg[6] - dbg[0]),
+              ("| k_reduce_and_step: state in %d, rows folded %d" % (dbg[7] - dbg[0], dbg[8] - dbg[7])) if a + b + c > 100000 else "", flush=True)
         H.close()

@@ -248,7 +248,8 @@ def test_one_rank_loopback_runs_the_sharded_forms_bit_for_bit(hip_module, form):
     us, n = H.gn_iter_timer()
     assert n > 0 and 1.0 < us / n < 500.0, (us, n)   # the device clocked the GN iterations of the sharded forms
     # the 1 M-class streaming forms as well (pre-built set: fused sweep + last-block fold + post | gather + step)
-    sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=300_001, n_line=77_777, n_point=13_000)
+    # (490 k factors: a full-chip grid, i.e. WIDE blocks -- the last block of eight waves folds with its first four)
+    sets, x_true, x_eval = synth.make_prebuilt(seed=4, n_plane=400_001, n_line=77_777, n_point=13_000)
     P0 = hip_module.HipRegistration()
     if form == "mailbox_fused":
         os.environ["TLOAM_FUSED_LARGE"] = "1"
@@ -263,7 +264,7 @@ def test_one_rank_loopback_runs_the_sharded_forms_bit_for_bit(hip_module, form):
     for R in (P0, P):
         for rt in range(3):
             R.set_correspondences(rt, *sets[rt])
-    assert P.info()["k3_single"] == 0
+    assert P.info()["k3_single"] == 0 and P.info()["k3_wide"] == (1 if P.info()["device_cus"] <= 256 else 0)
     xa, sa = P0.solve(x_eval); xb, sb = P.solve(x_eval)
     assert np.array_equal(xa, xb) and sa["gn_evaluations"] == sb["gn_evaluations"]
 

@@ -202,6 +202,7 @@ int tloam_get_info(tloam_ctx* c, tloam_ctx_info* out) {
   out->fallback_events = c->fallback_events;
   out->k3_grid = c->k3_grid;
   out->k3_single = c->k3_single ? 1 : 0;
+  out->k3_wide = c->k3_wide ? 1 : 0;
   out->one_launch_solve = (one_rank(c) && c->k3_single && !c->no_persistent_solve && solve_small_fits(c->k3_grid, c->device_cus)) ? 1 : 0;
   return TLOAM_OK;
 }

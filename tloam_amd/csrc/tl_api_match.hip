@@ -136,12 +136,12 @@ int launch_k3_timed(tloam_ctx* c, bool force) {
       c->ev_pool.resize(old + 256);
       for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
     }
-    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, force, c->stream, c->ev_pool[c->ev_used],
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, force, c->stream, c->ev_pool[c->ev_used],
               c->ev_pool[c->ev_used + 1]);
     c->ev_used += 2;
     c->ev_batch_idx.push_back(idx);
   } else {
-    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, force, c->stream);
+    launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, force, c->stream);
   }
   return TLOAM_OK;
 }
@@ -157,12 +157,12 @@ int launch_k3_step_timed(tloam_ctx* c) {
       c->ev_pool.resize(old + 256);
       for (size_t i = old; i < c->ev_pool.size(); ++i) HIPC(c, hipEventCreate(&c->ev_pool[i]));
     }
-    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream,
+    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, c->k3_ticket.p, c->k3_span.p, mb, c->stream,
                    c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], iter_span_of(c));
     c->ev_used += 2;
     c->ev_batch_idx.push_back(idx);
   } else {
-    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_ticket.p, c->k3_span.p, mb, c->stream, nullptr,
+    launch_k3_step(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, c->k3_ticket.p, c->k3_span.p, mb, c->stream, nullptr,
                    nullptr, iter_span_of(c));
   }
   return TLOAM_OK;
@@ -279,7 +279,7 @@ int enqueue_solve(tloam_ctx* c, bool armed, int sweeps, const WeightParams* wp =
       fuse.ticket = c->k3_ticket.p;
       fuse.out48 = c->red48.p;
       if (c->comm == COMM_MAILBOX) fuse.mb = c->mbox;
-      launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, false, fuse, c->stream);
+      launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, false, fuse, c->stream);
       c->batch_launches++;
       if (c->comm == COMM_MAILBOX) {
         launch_gn_step_mbox(c->state.p, c->mbox, c->stream, iter_span_of(c));
@@ -383,7 +383,7 @@ int tloam_sm_begin(tloam_ctx* c, const double predict[16], const double* omega3)
   {
     int caps[kKinds];
     for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
-    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single);
+    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single, &c->k3_wide);
     (void)total_cap;
   }
   {
@@ -1052,8 +1052,12 @@ int tloam_sm_end(tloam_ctx* c, double result[16], tloam_stats* stats) {
 int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega3, double result[16],
                      double* scan_xyz, size_t n_scan, tloam_stats* stats) {
   if (n_scan > kMaxPoints) return TLOAM_E_INVALID;
+  static const bool stamps = getenv("TLOAM_HOST_STAMPS") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double hs0 = stamps ? now_us() : 0.0;
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
+  const double hs1 = stamps ? now_us() : 0.0;
   int done = 0;
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
@@ -1085,7 +1089,22 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     if (rc == TLOAM_E_WEIGHT_RANGE) { weight_violation = true; continue; }  // reported after the solve
     if (rc != TLOAM_OK) return rc;
   }
+  const double hs2 = stamps ? now_us() : 0.0;
   rc = tloam_sm_end(c, result, stats);
+  if (stamps && c) {
+    const double hs3 = now_us();
+    if (c->hs_exit > 0.0) c->hs[0] += hs0 - c->hs_exit;   // the caller, between two calls
+    c->hs[1] += hs1 - hs0;                                 // sm_begin: set-up + the grid build's launches
+    c->hs[2] += hs2 - hs1 - c->wait_us;                    // the loop: enqueueing, bookkeeping (without the wait)
+    c->hs[3] += c->wait_us;
+    c->hs[4] += hs3 - hs2;                                 // sm_end
+    c->hs_exit = hs3;
+    if (++c->hs_n % 200 == 0) {
+      fprintf(stderr, "[tloam host stamps] per frame over 200: caller %.2f  begin %.2f  loop-without-wait %.2f  wait %.2f  end %.2f us\n",
+              c->hs[0] / 200, c->hs[1] / 200, c->hs[2] / 200, c->hs[3] / 200, c->hs[4] / 200);
+      for (int i = 0; i < 8; ++i) c->hs[i] = 0.0;
+    }
+  }
   if (rc == TLOAM_E_HIP && c->no_scan_1p && !c->scan1p_retried) {
     // a look-back scan of this frame gave up (check_device_faults): the clouds are intact in HBM and the context has been
     // switched to the multi-launch scans -- run the frame again, once
@@ -1366,7 +1385,7 @@ int tloam_set_correspondences(tloam_ctx* c, int res_type, size_t n, const double
   {
     int caps[kKinds];
     for (int k = 0; k < kKinds; ++k) caps[k] = (int)c->kd[k].c_cap;
-    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single);
+    k3_plan(caps, c->device_cus, &c->k3_grid, &c->k3_single, &c->k3_wide);
     (void)total_cap;
   }
   return reserve_partials(c);
@@ -1464,7 +1483,7 @@ int tloam_time_accumulate(tloam_ctx* c, const double se3[6], int launches, doubl
   HIPC(c, hipEventCreate(&e0));
   HIPC(c, hipEventCreate(&e1));
   HIPC(c, hipEventRecord(e0, c->stream));
-  for (int i = 0; i < launches; ++i) launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, true, c->stream);
+  for (int i = 0; i < launches; ++i) launch_k3(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, true, c->stream);
   HIPC(c, hipEventRecord(e1, c->stream));
   HIPC(c, hipEventSynchronize(e1));
   float ms = 0.f;
@@ -1499,7 +1518,7 @@ int tloam_time_sharded_sweep(tloam_ctx* c, const double se3[6], int launches, in
   HIPC(c, hipEventRecord(e0, c->stream));
   int rc = TLOAM_OK;
   for (int i = 0; i < launches && rc == TLOAM_OK; ++i) {
-    launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, true, fuse, c->stream);
+    launch_k3_fused(c->cv, c->state.p, c->partials.p, c->k3_grid, c->k3_single, c->k3_wide, true, fuse, c->stream);
     if (mbox) launch_mbox_gather_only(c->red48.p, c->mbox, c->stream);
     else if (with_exchange) rc = allreduce(c, c->red48.p, kReduceBuf);
   }

@@ -507,8 +507,9 @@ void launch_feat_select(const FeatArgs& A, const FeatSelect& S, unsigned long lo
 
 // K3 and the minimiser
 int k3_grid_for(int total_cap, int device_cus);
-void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single);  // one wave per chunk (small sets) vs the streaming variant
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
+// one wave per chunk (small sets) vs the streaming variant (wide: blocks of eight waves, see tl_gn.hip); *grid = blocks launched = rows
+void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single, bool* wide);
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, bool force, hipStream_t s,
                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // sharded contexts: the sweep whose LAST block (ticket counter) also folds the block rows into out48 and, with a
 // mailbox, posts them to every rank -- the sweep of a sharded GN iteration is then 2 launches (+ the collective)
@@ -517,12 +518,12 @@ struct K3Fuse {
   double* out48;     // this rank's totals (all-reduced by RCCL / the callback when there is no mailbox)
   MboxView mb;       // mb.nranks == 0: no mailbox
 };
-void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
+void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, bool force,
                      const K3Fuse& fuse, hipStream_t s);
 // one GN iteration in ONE launch, whatever the size of the set: the sweep whose last block folds the rows and advances the
 // minimiser (mailbox contexts: posts, gathers and advances) -- k3_sweep_step, tl_gn.hip.  span: see K3Step (may be null)
 // iter_span (every launcher of a kernel that ends a GN iteration): the device-side period counter of tloam_gn_iter_timer, or null
-void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
+void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, int* ticket, unsigned long long* span,
                     const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
                     unsigned long long* iter_span = nullptr);
 void launch_gn_step_mbox(GnState* st, const MboxView& mb, hipStream_t s, unsigned long long* iter_span = nullptr);   // gather (rank order) + consume

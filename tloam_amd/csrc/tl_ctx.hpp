@@ -187,6 +187,7 @@ struct tloam_ctx {
   double* h_small = nullptr;   // pinned scratch (>= 64*6*4 doubles)
   int k3_grid = 1;
   bool k3_single = false;
+  bool k3_wide = false;        // the streaming sweep goes out as blocks of eight waves (k3_plan); k3_grid = blocks launched = rows
   int dbg_max_sweeps = 0;          // development knobs, read from the environment once at create
   bool dbg_no_build_reuse = false;
   bool dbg_no_eval_reuse = false;
@@ -203,6 +204,9 @@ struct tloam_ctx {
   double tgt_box[tl::kKinds][6];
   bool tgt_box_valid[tl::kKinds] = {false, false, false, false};
   double wait_us = 0.0;            // time the host spent waiting for the device in the current scan_match
+  double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // development aid (TLOAM_HOST_STAMPS): where the calling thread's time goes, per frame
+  long hs_n = 0;
+  double hs_exit = 0.0;
   tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
   tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;

@@ -490,11 +490,19 @@ __device__ __forceinline__ bool mbox_gather(const MboxView& mb, unsigned long lo
 // each other) followed by a wait for their completion and the ticket; the last block reads the rows with device-scope
 // loads.  No cache-wide release / acquire (a `__threadfence()` here writes back and invalidates the whole L2 of the
 // XCD: that is what made round 1's fused sweep + step cost what the launch boundary it removed did).
+// the block's row from its waves' totals: four waves in order; a WIDE block (eight waves, launch_k3) adds its two halves
+template <int W>
+__device__ __forceinline__ double block_row(const double (*red)[32], int c) {
+  double t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+#pragma unroll
+  for (int q = 4; q < W; q += 4) t += ((red[q][c] + red[q + 1][c]) + red[q + 2][c]) + red[q + 3][c];
+  return t;
+}
+template <int W = 4>
 __device__ __forceinline__ bool k3_take_ticket(double* __restrict__ partials, const double (*red)[32], int* ticket) {
   __shared__ int s_last;
   if (threadIdx.x < kAccStride)
-    __hip_atomic_store(partials + (size_t)blockIdx.x * kAccStride + threadIdx.x,
-                       ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x],
+    __hip_atomic_store(partials + (size_t)blockIdx.x * kAccStride + threadIdx.x, block_row<W>(red, threadIdx.x),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // The row must have REACHED the coherence point before the ticket is taken: row store and ticket RMW travel through
   // different L2 channels and are not ordered with each other.  A workgroup-scope release emits no vmcnt wait on gfx950
@@ -518,12 +526,14 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
   double v[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) v[u] = 0.0;
+  // (a wide block -- eight waves, k3_plan -- folds with its first 256 threads; the others only meet the barriers)
+  const int rows_mine = threadIdx.x < 256 ? rows : 0;
   // FOUR passes of sixteen loads requested before the first is added (a full-chip grid of 512 rows is four passes: four dependent
   // trips to memory became one -- round 6: the 1 M GN iteration 21.8 -> 21.5 us, three interleaved pairs on one box); the additions
   // keep the order of the one-pass-at-a-time form, so the sums keep their bits
   // (kP = 4 where the kernel has the registers -- the step kernels, one wave per SIMD; the sweeps that fold in their last block run
   //  at 128 registers per wave and keep one pass in flight: 64 more doubles there are scratch)
-  for (int b00 = grp; b00 < rows; b00 += kP * kU * 8) {
+  for (int b00 = grp; b00 < rows_mine; b00 += kP * kU * 8) {
     double x[kP][kU];
 #pragma unroll
     for (int q = 0; q < kP; ++q)
@@ -543,7 +553,7 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
   for (int w = kU / 2; w >= 1; w >>= 1)
 #pragma unroll
     for (int u = 0; u < w; ++u) v[u] += v[u + w];
-  s_grp[grp * 33 + comp] = v[0];
+  if (threadIdx.x < 256) s_grp[grp * 33 + comp] = v[0];
   __syncthreads();
   if (threadIdx.x < kReduceBuf) {
     double t = 0.0;
@@ -637,10 +647,11 @@ __device__ __forceinline__ bool poll_fold_tagged(const double* __restrict__ part
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   return ok_all;
 }
+template <int W = 4>
 __device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partials, const double (*red)[32], const K3Fuse& fuse) {
   __shared__ double s_grp[8 * 33];
   __shared__ double s_tot[kReduceBuf];
-  if (!k3_take_ticket(partials, red, fuse.ticket)) return;
+  if (!k3_take_ticket<W>(partials, red, fuse.ticket)) return;
   fold_rows<true>(partials, (int)gridDim.x, s_grp, s_tot);
   if (threadIdx.x < kReduceBuf) fuse.out48[threadIdx.x] = s_tot[threadIdx.x];
   if (threadIdx.x == 0) __hip_atomic_store(fuse.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
@@ -654,16 +665,18 @@ __device__ __forceinline__ void k3_last_block_reduce(double* __restrict__ partia
 // the segment sizes and the output rows -- are preloaded into SGPRs by the command processor
 // (-mllvm -amdgpu-kernarg-preload-count=12, see build.py), so the wave's first chunk AND the state's scalar loads
 // are requested in the first instructions, before the kernel-argument segment itself has been read.
-template <bool SINGLE, bool FUSE>
-__global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const double* __restrict__ seg0, int stride0, int cap0,
+// W: waves per block.  4, two blocks per CU; 8 (WIDE, streaming form on a full-chip grid): one block per CU, the same waves over the
+// same chunks, HALF the rows for the one block that folds them afterwards.
+template <bool SINGLE, bool FUSE, int W = 4>
+__global__ __launch_bounds__(64 * W, TLOAM_K3_WAVES) void k3_accumulate(const double* __restrict__ seg0, int stride0, int cap0,
                                                         int force, GnState* __restrict__ st,
                                                         const int* __restrict__ seg_n, double* __restrict__ partials,
                                                         CorrView cv, K3Fuse fuse) {
-  __shared__ double red[4][32];
+  __shared__ double red[W][32];
   // the wave index is wave-uniform: tell the compiler (readfirstlane) so that chunk -> segment
   // pointers are scalar (SGPR) work instead of per-lane loads of the kernel-argument table
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * 4 + wave;
+  const int gw = blockIdx.x * W + wave;
   // Speculative first fetch: the wave's first chunk of the planar segment is requested straight from the
   // preloaded arguments, BEFORE the dependent scalar loads of the state (done flag, pose, segment sizes)
   // come back -- their latency overlaps the first HBM round trip.  The capacity bound keeps it in range.
@@ -689,7 +702,7 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
 #endif
   if (SINGLE) sweep_single(cv, seg_n, T, wk, pre, a);
-  else sweep_all(cv, seg_n, T, gw, gridDim.x * 4, lane, a, pre, spec);
+  else sweep_all(cv, seg_n, T, gw, gridDim.x * W, lane, a, pre, spec);
 #ifdef TLOAM_K3_PROFILE
   __builtin_amdgcn_s_waitcnt(0);
   const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
@@ -698,10 +711,9 @@ __global__ __launch_bounds__(256, TLOAM_K3_WAVES) void k3_accumulate(const doubl
   if ((lane & 1) == 0) red[wave][lane >> 1] = tot;
   __syncthreads();
   if (FUSE) {
-    k3_last_block_reduce(partials, red, fuse);
+    k3_last_block_reduce<W>(partials, red, fuse);
   } else if (threadIdx.x < kAccStride) {
-    partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] =
-        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    partials[(size_t)blockIdx.x * kAccStride + threadIdx.x] = block_row<W>(red, threadIdx.x);
   }
 #ifdef TLOAM_K3_PROFILE
   if (threadIdx.x == 0) {  // development aid (scripts/k3_profile.py): wave 0's timeline in the spare columns
@@ -732,14 +744,20 @@ int k3_grid_for(int total_cap, int device_cus) {
     // balance: every wave gets the same number of chunks
     const int per_wave = (waves + resident * 4 - 1) / (resident * 4);
     const int need_waves = (waves + per_wave - 1) / per_wave;
-    blocks = (need_waves + 3) / 4;
+    blocks = (need_waves + 7) / 8 * 2;   // an even count: a full-chip grid goes out as wide blocks of eight waves (k3_plan)
   }
   return blocks;
 }
 // The sweep of a set with segment capacities cap[k] (multiples of kChunk): one wave per chunk (sweep_single: chunks of
 // single_chunk_of(kind) correspondences) while that fits the resident chip, the streaming variant otherwise.
-void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single) {
+// wide: the streaming sweep of a grid of at least 1.5 four-wave blocks per CU goes out as HALF as many blocks of EIGHT waves -- the
+// same waves over the same chunks with the same registers, one block per CU instead of two, and half the rows for the one block
+// that folds them afterwards (k_reduce_and_step, the last block of the fused forms): the fold is a stream of 256 B per row through
+// ONE CU, ~13 cycles per row -- round 6, 1 M frame: fold 7500 -> 4100 cycles, GN iteration 22.6 -> 21.0 us, three interleaved pairs;
+// blocks of sixteen waves leave half the CUs idle: K3 12.3 -> 17.3 us).  *grid = blocks LAUNCHED = rows written.
+void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single, bool* wide) {
   long long waves = 0, total = 0;
+  *wide = false;
   for (int k = 0; k < kKinds; ++k) {
     waves += (cap[k] + single_chunk_of(k) - 1) / single_chunk_of(k);
     total += cap[k];
@@ -752,31 +770,37 @@ void k3_plan(const int cap[kKinds], int device_cus, int* grid, bool* single) {
   }
   *grid = k3_grid_for((int)total, device_cus);
   *single = ((total + kChunk - 1) / kChunk <= (long long)*grid * 4) && TLOAM_SMALL_LINE_CHUNK == kChunk;
+  static const bool no_wide = getenv("TLOAM_K3_NARROW") != nullptr;   // tuning aid / A-B
+  if (!*single && !no_wide && *grid % 2 == 0 && 2 * *grid >= 3 * (device_cus > 0 ? device_cus : 256)) {
+    *wide = true;
+    *grid /= 2;
+  }
 }
 // bit 1 of the sweep kernels' flag word: the planar segment's weight pointer is the segment's SECOND weight stream (the planar
 // streams are addressed from the preloaded (base, stride), not through the view -- see fetch_spec)
 static int w2_flag(const CorrView& cv) {
   return (cv.k[0].w != nullptr && cv.k[0].w == cv.k[0].px + (size_t)(SS_W2 - SS_PX) * (size_t)cv.k[0].stride) ? 2 : 0;
 }
-void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force, hipStream_t s,
+void launch_k3(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, bool force, hipStream_t s,
                hipEvent_t ev_start, hipEvent_t ev_stop) {
-  auto kern = single ? k3_accumulate<true, false> : k3_accumulate<false, false>;
+  auto kern = single ? k3_accumulate<true, false> : wide ? k3_accumulate<false, false, 8> : k3_accumulate<false, false>;
+  const int threads = wide ? 512 : 256;
   K3Fuse none;
   memset(&none, 0, sizeof(none));
   if (ev_start && ev_stop) {
     // HIP events bound to THIS dispatch (start/stop taken from the kernel's own dispatch packet):
     // their elapsed time is the kernel duration itself, the number rocprofv3 --kernel-trace reports
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
                           cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st, cv.seg_n, partials, cv, none);
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
                        cv.seg_n, partials, cv, none);
   }
 }
-void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool force,
+void launch_k3_fused(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, bool force,
                      const K3Fuse& fuse, hipStream_t s) {
-  auto kern = single ? k3_accumulate<true, true> : k3_accumulate<false, true>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
+  auto kern = single ? k3_accumulate<true, true> : wide ? k3_accumulate<false, true, 8> : k3_accumulate<false, true>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(wide ? 512 : 256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, (force ? 1 : 0) | w2_flag(cv), st,
                      cv.seg_n, partials, cv, fuse);
 }
 
@@ -950,7 +974,14 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_and_step(const double* _
     const unsigned long long w = threadIdx.x < kWords ? reinterpret_cast<const unsigned long long*>(st)[threadIdx.x] : 0ull;
     if (threadIdx.x < kWords) reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = w;
   }
+#ifdef TLOAM_STEP_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) st->dbg[7] = (double)__builtin_readcyclecounter();   // the state has arrived
+#endif
   fold_rows<false, 4>(partials, rows, lds, tot);  // (its barriers also publish s_in)
+#ifdef TLOAM_STEP_PROFILE
+  if (threadIdx.x == 0) st->dbg[8] = (double)__builtin_readcyclecounter();   // the rows are folded
+#endif
   if (s_in.done) return;  // after a tolerance exit the remaining launches are no-ops
   const bool first = s_in.phase == PH_ITER0;
   if (threadIdx.x < 64) gn_consume(st, tot, threadIdx.x, &s_in, lds /* free again: the fold is over */);
@@ -981,17 +1012,17 @@ struct K3Step {
   unsigned long long* iter_span;   // iter_span_note, or null
   MboxView mb;                 // mb.nranks == 0: one rank
 };
-template <bool SINGLE>
-__global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict__ seg0, int stride0, int cap0, int unused,
+template <bool SINGLE, int W = 4>
+__global__ __launch_bounds__(64 * W, 2) void k3_sweep_step(const double* __restrict__ seg0, int stride0, int cap0, int unused,
                                                         GnState* __restrict__ st, const int* __restrict__ seg_n,
                                                         double* __restrict__ partials, CorrView cv, K3Step fs) {
-  __shared__ double red[4][32];
+  __shared__ double red[W][32];
   __shared__ double s_grp[8 * 33];
   __shared__ double tot[kMboxSlot];
   __shared__ GnState s_in;
   const bool w2 = (unused & 2) != 0;   // (as k3_accumulate's flag word)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = blockIdx.x * 4 + wave;
+  const int gw = blockIdx.x * W + wave;
   ChunkData pre;
   SingleWork wk{-1, 0};
   const bool spec = !SINGLE && (gw + 1) * kChunk <= cap0;
@@ -1005,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
     __hip_atomic_store(fs.span, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   {
     constexpr int kWords = (int)(sizeof(GnState) / 8);
-    static_assert(kWords <= 256, "one word per thread");
+    static_assert(kWords <= 256, "one word per thread");   // (the first 256 threads of a wide block)
     if (threadIdx.x < kWords)
       reinterpret_cast<unsigned long long*>(&s_in)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(st)[threadIdx.x];
   }
@@ -1013,11 +1044,11 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
   const Rt T = st->Rt_eval;
   Acc a;
   if (SINGLE) sweep_single(cv, seg_n, T, wk, pre, a);
-  else sweep_all(cv, seg_n, T, gw, gridDim.x * 4, lane, a, pre, spec);
+  else sweep_all(cv, seg_n, T, gw, gridDim.x * W, lane, a, pre, spec);
   const double wtot = wave_reduce_acc(a, lane);
   if ((lane & 1) == 0) red[wave][lane >> 1] = wtot;
   __syncthreads();                 // (also publishes s_in)
-  if (!k3_take_ticket(partials, red, fs.ticket)) return;
+  if (!k3_take_ticket<W>(partials, red, fs.ticket)) return;
   // ---- the last block: every row has reached the coherence point
   if (fs.span && threadIdx.x == 0) {
     const unsigned long long t1 = wall_clock64();
@@ -1047,9 +1078,9 @@ __global__ __launch_bounds__(256, 2) void k3_sweep_step(const double* __restrict
   gn_consume(st, tot, (int)threadIdx.x, &s_in, s_grp /* free again: the fold is over */);
   if (threadIdx.x == 0) iter_span_note(fs.iter_span, first);
 }
-void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, int* ticket, unsigned long long* span,
+void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid, bool single, bool wide, int* ticket, unsigned long long* span,
                     const MboxView* mb_or_null, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop, unsigned long long* iter_span) {
-  auto kern = single ? k3_sweep_step<true> : k3_sweep_step<false>;
+  auto kern = single ? k3_sweep_step<true> : wide ? k3_sweep_step<false, 8> : k3_sweep_step<false>;
   K3Step fs;
   memset(&fs, 0, sizeof(fs));
   fs.ticket = ticket;
@@ -1057,10 +1088,10 @@ void launch_k3_step(const CorrView& cv, GnState* st, double* partials, int grid,
   fs.iter_span = iter_span;
   if (mb_or_null) fs.mb = *mb_or_null;
   if (ev_start && ev_stop) {
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(wide ? 512 : 256), 0, s, ev_start, ev_stop, 0, (const double*)cv.k[0].px, cv.k[0].stride,
                           cv.k[0].cap, w2_flag(cv), st, cv.seg_n, partials, cv, fs);
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, w2_flag(cv), st, cv.seg_n,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wide ? 512 : 256), 0, s, (const double*)cv.k[0].px, cv.k[0].stride, cv.k[0].cap, w2_flag(cv), st, cv.seg_n,
                        partials, cv, fs);
   }
 }

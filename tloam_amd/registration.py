@@ -67,7 +67,8 @@ class CtxInfo(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("device_cus", C.c_int32), ("comm_mode", C.c_int32),
                 ("rank", C.c_int32), ("nranks", C.c_int32), ("rccl_comm_count", C.c_int32), ("rccl_comm_rank", C.c_int32),
                 ("fallbacks_taken", C.c_int32), ("fallback_events", C.c_int32), ("k3_grid", C.c_int32), ("k3_single", C.c_int32),
-                ("one_launch_solve", C.c_int32), ("loopback", C.c_int32), ("direct_set", C.c_int32), ("set_stale", C.c_int32)]
+                ("one_launch_solve", C.c_int32), ("loopback", C.c_int32), ("direct_set", C.c_int32), ("set_stale", C.c_int32),
+                ("k3_wide", C.c_int32)]
 
 
 class Stats(C.Structure):
