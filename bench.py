@@ -185,8 +185,37 @@ def parse():
     return ap.parse_args()
 
 
+_LINE_FD = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 of this process carries ONE thing, the JSON line: the descriptor is kept aside for it and
+    everything else that writes to stdout -- this script's own prints, and libraries that print through C stdio (RCCL's version
+    banner sits in a stdio buffer until exit, i.e. it would come out BEHIND the line) -- goes to stderr."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    """the JSON line, whole, on the real stdout"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)    # C stdio buffers of any library, to wherever descriptor 1 points now
+    except OSError:
+        pass
+    sys.stdout.flush()
+    data = (json.dumps(out) + "\n").encode()
+    fd = _LINE_FD if _LINE_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
     args = parse()
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -519,7 +548,7 @@ def main():
             out.update(sharded_flat(sharded, world))
         if not finished:   # a thread of this process is stuck inside a collective: nothing can be torn down in order
             if rank == 0:
-                print(json.dumps(out), flush=True)
+                emit(out)
             sys.stdout.flush()
             os._exit(0)
 
@@ -553,7 +582,7 @@ def main():
         if args.kitti_dir:
             out["kitti_replay"] = kitti_replay(args, reg, torch, local_rank)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if multi:
         def leave():
             dist.barrier()
@@ -608,7 +637,7 @@ def guarded(fn, seconds, name, out, rank):
     out[name] = {"error": "%s did not finish within %.0f s; every GPU figure of this line was measured before it started" % (name, seconds),
                  "kind": "port"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     sys.stdout.flush()
     os._exit(0)
 
