@@ -12,7 +12,7 @@
 set -u
 TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; P=$O/profiles; mkdir -p $O $P
-(cd $R && timeout 1500 python -X faulthandler -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -5) > $O/pytest.txt; cat $O/pytest.txt
+(cd $R && timeout 1500 python -X faulthandler -m pytest tests -m gpu -q --timeout 300 2>&1 | grep -E "passed|failed|rror" | tail -5) > $O/pytest.txt; cat $O/pytest.txt
 cd /tmp && export TMPDIR=/tmp
 for S in 1 4; do
   N=$([ $S = 1 ] && echo prebuilt || echo cold)

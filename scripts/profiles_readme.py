@@ -34,7 +34,7 @@ def k3_row(path):
     try:
         for row in csv.DictReader(open(path)):
             nm = row.get("name") or row.get("Name") or ""
-            if nm.startswith("k3_accumulate<false, false>") or "k3_accumulate<false, false>" in nm:
+            if "k3_accumulate<false, false" in nm:   # (<false, false, 8>: the wide blocks of round 6)
                 return row
     except OSError:
         pass
@@ -56,6 +56,30 @@ try:
           % (b["value"], b["ms_per_step"], r["frac"], r["avg_launch_us"], r["l3_resident"]["frac"], r["l3_resident"]["avg_launch_us"]))
 except Exception as e:  # noqa: BLE001
     print("\n(bench line not readable: %r)" % (e,))
+try:
+    # the sweep INSIDE the 1 M frame and the GN iteration around it, from the kernel trace of the frame (the bench line's
+    # roofline.in_frame_frac / gn_iteration_frac come from HIP event pairs / the device's clock in an unprofiled run)
+    rows = []
+    for ln in open(os.path.join(d, tag + "_m1_frame_timeline.txt")):
+        f = ln.split()
+        if len(f) > 5 and f[0].isdigit() and "dur" in f:
+            rows.append((" ".join(f[1:f.index("dur")]), float(f[f.index("dur") + 1]), float(f[f.index("gap_before") + 1])))
+    k3 = [r[1] for r in rows if r[0].startswith("k3_accumulate")]
+    periods = [rows[i][1] + rows[i][2] + rows[i + 1][1] + rows[i + 1][2] for i in range(len(rows) - 2)
+               if rows[i][0].startswith("k3_accumulate") and rows[i + 1][0].startswith("k_reduce_and_step") and rows[i + 2][0].startswith("k3_accumulate")]
+    byt = b["roofline"]["in_frame"]["algorithmic_bytes_per_launch"]
+    k3m, pm = sum(k3) / len(k3), sum(periods) / len(periods)
+    print("\n`%s_m1_frame_timeline.txt`: %d sweeps of a frame, mean of the medians %.2f us -> %.0f B / %.2f us / 8 TB/s = **%.3f** in the frame "
+          "(bench: in_frame_frac %.3f by event pairs, which add ~1 us); sweep + fold / step with its successor's gap, %d periods: %.2f us -> "
+          "**%.3f** of the HBM peak per GN iteration (bench: gn_iteration_us %.2f by the device's clock, gn_iteration_frac %.3f)."
+          % (tag, len(k3), k3m, byt, k3m, byt / (k3m * 1e-6) / 8e12, b["roofline"]["in_frame_frac"], len(periods), pm,
+             byt / (pm * 1e-6) / 8e12, b["roofline"]["gn_iteration_us"], b["roofline"]["gn_iteration_frac"]))
+    rs = b["roofline"]
+    print("\nRead-stream ceiling measured by the same bench run (`tloam_time_read_stream`): %.0f GB/s from HBM, %.0f GB/s Infinity-Cache "
+          "resident; the cold sweep is at %.3f of the former, the contract set at %.3f of the latter."
+          % (rs["read_stream_GBps"], rs["read_stream_l3_GBps"], rs["frac_of_read_stream"], rs["config3_frac_of_read_stream_l3"]))
+except Exception as e:  # noqa: BLE001
+    print("\n(1 M frame timeline not readable: %r)" % (e,))
 try:
     q = json.loads(open(os.path.join(d, tag + "_kitti_sequence_4540.json")).read().strip().splitlines()[-1])["kitti_sequence"]
     print("\n`%s_kitti_sequence_4540.json`: %d frames, %.4f ms/frame mean / %.4f p50 / %.4f p99, %.1f GN iter/s, %.2f GN iterations per frame; "
