@@ -36,7 +36,7 @@ def test_sharded_summary_reports_what_had_finished():
     none = bench.sharded_summary({}, False, 300.0)
     assert "ms_per_frame" not in none and "mailbox: did not finish" in none["error"] and "rccl: did not finish" in none["error"]
     flat = bench.sharded_flat(none, 8)
-    assert flat["sharded_1m_verified"] is False and flat["sharded_1m_ms_per_frame"] is None and flat["sharded_1m_predicted_speedup"] == 3.05
+    assert flat["sharded_1m_verified"] is False and flat["sharded_1m_ms_per_frame"] is None and flat["sharded_1m_predicted_speedup"] == 1.54
     # both ran: the faster one on top, nothing else added
     both = bench.sharded_summary({"modes": ["mailbox", "rccl"], "mailbox": mailbox, "rccl": dict(mailbox, exchange="rccl", ms_per_frame=1.2)},
                                  True, 300.0)
