@@ -431,3 +431,42 @@ def test_one_context_through_direct_compact_small_and_prebuilt_frames(hip_module
         F.close()
     for H in ctx.values():
         H.close()
+
+
+@pytest.mark.parametrize("direct", [False, True], ids=["compact", "direct"])
+def test_getters_after_a_new_source_cloud_describe_the_frame_that_was_solved(hip_module, direct):
+    """The weights and the correspondences a context hands out are those of the frame its last scanMatching began with, whatever
+    source cloud has been registered since.  Until round 6 tloam_get_weights (and the direct set's getters) took their sizes from
+    the REGISTERED cloud: a larger cloud handed over after a solve turned the getter into a copy past the end of the weights
+    (TLOAM_E_HIP, found by tests/tools/fuzz_call_order.py once it stopped accepting that status)."""
+    import ctypes as C
+    if direct:
+        n_src, n_tgt = (70_000, 40_000, 30_000, 6_000), (80_000, 50_000, 40_000, 8_000)
+        cfg = hip_module.default_config(planar_maxnum=BIG, ground_maxnum=BIG, edge_maxnum=BIG, sphere_maxnum=BIG)
+        sc = synth.make_scene(seed=5, n_src=n_src, n_tgt=n_tgt, density=40.0)
+        other = synth.make_scene(seed=6, n_src=tuple(2 * v for v in n_src), n_tgt=n_tgt, density=40.0)
+    else:
+        cfg = hip_module.default_config()
+        sc = synth.make_scene(seed=11)
+        other = synth.make_scene(seed=12, n_src=tuple(3 * len(sc.source.cloud(k)) for k in range(4)))
+    H = hip_module.HipRegistration(cfg)
+    H.set_frames(sc.source, sc.target)
+    rc, T, st = H.scan_match(sc.T_pred)
+    assert rc == 0 and H.info()["direct_set"] == (1 if direct else 0)
+    w0 = [H.get_weights(k).copy() for k in range(4)]
+    c0 = [H.get_correspondences(k) for k in range(4)]
+    sizes0 = [len(w) for w in w0]
+    H.set_input_source(other.source)            # a LARGER cloud of every kind; nothing is solved with it yet
+    for k in range(4):
+        n = C.c_size_t(0)
+        cap = 4 * max(sizes0) + 16
+        w = np.zeros(cap)
+        rc = H.L.tloam_get_weights(H.h, k, cap, C.byref(n), w.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0 and n.value == sizes0[k], (k, rc, n.value, sizes0[k])
+        assert np.array_equal(w[:n.value], w0[k])
+        c1 = H.get_correspondences(k, capacity=cap)
+        assert c1["idx"].tolist() == c0[k]["idx"].tolist() and np.array_equal(c1["w"], c0[k]["w"]) and np.array_equal(c1["a"], c0[k]["a"])
+    # ... and the next solve is the new frame's
+    rc, T2, st2 = H.scan_match(sc.T_pred)
+    assert rc == 0 and [len(H.get_weights(k)) for k in range(4)] == [2 * v if direct else 3 * v for v in sizes0]
+    H.close()

@@ -47,7 +47,11 @@ def main():
     # two larger frames for the hand-over ops only (four-lane and thread-per-query search, the large-set sweep and finish kernels,
     # the query sort): what is checked on them is "a status code and the context stays good", not the pose
     big = [synth.make_scene(seed=80, n_src=(6000, 8000, 5000, 1000), n_tgt=(8000, 9000, 6000, 1500)),
-           synth.make_scene(seed=81, n_src=(40_000, 50_000, 35_000, 8_000), n_tgt=(30_000, 30_000, 20_000, 5_000))]
+           synth.make_scene(seed=81, n_src=(40_000, 50_000, 35_000, 8_000), n_tgt=(30_000, 30_000, 20_000, 5_000)),
+           # above the thread-per-query limit: with the caps lifted (a context re-created by op 27 may have them so) the frame keeps
+           # its factors as a DIRECT set (rows in the search's order, two weight streams, the finish riding on the next search)
+           synth.make_scene(seed=82, n_src=(70_000, 40_000, 30_000, 8_000), n_tgt=(40_000, 30_000, 20_000, 5_000))]
+    LIFTED = dict(planar_maxnum=1 << 30, ground_maxnum=1 << 30, edge_maxnum=1 << 30, sphere_maxnum=1 << 30)
     H = reg.HipRegistration()
     L, h = H.L, H.h
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))          # noqa: E731
@@ -61,6 +65,9 @@ def main():
             print("   -> %s: %s %s" % (name, reg.STATUS.get(rc, rc), (L.tloam_last_error(h) or b"").decode()[:100] if rc else ""), file=sys.stderr, flush=True)
         counts[name] = counts.get(name, 0) + 1
         assert rc in KNOWN, (name, rc)
+        # no call of this tool may end in a failed HIP call: nothing it does exhausts the device, so TLOAM_E_HIP here is a defect of
+        # the library (round 6: a getter that copied past the end of a buffer was "a documented status" for a round)
+        assert reg.STATUS.get(rc) != "TLOAM_E_HIP", (name, (L.tloam_last_error(h) or b"").decode()[:300])
         seen.setdefault(name, set()).add(rc)
 
     def cloud(n):
@@ -99,7 +106,7 @@ def main():
         if only is not None and i not in only:
             continue
         h = H.h
-        op = int(rng.integers(0, 29))
+        op = int(rng.integers(0, 33))
         kind = int(rng.choice([-1, 0, 1, 2, 3, 4, 7]))
         n = int(rng.choice([0, 1, 9, 10, 11, 200, 3000]))
         if os.environ.get("FUZZ_LOG"):     # (a fault of the GPU ends the process: the last lines say which call it was)
@@ -113,7 +120,7 @@ def main():
         elif op == 2:
             note("set_source(null)", L.tloam_set_source(h, kind, null_d, n))
         elif op == 3:
-            j = int(rng.integers(0, 16))
+            j = int(rng.integers(0, 17))
             sc = big[j - 14] if j >= 14 else scenes[j % 3]
             H.set_frames(sc.source, sc.target)
         elif op == 4:
@@ -249,7 +256,8 @@ def main():
             # place: it is handed the dead one's device memory
             if rng.integers(0, 4) == 0:
                 H.close()
-                H.__init__()
+                # (every third successor with the caps lifted: the clean-frame check holds either way -- the scenes' caps do not bind)
+                H.__init__(reg.default_config(**LIFTED) if rng.integers(0, 3) == 0 else None)
                 h = H.h
                 note("destroy + create", 0)
         elif op == 28:
@@ -263,6 +271,27 @@ def main():
                 m = int(rng.choice([100, 5000, 60000]))
                 X.set_correspondences(0, cloud(m), cloud(m), None, rng.normal(0, 1, m), None)
             X.close()
+        elif op == 29:
+            ci = reg.CtxInfo()
+            note("get_info", L.tloam_get_info(h, C.byref(ci) if rng.integers(0, 4) else None))
+            assert ci.fallbacks_taken == 0 and 0 <= ci.k3_wide <= 1 and ci.nranks >= 0
+        elif op == 30:
+            us = C.c_double(0); cnt = C.c_int64(0)
+            note("gn_iter_timer", L.tloam_gn_iter_timer(h, int(rng.integers(0, 2)), C.byref(us), C.byref(cnt)))
+            assert cnt.value >= 0 and us.value >= 0.0
+        elif op == 31:
+            gb = C.c_double(0)
+            nb = int(rng.choice([0, 1, 4096, 10_000_000]))
+            note("time_read_stream", L.tloam_time_read_stream(h, C.c_size_t(nb), int(rng.choice([0, 1, 3])), C.byref(gb)))
+        elif op == 32:
+            # a VALID one-rank mailbox set-up: from here on the context runs the sharded launch forms with a loop-back exchange
+            # (same results bit for bit: the clean-frame check keeps holding) -- and a second set-up on a context that has one
+            if rng.integers(0, 6) == 0:
+                buf = C.create_string_buffer(64)
+                rc = L.tloam_comm_mailbox_export(h, C.cast(buf, C.c_void_p))
+                note("comm_mailbox_export", rc)
+                if rc == 0:
+                    note("comm_init_mailbox(loop-back)", L.tloam_comm_init_mailbox(h, 0, 1, C.cast(buf, C.c_void_p)))
         if os.environ.get("FUZZ_SYNC"):   # a blocking copy after every call: a GPU fault is then reported in the call that caused it
             L.tloam_debug_state(h, dp(sync_buf), 8)
         if i % 250 == 249 and only is None:

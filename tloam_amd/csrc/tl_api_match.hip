@@ -1198,7 +1198,7 @@ static int regen_direct_set(tloam_ctx* c) {
 static int get_correspondences_direct(tloam_ctx* c, int kind, size_t capacity, size_t* n, int32_t* src_index, double* a, double* b,
                                       double* d, double* w, double* cost) {
   if (c->set_stale) { const int rc = regen_direct_set(c); if (rc != TLOAM_OK) return rc; }
-  const size_t rows = c->kd[kind].n_src;
+  const size_t rows = (size_t)(c->sv.slot_off[kind + 1] - c->sv.slot_off[kind]);   // (of the frame the solve began with, not of the cloud registered now)
   const CorrSeg& s = c->cv.k[kind];
   std::vector<int> idx(rows);
   if (rows > 0) HIPC(c, hipMemcpy(idx.data(), s.idx, sizeof(int) * rows, hipMemcpyDeviceToHost));
@@ -1253,9 +1253,13 @@ int tloam_get_correspondences(tloam_ctx* c, int kind, size_t capacity, size_t* n
 int tloam_get_weights(tloam_ctx* c, int kind, size_t capacity, size_t* n, double* w) {
   if (!c || kind < 0 || kind >= kKinds || !n) return TLOAM_E_INVALID;
   HIPC(c, hipSetDevice(c->device));
-  const size_t m = c->kd[kind].n_src;
+  // the weights are those of the frame the last scanMatching BEGAN with (its slot table), whatever source cloud has been handed over
+  // since (until round 6 the size came from the registered cloud: a larger cloud handed over after a solve made this a copy past
+  // the end of the weights -- tests/tools/fuzz_call_order.py, TLOAM_E_HIP from a getter)
+  const bool begun = c->w_src.p != nullptr && c->sv.slot_off[kKinds] > 0;
+  const size_t m = begun ? (size_t)(c->sv.slot_off[kind + 1] - c->sv.slot_off[kind]) : c->kd[kind].n_src;
   *n = m;
-  if (m > capacity || !c->w_src.p) return TLOAM_E_INVALID;
+  if (m > capacity || !begun) return TLOAM_E_INVALID;
   HIPC(c, hipStreamSynchronize(c->stream));
   if (c->direct && !c->prebuilt) {   // the current GNC weights live in the rows' weight stream `w_parity`: back to source-index order
     if (w && m > 0 && !c->have_build) {   // (no search has run in this frame yet: registration.cpp:931-949, every weight is 1)
@@ -1265,7 +1269,7 @@ int tloam_get_weights(tloam_ctx* c, int kind, size_t capacity, size_t* n, double
       std::vector<double> wr(m);
       HIPC(c, hipMemcpy(idx.data(), c->cv.k[kind].idx, sizeof(int) * m, hipMemcpyDeviceToHost));
       HIPC(c, hipMemcpy(wr.data(), direct_w_stream(c, kind, c->w_parity), sizeof(double) * m, hipMemcpyDeviceToHost));
-      for (size_t r = 0; r < m; ++r) w[(size_t)(idx[r] >= 0 ? idx[r] : ~idx[r]) - c->kd[kind].src_lo] = wr[r];
+      for (size_t r = 0; r < m; ++r) w[(size_t)(idx[r] >= 0 ? idx[r] : ~idx[r]) - (size_t)c->sv.src_lo[kind]] = wr[r];
     }
     return TLOAM_OK;
   }
