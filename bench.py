@@ -168,6 +168,8 @@ def parse():
     ap.add_argument("--m1-steps", type=int, default=10, help="timed frames of the 1 M block")
     ap.add_argument("--sharded-timeout", type=float, default=300.0,
                     help="N > 1: seconds the sharded 1 M frame (both exchanges) may take before the line is printed without it")
+    ap.add_argument("--sharded-child", action="store_true",
+                    help="(internal) this process is a rank's CHILD that runs the sharded 1 M frame and nothing else, see sharded_in_children")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kitti", action="store_true")
     ap.add_argument("--no-side", action="store_true",
@@ -252,8 +254,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- workloads ----------------
     big = 1 << 30
+    if args.sharded_child:
+        # a rank's child (sharded_in_children): the sharded 1 M frame and nothing else; rank 0's child hands the result to its parent
+        cfg = reg.default_config(planar_maxnum=big, ground_maxnum=big, edge_maxnum=big, sphere_maxnum=big)
+        if os.environ.get("TLOAM_BENCH_CHILD_CRASH") == str(rank):   # test hook: this rank's child dies the way a GPU fault kills it
+            os.abort()
+        sharded = {}
+        finished = within(lambda: sharded_frame(args, reg, synth, torch, dist, cfg, synth.M1_SRC, synth.M1_TGT, rank, world,
+                                                local_rank, barrier, cdev, sharded), args.sharded_timeout)
+        if rank == 0:
+            emit({"sharded": sharded, "finished": bool(finished)})
+        os._exit(0)    # (nothing to tear down in order: a stuck collective of a cut-off form may still hold a thread)
+
+    # ---------------- workloads ----------------
     WL = {
         "kitti": dict(n_src=synth.KITTI_SRC, n_tgt=synth.KITTI_TGT, cfg=reg.default_config(),
                       name="synthetic KITTI-density sequence, every step a DISTINCT frame pair (9.4k src / 83.5k tgt pts per frame, "
@@ -531,9 +545,7 @@ def main():
     if multi and side is not None:
         # (on a deadline: RCCL with N > 1 ranks and the mailbox over xGMI run for the first time on the driver's 8-GPU node --
         #  a collective that never returns must not cost the run its line.  What has finished by then is reported.)
-        sharded = {}
-        finished = within(lambda: sharded_frame(args, reg, synth, torch, dist, m1["cfg"], m1["n_src"], m1["n_tgt"], rank, world,
-                                                local_rank, barrier, cdev, sharded), args.sharded_timeout)
+        sharded, finished = sharded_in_children(args, torch, dist, rank, cdev)
         if rank == 0:
             sharded = sharded_summary(sharded, finished, args.sharded_timeout)
             sharded["replica_ms_per_frame"] = round(side["ms_per_frame"], 4)
@@ -546,11 +558,6 @@ def main():
             sharded["predicted_speedup"] = PREDICTED_SHARDED_SPEEDUP.get(world)
             out["sharded_1m"] = sharded
             out.update(sharded_flat(sharded, world))
-        if not finished:   # a thread of this process is stuck inside a collective: nothing can be torn down in order
-            if rank == 0:
-                emit(out)
-            sys.stdout.flush()
-            os._exit(0)
 
     # ---------------- sequence, adjacent rows, odometry loop, CPU baseline: rank 0, N = 1 only ----------------
     if rank == 0 and not multi:
@@ -590,6 +597,58 @@ def main():
         if not within(leave, 120.0):   # (a rank that gave up above is gone: the line is out, leave without it)
             sys.stdout.flush()
             os._exit(0)
+
+
+def sharded_in_children(args, torch, dist, rank, cdev):
+    """The sharded 1 M frame runs in a CHILD process of every rank (this script with --sharded-child; a process group of the
+    children's own, one port up).  The exchange forms it times -- the peer mailbox over hipIpc handles, RCCL with N ranks -- have
+    never met two devices before the driver's first multi-GPU run: a GPU fault there ends the process it happens in, and with the
+    frame inside the ranks themselves that was the whole job and its JSON line.  Now it ends a child: the parents notice (they
+    poll their children and agree on what they see through the launcher's group twice a second), end the other children, and the
+    line goes out with the replica headline and the reason in `sharded_1m`.  Returns (what rank 0's child reported, finished)."""
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 211)
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "False"     # (the children's rank 0 hosts their store: the launcher's agent does not know them)
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--m1-steps", str(args.m1_steps), "--seed", str(args.seed),
+           "--sharded-timeout", str(args.sharded_timeout)]
+    res = tempfile.TemporaryFile()
+    child = subprocess.Popen(cmd, env=env, stdout=res, stdin=subprocess.DEVNULL)
+    limit = args.sharded_timeout + 120.0      # (the child's own deadline, plus its start: imports, process group, contexts)
+    t0 = time.time()
+    verdict = "finished"
+    while True:
+        rc = child.poll()
+        flags = torch.tensor([1.0 if (rc is not None and rc != 0) else 0.0, 1.0 if rc is None else 0.0,
+                              1.0 if time.time() - t0 > limit else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        failed, running, late = (float(v) > 0.0 for v in flags.tolist())
+        if failed or late:
+            verdict = "a rank's child process ended abnormally (exit code %s here)" % rc if failed else "no result after %.0f s" % limit
+            if child.poll() is None:
+                child.kill()          # (this rank's own child, by its process id)
+            child.wait()
+            break
+        if not running:
+            break
+        time.sleep(0.5)
+    out, finished = {}, False
+    if rank == 0:
+        res.seek(0)
+        text = res.read().decode(errors="replace").strip()
+        try:
+            d = json.loads(text.splitlines()[-1]) if text else {}
+            out, finished = d.get("sharded", {}), bool(d.get("finished"))
+        except (ValueError, IndexError):
+            pass
+        if verdict != "finished":
+            out = dict(out)
+            out["child_error"] = verdict
+            finished = False
+    res.close()
+    return out, finished
 
 
 def within(fn, seconds):
@@ -851,10 +910,13 @@ def sharded_summary(res, finished, seconds):
     off says so"""
     res = dict(res)
     modes = res.pop("modes", list(SHARDED_MODES))
+    child_error = res.pop("child_error", None)   # (sharded_in_children: a rank's child ended abnormally / never answered)
     for m in modes:
         if m not in res:
-            res[m] = {"error": "did not finish within the %.0f s of --sharded-timeout" % seconds}
-    if not finished:
+            res[m] = {"error": ("not run: " + child_error) if child_error else "did not finish within the %.0f s of --sharded-timeout" % seconds}
+    if child_error:
+        res["note"] = "the sharded frame runs in child processes of the ranks: " + child_error + "; the replica headline of this line is unaffected"
+    elif not finished:
         res["note"] = "cut off by --sharded-timeout: the figures are those of the exchanges that had finished"
     ran = [m for m in modes if "ms_per_frame" in res[m] and res[m].get("verified")]
     if ran:

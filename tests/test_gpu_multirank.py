@@ -463,3 +463,29 @@ def test_bench_sharded_deadline_prints_the_line(hip_module):
     assert "cut off" in sh["note"] and "ms_per_frame" not in sh
     assert "did not finish" in sh["mailbox"]["error"] and "did not finish" in sh["rccl"]["error"]
     assert d["sharded_1m_verified"] is False and d["sharded_1m_ms_per_frame"] is None
+
+
+def test_bench_line_survives_a_rank_whose_sharded_child_dies(hip_module):
+    """The sharded 1 M frame runs in a CHILD process of every rank (bench.py sharded_in_children): its exchange forms have never met
+    two devices, and a GPU fault ends the process it happens in.  Here rank 1's child aborts (TLOAM_BENCH_CHILD_CRASH, the way the
+    runtime ends a process on a memory-access fault): the parents notice within a second, end the other child, and the line goes
+    out -- replica headline intact, `sharded_1m` saying what happened -- with exit code 0, long before any deadline."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TLOAM_BENCH_ONE_DEVICE="1", TLOAM_BENCH_CHILD_CRASH="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--m1-steps", "2"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-1500:]
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["frames_per_step"] == 2
+    assert d["sharded_1m_verified"] is False and d["sharded_1m_ms_per_frame"] is None
+    assert "ended abnormally" in d["sharded_1m"]["note"] and "ended abnormally" in (d["sharded_1m_error"] or "")
+    assert took < 240.0, took      # (not the 300 s of --sharded-timeout, nor the parents' own limit)
