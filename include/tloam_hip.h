@@ -131,7 +131,7 @@ const char* tloam_status_string(int status);
 /* text of the last HIP/RCCL error seen by this context ("" if none) */
 const char* tloam_last_error(const tloam_ctx* ctx);
 
-/* Sizes: a cloud, a correspondence set or a query batch holds at most 2^29 points (slots, cells and ranks are 32-bit integers on
+/* Sizes: a cloud, a correspondence set or a query batch holds at most 2^28 points (slots, cells and ranks are 32-bit integers on
  * the device, and the four kinds of a frame share one slot space); more is TLOAM_E_INVALID at the entry point. */
 /* What a context is and what has happened to it -- read by the bench (so that a multi-GPU line says what it ran on), by the
  * co-residency test and by anybody who wants to know whether a context has left its fast forms. */

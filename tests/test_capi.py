@@ -128,8 +128,8 @@ def test_graft_entry_build_runs():
 
 
 def test_sizes_beyond_the_32_bit_slot_space_are_refused_at_the_header_level():
-    """include/tloam_hip.h: at most 2^29 points per cloud / set / batch (TLOAM_E_INVALID).  Without a device the entry points
+    """include/tloam_hip.h: at most 2^28 points per cloud / set / batch (TLOAM_E_INVALID).  Without a device the entry points
     answer TLOAM_E_HIP / refuse the context first; what can be checked here is that the bound is stated where a host reads it."""
     import os
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tloam_hip.h")).read()
-    assert "2^29 points" in hdr and "TLOAM_E_INVALID at the entry point" in hdr
+    assert "2^28 points" in hdr and "TLOAM_E_INVALID at the entry point" in hdr

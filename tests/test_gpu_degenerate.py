@@ -249,7 +249,7 @@ def test_large_frame_after_prebuilt_sets_on_a_used_context(hip_module):
 
 
 def test_sizes_beyond_the_slot_space_are_refused(hip_module):
-    """A count of more than 2^29 points (slots, cells and ranks are 32-bit integers on the device) is TLOAM_E_INVALID at every entry
+    """A count of more than 2^28 points (slots, cells and ranks are 32-bit integers on the device) is TLOAM_E_INVALID at every entry
     point that takes one -- before the buffer it claims to describe is touched -- and the context goes on working."""
     import ctypes as C
     sc = synth.make_scene(seed=59)
@@ -259,7 +259,7 @@ def test_sizes_beyond_the_slot_space_are_refused(hip_module):
     a = np.zeros((16, 3))
     dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
     ip = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))    # noqa: E731
-    huge = (1 << 29) + 1
+    huge = (1 << 28) + 1
     assert L.tloam_set_source(h, 0, dp(a), huge) == -1
     assert L.tloam_set_target(h, 1, dp(a), huge) == -1
     ptrs = (C.POINTER(C.c_double) * 4)(*[dp(a)] * 4)

@@ -1058,6 +1058,21 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
   const double hs1 = stamps ? now_us() : 0.0;
+  // A frame that fails on the way -- an unwritten result slot, a minimiser that "did not terminate", a time-out inside a launch --
+  // may have failed on the garbage a timed-out look-back scan left behind: the frame is closed, the fault words are looked at
+  // (check_device_faults moves the context to the forms that wait for nothing and clears them: the NEXT frame is not blamed), and
+  // if it was the scan the frame is run again, once per context, as tloam_sm_end's path does.
+  auto frame_failed = [&](int rc_in) -> int {
+    (void)hipStreamSynchronize(c->stream);
+    c->active = false;
+    const bool scan_fault_now = c->h_fault && __atomic_load_n(&c->h_fault[kFaultScan1p], __ATOMIC_ACQUIRE) != 0u;
+    (void)check_device_faults(c);
+    if (scan_fault_now && !c->scan1p_retried) {
+      c->scan1p_retried = true;
+      return tloam_scan_match(c, predict, omega3, result, scan_xyz, n_scan, stats);
+    }
+    return rc_in;
+  };
   int done = 0;
   bool weight_violation = false;
   // device-driven outer loop where the stepwise machinery is not asked for: one rank, a pinned mirror, the planned
@@ -1081,15 +1096,17 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
       weight_violation = false;
       rc = scan_match_device_loop(c, &weight_violation);
     }
-    if (rc < 0) return rc;
+    if (rc < 0) return frame_failed(rc);
     done = rc == 0 ? 1 : 0;
   }
   while (!done) {
     rc = tloam_sm_outer(c, &done, nullptr);
     if (rc == TLOAM_E_WEIGHT_RANGE) { weight_violation = true; continue; }  // reported after the solve
-    if (rc != TLOAM_OK) return rc;
+    if (rc != TLOAM_OK) return frame_failed(rc);
   }
   const double hs2 = stamps ? now_us() : 0.0;
+  // (which bounded wait ran out, if any: tloam_sm_end's check_device_faults clears the words)
+  const bool scan_fault = c->h_fault && __atomic_load_n(&c->h_fault[kFaultScan1p], __ATOMIC_ACQUIRE) != 0u;
   rc = tloam_sm_end(c, result, stats);
   if (stamps && c) {
     const double hs3 = now_us();
@@ -1105,7 +1122,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
       for (int i = 0; i < 8; ++i) c->hs[i] = 0.0;
     }
   }
-  if (rc == TLOAM_E_HIP && c->no_scan_1p && !c->scan1p_retried) {
+  if (rc == TLOAM_E_HIP && scan_fault && !c->scan1p_retried) {
     // a look-back scan of this frame gave up (check_device_faults): the clouds are intact in HBM and the context has been
     // switched to the multi-launch scans -- run the frame again, once
     c->scan1p_retried = true;

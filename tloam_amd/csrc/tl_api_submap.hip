@@ -279,6 +279,11 @@ static int submap_update_body(tloam_ctx* c, const double pose[16], const double*
     n_in[s] = n_old[s] + accs[s].n;
     n_all += n_in[s];
   }
+  // (an accumulated cloud is a cloud: the bound of the entry points holds for what they add up to as well)
+  if (n_in[0] > kMaxPoints || n_in[1] > kMaxPoints) {
+    c->last_error = "submap update: an accumulated cloud would exceed the 2^28 points a cloud may hold";
+    return TLOAM_E_INVALID;
+  }
   {  // a buffer about to be regrown (hipFree) must not be in use by the kernels still in flight: synchronise
      // only then -- in steady state the capacities suffice and the update runs without a host wait
     const size_t m = std::max<size_t>(n_all, 1);

@@ -305,9 +305,11 @@ constexpr int kMirrorSlots = 8;
 constexpr int kFaultWords = 16;
 constexpr int kFaultScan1p = 0, kFaultVoxEmit = 1;   // tloam_ctx::h_fault
 // Points a single cloud / correspondence set / query batch may hold: slots, cells and ranks are 32-bit integers throughout, and the
-// four kinds of a frame share one slot space -- 2^29 points (12.9 GB as doubles) per cloud keeps every sum and every 3 n inside it.
+// four kinds of a frame share one slot space -- 2^28 points (6.4 GB as doubles) per cloud keeps every sum over the four kinds
+// (<= 2^30) and every 3 n inside it (2^29 did not: four clouds at the bound sum to INT_MAX + 1).  Sums that grow behind the
+// entry points -- a submap's accumulated clouds -- are checked where they are formed (submap_update_body).
 // More is TLOAM_E_INVALID at the entry point, not an overflow behind it.
-constexpr size_t kMaxPoints = (size_t)1 << 29;
+constexpr size_t kMaxPoints = (size_t)1 << 28;
 
 namespace tlh {
 // ---- small helpers shared by the API units

@@ -576,6 +576,13 @@ __device__ __forceinline__ void fold_rows(const double* __restrict__ partials, i
 // grid are resident at once (a dozen blocks on 256 CUs); the spin is bounded all the same (~1 s, then the Solve is
 // stopped with GnState::comm_error).
 constexpr int kTaggedRows = 16;
+// (The ROW segments below enter their check word by a plain XOR, not through seg_word: their payload is seven fp64 SUMS that
+//  change from one GN iteration to the next.  A segment that mixes old and new words passes only if the words that are still old
+//  changed by the same 64-bit pattern: one such word -> it did not change, the segment reads as what it is; two -> two sums whose
+//  old and new bit patterns XOR alike, which for sums of squares and products of residuals means both unchanged or both a pure
+//  sign flip of a zero -- values that add to the same totals either way.  The poll sits on the dependent chain of every GN
+//  iteration of a KITTI-size frame; seven 64-bit multiplies per look are not spent there.  Segments with integers in them --
+//  post_ext_segment, the host's slots -- do go through seg_word.)
 __device__ __forceinline__ unsigned long long xor8(unsigned long long x) {  // XOR over aligned groups of eight lanes
   x ^= __shfl_xor(x, 1, 64);
   x ^= __shfl_xor(x, 2, 64);
@@ -1217,7 +1224,9 @@ __device__ __forceinline__ void post_ext_segment(double* __restrict__ partials, 
   if (lane == 0) wd = (unsigned long long)__double_as_longlong(cs0);
   else if (lane == 1) wd = (unsigned long long)__double_as_longlong(bad0);
   else if (lane == 2) wd = (unsigned long long)(long long)kind;
-  const unsigned long long x = xor8(wd);
+  // (position-dependent, non-linear entry of the payload into the check word, as the segments the host reads: this one mixes a
+  //  double with small integers -- a count, a kind -- the class of payload where two stale words can XOR like two new ones)
+  const unsigned long long x = xor8(lane < 7 ? seg_word(wd, lane) : 0ull);
   if (lane == 7) wd = check_mix(tag) ^ x;
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + base_word + (size_t)gw * 8 + lane, wd, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -1235,9 +1244,9 @@ __device__ __forceinline__ bool poll_fold_ext(const double* __restrict__ partial
   for (unsigned spins = 1;; ++spins) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long x = w[0];
+    unsigned long long x = w[7];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) x ^= w[i];
+    for (int i = 0; i < 7; ++i) x ^= seg_word(w[i], i);
     ok_all = __all((!have || x == mtag) ? 1 : 0) != 0;
     if (ok_all) break;
     if ((spins & 63u) == 0 && wall_clock64() - t0 > 100000000ull) break;

@@ -363,7 +363,9 @@ size_t scan_1p_ctl_elems(size_t n) { return (n + kTile1p - 1) / kTile1p + 8; }
 // busy one a block still only waits for blocks of lower index, which the dispatcher started earlier (a CPX partition or a
 // CU-masked device reports fewer CUs and gets the multi-launch scan; round 4 stopped at 240 tiles).  The wait is bounded either way.
 bool scan_1p_applies(size_t n, int device_cus) {
-  return (n + kScanTile - 1) / kScanTile > 1024 && (long long)((n + kTile1p - 1) / kTile1p) <= (long long)device_cus;
+  // (a sixteenth of the CUs to spare for whatever else runs on the device -- another context's stream, another rank: the look-back
+  //  waits for blocks that have to be running; as vox_emit_resident_blocks)
+  return (n + kScanTile - 1) / kScanTile > 1024 && (long long)((n + kTile1p - 1) / kTile1p) <= (long long)(device_cus - device_cus / 16);
 }
 void launch_scan_counts_1p(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* ctl, unsigned* fault,
                            hipStream_t s) {

@@ -18,6 +18,7 @@
 // Voxel membership uses an open-addressing hash table keyed by the packed voxel coordinates
 // (ix | iy << 21 | iz << 42); per-voxel member lists are ordered by index with a rank-by-counting pass so the
 // floating-point accumulation order is the reference's (ascending index).  Compiled with -ffp-contract=off.
+#include <atomic>
 #include <algorithm>
 #include <string.h>
 
@@ -583,11 +584,15 @@ void launch_soa_to_aos(const double* x, const double* y, const double* z, size_t
 }
 
 int vox_emit_resident_blocks(int device_cus) {
-  static int per_cu = -1;   // (one kernel, one architecture: the same for every device of the process)
+  // (one kernel, one architecture: the same for every gfx950 device of the process; contexts are created from several host
+  //  threads -- an atomic, and two threads that both find it unset both store the same value)
+  static std::atomic<int> per_cu_cache{-1};
+  int per_cu = per_cu_cache.load(std::memory_order_relaxed);
   if (per_cu < 0) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_vox_emit, 256, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }
     per_cu = occ;
+    per_cu_cache.store(occ, std::memory_order_relaxed);
   }
   const long long all = (long long)device_cus * per_cu;
   return (int)(all - all / 16);   // with room to spare for whatever else is on the device
