@@ -1,6 +1,7 @@
 // tl_api_frames.hip -- HBM residency of the C ABI (include/tloam_hip.h): setInputSource / setInputTarget
 // (registration.cpp:232-248) through pinned staging, the search grids over the registered targets (the role of
 // KDTreeFlann::SetGeometry, :889-915), frames staged ahead of their solve, and the host's waits on pinned result words.
+#include <chrono>
 #include "tl_ctx.hpp"
 
 using namespace tl;
@@ -264,7 +265,10 @@ int build_grids_over(tloam_ctx* c, GridBuffers& G, const double radius[kKinds], 
     frame->fi.n_tile_cnt = (int)ntiles + 1;
     frame->consumed = true;
   }
+  const bool stamp = frame && c->hs_entry > 0.0;   // (TLOAM_HOST_STAMPS: when the frame's FIRST launch went out / had been issued)
+  if (stamp) c->hs[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->hs_entry;
   launch_grid_count_all(gs, G.cell_cnt.p, G.cell_of_pt.p, G.rank_of_pt.p, c->stream, frame);
+  if (stamp) c->hs[6] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->hs_entry;
   if (!c->no_scan_1p && scan_1p_applies(nc + 1, c->device_cus)) {
     // 1 M-class tables: count | scan + finalize in ONE single-pass launch | scatter (three launches and one pass over the table
     // less than tile scan + scan of the totals + add + finalize)

@@ -1055,6 +1055,7 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
   static const bool stamps = getenv("TLOAM_HOST_STAMPS") != nullptr;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double hs0 = stamps ? now_us() : 0.0;
+  if (c) c->hs_entry = hs0;
   int rc = tloam_sm_begin(c, predict, omega3);
   if (rc != TLOAM_OK) return rc;
   const double hs1 = stamps ? now_us() : 0.0;
@@ -1117,8 +1118,9 @@ int tloam_scan_match(tloam_ctx* c, const double predict[16], const double* omega
     c->hs[4] += hs3 - hs2;                                 // sm_end
     c->hs_exit = hs3;
     if (++c->hs_n % 200 == 0) {
-      fprintf(stderr, "[tloam host stamps] per frame over 200: caller %.2f  begin %.2f  loop-without-wait %.2f  wait %.2f  end %.2f us\n",
-              c->hs[0] / 200, c->hs[1] / 200, c->hs[2] / 200, c->hs[3] / 200, c->hs[4] / 200);
+      fprintf(stderr, "[tloam host stamps] per frame over 200: caller %.2f  begin %.2f (first launch called at %.2f, issued at %.2f)  "
+                      "loop-without-wait %.2f  wait %.2f  end %.2f us\n",
+              c->hs[0] / 200, c->hs[1] / 200, c->hs[5] / 200, c->hs[6] / 200, c->hs[2] / 200, c->hs[3] / 200, c->hs[4] / 200);
       for (int i = 0; i < 8; ++i) c->hs[i] = 0.0;
     }
   }

@@ -207,6 +207,7 @@ struct tloam_ctx {
   double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // development aid (TLOAM_HOST_STAMPS): where the calling thread's time goes, per frame
   long hs_n = 0;
   double hs_exit = 0.0;
+  double hs_entry = 0.0;          // > 0: stamping, entry time of the scan_match in progress (us, steady clock)
   tl::MirrorSlot* h_mirror = nullptr;       // pinned, device-visible result slots (HostMirror targets), 64-byte aligned
   tl::MirrorSlot* h_mirror_dev = nullptr;   // ... as the device addresses them
   unsigned long long mirror_seq = 0;
