@@ -561,7 +561,19 @@ def main():
     if multi and side is not None:
         # (on a deadline: RCCL with N > 1 ranks and the mailbox over xGMI run for the first time on the driver's 8-GPU node --
         #  a collective that never returns must not cost the run its line.  What has finished by then is reported.)
-        sharded, finished = sharded_in_children(args, torch, dist, rank, cdev)
+        # In a child process of every rank (a GPU fault there does not take the line with it) -- except when MORE THAN FOUR ranks
+        # share ONE device (TLOAM_BENCH_ONE_DEVICE, a development set-up): sixteen processes oversubscribe the device's hardware
+        # queues, the runlist is time-sliced in milliseconds and a gather that spins on a peer's post waits for the peer's queue to
+        # be mapped again -- 22 ms per exchange instead of 29 us (profiles of round 6).  On one GPU per rank it is two processes.
+        in_process = os.environ.get("TLOAM_BENCH_SHARDED_IN_PROCESS") == "1" or (one_dev and world > 4)
+        stuck = False
+        if in_process:
+            sharded = {}
+            finished = within(lambda: sharded_frame(args, reg, synth, torch, dist, m1["cfg"], m1["n_src"], m1["n_tgt"], rank, world,
+                                                    local_rank, barrier, cdev, sharded), args.sharded_timeout)
+            stuck = not finished   # a thread of this process is stuck inside a collective: nothing can be torn down in order
+        else:
+            sharded, finished = sharded_in_children(args, torch, dist, rank, cdev)
         if rank == 0:
             sharded = sharded_summary(sharded, finished, args.sharded_timeout)
             sharded["replica_ms_per_frame"] = round(side["ms_per_frame"], 4)
@@ -572,8 +584,14 @@ def main():
                 sharded["speedup_vs_one_gpu_frame"] = round(one / sharded["ms_per_frame"], 3)
                 sharded["speedup_vs_replica_frame"] = round(side["ms_per_frame"] / sharded["ms_per_frame"], 3)
             sharded["predicted_speedup"] = PREDICTED_SHARDED_SPEEDUP.get(world)
+            sharded["ran_in"] = "the ranks' own processes" if in_process else "a child process of every rank"
             out["sharded_1m"] = sharded
             out.update(sharded_flat(sharded, world))
+        if stuck:
+            if rank == 0:
+                emit(out)
+            sys.stdout.flush()
+            os._exit(0)
 
     # ---------------- sequence, adjacent rows, odometry loop, CPU baseline: rank 0, N = 1 only ----------------
     if rank == 0 and not multi:

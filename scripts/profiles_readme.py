@@ -14,7 +14,7 @@ WHAT = {
     "m1_frame_timeline.txt": "the same for the 1 M frame (`bench.py --workload m1`)",
     "solve_all_timeline.txt": "`scripts/solve_profile2.py` on a `-DTLOAM_STEP_PROFILE` build: wall-clock stamps (10 ns) inside the one-launch Solve `k_solve_all` per GN iteration -- lead block's stepper wave and one other wave",
     "kitti_sequence_4540.json": "`python bench.py --kitti-frames 4540 --no-m1 --no-cpu-baseline` (`scripts/gpu_seq4540.sh`): the KITTI-density sequence over the WHOLE published KITTI-00 trajectory of the reference (SURVEY 8(d) config 2); numbers below",
-    "bench_gpus2_one_device.json": "`bench.py --gpus 2` launched as the driver launches it (`torch.distributed.run`, one rank per process) with `TLOAM_BENCH_ONE_DEVICE=1` -- every rank on the ONE GPU of the box, launcher collectives over gloo.  NOT a scaling measurement (the ranks share the GPU): the replica headline aggregating over the ranks, and the SELF-VERIFYING sharded 1 M frame (BASELINE.json configs[3]): every exchange form against the one-rank solve of the same frame (`sharded_1m_verified`, `sharded_1m_pose_delta`, ranks bit-identical, counters equal) in flat top-level scalars; RCCL refuses two ranks on one device and is reported as such (`rccl_nranks` null)",
+    "bench_gpus2_one_device.json": "`bench.py --gpus 2` launched as the driver launches it (`torch.distributed.run`, one rank per process) with `TLOAM_BENCH_ONE_DEVICE=1` -- every rank on the ONE GPU of the box, launcher collectives over gloo.  NOT a scaling measurement (the ranks share the GPU): the replica headline aggregating over the ranks, and the SELF-VERIFYING sharded 1 M frame (BASELINE.json configs[3]): every exchange form against the one-rank solve of the same frame (`sharded_1m_verified`, `sharded_1m_pose_delta`, ranks bit-identical, counters equal) in flat top-level scalars, run in a child process of every rank (`sharded_1m.ran_in`; more than four ranks on ONE device: in the ranks' own processes -- sixteen processes oversubscribe the device's hardware queues); RCCL refuses two ranks on one device and is reported as such (`rccl_nranks` null)",
     "bench_gpus4_one_device.json": "the same with 4 ranks",
     "bench_gpus8_one_device.json": "the same with 8 ranks",
     "pmc_sq_k_solve_all.json": "`scripts/gpu_pmc_kitti.sh`: one `rocprofv3 --pmc` pass (SQ counters, `--kernel-trace` only) over `bench.py --workload kitti`, per-launch means for the one-launch Solve: `SQ_WAVE_CYCLES` / `SQ_WAIT_ANY` / `SQ_ACTIVE_INST_ANY` / `SQ_WAIT_INST_ANY` count quad-cycles summed over the launch's 64 waves -- 70 % parked (block barrier, row polls), 27 % issuing, 2.6 % issue stalls; 4.6 k VALU instructions per wave per launch",
