@@ -44,7 +44,8 @@ extern "C" {
                                * 5: tloam_frame_stash / tloam_frame_select (frames staged in HBM ahead of their solve)
                                * 6: tloam_k3_span, tloam_shard_ranges_frame
                                * 7: tloam_debug_raise_fault
-                               * 8: tloam_get_info, tloam_gn_iter_timer, tloam_time_read_stream */
+                               * 8: tloam_get_info, tloam_gn_iter_timer, tloam_time_read_stream; a mailbox / RCCL set-up with nranks == 1
+                               *    is a loop-back (the sharded forms run); a cloud holds at most 2^28 points (was 2^29) */
 
 /* feature kinds; order = the builder order of registration.cpp:981-992 */
 #define TLOAM_KIND_PLANAR 0 /* addSurfCostFactor    -> point-to-plane  */
