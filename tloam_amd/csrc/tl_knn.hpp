@@ -118,9 +118,15 @@ __device__ __forceinline__ bool keys_ambiguous(const KeyList<N>& L, unsigned kee
 }
 // the first K entries as a (distance, position) list: the distance is recomputed from the record, exactly as
 // the scan computed it before truncation
+// The coordinates of the K entries, kept from the records a list was unpacked from (knn_rows hands them to the per-query fits of
+// K2, which used to fetch them again: 15 of the ~90 scattered loads of a five-neighbour query).  Entry m is defined where tk.j[m] >= 0.
+template <int K>
+struct NbrXyz {
+  double x[K], y[K], z[K];
+};
 template <int K, int N>
 __device__ __forceinline__ void keys_unpack(const KeyList<N>& L, const PtsGlobal& pts, double qx, double qy, double qz,
-                                            unsigned keep_mask, TopK<K>& tk) {
+                                            unsigned keep_mask, TopK<K>& tk, NbrXyz<K>* xyz = nullptr) {
 #pragma unroll
   for (int m = 0; m < K; ++m) {
     const bool have = L.k[m] < __builtin_inf();
@@ -128,6 +134,16 @@ __device__ __forceinline__ void keys_unpack(const KeyList<N>& L, const PtsGlobal
     const double4 p = pts.p[j];
     tk.d[m] = have ? sqdist(qx, qy, qz, p.x, p.y, p.z) : __builtin_inf();
     tk.j[m] = have ? j : -1;
+    if (xyz) { xyz->x[m] = p.x; xyz->y[m] = p.y; xyz->z[m] = p.z; }
+  }
+}
+// the same from the point source (lists that were NOT unpacked from keys: the exact redo of an ambiguous query)
+template <int K>
+__device__ __forceinline__ void nbr_fetch(const PtsGlobal& pts, const TopK<K>& tk, NbrXyz<K>* xyz) {
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const double4 p = pts.p[tk.j[m] >= 0 ? tk.j[m] : 0];
+    xyz->x[m] = p.x; xyz->y[m] = p.y; xyz->z[m] = p.z;
   }
 }
 

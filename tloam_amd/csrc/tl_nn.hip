@@ -628,30 +628,21 @@ struct RawRec {
 };
 
 // addSphereCostFactor registration.cpp:517-559
-template <class P>
-__device__ __forceinline__ void finish_sphere(const P& pts, const TopK<1>& tk, double radius, RawRec& r) {
+// (the neighbour's coordinates: from the point source, or -- knn_rows' NbrXyz -- from the record its list entry was unpacked from)
+__device__ __forceinline__ void finish_sphere_xyz(const TopK<1>& tk, double x, double y, double z, double radius, RawRec& r) {
   const int cnt = radius_cut<1>(tk, radius);
   const bool found = cnt > 0;
   const bool skip = found && (tk.d[0] > 0.2);  // :536 squared distance vs 0.2 -> `continue`
   const bool valid = found && !skip;
   const bool counted = !skip;                    // :551 sphere_sum++ for every non-`continue`d point
-  if (valid) { r.a[0] = pts.X(tk.j[0]); r.a[1] = pts.Y(tk.j[0]); r.a[2] = pts.Z(tk.j[0]); }
+  if (valid) { r.a[0] = x; r.a[1] = y; r.a[2] = z; }
   r.flag = ((unsigned long long)(valid ? 1 : 0) << 32) | (unsigned long long)(counted ? 1 : 0);
 }
-
 // addEdgeCostFactor :427-505 (kind == edge) / addSurfCostFactor :571-635, addGroundCostFactor :714-778
-template <class P>
-__device__ __forceinline__ void finish_knn5(int kind, const P& pts, const TopK<5>& tk, double radius,
-                                            double edge_dir_thres, RawRec& r) {
-  const int cnt = radius_cut<5>(tk, radius);
+// (cnt neighbours inside the radius, their coordinates in ascending (distance, index) order, 0 beyond cnt)
+__device__ __forceinline__ void finish_knn5_xyz(int kind, int cnt, const double (&nx)[5], const double (&ny)[5], const double (&nz)[5],
+                                                double edge_dir_thres, RawRec& r) {
   bool valid = false;
-  double nx[5], ny[5], nz[5];
-#pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    const bool in = m < cnt;
-    const int j = in ? tk.j[m] : 0;
-    nx[m] = in ? pts.X(j) : 0.0; ny[m] = in ? pts.Y(j) : 0.0; nz[m] = in ? pts.Z(j) : 0.0;
-  }
   if (kind == TLOAM_KIND_EDGE) {
     if (cnt > 3) {  // :445
       double cum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -699,6 +690,18 @@ __device__ __forceinline__ void finish_knn5(int kind, const P& pts, const TopK<5
   // the cap tests (:448 / :592 / :735) only matter once num >= maxnum, and num counts ADDED factors:
   // "added iff valid && #valid before < maxnum" (see launch_compact).
   r.flag = valid ? ((1ull << 32) | 1ull) : 0ull;
+}
+// ... with the coordinates knn_rows kept from the records the list was unpacked from (NbrXyz)
+__device__ __forceinline__ void finish_knn5_kept(int kind, const TopK<5>& tk, const NbrXyz<5>& c, double radius, double edge_dir_thres,
+                                                 RawRec& r) {
+  const int cnt = radius_cut<5>(tk, radius);
+  double nx[5], ny[5], nz[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const bool in = m < cnt;
+    nx[m] = in ? c.x[m] : 0.0; ny[m] = in ? c.y[m] : 0.0; nz[m] = in ? c.z[m] : 0.0;
+  }
+  finish_knn5_xyz(kind, cnt, nx, ny, nz, edge_dir_thres, r);
 }
 
 // the (counted | valid << 32) flag of a slot, and its one-byte twin for the self-compacting Solve (SlotView::flagb)
@@ -910,17 +913,20 @@ __device__ __forceinline__ bool query_one(const BuildArgs& A, int kind, const Po
   rec.a[0] = rec.a[1] = rec.a[2] = rec.b[0] = rec.b[1] = rec.b[2] = rec.d = 0.0;
   rec.flag = 0ull;
   const double radius = A.bp.radius[kind];
+  // (the neighbours' coordinates stay in registers from the records the walk's list was unpacked from: the fits do not fetch them again)
   if (kind == TLOAM_KIND_SPHERE) {
     TopK<1> tk;
-    knn_rows<1, LPQ>(g, pts, pw, sub, tk, lds_rows, radius);
-    if (sub == 0) finish_sphere<PtsGlobal>(pts, tk, radius, rec);
+    NbrXyz<1> c;
+    knn_rows<1, LPQ>(g, pts, pw, sub, tk, lds_rows, radius, &c);
+    if (sub == 0) finish_sphere_xyz(tk, c.x[0], c.y[0], c.z[0], radius, rec);
   } else {
     TopK<5> tk;
-    knn_rows<5, LPQ>(g, pts, pw, sub, tk, lds_rows, radius);
+    NbrXyz<5> c;
+    knn_rows<5, LPQ>(g, pts, pw, sub, tk, lds_rows, radius, &c);
 #ifdef TLOAM_K1_DBG_NOFIT   // timing experiment only: the walk without the per-query fit
     if (sub == 0) { rec.a[0] = tk.d[0] + tk.d[4]; rec.flag = (tk.j[4] >= 0) ? ((1ull << 32) | 1ull) : 0ull; }
 #else
-    if (sub == 0) finish_knn5<PtsGlobal>(kind, pts, tk, radius, A.bp.edge_dir_thres, rec);
+    if (sub == 0) finish_knn5_kept(kind, tk, c, radius, A.bp.edge_dir_thres, rec);
 #endif
   }
   TL_K1_STAMP(6)

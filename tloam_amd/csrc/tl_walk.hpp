@@ -19,7 +19,7 @@ namespace tl {
 
 template <int K, int LPQ>
 __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts, Vec3 pw, int sub, TopK<K>& tk,
-                                         int2* __restrict__ lds_rows, double radius) {
+                                         int2* __restrict__ lds_rows, double radius, NbrXyz<K>* xyz = nullptr) {
   TL_K1_STAMP(1)
   const int cx = cell_coord(pw.x, g.org[0], g.inv_cell, g.dim[0]);
   const int cy = cell_coord(pw.y, g.org[1], g.inv_cell, g.dim[1]);
@@ -131,13 +131,14 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
       for (int u = 0; u < kCpt; ++u) { jc[u] = jn[u]; vc[u] = vn[u]; rc[u] = rn[u]; }
     }
     if (!keys_ambiguous<K + 1>(L, keep_mask)) {
-      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
+      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk, xyz);
     } else {  // two kept distances agree in every mantissa bit the key keeps: redo with the exact (d, original index) order
       topk_clear<K>(tk);
       for (int q = 0; q < nr; ++q) {
         const int2 v = lds_rows[q * 64 + lane];
         scan_range<K>(pts, v.x, v.y, pw.x, pw.y, pw.z, tk);
       }
+      if (xyz) nbr_fetch<K>(pts, tk, xyz);
     }
   } else {
     const unsigned keep_mask = ~((1u << key_bits_for(g.n)) - 1u);
@@ -184,7 +185,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
 #endif
     TL_K1_STAMP(4)
     if (!keys_ambiguous<K + 1>(L, keep_mask)) {  // (the same verdict on all lanes of the quad)
-      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk);
+      keys_unpack<K, K + 1>(L, pts, pw.x, pw.y, pw.z, keep_mask, tk, xyz);
       TL_K1_STAMP(5)
     } else {  // redo with the exact (d, original index) order
       for (int s = 0; s < len; ++s) {
@@ -206,6 +207,7 @@ __device__ __forceinline__ void knn_rows(const GridView& g, const PtsGlobal& pts
         for (int m = 0; m < K; ++m)
           if (oj[m] >= 0) topk_insert<K, PtsGlobal>(tk, pts, od[m], oj[m]);
       }
+      if (xyz) nbr_fetch<K>(pts, tk, xyz);
     }
   }
 }
