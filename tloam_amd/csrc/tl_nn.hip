@@ -58,6 +58,7 @@ constexpr int kScanPer = 4;                            // consecutive elements p
 constexpr int kScanRowElems = 64 * kScanPer;           // 256 elements = 2 KiB per wave row
 constexpr int kScanRows = kScanTile / (kScanThreads / 64) / kScanRowElems;   // rows per wave (2)
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(8)));   // (8-byte aligned: any element of a u64 array)
 // Wave-level exclusive scan of ROWS x 256 consecutive elements starting at `wbase`: lane l holds the four
 // elements 4l .. 4l+3 of each row, so a wave instruction covers 2 KiB (16 cache lines) and one shuffle scan
 // serves 256 elements.  The fully blocked layout (8-16 consecutive elements per thread) made every wave
@@ -67,14 +68,27 @@ template <int ROWS>
 __device__ __forceinline__ unsigned long long wave_scan_rows(const unsigned long long* __restrict__ in, size_t n,
                                                              size_t wbase, int lane, unsigned long long (&ex)[ROWS],
                                                              unsigned long long (&a)[ROWS][kScanPer]) {
+  static_assert(kScanPer == 4, "a lane's elements of a row are loaded as two 16-byte halves");
+  if (wbase + (size_t)ROWS * kScanRowElems <= n) {
+    // a wave whose rows all lie inside the array (every wave but the last): a lane's four elements as TWO 16-byte loads -- what the
+    // CU's L1 is asked for is accesses per lane, not bytes (64 eight-byte loads per thread of a 16 Ki tile were half of what the
+    // single-pass scans waited for)
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i)
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {  // unconditional (clamped) loads: all in flight together
-      const size_t idx = wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j;
-      const unsigned long long x = in[idx < n ? idx : n - 1];
-      a[i][j] = idx < n ? x : 0ull;
+    for (int i = 0; i < ROWS; ++i) {
+      const u64x2* __restrict__ p = reinterpret_cast<const u64x2*>(in + wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer);
+      const u64x2 lo = p[0], hi = p[1];
+      a[i][0] = lo.x; a[i][1] = lo.y; a[i][2] = hi.x; a[i][3] = hi.y;
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+      for (int j = 0; j < kScanPer; ++j) {  // unconditional (clamped) loads: all in flight together
+        const size_t idx = wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j;
+        const unsigned long long x = in[idx < n ? idx : n - 1];
+        a[i][j] = idx < n ? x : 0ull;
+      }
+  }
   unsigned long long carry = 0;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
@@ -96,6 +110,16 @@ template <int ROWS>
 __device__ __forceinline__ void wave_store_rows(unsigned long long* __restrict__ out, size_t n, size_t wbase, int lane,
                                                 unsigned long long add, const unsigned long long (&ex)[ROWS],
                                                 const unsigned long long (&a)[ROWS][kScanPer]) {
+  if (wbase + (size_t)ROWS * kScanRowElems <= n) {   // (as the loads: two 16-byte stores per lane and row)
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const unsigned long long r0 = add + ex[i], r1 = r0 + a[i][0], r2 = r1 + a[i][1], r3 = r2 + a[i][2];
+      u64x2* __restrict__ p = reinterpret_cast<u64x2*>(out + wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer);
+      p[0] = u64x2{r0, r1};
+      p[1] = u64x2{r2, r3};
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
     unsigned long long run = add + ex[i];
@@ -318,9 +342,28 @@ __global__ __launch_bounds__(kScanThreads) void k_grid_scan_finalize_1p(GridSet 
   const int lane = threadIdx.x & 63;
   if (bid == 0 && threadIdx.x < kKinds && gs.ncell[threadIdx.x] == 0)   // a kind without a grid: just its terminator
     cell_start[gs.cell_base[threadIdx.x] + threadIdx.x] = gs.n[threadIdx.x];
+  typedef int int4s __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
   for (int i = 0; i < kRows1p; ++i) {
     unsigned long long run = base + ex[i];
+    {
+      // the common case -- the lane's four cells lie inside ONE kind's table and its last cell is not among them: one 16-byte store
+      // of the four starts, two of the zeroes (the general form below is four conditional stores per cell)
+      const long long e0 = (long long)(wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer);
+      int kf = -1;
+#pragma unroll
+      for (int k = 0; k < kKinds; ++k)
+        if (e0 >= gs.cell_base[k] && e0 + (kScanPer - 1) < gs.cell_base[k] + gs.ncell[k] - 1) kf = k;
+      if (kf >= 0 && (size_t)e0 + kScanPer <= n) {
+        const unsigned long long off = (unsigned long long)gs.tgt_off[kf];
+        const unsigned long long r0 = run - off, r1 = r0 + a[i][0], r2 = r1 + a[i][1], r3 = r2 + a[i][2];
+        *reinterpret_cast<int4s*>(cell_start + e0 + kf) = int4s{(int)r0, (int)r1, (int)r2, (int)r3};
+        u64x2* __restrict__ z = reinterpret_cast<u64x2*>(cell_cnt + e0);
+        z[0] = u64x2{0ull, 0ull};
+        z[1] = u64x2{0ull, 0ull};
+        continue;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
       const long long e = (long long)(wbase + (size_t)i * kScanRowElems + (size_t)lane * kScanPer + j);
