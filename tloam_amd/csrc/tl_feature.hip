@@ -59,9 +59,9 @@ __global__ __launch_bounds__(64) void k_pca_info(FeatArgs A) {
 #pragma unroll
     for (int m = 0; m < kFeatK; ++m) {
       if (m < cnt) {  // :80-91 neighbours in ascending distance
-        const int j = tk.j[m];
-        const double x = pts.X(j), y = pts.Y(j), z = pts.Z(j);
-        nb[m] = pts.I(j);
+        const double4 p = pts.p[tk.j[m]];   // (ONE record load, two 16-byte accesses: X / Y / Z / I apart were four -- the L1 is asked per lane access)
+        const double x = p.x, y = p.y, z = p.z;
+        nb[m] = (int)__double_as_longlong(p.w);
         cum[0] += x; cum[1] += y; cum[2] += z;
         cum[3] += x * x; cum[4] += x * y; cum[5] += x * z;
         cum[6] += y * y; cum[7] += y * z; cum[8] += z * z;
@@ -89,6 +89,13 @@ __global__ __launch_bounds__(64) void k_pca_info(FeatArgs A) {
   A.flatness[i] = flat; A.cvr[i] = cvr; A.sphericity[i] = sph;
   A.normal[3 * (size_t)i] = nx; A.normal[3 * (size_t)i + 1] = ny; A.normal[3 * (size_t)i + 2] = nz;
   A.num_sum[i] = num;
+  if (A.K == kFeatK) {   // (the configured K: a point's twenty indices as five 16-byte stores instead of twenty scattered 4-byte ones)
+    typedef int int4s __attribute__((ext_vector_type(4), aligned(16)));
+    int4s* __restrict__ o = reinterpret_cast<int4s*>(A.neigh + (size_t)i * kFeatK);
+#pragma unroll
+    for (int m = 0; m < kFeatK; m += 4) o[m / 4] = int4s{nb[m], nb[m + 1], nb[m + 2], nb[m + 3]};
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < kFeatK; ++m)
     if (m < A.K) A.neigh[(size_t)i * A.K + m] = nb[m];
