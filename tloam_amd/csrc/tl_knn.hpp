@@ -116,14 +116,15 @@ __device__ __forceinline__ bool keys_ambiguous(const KeyList<N>& L, unsigned kee
   }
   return amb;
 }
-// the first K entries as a (distance, position) list: the distance is recomputed from the record, exactly as
-// the scan computed it before truncation
-// The coordinates of the K entries, kept from the records a list was unpacked from (knn_rows hands them to the per-query fits of
-// K2, which used to fetch them again: 15 of the ~90 scattered loads of a five-neighbour query).  Entry m is defined where tk.j[m] >= 0.
+// The coordinates of a list's K entries, kept from the records the list was unpacked from (knn_rows hands them to the per-query
+// fits of K2, which used to fetch them again: 15 of the ~90 scattered loads of a five-neighbour query).  Entry m is defined where
+// tk.j[m] >= 0.
 template <int K>
 struct NbrXyz {
   double x[K], y[K], z[K];
 };
+// the first K entries as a (distance, position) list: the distance is recomputed from the record, exactly as
+// the scan computed it before truncation (xyz: the records' coordinates are kept as well)
 template <int K, int N>
 __device__ __forceinline__ void keys_unpack(const KeyList<N>& L, const PtsGlobal& pts, double qx, double qy, double qz,
                                             unsigned keep_mask, TopK<K>& tk, NbrXyz<K>* xyz = nullptr) {
