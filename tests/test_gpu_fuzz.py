@@ -21,3 +21,18 @@ def test_random_call_orders_end_in_status_codes(hip_module, seed):
     lines = {l.split()[0]: l for l in r.stdout.splitlines() if l.startswith("  ")}
     assert "TLOAM_E_BAD_POSE" in lines["scan_match"] and "'OK'" in lines["scan_match"]
     assert "TLOAM_E_BAD_POSE" in lines["submap_update"]
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_dirty_frames_agree_with_the_restatement(hip_module, seed):
+    """A short standing run of tests/tools/stress_dirty.py (lattice-quantised clouds, duplicates, NaN / infinite points, ten-point
+    clouds, caps of 0 / 1, lifted thresholds): every frame's status, pose, counters, index lists and weights against the CPU
+    restatement.  A frame may part only where its scaled normal equations are singular (eigenvalue ratio below 1e-6: the tool's
+    bar) and is then listed, not failed; anything else ends the tool with a non-zero code."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "stress_dirty.py"), "250", str(seed)],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "dirty sweep ok: 250 frames" in r.stdout
+    assert "FAILED" not in r.stdout
+    parted = sum(1 for l in r.stdout.splitlines() if "decisions parted" in l)
+    assert parted <= 3, r.stdout[-3000:]      # (12 000 frames over four seeds: nine, all rank-deficient)
