@@ -36,3 +36,14 @@ def test_dirty_frames_agree_with_the_restatement(hip_module, seed):
     assert "FAILED" not in r.stdout
     parted = sum(1 for l in r.stdout.splitlines() if "decisions parted" in l)
     assert parted <= 3, r.stdout[-3000:]      # (12 000 frames over four seeds: nine, all rank-deficient)
+
+
+def test_random_submap_sequences_and_feature_clouds_bit_for_bit(hip_module):
+    """A short standing run of tests/tools/stress_rows.py: the device submap and the PCA features (next-2)
+    over sizes, contents and configurations the fixed cases do not enumerate (0 / 1 / thousands of points, duplicates, points on
+    voxel and crop boundaries, non-finite points, every K / radius / voxel size) -- bit for bit against the restatement, call by
+    call, status by status."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "stress_rows.py"), "200", "11"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "rows sweep ok: 200 submap sequences + 200 feature clouds" in r.stdout
